@@ -1,0 +1,125 @@
+"""ctypes binding of the C ABI declared in include/dq_sufsort.h.
+
+This is the same surface the C# P/Invoke shim binds (bindings/csharp/HipSuffixSort.cs).
+The library is loaded on first use and the load FAILS LOUDLY if the HIP backend has not
+been built: there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from . import build as _build
+
+DQ_OK = 0
+DQ_ERR_BAD_ARGS = -1
+DQ_ERR_OOM = -2
+DQ_ERR_HIP = -3
+DQ_ERR_TOO_LARGE = -4
+DQ_ERR_NO_DEVICE = -5
+
+KERNEL_CATEGORIES = 8
+K_RADIX_RANK_SCATTER = 3
+
+# every symbol include/dq_sufsort.h declares
+EXPORTS = (
+    "dq_abi_version", "dq_device_count", "dq_last_error",
+    "dq_sufsort_hip_i32", "dq_sufsort_hip_i64",
+    "dq_sufsort_hip_dev_i32", "dq_sufsort_hip_dev_i64",
+    "dq_sufsort_hip_batch_i32",
+    "dq_sufsort_hip_workspace_bytes", "dq_sufsort_hip_release",
+    "dq_profile_enable", "dq_profile_reset", "dq_profile_get", "dq_profile_kernel_name",
+    "dq_last_sort_info",
+)
+
+
+class BackendMissingError(RuntimeError):
+    """libdq_sufsort_hip.so is absent or unloadable -- the product cannot run."""
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return os.environ.get("DQ_SUFSORT_LIB", _build.LIB_PATH)
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise BackendMissingError(
+            f"{path} not found: build the MI355X backend first "
+            "(python -m deltaq_amd.build, or __graft_entry__.build()). There is no CPU fallback.")
+    try:
+        L = ctypes.CDLL(path)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise BackendMissingError(f"cannot load {path}: {e}") from e
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.dq_abi_version.restype = i32
+    L.dq_abi_version.argtypes = []
+    L.dq_device_count.restype = i32
+    L.dq_device_count.argtypes = []
+    L.dq_last_error.restype = ctypes.c_char_p
+    L.dq_last_error.argtypes = []
+    for name in ("dq_sufsort_hip_i32", "dq_sufsort_hip_i64"):
+        getattr(L, name).restype = i32
+        getattr(L, name).argtypes = [vp, i64, vp, i32]
+    for name in ("dq_sufsort_hip_dev_i32", "dq_sufsort_hip_dev_i64"):
+        getattr(L, name).restype = i32
+        getattr(L, name).argtypes = [vp, i64, vp, i32, vp]
+    L.dq_sufsort_hip_batch_i32.restype = i32
+    L.dq_sufsort_hip_batch_i32.argtypes = [i32, vp, vp, vp, i32, vp]
+    L.dq_sufsort_hip_workspace_bytes.restype = i64
+    L.dq_sufsort_hip_workspace_bytes.argtypes = [i64, i32]
+    L.dq_sufsort_hip_release.restype = None
+    L.dq_sufsort_hip_release.argtypes = []
+    L.dq_profile_enable.restype = i32
+    L.dq_profile_enable.argtypes = [i32]
+    L.dq_profile_reset.restype = None
+    L.dq_profile_reset.argtypes = []
+    L.dq_profile_get.restype = i32
+    L.dq_profile_get.argtypes = [i32, ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double),
+                                 ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    L.dq_profile_kernel_name.restype = ctypes.c_char_p
+    L.dq_profile_kernel_name.argtypes = [i32]
+    L.dq_last_sort_info.restype = i32
+    L.dq_last_sort_info.argtypes = [ctypes.POINTER(i64)] * 3
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return load().dq_last_error().decode("utf-8", "replace")
+
+
+class SuffixSortError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"dq_sufsort_hip failed ({code}): {message}")
+        self.code = code
+
+
+def check(code: int) -> None:
+    if code != DQ_OK:
+        raise SuffixSortError(code, last_error())
+
+
+def profile_snapshot() -> dict:
+    """{kernel name: {launches, ms, elements, alg_bytes}} accumulated since dq_profile_reset."""
+    L = load()
+    out = {}
+    for cat in range(KERNEL_CATEGORIES):
+        n, ms, el, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
+        L.dq_profile_get(cat, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(el), ctypes.byref(by))
+        out[L.dq_profile_kernel_name(cat).decode()] = {
+            "launches": n.value, "ms": ms.value, "elements": el.value, "alg_bytes": by.value}
+    return out
+
+
+def last_sort_info() -> dict:
+    L = load()
+    a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    L.dq_last_sort_info(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+    return {"rounds": a.value, "initial_active": b.value, "sum_active": c.value}

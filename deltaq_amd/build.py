@@ -1,0 +1,51 @@
+"""Build recipe for libdq_sufsort_hip.so (hipcc, gfx950 only).
+
+The shared library is built IN-TREE (deltaq_amd/libdq_sufsort_hip.so) so that it
+travels with the repository snapshot; it is git-ignored.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_NAME = "libdq_sufsort_hip.so"
+LIB_PATH = os.path.join(HERE, LIB_NAME)
+SOURCES = ["dq_sufsort_hip.hip"]
+HEADERS = ["dq_device_utils.h", "dq_radix.h", "dq_sa_kernels.h", os.path.join("..", "..", "include", "dq_sufsort.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X backend cannot be built")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into deltaq_amd/libdq_sufsort_hip.so."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function", "-pthread"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,541 @@
+// dq_sufsort_hip.hip -- host runtime + C ABI of libdq_sufsort_hip.so.
+//
+// Suffix-array construction for byte text on one MI355X (gfx950):
+//   round 0   pack 8-byte keys, stable LSD radix ranking of (key, suffix) pairs
+//             (8 digit passes), mark group heads, device-wide scan -> ranks
+//   round r   for the suffixes still tied: key2 = rank of the suffix h bytes further on,
+//             sort by (rank, key2), rebucket, h *= 2   (prefix doubling; only the active
+//             suffixes are touched), until no group has more than one member.
+// The result is the unique suffix array, hence bit-identical to the reference's
+// LibDivSufSort.Sort() (LibDivSufSort.cs:12-29; order = LibDivSufSortTests.cs:43-59).
+//
+// This file contains no CPU sorting path: if HIP is unusable the entry points fail.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/dq_sufsort.h"
+#include "dq_radix.h"
+#include "dq_sa_kernels.h"
+
+namespace {
+
+using namespace dq;
+
+// ------------------------------------------------------------------ errors
+thread_local std::string t_err;
+thread_local int64_t t_info[3] = {0, 0, 0};
+
+int fail(int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    t_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? DQ_ERR_OOM : DQ_ERR_HIP, #expr, e_); \
+    } while (0)
+
+// ------------------------------------------------------------------ profiling
+struct KernelStat { int64_t launches = 0; double ms = 0; int64_t elems = 0; int64_t bytes = 0; };
+std::mutex g_prof_mu;
+KernelStat g_prof[DQ_K_COUNT];
+std::atomic<int> g_prof_on{0};
+
+const char *const kKernelNames[DQ_K_COUNT] = {
+    "pack_keys_kernel", "radix_upsweep_kernel", "radix_scan_kernel", "radix_rank_scatter_kernel",
+    "seg_reduce_kernel", "seg_scan_kernel", "seg_apply_kernel", "gather_key2_kernel"};
+
+struct ProfRec { int cat; hipEvent_t a, b; int64_t elems, bytes; };
+
+// ------------------------------------------------------------------ per-device context
+struct DeviceCtx {
+    std::mutex mu;
+    int dev = -1;
+    hipStream_t stream = nullptr;
+    char *ws = nullptr;
+    size_t ws_bytes = 0;
+    int64_t *pinned = nullptr;          // 64 B pinned readback area
+    std::vector<ProfRec> pending;
+    std::vector<hipEvent_t> pool;
+};
+constexpr int kMaxDevices = 64;
+DeviceCtx g_ctx[kMaxDevices];
+
+int init_ctx(DeviceCtx &c, int dev)
+{
+    HIP_TRY(hipSetDevice(dev));
+    if (c.dev == dev) return DQ_OK;
+    c.dev = dev;
+    HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc((void **)&c.pinned, 64, hipHostMallocDefault));
+    return DQ_OK;
+}
+
+int ensure_ws(DeviceCtx &c, size_t bytes)
+{
+    if (c.ws_bytes >= bytes) return DQ_OK;
+    if (c.ws) { (void)hipFree(c.ws); c.ws = nullptr; c.ws_bytes = 0; }
+    hipError_t e = hipMalloc((void **)&c.ws, bytes);
+    if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(workspace)", e);
+    c.ws_bytes = bytes;
+    return DQ_OK;
+}
+
+struct Launcher {
+    DeviceCtx &c;
+    hipStream_t st;
+    bool prof;
+    int begin(int cat, int64_t elems, int64_t bytes)
+    {
+        if (!prof) return DQ_OK;
+        ProfRec r{cat, nullptr, nullptr, elems, bytes};
+        for (hipEvent_t *ev : {&r.a, &r.b}) {
+            if (!c.pool.empty()) { *ev = c.pool.back(); c.pool.pop_back(); }
+            else HIP_TRY(hipEventCreate(ev));
+        }
+        HIP_TRY(hipEventRecord(r.a, st));
+        c.pending.push_back(r);
+        return DQ_OK;
+    }
+    int end()
+    {
+        if (!prof) return DQ_OK;
+        HIP_TRY(hipEventRecord(c.pending.back().b, st));
+        return DQ_OK;
+    }
+};
+
+int flush_profile(DeviceCtx &c)
+{
+    if (c.pending.empty()) return DQ_OK;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (ProfRec &r : c.pending) {
+        float ms = 0;
+        HIP_TRY(hipEventSynchronize(r.b));
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        KernelStat &s = g_prof[r.cat];
+        s.launches += 1; s.ms += ms; s.elems += r.elems; s.bytes += r.bytes;
+        c.pool.push_back(r.a); c.pool.push_back(r.b);
+    }
+    c.pending.clear();
+    return DQ_OK;
+}
+
+#define LAUNCH(L, cat, elems, bytes, ...)                 \
+    do {                                                  \
+        int rc_ = (L).begin(cat, elems, bytes);           \
+        if (rc_ != DQ_OK) return rc_;                     \
+        __VA_ARGS__;                                      \
+        HIP_TRY(hipGetLastError());                       \
+        rc_ = (L).end();                                  \
+        if (rc_ != DQ_OK) return rc_;                     \
+    } while (0)
+
+// ------------------------------------------------------------------ workspace carving
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+template <typename IdxT>
+struct Workspace {
+    uint8_t *text;
+    uint64_t *K0, *K1;
+    IdxT *Va, *Vb, *ISA, *SAbuf;
+    uint32_t *blockhist;
+    IdxT *blockbase;
+    SegPartials<IdxT> part;
+    int64_t *totals;
+    size_t bytes;
+};
+
+template <typename IdxT>
+Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
+{
+    Workspace<IdxT> w{};
+    size_t off = 0;
+    auto take = [&](size_t b) { char *p = base ? base + off : nullptr; off += align_up(b); return p; };
+    const size_t un = (size_t)n;
+    w.text = (uint8_t *)take(un + 64);
+    w.K0 = (uint64_t *)take(un * 8);
+    w.K1 = (uint64_t *)take(un * 8);
+    w.Va = (IdxT *)take(un * sizeof(IdxT));
+    w.Vb = (IdxT *)take(un * sizeof(IdxT));
+    w.ISA = (IdxT *)take(un * sizeof(IdxT));
+    w.SAbuf = with_sa ? (IdxT *)take(un * sizeof(IdxT)) : nullptr;
+    w.blockhist = (uint32_t *)take((size_t)kMaxSweepBlocks * kRadixSize * 4);
+    w.blockbase = (IdxT *)take((size_t)kMaxSweepBlocks * kRadixSize * sizeof(IdxT));
+    const size_t nparts = (un + kSegTile - 1) / kSegTile + 1;
+    w.part.nh = (IdxT *)take(nparts * sizeof(IdxT));
+    w.part.gh = (IdxT *)take(nparts * sizeof(IdxT));
+    w.part.cnt = (IdxT *)take(nparts * sizeof(IdxT));
+    w.totals = (int64_t *)take(64);
+    w.bytes = off;
+    return w;
+}
+
+inline int bit_length(uint64_t x) { return x == 0 ? 1 : 64 - __builtin_clzll(x); }
+
+// ------------------------------------------------------------------ radix sort driver
+template <typename IdxT>
+int radix_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V[2], int64_t m,
+                     int total_bits, bool synth_first, int &cur)
+{
+    const int passes = (total_bits + kRadixBits - 1) / kRadixBits;
+    const int64_t ntiles = (m + kTile - 1) / kTile;
+    int64_t G = std::min<int64_t>(ntiles, kMaxSweepBlocks);
+    const int tpb = (int)((ntiles + G - 1) / G);
+    G = (ntiles + tpb - 1) / tpb;
+    const int64_t wb = (int64_t)sizeof(IdxT);
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * kRadixBits;
+        LAUNCH(L, DQ_K_RADIX_UPSWEEP, m, m * 8,
+               hipLaunchKernelGGL(radix_upsweep_kernel, dim3((unsigned)G), dim3(kBlock), 0, L.st,
+                                  K[cur], m, shift, tpb, w.blockhist));
+        LAUNCH(L, DQ_K_RADIX_SCAN, G * kRadixSize, G * kRadixSize * (4 + wb),
+               hipLaunchKernelGGL(radix_scan_kernel<IdxT>, dim3(1), dim3(1024), 0, L.st,
+                                  w.blockhist, (int)G, w.blockbase));
+        if (synth_first && p == 0) {
+            LAUNCH(L, DQ_K_RADIX_RANK_SCATTER, m, m * (8 + 8 + wb),
+                   hipLaunchKernelGGL((radix_rank_scatter_kernel<IdxT, true>), dim3((unsigned)G),
+                                      dim3(kBlock), 0, L.st, K[cur], (const IdxT *)nullptr,
+                                      K[cur ^ 1], V[cur ^ 1], m, shift, tpb, w.blockbase));
+        } else {
+            LAUNCH(L, DQ_K_RADIX_RANK_SCATTER, m, m * 2 * (8 + wb),
+                   hipLaunchKernelGGL((radix_rank_scatter_kernel<IdxT, false>), dim3((unsigned)G),
+                                      dim3(kBlock), 0, L.st, K[cur], V[cur], K[cur ^ 1], V[cur ^ 1],
+                                      m, shift, tpb, w.blockbase));
+        }
+        cur ^= 1;
+    }
+    return DQ_OK;
+}
+
+template <typename IdxT, bool kInitial>
+int seg_count(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *keys, int64_t m,
+              int kbits, int64_t *active_out)
+{
+    const int64_t nparts = (m + kSegTile - 1) / kSegTile;
+    const int64_t wb = (int64_t)sizeof(IdxT);
+    LAUNCH(L, DQ_K_SEG_REDUCE, m, m * 8,
+           hipLaunchKernelGGL((seg_reduce_kernel<IdxT, kInitial>), dim3((unsigned)nparts),
+                              dim3(kBlock), 0, L.st, keys, m, kbits, w.part));
+    LAUNCH(L, DQ_K_SEG_SCAN, nparts, nparts * 6 * wb,
+           hipLaunchKernelGGL(seg_scan_kernel<IdxT>, dim3(1), dim3(1024), 0, L.st, w.part, nparts,
+                              w.totals));
+    HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 8, hipMemcpyDeviceToHost, L.st));
+    HIP_TRY(hipStreamSynchronize(L.st));
+    *active_out = c.pinned[0];
+    return DQ_OK;
+}
+
+// ------------------------------------------------------------------ the suffix sorter
+// d_text: the workspace's padded copy of the text; d_sa: n entries on the device.
+template <typename IdxT>
+int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, IdxT *d_sa)
+{
+    Launcher L{c, st, g_prof_on.load() != 0};
+    const int64_t wb = (int64_t)sizeof(IdxT);
+    t_info[0] = t_info[1] = t_info[2] = 0;
+
+    // ---- round 0: 8-byte keys, full radix ranking
+    {
+        const int64_t nquads = (n + 3) / 4;
+        const int64_t blocks = std::min<int64_t>((nquads + kBlock - 1) / kBlock, 256 * 8);
+        LAUNCH(L, DQ_K_PACK_KEYS, n, n * 9,
+               hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st,
+                                  w.text, n, w.K0));
+    }
+    int64_t active = 0;
+    {
+        const int passes = 64 / kRadixBits;
+        uint64_t *K[2] = {w.K0, w.K1};
+        IdxT *V[2];
+        V[passes & 1] = d_sa;            // the last pass must land in the caller's SA buffer
+        V[(passes & 1) ^ 1] = w.Va;
+        int cur = 0;
+        int rc = radix_sort_pairs<IdxT>(L, w, K, V, n, 64, /*synth_first=*/true, cur);
+        if (rc != DQ_OK) return rc;
+        // sorted keys are in K[cur], suffixes in V[cur] == d_sa
+        rc = seg_count<IdxT, true>(L, c, w, K[cur], n, 0, &active);
+        if (rc != DQ_OK) return rc;
+        t_info[1] = active;
+        if (active == 0) return flush_profile(c);
+        const int64_t nparts = (n + kSegTile - 1) / kSegTile;
+        uint64_t *act_rank = K[cur ^ 1];
+        LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb + wb) + active * (8 + wb),
+               hipLaunchKernelGGL((seg_apply_kernel<IdxT, true, false>), dim3((unsigned)nparts),
+                                  dim3(kBlock), 0, st, K[cur], (const IdxT *)d_sa, n, 0, w.part,
+                                  d_sa, w.ISA, act_rank, w.Va));
+        // refinement ping-pong: (act_rank buffer, Va) <-> (other key buffer, Vb)
+        uint64_t *Kr[2] = {act_rank, K[cur]};
+        IdxT *Vr[2] = {w.Va, w.Vb};
+        int rcur = 0;
+        int64_t m = active;
+        int64_t h = 8;
+        const int rbits = bit_length((uint64_t)(n - 1));
+        while (m > 0) {
+            t_info[0] += 1;
+            t_info[2] += m;
+            const int kbits = bit_length((uint64_t)(n - 1) + (uint64_t)h);
+            if (kbits + rbits > 64) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
+            const int64_t gblocks = std::min<int64_t>((m + kBlock - 1) / kBlock, 256 * 16);
+            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8),
+                   hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3((unsigned)gblocks), dim3(kBlock),
+                                      0, st, Kr[rcur], (const IdxT *)Vr[rcur], (const IdxT *)w.ISA, m,
+                                      n, h, kbits));
+            rc = radix_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, false, rcur);
+            if (rc != DQ_OK) return rc;
+            int64_t m2 = 0;
+            rc = seg_count<IdxT, false>(L, c, w, Kr[rcur], m, kbits, &m2);
+            if (rc != DQ_OK) return rc;
+            const int64_t np = (m + kSegTile - 1) / kSegTile;
+            LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + wb + wb + wb) + m2 * (8 + wb),
+                   hipLaunchKernelGGL((seg_apply_kernel<IdxT, false, true>), dim3((unsigned)np),
+                                      dim3(kBlock), 0, st, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits,
+                                      w.part, d_sa, w.ISA, Kr[rcur ^ 1], Vr[rcur ^ 1]));
+            rcur ^= 1;
+            m = m2;
+            h *= 2;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return flush_profile(c);
+}
+
+int resolve_device(int32_t device, int *out)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(DQ_ERR_NO_DEVICE, "no HIP device available", e);
+    if (device < 0) {
+        const char *env = getenv("DQ_HIP_DEVICE");
+        device = env ? atoi(env) : 0;
+    }
+    if (device < 0 || device >= count || device >= kMaxDevices)
+        return fail(DQ_ERR_BAD_ARGS, "device ordinal out of range");
+    *out = device;
+    return DQ_OK;
+}
+
+template <typename IdxT>
+int check_args(const void *text, int64_t n, const void *sa)
+{
+    if (n < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
+    if (n > 0 && (!text || !sa)) return fail(DQ_ERR_BAD_ARGS, "null buffer");
+    if (sizeof(IdxT) == 4 && n > 0x7fffffffLL)
+        return fail(DQ_ERR_TOO_LARGE, "n exceeds 2^31-1; use the i64 entry point");
+    return DQ_OK;
+}
+
+// host buffers in / out  (ISuffixSort.Sort(text, suffixes))
+template <typename IdxT>
+int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device)
+{
+    int rc = check_args<IdxT>(text, n, sa);
+    if (rc != DQ_OK) return rc;
+    int dev = 0;
+    rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    // DivSufSort.cs:22-38: the reference special-cases n = 0, 1, 2
+    if (n == 0) return DQ_OK;
+    if (n == 1) { sa[0] = 0; return DQ_OK; }
+    if (n == 2) {
+        const bool lt = text[0] < text[1];
+        sa[0] = lt ? 0 : 1; sa[1] = lt ? 1 : 0;
+        return DQ_OK;
+    }
+    DeviceCtx &c = g_ctx[dev];
+    std::lock_guard<std::mutex> lk(c.mu);
+    rc = init_ctx(c, dev);
+    if (rc != DQ_OK) return rc;
+    Workspace<IdxT> w = carve<IdxT>(nullptr, n, true);
+    rc = ensure_ws(c, w.bytes);
+    if (rc != DQ_OK) return rc;
+    w = carve<IdxT>(c.ws, n, true);
+    hipStream_t st = c.stream;
+    HIP_TRY(hipMemcpyAsync(w.text, text, (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(w.text + n, 0, 64, st));
+    rc = sufsort_device<IdxT>(c, st, w, n, w.SAbuf);
+    if (rc != DQ_OK) { (void)hipStreamSynchronize(st); c.pending.clear(); return rc; }
+    HIP_TRY(hipMemcpyAsync(sa, w.SAbuf, (size_t)n * sizeof(IdxT), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return DQ_OK;
+}
+
+// device buffers in / out
+template <typename IdxT>
+int sufsort_dev(const void *d_text, int64_t n, void *d_sa, int32_t device, void *stream)
+{
+    int rc = check_args<IdxT>(d_text, n, d_sa);
+    if (rc != DQ_OK) return rc;
+    int dev = 0;
+    rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    if (n == 0) return DQ_OK;
+    DeviceCtx &c = g_ctx[dev];
+    std::lock_guard<std::mutex> lk(c.mu);
+    rc = init_ctx(c, dev);
+    if (rc != DQ_OK) return rc;
+    Workspace<IdxT> w = carve<IdxT>(nullptr, n, false);
+    rc = ensure_ws(c, w.bytes);
+    if (rc != DQ_OK) return rc;
+    w = carve<IdxT>(c.ws, n, false);
+    hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+    HIP_TRY(hipMemcpyAsync(w.text, d_text, (size_t)n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemsetAsync(w.text + n, 0, 64, st));
+    rc = sufsort_device<IdxT>(c, st, w, n, (IdxT *)d_sa);
+    if (rc != DQ_OK) { (void)hipStreamSynchronize(st); c.pending.clear(); return rc; }
+    HIP_TRY(hipStreamSynchronize(st));
+    return DQ_OK;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+int32_t dq_abi_version(void) { return DQ_ABI_VERSION; }
+
+int32_t dq_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+const char *dq_last_error(void) { return t_err.c_str(); }
+
+int32_t dq_sufsort_hip_i32(const uint8_t *text, int64_t n, int32_t *sa, int32_t device)
+{
+    return sufsort_host<int32_t>(text, n, sa, device);
+}
+
+int32_t dq_sufsort_hip_i64(const uint8_t *text, int64_t n, int64_t *sa, int32_t device)
+{
+    return sufsort_host<int64_t>(text, n, sa, device);
+}
+
+int32_t dq_sufsort_hip_dev_i32(const void *d_text, int64_t n, void *d_sa, int32_t device, void *stream)
+{
+    return sufsort_dev<int32_t>(d_text, n, d_sa, device, stream);
+}
+
+int32_t dq_sufsort_hip_dev_i64(const void *d_text, int64_t n, void *d_sa, int32_t device, void *stream)
+{
+    return sufsort_dev<int64_t>(d_text, n, d_sa, device, stream);
+}
+
+int32_t dq_sufsort_hip_batch_i32(int32_t count, const uint8_t *const *texts, const int64_t *lens,
+                                 int32_t *const *sas, int32_t ndev, const int32_t *devs)
+{
+    if (count < 0 || ndev <= 0 || (count > 0 && (!texts || !lens || !sas)))
+        return fail(DQ_ERR_BAD_ARGS, "bad batch arguments");
+    if (count == 0) return DQ_OK;
+    // longest-processing-time-first assignment of inputs to devices
+    std::vector<int> order(count);
+    for (int i = 0; i < count; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+    std::vector<std::vector<int>> share(ndev);
+    std::vector<int64_t> load(ndev, 0);
+    for (int j : order) {
+        int best = 0;
+        for (int d = 1; d < ndev; ++d)
+            if (load[d] < load[best]) best = d;
+        share[best].push_back(j);
+        load[best] += lens[j];
+    }
+    std::vector<int> rcs(ndev, DQ_OK);
+    std::vector<std::string> errs(ndev);
+    std::vector<std::thread> threads;
+    for (int d = 0; d < ndev; ++d) {
+        threads.emplace_back([&, d]() {
+            const int device = devs ? devs[d] : d;
+            for (int j : share[d]) {
+                int rc = sufsort_host<int32_t>(texts[j], lens[j], sas[j], device);
+                if (rc != DQ_OK) { rcs[d] = rc; errs[d] = t_err; return; }
+            }
+        });
+    }
+    for (auto &t : threads) t.join();
+    for (int d = 0; d < ndev; ++d)
+        if (rcs[d] != DQ_OK) { t_err = errs[d]; return rcs[d]; }
+    return DQ_OK;
+}
+
+int64_t dq_sufsort_hip_workspace_bytes(int64_t n, int32_t index_bytes)
+{
+    if (n < 0) return -1;
+    if (index_bytes == 4) return (int64_t)carve<int32_t>(nullptr, n, false).bytes;
+    if (index_bytes == 8) return (int64_t)carve<int64_t>(nullptr, n, false).bytes;
+    return -1;
+}
+
+void dq_sufsort_hip_release(void)
+{
+    for (int d = 0; d < kMaxDevices; ++d) {
+        DeviceCtx &c = g_ctx[d];
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (c.dev < 0) continue;
+        if (hipSetDevice(c.dev) != hipSuccess) continue;
+        if (c.ws) (void)hipFree(c.ws);
+        c.ws = nullptr; c.ws_bytes = 0;
+        for (hipEvent_t e : c.pool) (void)hipEventDestroy(e);
+        c.pool.clear();
+        if (c.pinned) (void)hipHostFree(c.pinned);
+        c.pinned = nullptr;
+        if (c.stream) (void)hipStreamDestroy(c.stream);
+        c.stream = nullptr;
+        c.dev = -1;
+    }
+}
+
+int32_t dq_profile_enable(int32_t on) { g_prof_on.store(on ? 1 : 0); return DQ_OK; }
+
+void dq_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &s : g_prof) s = KernelStat{};
+}
+
+int32_t dq_profile_get(int32_t category, int64_t *launches, double *total_ms, int64_t *elements,
+                       int64_t *alg_bytes)
+{
+    if (category < 0 || category >= DQ_K_COUNT) return DQ_ERR_BAD_ARGS;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const KernelStat &s = g_prof[category];
+    if (launches) *launches = s.launches;
+    if (total_ms) *total_ms = s.ms;
+    if (elements) *elements = s.elems;
+    if (alg_bytes) *alg_bytes = s.bytes;
+    return DQ_OK;
+}
+
+const char *dq_profile_kernel_name(int32_t category)
+{
+    return (category >= 0 && category < DQ_K_COUNT) ? kKernelNames[category] : "";
+}
+
+int32_t dq_last_sort_info(int64_t *rounds, int64_t *initial_active, int64_t *sum_active)
+{
+    if (rounds) *rounds = t_info[0];
+    if (initial_active) *initial_active = t_info[1];
+    if (sum_active) *sum_active = t_info[2];
+    return DQ_OK;
+}
+
+}  // extern "C"

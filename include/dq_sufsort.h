@@ -1,0 +1,103 @@
+/*
+ * dq_sufsort.h -- C ABI of libdq_sufsort_hip.so, the MI355X (gfx950) suffix-sorting
+ * backend that drops in behind DeltaQ's ISuffixSort plugin interface.
+ *
+ * Reference interface replaced (paths relative to the jzebedee/deltaq tree):
+ *   src/DeltaQ.SuffixSorting.Abstractions/ISuffixSort.cs:18   IMemoryOwner<int> Sort(ReadOnlySpan<byte> text)
+ *   src/DeltaQ.SuffixSorting.Abstractions/ISuffixSort.cs:27   void Sort(ReadOnlySpan<byte> text, Span<int> suffixes)
+ *   src/DeltaQ.SuffixSorting.LibDivSufSort/LibDivSufSort.cs:12-29  (the default provider both overloads end in
+ *   DivSufSort.divsufsort(T, SA), DivSufSort.cs:18-42)
+ * The only production caller is Diff.Create (src/DeltaQ.BsDiff/Diff.cs:89-90):
+ *   suffixSort.Sort(oldData, I[..^1]).
+ *
+ * Contract (identical to the reference's): sa receives exactly n entries, a permutation
+ * of 0..n-1 in strict lexicographic suffix order over UNSIGNED bytes where a proper
+ * prefix sorts first (ReadOnlySpan<byte>.SequenceCompareTo, LibDivSufSortTests.cs:43-59).
+ * That array is unique, so the output is bit-identical to LibDivSufSort.Sort().
+ * No sentinel slot is written: sa[n] (Diff.cs:78 allocates n+1) is never touched.
+ *
+ * All entry points are blocking, re-entrant and thread-safe; none retains a caller
+ * pointer after returning; none throws or aborts.  There is NO CPU fallback in this
+ * library: without a usable HIP device every sort entry point fails with DQ_ERR_NO_DEVICE.
+ */
+#ifndef DQ_SUFSORT_H
+#define DQ_SUFSORT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DQ_ABI_VERSION 1
+
+/* return codes */
+#define DQ_OK              0
+#define DQ_ERR_BAD_ARGS   (-1)   /* null pointer with n > 0, negative n, bad device / count        */
+#define DQ_ERR_OOM        (-2)   /* device (or pinned host) allocation failed                       */
+#define DQ_ERR_HIP        (-3)   /* any other HIP runtime error; see dq_last_error()                */
+#define DQ_ERR_TOO_LARGE  (-4)   /* n exceeds the index width (i32: n > 2^31-1, ISuffixSort's limit)*/
+#define DQ_ERR_NO_DEVICE  (-5)   /* no HIP device visible                                           */
+
+int32_t dq_abi_version(void);
+int32_t dq_device_count(void);                 /* 0 when no device / no driver                      */
+const char *dq_last_error(void);               /* thread-local, never NULL                          */
+
+/* ---- ISuffixSort.Sort(text, suffixes): host buffers in, host buffers out -----------------------
+ * text: n bytes; sa: n entries, written only (may hold garbage, LibDivSufSort.cs:14).
+ * n == 0 is a no-op; n == 1 -> {0}; n == 2 -> {0,1} iff text[0] < text[1] else {1,0}
+ * (DivSufSort.cs:22-38).  device: HIP device ordinal, or -1 for DQ_HIP_DEVICE / device 0. */
+int32_t dq_sufsort_hip_i32(const uint8_t *text, int64_t n, int32_t *sa, int32_t device);
+/* Same contract with 64-bit indices, for inputs beyond ISuffixSort's int limit (n >= 2^31). */
+int32_t dq_sufsort_hip_i64(const uint8_t *text, int64_t n, int64_t *sa, int32_t device);
+
+/* ---- device-resident variant: text and sa are device pointers on `device` ----------------------
+ * d_text: n bytes, any alignment; d_sa: n entries.  Work is enqueued on `stream`
+ * (a hipStream_t, NULL = the library's own stream for that device) and the call returns
+ * after the stream has drained.  The next consumer (Diff.Create's match search,
+ * Diff.cs:100-125) can read d_sa without a D2H copy. */
+int32_t dq_sufsort_hip_dev_i32(const void *d_text, int64_t n, void *d_sa, int32_t device, void *stream);
+int32_t dq_sufsort_hip_dev_i64(const void *d_text, int64_t n, void *d_sa, int32_t device, void *stream);
+
+/* ---- batch of independent inputs (the many-files bsdiff path) -----------------------------------
+ * count inputs, texts[j] of lens[j] bytes -> sas[j] (lens[j] entries).  Inputs are assigned to
+ * the ndev devices in devs[] longest-first (LPT); each device runs its share on its own host
+ * thread.  devs == NULL means devices 0..ndev-1.  Returns the first failing input's code. */
+int32_t dq_sufsort_hip_batch_i32(int32_t count, const uint8_t *const *texts, const int64_t *lens,
+                                 int32_t *const *sas, int32_t ndev, const int32_t *devs);
+
+/* Device workspace (bytes) a sort of n bytes with index_bytes (4 or 8) wide indices needs,
+ * excluding the caller's text and sa buffers. */
+int64_t dq_sufsort_hip_workspace_bytes(int64_t n, int32_t index_bytes);
+/* Free every cached device workspace / pinned staging buffer / stream. */
+void dq_sufsort_hip_release(void);
+
+/* ---- measurement hooks (bench.py) -----------------------------------------------------------------
+ * With profiling on, every kernel launch is bracketed by hipEvents on the launch stream and the
+ * elapsed time is accumulated per kernel category when the sort finishes. */
+#define DQ_K_PACK_KEYS           0
+#define DQ_K_RADIX_UPSWEEP       1
+#define DQ_K_RADIX_SCAN          2
+#define DQ_K_RADIX_RANK_SCATTER  3   /* the dominant kernel; roofline = 2*(8+w) B/element/launch */
+#define DQ_K_SEG_REDUCE          4
+#define DQ_K_SEG_SCAN            5
+#define DQ_K_SEG_APPLY           6
+#define DQ_K_GATHER_KEY2         7
+#define DQ_K_COUNT               8
+
+int32_t dq_profile_enable(int32_t on);
+void    dq_profile_reset(void);
+/* launches, summed milliseconds, summed elements processed, summed algorithmic bytes */
+int32_t dq_profile_get(int32_t category, int64_t *launches, double *total_ms, int64_t *elements,
+                       int64_t *alg_bytes);
+const char *dq_profile_kernel_name(int32_t category);
+
+/* Shape of the last sort on this thread: doubling rounds after the initial 8-byte sort, number
+ * of suffixes still in non-singleton groups after the initial sort, and the sum of that count
+ * over all rounds. */
+int32_t dq_last_sort_info(int64_t *rounds, int64_t *initial_active, int64_t *sum_active);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DQ_SUFSORT_H */

@@ -1,0 +1,183 @@
+"""CPU oracle for the suffix-sorting hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package.  The product (``deltaq_amd``) never does.
+
+It wraps ``oracle/libdq_oracle.so`` (plain C, built by ``oracle/Makefile``):
+the restatement of the reference's LibDivSufSort (DivSufSort.cs / SsSort.cs /
+TrSort.cs), the reference's own checkers (LibDivSufSortTests.Verify,
+LDSSChecker.Check), a naive suffix array, the .NET ``Random`` generator used by
+the reference's tests, and the synthetic workload generators.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdq_oracle.so")
+
+CHECK_DONE = 0
+CHECK_BAD_ARGUMENTS = -1
+CHECK_OUT_OF_RANGE = -2
+CHECK_WRONG_ORDER = -3
+CHECK_WRONG_POSITION = -4
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (a few seconds)."""
+    if force or not os.path.exists(_LIB_PATH) or _stale():
+        subprocess.run(["make", "-C", _HERE, "-s", "libdq_oracle.so"], check=True)
+    return _LIB_PATH
+
+
+def _stale() -> bool:
+    t = os.path.getmtime(_LIB_PATH)
+    for f in os.listdir(_HERE):
+        if f.endswith((".c", ".h")) and os.path.getmtime(os.path.join(_HERE, f)) > t:
+            return True
+    return False
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        u8p = ctypes.c_void_p
+        i64 = ctypes.c_int64
+        for suf in ("i32", "i64"):
+            getattr(L, f"dq_oracle_verify_strict_{suf}").restype = i64
+            getattr(L, f"dq_oracle_verify_strict_{suf}").argtypes = [u8p, u8p, i64]
+            getattr(L, f"dq_oracle_verify_sampled_{suf}").restype = i64
+            getattr(L, f"dq_oracle_verify_sampled_{suf}").argtypes = [u8p, u8p, i64, i64, ctypes.c_uint64]
+            getattr(L, f"dq_oracle_sufcheck_{suf}").restype = ctypes.c_int32
+            getattr(L, f"dq_oracle_sufcheck_{suf}").argtypes = [u8p, i64, u8p, i64]
+            if hasattr(L, f"dq_oracle_divsufsort_{suf}"):
+                getattr(L, f"dq_oracle_divsufsort_{suf}").restype = ctypes.c_int32
+                getattr(L, f"dq_oracle_divsufsort_{suf}").argtypes = [u8p, u8p, i64]
+        L.dq_oracle_naive_sa_i32.restype = ctypes.c_int32
+        L.dq_oracle_naive_sa_i32.argtypes = [u8p, u8p, i64]
+        L.dq_oracle_netrandom_bytes.restype = None
+        L.dq_oracle_netrandom_bytes.argtypes = [ctypes.c_int32, u8p, i64]
+        L.dq_oracle_netrandom_first_sample.restype = ctypes.c_int32
+        L.dq_oracle_netrandom_first_sample.argtypes = [ctypes.c_int32]
+        L.dq_oracle_gen_uniform.restype = None
+        L.dq_oracle_gen_uniform.argtypes = [u8p, i64, ctypes.c_uint64]
+        L.dq_oracle_gen_enwik_like.restype = None
+        L.dq_oracle_gen_enwik_like.argtypes = [u8p, i64, ctypes.c_uint64, i64]
+        if hasattr(L, "dq_oracle_last_phase_seconds"):
+            L.dq_oracle_last_phase_seconds.restype = None
+            L.dq_oracle_last_phase_seconds.argtypes = [ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _text(text) -> np.ndarray:
+    if isinstance(text, (bytes, bytearray, memoryview)):
+        text = np.frombuffer(bytes(text), dtype=np.uint8)
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    return text
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data if a.size else 0
+
+
+def _suf(sa: np.ndarray) -> str:
+    if sa.dtype == np.int32:
+        return "i32"
+    if sa.dtype == np.int64:
+        return "i64"
+    raise TypeError(f"suffix array must be int32 or int64, not {sa.dtype}")
+
+
+# ---- reference algorithm restated -------------------------------------------------
+def divsufsort(text, dtype=np.int32) -> np.ndarray:
+    """Restatement of LibDivSufSort.Sort(text) (LibDivSufSort.cs:12-19)."""
+    T = _text(text)
+    sa = np.empty(T.size, dtype=dtype)
+    fn = getattr(lib(), f"dq_oracle_divsufsort_{_suf(sa)}")
+    rc = fn(_ptr(T), _ptr(sa), T.size)
+    if rc != 0:
+        raise RuntimeError(f"oracle divsufsort failed: {rc}")
+    return sa
+
+
+def last_phase_seconds():
+    out = (ctypes.c_double * 5)()
+    lib().dq_oracle_last_phase_seconds(out)
+    return dict(zip(("classify", "sssort", "trsort", "place_bstar", "induce"), list(out)))
+
+
+def naive_sa(text) -> np.ndarray:
+    T = _text(text)
+    sa = np.empty(T.size, dtype=np.int32)
+    lib().dq_oracle_naive_sa_i32(_ptr(T), _ptr(sa), T.size)
+    return sa
+
+
+# ---- reference checkers restated ---------------------------------------------------
+def verify_strict(text, sa) -> int:
+    """-1 when strictly sorted (LibDivSufSortTests.cs:43-59), else first bad i."""
+    T = _text(text)
+    sa = np.ascontiguousarray(sa)
+    return int(getattr(lib(), f"dq_oracle_verify_strict_{_suf(sa)}")(_ptr(T), _ptr(sa), T.size))
+
+
+def verify_sampled(text, sa, samples=1_000_000, seed=1) -> int:
+    T = _text(text)
+    sa = np.ascontiguousarray(sa)
+    return int(getattr(lib(), f"dq_oracle_verify_sampled_{_suf(sa)}")(_ptr(T), _ptr(sa), T.size, samples, seed))
+
+
+def sufcheck(text, sa) -> int:
+    """LDSSChecker.Check result code (LDSSChecker.cs:23-119)."""
+    T = _text(text)
+    sa = np.ascontiguousarray(sa)
+    return int(getattr(lib(), f"dq_oracle_sufcheck_{_suf(sa)}")(_ptr(T), T.size, _ptr(sa), sa.size))
+
+
+def verify(text, sa) -> None:
+    """LibDivSufSortTests.Verify: strict order, then sufcheck == Done."""
+    rc = sufcheck(text, sa)  # range-check first so the strict loop cannot read out of bounds
+    if rc == CHECK_OUT_OF_RANGE or rc == CHECK_BAD_ARGUMENTS:
+        raise AssertionError(f"sufcheck returned {rc}")
+    bad = verify_strict(text, sa)
+    if bad >= 0:
+        raise AssertionError(f"Input was unsorted at i={bad}, j={bad + 1}")
+    if rc != CHECK_DONE:
+        raise AssertionError(f"sufcheck returned {rc}")
+
+
+# ---- input generators ----------------------------------------------------------------
+REFERENCE_SEED = 63 * 13 * 63 * 13  # LibDivSufSortTests.cs:29
+
+
+def net_random_bytes(size: int, seed: int = REFERENCE_SEED) -> np.ndarray:
+    """new Random(seed).NextBytes(new byte[size])."""
+    out = np.empty(size, dtype=np.uint8)
+    lib().dq_oracle_netrandom_bytes(seed, _ptr(out), size)
+    return out
+
+
+def net_random_first_sample(seed: int) -> int:
+    return int(lib().dq_oracle_netrandom_first_sample(seed))
+
+
+def gen_uniform(n: int, seed: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint8)
+    lib().dq_oracle_gen_uniform(_ptr(out), n, seed)
+    return out
+
+
+def gen_enwik_like(n: int, seed: int = 0xD17A0, repeat_period: int = 256 * 1024) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint8)
+    lib().dq_oracle_gen_enwik_like(_ptr(out), n, seed, repeat_period)
+    return out
