@@ -44,6 +44,25 @@ def lib_path() -> str:
     return os.environ.get("DQ_SUFSORT_LIB", _build.LIB_PATH)
 
 
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  Two HIP runtimes in one
+    process cannot both own the GPU, so when torch is installed its runtime is mapped
+    first and libdq_sufsort_hip.so (NEEDED libamdhip64.so.7) binds to that same copy.
+    A host without torch (the C# shim, a C program) uses the system ROCm runtime."""
+    if os.environ.get("DQ_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:  # pragma: no cover - best effort
+        pass
+
+
 def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
@@ -53,6 +72,7 @@ def load() -> ctypes.CDLL:
         raise BackendMissingError(
             f"{path} not found: build the MI355X backend first "
             "(python -m deltaq_amd.build, or __graft_entry__.build()). There is no CPU fallback.")
+    _preload_torch_hip_runtime()
     try:
         L = ctypes.CDLL(path)
     except OSError as e:  # pragma: no cover - depends on the machine

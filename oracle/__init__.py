@@ -15,10 +15,15 @@ import ctypes
 import os
 import subprocess
 
+import sys
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libdq_oracle.so")
+_ROOT = os.path.dirname(_HERE)
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
 
 CHECK_DONE = 0
 CHECK_BAD_ARGUMENTS = -1
@@ -68,10 +73,6 @@ def lib() -> ctypes.CDLL:
         L.dq_oracle_netrandom_bytes.argtypes = [ctypes.c_int32, u8p, i64]
         L.dq_oracle_netrandom_first_sample.restype = ctypes.c_int32
         L.dq_oracle_netrandom_first_sample.argtypes = [ctypes.c_int32]
-        L.dq_oracle_gen_uniform.restype = None
-        L.dq_oracle_gen_uniform.argtypes = [u8p, i64, ctypes.c_uint64]
-        L.dq_oracle_gen_enwik_like.restype = None
-        L.dq_oracle_gen_enwik_like.argtypes = [u8p, i64, ctypes.c_uint64, i64]
         if hasattr(L, "dq_oracle_last_phase_seconds"):
             L.dq_oracle_last_phase_seconds.restype = None
             L.dq_oracle_last_phase_seconds.argtypes = [ctypes.c_void_p]
@@ -172,12 +173,10 @@ def net_random_first_sample(seed: int) -> int:
 
 
 def gen_uniform(n: int, seed: int) -> np.ndarray:
-    out = np.empty(n, dtype=np.uint8)
-    lib().dq_oracle_gen_uniform(_ptr(out), n, seed)
-    return out
+    from tools import datagen
+    return datagen.gen_uniform(n, seed)
 
 
 def gen_enwik_like(n: int, seed: int = 0xD17A0, repeat_period: int = 256 * 1024) -> np.ndarray:
-    out = np.empty(n, dtype=np.uint8)
-    lib().dq_oracle_gen_enwik_like(_ptr(out), n, seed, repeat_period)
-    return out
+    from tools import datagen
+    return datagen.gen_enwik_like(n, seed, repeat_period)

@@ -73,10 +73,6 @@ int32_t dq_oracle_sufcheck_i64(const uint8_t *T, int64_t n, const int64_t *SA, i
 void dq_oracle_netrandom_bytes(int32_t seed, uint8_t *out, int64_t n);
 int32_t dq_oracle_netrandom_first_sample(int32_t seed);
 
-/* Synthetic workload generators. Integer-only. */
-void dq_oracle_gen_uniform(uint8_t *out, int64_t n, uint64_t seed);
-void dq_oracle_gen_enwik_like(uint8_t *out, int64_t n, uint64_t seed, int64_t repeat_period);
-
 #ifdef __cplusplus
 }
 #endif

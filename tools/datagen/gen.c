@@ -1,11 +1,15 @@
 /*
- * gen.c -- synthetic workload generators shared by tests and bench
+ * gen.c -- synthetic workload generators shared by tests and bench.py
  * (BASELINE.json configs).  Integer-only so every platform
- * produces identical bytes.  TEST/BENCH INFRASTRUCTURE ONLY (see dq_oracle.h).
+ * produces identical bytes.  Data generation only: not part of the sort path and
+ * not part of the oracle.
  */
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
-#include "dq_oracle.h"
+
+void dq_gen_uniform(uint8_t *out, int64_t n, uint64_t seed);
+void dq_gen_enwik_like(uint8_t *out, int64_t n, uint64_t seed, int64_t repeat_period);
 
 typedef struct { uint64_t x; } sm64_t;
 
@@ -20,7 +24,7 @@ static inline uint64_t sm64_next(sm64_t *s)
 static inline uint64_t sm64_below(sm64_t *s, uint64_t m) { return sm64_next(s) % m; }
 
 /* i.i.d. uniform bytes: 8 bytes per draw, little-endian. */
-void dq_oracle_gen_uniform(uint8_t *out, int64_t n, uint64_t seed)
+void dq_gen_uniform(uint8_t *out, int64_t n, uint64_t seed)
 {
     sm64_t s = { seed };
     int64_t i = 0;
@@ -54,7 +58,7 @@ static inline void put(sink_t *k, uint8_t c)
 }
 static void puts_(sink_t *k, const char *s) { while (*s) put(k, (uint8_t)*s++); }
 
-void dq_oracle_gen_enwik_like(uint8_t *out, int64_t n, uint64_t seed, int64_t R)
+void dq_gen_enwik_like(uint8_t *out, int64_t n, uint64_t seed, int64_t R)
 {
     sm64_t s = { seed };
     if (R <= 0) R = 256 * 1024;
