@@ -10,7 +10,7 @@ buffers (weak scaling) and value = total MB sorted / max-over-ranks time.
     python bench.py [--gpus 1] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live: every radix_rank_scatter
+Prints ONE JSON line (rank 0).  `roofline` is measured live: every radix_rank_kernel
 launch in the timed region is bracketed by hipEvents on its launch stream (library-side,
 dq_profile_*).  `cpu_baseline` times the oracle's single-threaded restatement of the
 reference's LibDivSufSort on this host (rank 0, N=1 only) and bit-compares its SA with the
@@ -106,12 +106,12 @@ def main() -> int:
     if rank == 0:
         total_mb = world * n * args.steps / 1e6
         value = total_mb / elapsed
-        rs = prof["radix_rank_scatter_kernel"]
+        rs = prof["radix_rank_kernel"]
         roofline = None
         if rs["launches"]:
             achieved = rs["alg_bytes"] / (rs["ms"] * 1e-3) / 1e9
             roofline = {
-                "kernel": "radix_rank_scatter_kernel", "bound": "hbm",
+                "kernel": "radix_rank_kernel", "bound": "hbm",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,

@@ -1,0 +1,391 @@
+// dq_onesweep.h -- single-read LSD radix ranking ("onesweep" shape) for gfx950.
+//
+// One digit pass = ONE kernel that reads every (key, suffix) pair once and writes it once:
+//   radix_hist_kernel       all digit histograms of the keys in a single read (per-workgroup
+//                           partials, reduced + scanned by radix_hist_scan_kernel)
+//   radix_rank_kernel       per tile: ticket -> load -> wave64 ballot multi-split rank ->
+//                           publish the tile's 256 digit counts -> decoupled look-back over
+//                           the predecessor tiles' status words -> stage through LDS -> write
+//
+// Inter-workgroup protocol (MI355X: 8 XCDs, L2s not coherent with each other): the ONLY thing a
+// tile hands to later tiles is one self-describing status word per digit -- {2-bit state,
+// count/prefix} written by ONE agent-scope relaxed atomic store and read by agent-scope relaxed
+// atomic loads (both lower to sc1 accesses that bypass the non-coherent levels).  The word is
+// its own flag ("the data IS the flag"), so no fence, no release/acquire pair and no ordering
+// between different words is needed.  Status words are zeroed by a memset node before every
+// sort; tiles are handed out by an atomic ticket, so a tile's predecessors are always already
+// running (no dependence on dispatch order or XCD placement); every spin is bounded and
+// reports through an error word instead of hanging.
+#pragma once
+#include "dq_radix.h"
+
+namespace dq {
+
+constexpr int kHistBlocks = 512;
+constexpr int kMaxPasses = 8;
+
+constexpr uint32_t kSpinLimit = 1u << 24;
+
+// ---------------------------------------------------------------------------------
+// radix_hist_kernel: partial[g][p][d] = #keys in workgroup g's share whose digit p is d,
+// for all kPasses digit places in ONE read of the keys.  LDS atomics into 4 interleaved
+// sub-histograms (hist[p][d][lane & 3]: equal digits from different lanes hit 4 banks);
+// a wave whose 64 keys share a digit (constant high digits of composite keys) adds once.
+// ---------------------------------------------------------------------------------
+template <int kPasses>
+__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t *__restrict__ keys,
+                                                            int64_t m, uint32_t *__restrict__ partial)
+{
+    __shared__ uint32_t hist[kPasses][kRadixSize * 4];     // kPasses * 4 KiB
+    const int tid = threadIdx.x;
+    const int lane = lane_id();
+    const int sub = tid & 3;
+    for (int i = tid; i < kPasses * kRadixSize * 4; i += kBlock) (&hist[0][0])[i] = 0;
+    __syncthreads();
+
+    const int64_t pairs = m >> 1;
+    const ulonglong2 *k2 = reinterpret_cast<const ulonglong2 *>(keys);
+    // i0 is wave-uniform, so a wave enters/leaves the loop as a whole and the wave-uniform
+    // shortcut below always sees 64 lanes; out-of-range lanes contribute nothing
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + (tid & ~(kWave - 1)); i0 < pairs;
+         i0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = i0 + lane;
+        const bool ok = i < pairs;
+        const bool full = (i0 + kWave) <= pairs;
+        ulonglong2 v;
+        v.x = 0; v.y = 0;
+        if (ok) v = k2[i];
+#pragma unroll
+        for (int p = 0; p < kPasses; ++p) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t d = digit_of(h ? v.y : v.x, p * kRadixBits);
+                const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+                if (full && __all(d == d0)) {
+                    if (lane == 0) atomicAdd(&hist[p][d0 << 2], (uint32_t)kWave);
+                } else if (ok) {
+                    atomicAdd(&hist[p][(d << 2) | sub], 1u);
+                }
+            }
+        }
+    }
+    if ((m & 1) && blockIdx.x == 0 && tid == 0) {
+        const uint64_t k = keys[m - 1];
+        for (int p = 0; p < kPasses; ++p) atomicAdd(&hist[p][digit_of(k, p * kRadixBits) << 2], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < kPasses * kRadixSize; i += kBlock) {
+        const uint32_t *h4 = &(&hist[0][0])[i * 4];
+        partial[(int64_t)blockIdx.x * (kMaxPasses * kRadixSize) + i] = h4[0] + h4[1] + h4[2] + h4[3];
+    }
+}
+
+// digit_offset[p][d] = number of keys whose digit p is < d   (one workgroup per digit place)
+__global__ __launch_bounds__(kBlock) void radix_hist_scan_kernel(const uint32_t *__restrict__ partial,
+                                                                 int nblocks,
+                                                                 int64_t *__restrict__ digit_offset)
+{
+    __shared__ int64_t tmp[kWavesPerBlock];
+    const int p = blockIdx.x;
+    const int d = threadIdx.x;
+    int64_t sum = 0;
+#pragma unroll 8
+    for (int g = 0; g < nblocks; ++g)
+        sum += partial[(int64_t)g * (kMaxPasses * kRadixSize) + p * kRadixSize + d];
+    int64_t total;
+    const int64_t excl = block_excl_sum(sum, tmp, &total);
+    digit_offset[p * kRadixSize + d] = excl;
+}
+
+// ---------------------------------------------------------------------------------
+// status words
+// ---------------------------------------------------------------------------------
+template <typename StatusT> struct StatusBits;
+template <> struct StatusBits<uint32_t> {
+    static constexpr uint32_t kAgg = 1u << 30, kPrefix = 2u << 30, kMask = (1u << 30) - 1;
+};
+template <> struct StatusBits<uint64_t> {
+    static constexpr uint64_t kAgg = 1ull << 62, kPrefix = 2ull << 62, kMask = (1ull << 62) - 1;
+};
+
+template <typename StatusT>
+__device__ __forceinline__ void status_store(StatusT *p, StatusT v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename StatusT>
+__device__ __forceinline__ StatusT status_load(StatusT *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct OnesweepCtl {
+    uint32_t ticket;        // next tile to hand out
+    uint32_t error;         // set when a look-back spin timed out
+};
+
+// ---------------------------------------------------------------------------------
+// radix_rank_kernel (onesweep): THE dominant kernel of the pipeline
+//   kItems   keys per thread per tile (tile = 256 * kItems)
+//   kMode    kPairs : (key, suffix) pairs are loaded            (every pass but the first)
+//            kText  : FIRST pass of round 0: keys are built on the fly from the text
+//                     (key = first kb bytes at the suffix, big-endian, zero padded past the
+//                     end) and the suffix index is synthesised.  Lanes own 4 consecutive
+//                     suffixes (3 dwords of text each); the pass need not be stable with
+//                     respect to the text order because members of a tie group are re-ranked
+//                     by the doubling rounds anyway.
+// ---------------------------------------------------------------------------------
+enum OnesweepMode { kPairs = 0, kText = 1 };
+
+template <typename IdxT, typename StatusT, int kItems, int kMode, int kMinWaves>
+__global__ __launch_bounds__(kBlock, kMinWaves) void radix_rank_kernel(
+    const uint64_t *__restrict__ kin, const IdxT *__restrict__ vin,
+    uint64_t *__restrict__ kout, IdxT *__restrict__ vout, int64_t m, int shift, int kb,
+    const int64_t *__restrict__ digit_offset /*[256] for this pass*/,
+    StatusT *__restrict__ status /*[ntiles][256]*/, OnesweepCtl *__restrict__ ctl,
+    int64_t *__restrict__ sticky_error)
+{
+    static_assert(kMode == kPairs || (kItems % 4) == 0, "text mode packs 4 suffixes per lane");
+    constexpr int kTileN = kBlock * kItems;
+    constexpr int kWaveN = kWave * kItems;
+    using SB = StatusBits<StatusT>;
+
+    __shared__ __attribute__((aligned(16))) uint64_t exch[kTileN];
+    __shared__ uint32_t whist[kWavesPerBlock][kRadixSize];
+    __shared__ uint32_t tile_base[kRadixSize];
+    __shared__ IdxT gofs[kRadixSize];
+    __shared__ uint32_t wtmp[kWavesPerBlock];
+    __shared__ uint32_t s_tile;
+
+    const int tid = threadIdx.x;
+    const int w = tid >> 6;
+    const int lane = lane_id();
+
+    if (tid == 0) s_tile = atomicAdd(&ctl->ticket, 1u);
+    for (int i = tid; i < kWavesPerBlock * kRadixSize; i += kBlock) (&whist[0][0])[i] = 0;
+    __syncthreads();
+    const int64_t tile = s_tile;
+    const int64_t base = tile * kTileN;
+    const int valid = (m - base) < kTileN ? (int)(m - base) : kTileN;
+    const int wbase = w * kWaveN + lane;
+
+    uint64_t key[kItems];
+    if (kMode == kText) {
+        const uint32_t *t32 = reinterpret_cast<const uint32_t *>(kin);
+        const int kshift = 8 * (8 - kb);
+#pragma unroll
+        for (int j = 0; j < kItems / 4; ++j) {
+            const int e0 = (j * kBlock + tid) * 4;             // first of this lane's 4 suffixes
+            if (e0 < valid) {
+                const int64_t qd = (base + e0) >> 2;
+                const uint32_t w0 = t32[qd], w1 = t32[qd + 1], w2 = t32[qd + 2];
+                const uint64_t x = __builtin_bswap64((uint64_t)w0 | ((uint64_t)w1 << 32));
+                const uint64_t y = (uint64_t)__builtin_bswap32(w2) << 32;
+                key[4 * j + 0] = x >> kshift;
+                key[4 * j + 1] = ((x << 8) | (y >> 56)) >> kshift;
+                key[4 * j + 2] = ((x << 16) | (y >> 48)) >> kshift;
+                key[4 * j + 3] = ((x << 24) | (y >> 40)) >> kshift;
+#pragma unroll
+                for (int c = 1; c < 4; ++c)
+                    if (e0 + c >= valid) key[4 * j + c] = ~0ull;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) key[4 * j + c] = ~0ull;
+            }
+        }
+    } else if (valid == kTileN) {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) key[k] = kin[base + wbase + k * kWave];
+    } else {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const int e = wbase + k * kWave;
+            key[k] = e < valid ? kin[base + e] : ~0ull;
+        }
+    }
+
+    // element index (inside the tile) of this lane's item k
+    auto elem = [&](int k) -> int {
+        return kMode == kText ? ((k >> 2) * kBlock + tid) * 4 + (k & 3) : wbase + k * kWave;
+    };
+
+    // ---- rank inside the wave: ballot multi-split + running per-wave digit counters ----
+    uint32_t pos[kItems];
+    uint32_t *myhist = whist[w];
+    if (valid == kTileN) {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const uint32_t d = digit_of(key[k], shift);
+            const uint64_t peers = match_digit8(d);
+            const uint32_t before = myhist[d];                 // same value for every peer
+            const int r = mask_rank_lt(peers);
+            if (r == 0) myhist[d] = before + (uint32_t)__popcll(peers);
+            pos[k] = before + (uint32_t)r;
+        }
+    } else {
+        // ragged last tile: out-of-range items take no part in the ranking
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const bool ok = elem(k) < valid;
+            const uint32_t d = digit_of(key[k], shift);
+            const uint64_t peers = match_digit8(d) & __ballot(ok);
+            pos[k] = 0;
+            if (ok) {
+                const uint32_t before = myhist[d];
+                const int r = mask_rank_lt(peers);
+                if (r == 0) myhist[d] = before + (uint32_t)__popcll(peers);
+                pos[k] = before + (uint32_t)r;
+            }
+        }
+    }
+
+    // values: issue the loads now, consume after the key exchange
+    IdxT val[kItems];
+    if (kMode == kText) {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) val[k] = (IdxT)(base + elem(k));
+    } else if (valid == kTileN) {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) val[k] = vin[base + wbase + k * kWave];
+    } else {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const int e = wbase + k * kWave;
+            val[k] = e < valid ? vin[base + e] : (IdxT)0;
+        }
+    }
+    __syncthreads();
+
+    // ---- digit totals of the tile (thread d owns digit d), publish, look back ----
+    {
+        uint32_t c[kWavesPerBlock], tot = 0;
+#pragma unroll
+        for (int i = 0; i < kWavesPerBlock; ++i) c[i] = whist[i][tid];
+#pragma unroll
+        for (int i = 0; i < kWavesPerBlock; ++i) { whist[i][tid] = tot; tot += c[i]; }
+
+        StatusT *mine = status + tile * kRadixSize + tid;
+        if (tile == 0) status_store<StatusT>(mine, SB::kPrefix | (StatusT)tot);
+        else status_store<StatusT>(mine, SB::kAgg | (StatusT)tot);
+
+        // tile-local exclusive scan over digits
+        uint32_t incl = wave_incl_sum(tot);
+        if (lane == kWave - 1) wtmp[w] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+#pragma unroll
+        for (int i = 0; i < kWavesPerBlock; ++i) if (i < w) off += wtmp[i];
+        const uint32_t excl_tile = off + incl - tot;
+        tile_base[tid] = excl_tile;
+
+        // decoupled look-back: sum predecessors' aggregates until an inclusive prefix shows up
+        StatusT excl = 0;
+        if (tile > 0) {
+            int64_t t = tile - 1;
+            uint32_t spins = 0;
+            for (;;) {
+                const StatusT s = status_load<StatusT>(status + t * kRadixSize + tid);
+                if (s & SB::kPrefix) { excl += s & SB::kMask; break; }
+                if (s & SB::kAgg) { excl += s & SB::kMask; --t; spins = 0; continue; }
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) { atomicExch(&ctl->error, 1u); *sticky_error = 1; break; }
+            }
+            status_store<StatusT>(mine, SB::kPrefix | (StatusT)(excl + tot));
+        }
+        gofs[tid] = (IdxT)(digit_offset[tid] + (int64_t)excl) - (IdxT)excl_tile;
+    }
+    __syncthreads();
+
+    // ---- stage keys in digit order through LDS, write coalesced runs ----
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const uint32_t d = digit_of(key[k], shift);
+        pos[k] += tile_base[d] + myhist[d];
+        if (valid == kTileN || elem(k) < valid) exch[pos[k]] = key[k];
+    }
+    __syncthreads();
+    IdxT out[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int q = k * kBlock + tid;
+        const uint64_t kk = exch[q];
+        out[k] = gofs[digit_of(kk, shift)] + (IdxT)q;
+        if (q < valid) kout[out[k]] = kk;
+    }
+    __syncthreads();
+    IdxT *exv = reinterpret_cast<IdxT *>(exch);
+#pragma unroll
+    for (int k = 0; k < kItems; ++k)
+        if (valid == kTileN || elem(k) < valid) exv[pos[k]] = val[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int q = k * kBlock + tid;
+        if (q < valid) vout[out[k]] = exv[q];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Round-0 digit histograms straight from the text: digit p of suffix i is the byte
+// T[i + kb-1-p] (zero past the end), so every digit place shares ONE byte histogram of the
+// text, corrected for the first / last kb-1 positions.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void text_hist_kernel(const uint8_t *__restrict__ text, int64_t n,
+                                                           uint32_t *__restrict__ partial /*[G][256]*/)
+{
+    // 4 interleaved sub-histograms (hist[d][lane & 3]) spread equal bytes over 4 banks
+    __shared__ uint32_t hist[kRadixSize * 4];
+    const int tid = threadIdx.x;
+    const int sub = tid & 3;
+    for (int i = tid; i < kRadixSize * 4; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const uint4 *t16 = reinterpret_cast<const uint4 *>(text);      // text is 16-byte aligned
+    const int64_t chunks = n >> 4;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + tid; i < chunks; i += (int64_t)gridDim.x * kBlock) {
+        const uint4 v = t16[i];
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) atomicAdd(&hist[(((wds[j] >> (8 * b)) & 0xff) << 2) | sub], 1u);
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = (chunks << 4) + tid; i < n; i += kBlock) atomicAdd(&hist[((uint32_t)text[i] << 2) | sub], 1u);
+    }
+    __syncthreads();
+    partial[(int64_t)blockIdx.x * kRadixSize + tid] =
+        hist[tid * 4] + hist[tid * 4 + 1] + hist[tid * 4 + 2] + hist[tid * 4 + 3];
+}
+
+// bytehist[d] = occurrences of byte d in the text (single workgroup)
+__global__ __launch_bounds__(kBlock) void text_hist_reduce_kernel(const uint32_t *__restrict__ partial,
+                                                                  int nblocks, int64_t *__restrict__ bytehist)
+{
+    const int d = threadIdx.x;
+    int64_t sum = 0;
+#pragma unroll 8
+    for (int g = 0; g < nblocks; ++g) sum += partial[(int64_t)g * kRadixSize + d];
+    bytehist[d] = sum;
+}
+
+// digit_offset[p][d] for p < kb (one workgroup per digit place p)
+__global__ __launch_bounds__(kBlock) void text_digit_offsets_kernel(const int64_t *__restrict__ bytehist,
+                                                                    const uint8_t *__restrict__ text,
+                                                                    int64_t n, int kb,
+                                                                    int64_t *__restrict__ digit_offset)
+{
+    __shared__ int64_t tmp[kWavesPerBlock];
+    const int p = blockIdx.x;
+    const int d = threadIdx.x;
+    const int64_t off = kb - 1 - p;                       // digit p of suffix i is T[i + off]
+    const int64_t lead = off < n ? off : n;               // text positions < off are never a digit p
+    int64_t c = bytehist[d];
+    for (int64_t j = 0; j < lead; ++j) c -= (text[j] == d);
+    if (d == 0) c += lead;                                // ... and `lead` suffixes read the zero pad
+    int64_t total;
+    const int64_t excl = block_excl_sum(c, tmp, &total);
+    digit_offset[p * kRadixSize + d] = excl;
+}
+
+}  // namespace dq

@@ -138,50 +138,57 @@ __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const uint64_t *__re
 }
 
 // Exclusive scan of the per-workgroup partials by ONE workgroup of 1024 threads
-// (prefix max, prefix max, prefix sum).  totals[0] receives the active count.
+// (prefix max, prefix max, prefix sum), in coalesced chunks of 4096 entries with a running
+// carry.  totals[0] receives the active count.
 template <typename IdxT>
 __global__ __launch_bounds__(1024) void seg_scan_kernel(SegPartials<IdxT> part, int64_t nparts,
                                                         int64_t *__restrict__ totals)
 {
-    __shared__ IdxT s_nh[1024], s_gh[1024], s_cnt[1024];
+    constexpr int kPer = 4;
+    constexpr int kWaves = 1024 / kWave;
+    __shared__ IdxT s_nh[kWaves], s_gh[kWaves], s_cnt[kWaves];
     const int tid = threadIdx.x;
-    const int64_t per = (nparts + 1023) / 1024;
-    const int64_t b0 = (int64_t)tid * per;
-    int64_t b1 = b0 + per;
-    if (b1 > nparts) b1 = nparts;
-
-    IdxT a = -1, b = -1, c = 0;
-    for (int64_t i = b0; i < b1; ++i) {
-        const IdxT x = part.nh[i], y = part.gh[i];
-        a = x > a ? x : a;
-        b = y > b ? y : b;
-        c += part.cnt[i];
-    }
-    s_nh[tid] = a; s_gh[tid] = b; s_cnt[tid] = c;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 thread partials
-    for (int o = 1; o < 1024; o <<= 1) {
-        IdxT x = -1, y = -1, z = 0;
-        if (tid >= o) { x = s_nh[tid - o]; y = s_gh[tid - o]; z = s_cnt[tid - o]; }
-        __syncthreads();
-        if (tid >= o) {
-            s_nh[tid] = x > s_nh[tid] ? x : s_nh[tid];
-            s_gh[tid] = y > s_gh[tid] ? y : s_gh[tid];
-            s_cnt[tid] += z;
+    const int lane = lane_id();
+    const int w = tid >> 6;
+    IdxT carry_nh = -1, carry_gh = -1, carry_cnt = 0;
+    for (int64_t c0 = 0; c0 < nparts; c0 += 1024 * kPer) {
+        const int64_t i0 = c0 + (int64_t)tid * kPer;
+        IdxT x[kPer], y[kPer], z[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const bool ok = i0 + k < nparts;
+            x[k] = ok ? part.nh[i0 + k] : (IdxT)-1;
+            y[k] = ok ? part.gh[i0 + k] : (IdxT)-1;
+            z[k] = ok ? part.cnt[i0 + k] : (IdxT)0;
         }
+        IdxT a = x[0], b = y[0], c = z[0];
+#pragma unroll
+        for (int k = 1; k < kPer; ++k) { a = x[k] > a ? x[k] : a; b = y[k] > b ? y[k] : b; c += z[k]; }
+        // inclusive scans across the 1024 threads
+        IdxT ia = wave_incl_max(a), ib = wave_incl_max(b), ic = wave_incl_sum(c);
+        if (lane == kWave - 1) { s_nh[w] = ia; s_gh[w] = ib; s_cnt[w] = ic; }
+        __syncthreads();
+        IdxT pa = carry_nh, pb = carry_gh, pc = carry_cnt;       // prefix of earlier waves + chunks
+        IdxT ta = carry_nh, tb = carry_gh, tc = carry_cnt;       // ... including this whole chunk
+#pragma unroll
+        for (int i = 0; i < kWaves; ++i) {
+            const IdxT u = s_nh[i], v = s_gh[i], q = s_cnt[i];
+            if (i < w) { pa = u > pa ? u : pa; pb = v > pb ? v : pb; pc += q; }
+            ta = u > ta ? u : ta; tb = v > tb ? v : tb; tc += q;
+        }
+        // exclusive value for this thread = earlier waves/chunks + earlier lanes of this wave
+        IdxT ea = __shfl_up(ia, 1, kWave), eb = __shfl_up(ib, 1, kWave), ec = __shfl_up(ic, 1, kWave);
+        if (lane == 0) { ea = -1; eb = -1; ec = 0; }
+        pa = ea > pa ? ea : pa; pb = eb > pb ? eb : pb; pc += ec;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            if (i0 + k < nparts) { part.nh[i0 + k] = pa; part.gh[i0 + k] = pb; part.cnt[i0 + k] = pc; }
+            pa = x[k] > pa ? x[k] : pa; pb = y[k] > pb ? y[k] : pb; pc += z[k];
+        }
+        carry_nh = ta; carry_gh = tb; carry_cnt = tc;
         __syncthreads();
     }
-    if (tid == 1023) totals[0] = (int64_t)s_cnt[1023];
-    // exclusive prefix for this thread's first partial
-    IdxT pa = -1, pb = -1, pc = 0;
-    if (tid > 0) { pa = s_nh[tid - 1]; pb = s_gh[tid - 1]; pc = s_cnt[tid - 1]; }
-    for (int64_t i = b0; i < b1; ++i) {
-        const IdxT x = part.nh[i], y = part.gh[i], z = part.cnt[i];
-        part.nh[i] = pa; part.gh[i] = pb; part.cnt[i] = pc;
-        pa = x > pa ? x : pa;
-        pb = y > pb ? y : pb;
-        pc += z;
-    }
+    if (tid == 0) totals[0] = (int64_t)carry_cnt;
 }
 
 template <typename IdxT, bool kInitial, bool kWriteSA>

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,6 +24,7 @@
 #include <vector>
 
 #include "../../include/dq_sufsort.h"
+#include "dq_onesweep.h"
 #include "dq_radix.h"
 #include "dq_sa_kernels.h"
 
@@ -59,8 +61,19 @@ KernelStat g_prof[DQ_K_COUNT];
 std::atomic<int> g_prof_on{0};
 
 const char *const kKernelNames[DQ_K_COUNT] = {
-    "pack_keys_kernel", "radix_upsweep_kernel", "radix_scan_kernel", "radix_rank_scatter_kernel",
-    "seg_reduce_kernel", "seg_scan_kernel", "seg_apply_kernel", "gather_key2_kernel"};
+    "pack_keys_kernel", "radix_upsweep_kernel", "radix_scan_kernel", "radix_rank_kernel",
+    "seg_reduce_kernel", "seg_scan_kernel", "seg_apply_kernel", "gather_key2_kernel",
+    "radix_hist_kernels"};
+
+// sort engine: 1 = onesweep (default), 0 = legacy upsweep/scan/downsweep (DQ_SORT_ENGINE=sweep3)
+int sort_engine()
+{
+    static int e = [] {
+        const char *v = getenv("DQ_SORT_ENGINE");
+        return (v && strcmp(v, "sweep3") == 0) ? 0 : 1;
+    }();
+    return e;
+}
 
 struct ProfRec { int cat; hipEvent_t a, b; int64_t elems, bytes; };
 
@@ -71,7 +84,7 @@ struct DeviceCtx {
     hipStream_t stream = nullptr;
     char *ws = nullptr;
     size_t ws_bytes = 0;
-    int64_t *pinned = nullptr;          // 64 B pinned readback area
+    int64_t *pinned = nullptr;          // 4 KiB pinned readback area
     std::vector<ProfRec> pending;
     std::vector<hipEvent_t> pool;
 };
@@ -84,7 +97,7 @@ int init_ctx(DeviceCtx &c, int dev)
     if (c.dev == dev) return DQ_OK;
     c.dev = dev;
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    HIP_TRY(hipHostMalloc((void **)&c.pinned, 64, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c.pinned, 4096, hipHostMallocDefault));
     return DQ_OK;
 }
 
@@ -159,7 +172,12 @@ struct Workspace {
     uint32_t *blockhist;
     IdxT *blockbase;
     SegPartials<IdxT> part;
-    int64_t *totals;
+    int64_t *totals;            // [0] active count, [1] sticky look-back timeout flag
+    uint32_t *hist_partial;     // [kHistBlocks][8][256]
+    int64_t *digit_offset;      // [8][256]
+    int64_t *bytehist;          // [256]
+    char *ctl_status;           // OnesweepCtl (256 B) followed by the status words
+    size_t ctl_status_bytes;
     size_t bytes;
 };
 
@@ -184,6 +202,11 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.part.gh = (IdxT *)take(nparts * sizeof(IdxT));
     w.part.cnt = (IdxT *)take(nparts * sizeof(IdxT));
     w.totals = (int64_t *)take(64);
+    w.hist_partial = (uint32_t *)take((size_t)kHistBlocks * kMaxPasses * kRadixSize * 4);
+    w.digit_offset = (int64_t *)take((size_t)kMaxPasses * kRadixSize * 8);
+    w.bytehist = (int64_t *)take((size_t)kRadixSize * 8);
+    w.ctl_status_bytes = 256 + (un / 4096 + 2) * kRadixSize * 8;
+    w.ctl_status = take(w.ctl_status_bytes);
     w.bytes = off;
     return w;
 }
@@ -225,6 +248,139 @@ int radix_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V[2]
     return DQ_OK;
 }
 
+// ------------------------------------------------------------------ onesweep driver
+template <typename IdxT> struct RankCfg;
+template <> struct RankCfg<int32_t> { static constexpr int kItems = 20, kMinWaves = 2; };
+template <> struct RankCfg<int64_t> { static constexpr int kItems = 16, kMinWaves = 2; };
+
+template <typename IdxT, typename StatusT, int kMode>
+int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin,
+                     uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb)
+{
+    constexpr int kItems = RankCfg<IdxT>::kItems;
+    constexpr int kTileN = kBlock * kItems;
+    const int64_t ntiles = (m + kTileN - 1) / kTileN;
+    const int64_t wb = (int64_t)sizeof(IdxT);
+    OnesweepCtl *ctl = reinterpret_cast<OnesweepCtl *>(w.ctl_status);
+    StatusT *status = reinterpret_cast<StatusT *>(w.ctl_status + 256);
+    const size_t need = 256 + (size_t)ntiles * kRadixSize * sizeof(StatusT);
+    if (need > w.ctl_status_bytes) return fail(DQ_ERR_HIP, "status buffer too small");
+    HIP_TRY(hipMemsetAsync(w.ctl_status, 0, need, L.st));
+    LAUNCH(L, DQ_K_RADIX_RANK_SCATTER, m, kMode == kText ? m * (1 + 8 + wb) : m * 2 * (8 + wb),
+           hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, kItems, kMode, RankCfg<IdxT>::kMinWaves>),
+                              dim3((unsigned)ntiles), dim3(kBlock), 0, L.st, kin, vin, kout, vout, m,
+                              pass * kRadixBits, kb, (const int64_t *)(w.digit_offset + pass * kRadixSize),
+                              status, ctl, w.totals + 1));
+    return DQ_OK;
+}
+
+template <typename IdxT, int kMode>
+int rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin, uint64_t *kout,
+              IdxT *vout, int64_t m, int pass, int kb)
+{
+    if (m < (1ll << 30)) return launch_rank_pass<IdxT, uint32_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb);
+    return launch_rank_pass<IdxT, uint64_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb);
+}
+
+template <int kPasses>
+void launch_hist(hipStream_t st, int blocks, const uint64_t *keys, int64_t m, uint32_t *partial)
+{
+    hipLaunchKernelGGL(radix_hist_kernel<kPasses>, dim3(blocks), dim3(kBlock), 0, st, keys, m, partial);
+}
+
+// generic pairs: all digit histograms in one read, then one radix_rank_kernel per digit
+template <typename IdxT>
+int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V[2], int64_t m,
+                        int total_bits, int &cur)
+{
+    const int passes = (total_bits + kRadixBits - 1) / kRadixBits;
+    const int blocks = (int)std::min<int64_t>(kHistBlocks, ((m >> 1) + kBlock - 1) / kBlock + 1);
+    int rc = L.begin(DQ_K_RADIX_HIST, m, m * 8);
+    if (rc != DQ_OK) return rc;
+    switch (passes) {
+        case 1: launch_hist<1>(L.st, blocks, K[cur], m, w.hist_partial); break;
+        case 2: launch_hist<2>(L.st, blocks, K[cur], m, w.hist_partial); break;
+        case 3: launch_hist<3>(L.st, blocks, K[cur], m, w.hist_partial); break;
+        case 4: launch_hist<4>(L.st, blocks, K[cur], m, w.hist_partial); break;
+        case 5: launch_hist<5>(L.st, blocks, K[cur], m, w.hist_partial); break;
+        case 6: launch_hist<6>(L.st, blocks, K[cur], m, w.hist_partial); break;
+        case 7: launch_hist<7>(L.st, blocks, K[cur], m, w.hist_partial); break;
+        default: launch_hist<8>(L.st, blocks, K[cur], m, w.hist_partial); break;
+    }
+    hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(passes), dim3(kBlock), 0, L.st,
+                       (const uint32_t *)w.hist_partial, blocks, w.digit_offset);
+    HIP_TRY(hipGetLastError());
+    rc = L.end();
+    if (rc != DQ_OK) return rc;
+    for (int p = 0; p < passes; ++p) {
+        rc = rank_pass<IdxT, kPairs>(L, w, K[cur], V[cur], K[cur ^ 1], V[cur ^ 1], m, p, 8);
+        if (rc != DQ_OK) return rc;
+        cur ^= 1;
+    }
+    return DQ_OK;
+}
+
+// Number of leading text bytes worth sorting in round 0: enough bits, under an order-0 model
+// of the text, to make ties among n suffixes rare (~n/1000); text-like inputs get all 8.
+int choose_key_bytes(const int64_t *bytehist, int64_t n)
+{
+    double h0 = 0;
+    for (int b = 0; b < 256; ++b) {
+        if (bytehist[b] > 0) {
+            const double p = (double)bytehist[b] / (double)n;
+            h0 -= p * std::log2(p);
+        }
+    }
+    const double need = std::log2((double)std::max<int64_t>(n, 2)) + 10.0;
+    if (h0 < 0.25) return 8;
+    int kb = (int)std::ceil(need / h0);
+    return std::min(8, std::max(3, kb));
+}
+
+// round 0, step 1: byte histogram of the text -> key width kb -> per-digit offsets
+template <typename IdxT>
+int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int *kb_out)
+{
+    const int blocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 4) + kBlock - 1) / kBlock + 1);
+    LAUNCH(L, DQ_K_RADIX_HIST, n, n,
+           hipLaunchKernelGGL(text_hist_kernel, dim3(blocks), dim3(kBlock), 0, L.st,
+                              (const uint8_t *)w.text, n, w.hist_partial);
+           hipLaunchKernelGGL(text_hist_reduce_kernel, dim3(1), dim3(kBlock), 0, L.st,
+                              (const uint32_t *)w.hist_partial, blocks, w.bytehist));
+    int kb = 8;
+    const char *force = getenv("DQ_KEY_BYTES");
+    if (force) {
+        kb = std::min(8, std::max(1, atoi(force)));
+    } else {
+        HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, 256 * 8, hipMemcpyDeviceToHost, L.st));
+        HIP_TRY(hipStreamSynchronize(L.st));
+        kb = choose_key_bytes(c.pinned, n);
+    }
+    *kb_out = kb;
+    hipLaunchKernelGGL(text_digit_offsets_kernel, dim3(kb), dim3(kBlock), 0, L.st,
+                       (const int64_t *)w.bytehist, (const uint8_t *)w.text, n, kb, w.digit_offset);
+    HIP_TRY(hipGetLastError());
+    return DQ_OK;
+}
+
+// round 0, step 2: kb digit passes; pass 0 builds its keys straight from the text and writes
+// buffer 1, pass p writes buffer (p+1)&1
+template <typename IdxT>
+int onesweep_sort_text_passes(Launcher &L, Workspace<IdxT> &w, int64_t n, uint64_t *K[2], IdxT *V[2],
+                              int kb, int &cur)
+{
+    int rc = rank_pass<IdxT, kText>(L, w, reinterpret_cast<const uint64_t *>(w.text), (const IdxT *)nullptr,
+                                    K[1], V[1], n, 0, kb);
+    if (rc != DQ_OK) return rc;
+    cur = 1;
+    for (int p = 1; p < kb; ++p) {
+        rc = rank_pass<IdxT, kPairs>(L, w, K[cur], V[cur], K[cur ^ 1], V[cur ^ 1], n, p, kb);
+        if (rc != DQ_OK) return rc;
+        cur ^= 1;
+    }
+    return DQ_OK;
+}
+
 template <typename IdxT, bool kInitial>
 int seg_count(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *keys, int64_t m,
               int kbits, int64_t *active_out)
@@ -237,9 +393,10 @@ int seg_count(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *key
     LAUNCH(L, DQ_K_SEG_SCAN, nparts, nparts * 6 * wb,
            hipLaunchKernelGGL(seg_scan_kernel<IdxT>, dim3(1), dim3(1024), 0, L.st, w.part, nparts,
                               w.totals));
-    HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 8, hipMemcpyDeviceToHost, L.st));
+    HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, L.st));
     HIP_TRY(hipStreamSynchronize(L.st));
     *active_out = c.pinned[0];
+    if (c.pinned[1] != 0) return fail(DQ_ERR_HIP, "radix look-back timed out (device spin bound hit)");
     return DQ_OK;
 }
 
@@ -251,25 +408,37 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
     Launcher L{c, st, g_prof_on.load() != 0};
     const int64_t wb = (int64_t)sizeof(IdxT);
     t_info[0] = t_info[1] = t_info[2] = 0;
+    HIP_TRY(hipMemsetAsync(w.totals, 0, 64, st));
 
-    // ---- round 0: 8-byte keys, full radix ranking
-    {
-        const int64_t nquads = (n + 3) / 4;
-        const int64_t blocks = std::min<int64_t>((nquads + kBlock - 1) / kBlock, 256 * 8);
-        LAUNCH(L, DQ_K_PACK_KEYS, n, n * 9,
-               hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st,
-                                  w.text, n, w.K0));
-    }
+    // ---- round 0: leading kb bytes of every suffix as a key, full radix ranking
     int64_t active = 0;
     {
-        const int passes = 64 / kRadixBits;
         uint64_t *K[2] = {w.K0, w.K1};
         IdxT *V[2];
-        V[passes & 1] = d_sa;            // the last pass must land in the caller's SA buffer
-        V[(passes & 1) ^ 1] = w.Va;
         int cur = 0;
-        int rc = radix_sort_pairs<IdxT>(L, w, K, V, n, 64, /*synth_first=*/true, cur);
-        if (rc != DQ_OK) return rc;
+        int kb = 8;
+        int rc;
+        if (sort_engine() == 1) {
+            // pass p writes buffer (p+1)&1, so the last pass (kb-1) writes buffer kb&1: that one
+            // must be the caller's SA, which is why the key width is chosen first
+            rc = onesweep_sort_text_prepare<IdxT>(L, c, w, n, &kb);
+            if (rc != DQ_OK) return rc;
+            V[kb & 1] = d_sa;
+            V[(kb & 1) ^ 1] = w.Va;
+            rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, cur);
+            if (rc != DQ_OK) return rc;
+        } else {
+            const int64_t nquads = (n + 3) / 4;
+            const int64_t blocks = std::min<int64_t>((nquads + kBlock - 1) / kBlock, 256 * 8);
+            LAUNCH(L, DQ_K_PACK_KEYS, n, n * 9,
+                   hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st,
+                                      w.text, n, w.K0));
+            const int passes = 64 / kRadixBits;
+            V[passes & 1] = d_sa;            // the last pass must land in the caller's SA buffer
+            V[(passes & 1) ^ 1] = w.Va;
+            rc = radix_sort_pairs<IdxT>(L, w, K, V, n, 64, /*synth_first=*/true, cur);
+            if (rc != DQ_OK) return rc;
+        }
         // sorted keys are in K[cur], suffixes in V[cur] == d_sa
         rc = seg_count<IdxT, true>(L, c, w, K[cur], n, 0, &active);
         if (rc != DQ_OK) return rc;
@@ -286,7 +455,7 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
         IdxT *Vr[2] = {w.Va, w.Vb};
         int rcur = 0;
         int64_t m = active;
-        int64_t h = 8;
+        int64_t h = kb;                  // bytes already compared: the round-0 key width
         const int rbits = bit_length((uint64_t)(n - 1));
         while (m > 0) {
             t_info[0] += 1;
@@ -298,7 +467,8 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
                    hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3((unsigned)gblocks), dim3(kBlock),
                                       0, st, Kr[rcur], (const IdxT *)Vr[rcur], (const IdxT *)w.ISA, m,
                                       n, h, kbits));
-            rc = radix_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, false, rcur);
+            rc = sort_engine() == 1 ? onesweep_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, rcur)
+                                    : radix_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, false, rcur);
             if (rc != DQ_OK) return rc;
             int64_t m2 = 0;
             rc = seg_count<IdxT, false>(L, c, w, Kr[rcur], m, kbits, &m2);

@@ -78,12 +78,13 @@ void dq_sufsort_hip_release(void);
 #define DQ_K_PACK_KEYS           0
 #define DQ_K_RADIX_UPSWEEP       1
 #define DQ_K_RADIX_SCAN          2
-#define DQ_K_RADIX_RANK_SCATTER  3   /* the dominant kernel; roofline = 2*(8+w) B/element/launch */
+#define DQ_K_RADIX_RANK_SCATTER  3   /* radix_rank_kernel: the dominant kernel; 2*(8+w) B/element/launch */
 #define DQ_K_SEG_REDUCE          4
 #define DQ_K_SEG_SCAN            5
 #define DQ_K_SEG_APPLY           6
 #define DQ_K_GATHER_KEY2         7
-#define DQ_K_COUNT               8
+#define DQ_K_RADIX_HIST          8   /* text / key digit histograms + offset scans */
+#define DQ_K_COUNT               9
 
 int32_t dq_profile_enable(int32_t on);
 void    dq_profile_reset(void);

@@ -34,7 +34,7 @@ def test_workspace_query(backend_lib):
     n = 1 << 20
     b4 = backend_lib.dq_sufsort_hip_workspace_bytes(n, 4)
     b8 = backend_lib.dq_sufsort_hip_workspace_bytes(n, 8)
-    assert 28 * n <= b4 < 32 * n
+    assert 28 * n <= b4 < 29 * n + (16 << 20)      # 28 B/byte + fixed tables
     assert b8 > b4
     assert backend_lib.dq_sufsort_hip_workspace_bytes(n, 3) == -1
     assert backend_lib.dq_sufsort_hip_workspace_bytes(-5, 4) == -1

@@ -1,0 +1,135 @@
+// kbench.hip -- developer micro-benchmark for the radix kernels (not part of the product).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/kbench/kbench.hip -o tools/kbench/kbench
+//   tools/kbench/kbench [log2_n=26] [skew=0]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "../../deltaq_amd/csrc/dq_onesweep.h"
+
+using namespace dq;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void gen_kernel(uint64_t *k, int32_t *v, int64_t m, int skew)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t x = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x1234567;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        if (skew == 1) x &= 0x0303030303030303ull;            // 4 symbols per digit
+        if (skew == 2) x = (x & 0xff) < 200 ? (x & ~0xffull) | 0x65 : x;   // 78% one digit value
+        if (skew == 3) x = 0;                                  // all equal
+        k[i] = x;
+        v[i] = (int32_t)i;
+    }
+}
+
+template <class F>
+float time_it(F &&f, int reps = 5)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f();
+    CK(hipDeviceSynchronize());
+    float best = 1e30f, sum = 0;
+    for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(a));
+        f();
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        best = std::min(best, ms); sum += ms;
+    }
+    CK(hipGetLastError());
+    return sum / reps;
+}
+
+struct Bufs {
+    uint64_t *k0, *k1, *k2; int32_t *v0, *v1, *v2;
+    uint32_t *blockhist; int32_t *blockbase; uint32_t *partial; int64_t *digit_offset;
+    uint32_t *status; OnesweepCtl *ctl;
+};
+
+template <int kItems, int kMinWaves>
+float run_onesweep(Bufs &B, int64_t m, int shift, bool synth, const char *tag)
+{
+    const int tile = kBlock * kItems;
+    const int64_t ntiles = (m + tile - 1) / tile;
+    auto f = [&]() {
+        CK(hipMemsetAsync(B.status, 0, (size_t)ntiles * 256 * 4));
+        CK(hipMemsetAsync(B.ctl, 0, sizeof(OnesweepCtl)));
+        if (synth)
+            hipLaunchKernelGGL((onesweep_kernel<int32_t, uint32_t, kItems, true, kMinWaves>), dim3((unsigned)ntiles), dim3(kBlock), 0, 0,
+                               B.k0, (const int32_t *)nullptr, B.k2, B.v2, m, shift, B.digit_offset + (shift / 8) * 256, B.status, B.ctl);
+        else
+            hipLaunchKernelGGL((onesweep_kernel<int32_t, uint32_t, kItems, false, kMinWaves>), dim3((unsigned)ntiles), dim3(kBlock), 0, 0,
+                               B.k0, (const int32_t *)B.v0, B.k2, B.v2, m, shift, B.digit_offset + (shift / 8) * 256, B.status, B.ctl);
+    };
+    float ms = time_it(f);
+    OnesweepCtl h; CK(hipMemcpy(&h, B.ctl, sizeof h, hipMemcpyDeviceToHost));
+    printf("%-34s items=%2d minwaves=%d : %8.1f us  %7.1f GB/s alg%s\n", tag, kItems, kMinWaves, ms * 1e3,
+           (double)m * (synth ? 20 : 24) / (ms * 1e-3) / 1e9, h.error ? "  LOOKBACK TIMEOUT" : "");
+    return ms;
+}
+
+bool same(const void *a, const void *b, size_t bytes)
+{
+    std::vector<char> ha(bytes), hb(bytes);
+    CK(hipMemcpy(ha.data(), a, bytes, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hb.data(), b, bytes, hipMemcpyDeviceToHost));
+    return memcmp(ha.data(), hb.data(), bytes) == 0;
+}
+
+int main(int argc, char **argv)
+{
+    const int lg = argc > 1 ? atoi(argv[1]) : 26;
+    const int skew = argc > 2 ? atoi(argv[2]) : 0;
+    const int64_t m = ((int64_t)1 << lg) + (argc > 3 ? atoi(argv[3]) : 0);
+    printf("m = %lld  skew=%d\n", (long long)m, skew);
+    Bufs B;
+    CK(hipMalloc(&B.k0, m * 8)); CK(hipMalloc(&B.k1, m * 8)); CK(hipMalloc(&B.k2, m * 8));
+    CK(hipMalloc(&B.v0, m * 4)); CK(hipMalloc(&B.v1, m * 4)); CK(hipMalloc(&B.v2, m * 4));
+    CK(hipMalloc(&B.blockhist, kMaxSweepBlocks * 256 * 4)); CK(hipMalloc(&B.blockbase, kMaxSweepBlocks * 256 * 4));
+    CK(hipMalloc(&B.partial, kHistBlocks * kMaxPasses * 256 * 4)); CK(hipMalloc(&B.digit_offset, kMaxPasses * 256 * 8));
+    CK(hipMalloc(&B.status, ((size_t)m / 2048 + 2) * 256 * 4)); CK(hipMalloc(&B.ctl, sizeof(OnesweepCtl)));
+    hipLaunchKernelGGL(gen_kernel, dim3(2048), dim3(256), 0, 0, B.k0, B.v0, m, skew);
+    CK(hipDeviceSynchronize());
+
+    const int shift = 8;
+    // ---- baseline: upsweep + scan + downsweep
+    const int64_t ntiles = (m + kTile - 1) / kTile;
+    int64_t G = std::min<int64_t>(ntiles, kMaxSweepBlocks);
+    const int tpb = (int)((ntiles + G - 1) / G);
+    G = (ntiles + tpb - 1) / tpb;
+    float t_up = time_it([&]() { hipLaunchKernelGGL(radix_upsweep_kernel, dim3((unsigned)G), dim3(kBlock), 0, 0, B.k0, m, shift, tpb, B.blockhist); });
+    float t_sc = time_it([&]() { hipLaunchKernelGGL(radix_scan_kernel<int32_t>, dim3(1), dim3(1024), 0, 0, B.blockhist, (int)G, B.blockbase); });
+    float t_dn = time_it([&]() { hipLaunchKernelGGL((radix_rank_scatter_kernel<int32_t, false>), dim3((unsigned)G), dim3(kBlock), 0, 0, B.k0, (const int32_t *)B.v0, B.k1, B.v1, m, shift, tpb, B.blockbase); });
+    printf("baseline upsweep %8.1f us  scan %6.1f us  downsweep %8.1f us (%.1f GB/s alg)\n", t_up * 1e3, t_sc * 1e3, t_dn * 1e3, (double)m * 24 / (t_dn * 1e-3) / 1e9);
+
+    // ---- global histograms
+    float t_h = time_it([&]() { hipLaunchKernelGGL(radix_hist_kernel, dim3(kHistBlocks), dim3(kBlock), 0, 0, B.k0, m, 8, B.partial); });
+    float t_hs = time_it([&]() { hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(8), dim3(kBlock), 0, 0, B.partial, kHistBlocks, B.digit_offset); });
+    printf("hist (8 digits, one read) %8.1f us (%.1f GB/s)   hist_scan %6.1f us\n", t_h * 1e3, (double)m * 8 / (t_h * 1e-3) / 1e9, t_hs * 1e3);
+
+    // ---- onesweep variants
+    run_onesweep<16, 1>(B, m, shift, false, "onesweep");
+    printf("   keys %s  vals %s\n", same(B.k1, B.k2, m * 8) ? "MATCH" : "DIFFER", same(B.v1, B.v2, m * 4) ? "MATCH" : "DIFFER");
+    run_onesweep<16, 2>(B, m, shift, false, "onesweep");
+    run_onesweep<16, 3>(B, m, shift, false, "onesweep");
+    run_onesweep<16, 4>(B, m, shift, false, "onesweep");
+    printf("   keys %s  vals %s\n", same(B.k1, B.k2, m * 8) ? "MATCH" : "DIFFER", same(B.v1, B.v2, m * 4) ? "MATCH" : "DIFFER");
+    run_onesweep<8, 1>(B, m, shift, false, "onesweep");
+    run_onesweep<8, 4>(B, m, shift, false, "onesweep");
+    printf("   keys %s  vals %s\n", same(B.k1, B.k2, m * 8) ? "MATCH" : "DIFFER", same(B.v1, B.v2, m * 4) ? "MATCH" : "DIFFER");
+    run_onesweep<12, 3>(B, m, shift, false, "onesweep");
+    run_onesweep<12, 4>(B, m, shift, false, "onesweep");
+    run_onesweep<20, 2>(B, m, shift, false, "onesweep");
+    run_onesweep<24, 2>(B, m, shift, false, "onesweep");
+    printf("   keys %s  vals %s\n", same(B.k1, B.k2, m * 8) ? "MATCH" : "DIFFER", same(B.v1, B.v2, m * 4) ? "MATCH" : "DIFFER");
+    run_onesweep<16, 3>(B, m, shift, true, "onesweep synth-vals");
+    return 0;
+}
