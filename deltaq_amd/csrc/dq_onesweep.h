@@ -135,10 +135,22 @@ struct OnesweepCtl {
 //                     respect to the text order because members of a tie group are re-ranked
 //                     by the doubling rounds anyway.
 // ---------------------------------------------------------------------------------
+#ifndef DQ_LOOK_WIN
+#define DQ_LOOK_WIN 8
+#endif
 enum OnesweepMode { kPairs = 0, kText = 1 };
 
-template <typename IdxT, typename StatusT, int kItems, int kMode, int kMinWaves>
-__global__ __launch_bounds__(kBlock, kMinWaves) void radix_rank_kernel(
+// developer instrumentation (tools/kbench): per-tile phase timestamps from thread 0
+#ifdef DQ_KERNEL_PHASE_TIMING
+__device__ long long *g_phase_ts = nullptr;          // [ntiles][8]
+#define DQ_PHASE(i) do { if (threadIdx.x == 0 && g_phase_ts) g_phase_ts[(long long)s_tile * 8 + (i)] = clock64(); } while (0)
+#else
+#define DQ_PHASE(i) do { } while (0)
+#endif
+
+template <typename IdxT, typename StatusT, int kItems, int kMode, int kMinWaves, int kThreads = kBlock,
+          bool kEarlyVals = false, bool kLdsMatch = true>
+__global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     const uint64_t *__restrict__ kin, const IdxT *__restrict__ vin,
     uint64_t *__restrict__ kout, IdxT *__restrict__ vout, int64_t m, int shift, int kb,
     const int64_t *__restrict__ digit_offset /*[256] for this pass*/,
@@ -146,15 +158,17 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void radix_rank_kernel(
     int64_t *__restrict__ sticky_error)
 {
     static_assert(kMode == kPairs || (kItems % 4) == 0, "text mode packs 4 suffixes per lane");
-    constexpr int kTileN = kBlock * kItems;
+    static_assert(kThreads % kRadixSize == 0, "threads 0..255 own one digit each");
+    constexpr int kWavesB = kThreads / kWave;
+    constexpr int kTileN = kThreads * kItems;
     constexpr int kWaveN = kWave * kItems;
     using SB = StatusBits<StatusT>;
 
     __shared__ __attribute__((aligned(16))) uint64_t exch[kTileN];
-    __shared__ uint32_t whist[kWavesPerBlock][kRadixSize];
+    __shared__ uint32_t whist[kWavesB][kRadixSize];
     __shared__ uint32_t tile_base[kRadixSize];
     __shared__ IdxT gofs[kRadixSize];
-    __shared__ uint32_t wtmp[kWavesPerBlock];
+    __shared__ uint32_t wtmp[kRadixSize / kWave];
     __shared__ uint32_t s_tile;
 
     const int tid = threadIdx.x;
@@ -162,12 +176,23 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void radix_rank_kernel(
     const int lane = lane_id();
 
     if (tid == 0) s_tile = atomicAdd(&ctl->ticket, 1u);
-    for (int i = tid; i < kWavesPerBlock * kRadixSize; i += kBlock) (&whist[0][0])[i] = 0;
+    for (int i = tid; i < kWavesB * kRadixSize; i += kThreads) (&whist[0][0])[i] = 0;
+    if (kLdsMatch) {
+        // per-wave digit -> lane-mask tables live in the (not yet used) exchange buffer
+        static_assert(kItems >= kRadixSize / kWave, "exchange buffer must hold the match tables");
+        for (int i = tid; i < kWavesB * kRadixSize; i += kThreads) exch[i] = 0;
+    }
     __syncthreads();
+    DQ_PHASE(0);
     const int64_t tile = s_tile;
     const int64_t base = tile * kTileN;
     const int valid = (m - base) < kTileN ? (int)(m - base) : kTileN;
     const int wbase = w * kWaveN + lane;
+
+    // element index (inside the tile) of this lane's item k
+    auto elem = [&](int k) -> int {
+        return kMode == kText ? ((k >> 2) * kThreads + tid) * 4 + (k & 3) : wbase + k * kWave;
+    };
 
     uint64_t key[kItems];
     if (kMode == kText) {
@@ -175,7 +200,7 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void radix_rank_kernel(
         const int kshift = 8 * (8 - kb);
 #pragma unroll
         for (int j = 0; j < kItems / 4; ++j) {
-            const int e0 = (j * kBlock + tid) * 4;             // first of this lane's 4 suffixes
+            const int e0 = (j * kThreads + tid) * 4;           // first of this lane's 4 suffixes
             if (e0 < valid) {
                 const int64_t qd = (base + e0) >> 2;
                 const uint32_t w0 = t32[qd], w1 = t32[qd + 1], w2 = t32[qd + 2];
@@ -185,9 +210,6 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void radix_rank_kernel(
                 key[4 * j + 1] = ((x << 8) | (y >> 56)) >> kshift;
                 key[4 * j + 2] = ((x << 16) | (y >> 48)) >> kshift;
                 key[4 * j + 3] = ((x << 24) | (y >> 40)) >> kshift;
-#pragma unroll
-                for (int c = 1; c < 4; ++c)
-                    if (e0 + c >= valid) key[4 * j + c] = ~0ull;
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) key[4 * j + c] = ~0ull;
@@ -204,22 +226,55 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void radix_rank_kernel(
         }
     }
 
-    // element index (inside the tile) of this lane's item k
-    auto elem = [&](int k) -> int {
-        return kMode == kText ? ((k >> 2) * kBlock + tid) * 4 + (k & 3) : wbase + k * kWave;
+    // values (suffix indices): synthesised, or loaded -- early (more bytes in flight, more
+    // registers) or after the ranking loop
+    IdxT val[kItems];
+    auto load_vals = [&]() {
+        if (kMode == kText) {
+#pragma unroll
+            for (int k = 0; k < kItems; ++k) val[k] = (IdxT)(base + elem(k));
+        } else if (valid == kTileN) {
+#pragma unroll
+            for (int k = 0; k < kItems; ++k) val[k] = vin[base + wbase + k * kWave];
+        } else {
+#pragma unroll
+            for (int k = 0; k < kItems; ++k) {
+                const int e = wbase + k * kWave;
+                val[k] = e < valid ? vin[base + e] : (IdxT)0;
+            }
+        }
     };
+    if (kEarlyVals) load_vals();
+    if (kMode == kPairs) { asm volatile("" :: "v"(key[kItems - 1])); }
+    DQ_PHASE(1);
 
-    // ---- rank inside the wave: ballot multi-split + running per-wave digit counters ----
+    // ---- rank inside the wave.  peers(d) = lanes of this wave holding digit d in this round:
+    //      either 8 ballots (VALU heavy) or, default, through LDS: every lane ORs its lane bit
+    //      into a per-wave table entry mtab[d] (ds_or_b64), reads the entry back (LDS executes a
+    //      wave's instructions in order, so the read sees all 64 lanes' bits) and the group's
+    //      first lane clears it again.  rank = running per-wave digit count + peers below me. ----
     uint32_t pos[kItems];
     uint32_t *myhist = whist[w];
+    unsigned long long *mtab = reinterpret_cast<unsigned long long *>(exch) + w * kRadixSize;
+    const unsigned long long lanebit = 1ull << lane;
+    auto peers_of = [&](uint32_t d) -> uint64_t {
+        if (kLdsMatch) {
+            __hip_atomic_fetch_or(&mtab[d], lanebit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return __hip_atomic_load(&mtab[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return match_digit8(d);
+    };
     if (valid == kTileN) {
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
             const uint32_t d = digit_of(key[k], shift);
-            const uint64_t peers = match_digit8(d);
+            const uint64_t peers = peers_of(d);
             const uint32_t before = myhist[d];                 // same value for every peer
             const int r = mask_rank_lt(peers);
-            if (r == 0) myhist[d] = before + (uint32_t)__popcll(peers);
+            if (r == 0) {
+                myhist[d] = before + (uint32_t)__popcll(peers);
+                if (kLdsMatch) mtab[d] = 0;
+            }
             pos[k] = before + (uint32_t)r;
         }
     } else {
@@ -228,75 +283,69 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void radix_rank_kernel(
         for (int k = 0; k < kItems; ++k) {
             const bool ok = elem(k) < valid;
             const uint32_t d = digit_of(key[k], shift);
-            const uint64_t peers = match_digit8(d) & __ballot(ok);
             pos[k] = 0;
-            if (ok) {
-                const uint32_t before = myhist[d];
-                const int r = mask_rank_lt(peers);
-                if (r == 0) myhist[d] = before + (uint32_t)__popcll(peers);
-                pos[k] = before + (uint32_t)r;
+            if (kLdsMatch) {
+                if (ok) {
+                    const uint64_t peers = peers_of(d);
+                    const uint32_t before = myhist[d];
+                    const int r = mask_rank_lt(peers);
+                    if (r == 0) { myhist[d] = before + (uint32_t)__popcll(peers); mtab[d] = 0; }
+                    pos[k] = before + (uint32_t)r;
+                }
+            } else {
+                const uint64_t peers = match_digit8(d) & __ballot(ok);
+                if (ok) {
+                    const uint32_t before = myhist[d];
+                    const int r = mask_rank_lt(peers);
+                    if (r == 0) myhist[d] = before + (uint32_t)__popcll(peers);
+                    pos[k] = before + (uint32_t)r;
+                }
             }
         }
     }
-
-    // values: issue the loads now, consume after the key exchange
-    IdxT val[kItems];
-    if (kMode == kText) {
-#pragma unroll
-        for (int k = 0; k < kItems; ++k) val[k] = (IdxT)(base + elem(k));
-    } else if (valid == kTileN) {
-#pragma unroll
-        for (int k = 0; k < kItems; ++k) val[k] = vin[base + wbase + k * kWave];
-    } else {
-#pragma unroll
-        for (int k = 0; k < kItems; ++k) {
-            const int e = wbase + k * kWave;
-            val[k] = e < valid ? vin[base + e] : (IdxT)0;
-        }
-    }
+    if (kLdsMatch) __syncthreads();          // the match tables alias the exchange buffer
+    DQ_PHASE(2);
+    if (!kEarlyVals) load_vals();
     __syncthreads();
+    DQ_PHASE(3);
 
-    // ---- digit totals of the tile (thread d owns digit d), publish, look back ----
-    {
-        uint32_t c[kWavesPerBlock], tot = 0;
+    // ---- digit totals of the tile (thread d < 256 owns digit d): publish the aggregate and
+    //      start fetching the predecessors' status words; the look-back is RESOLVED LATE, after
+    //      the LDS exchanges, so its cross-XCD round trips and any straggling predecessor
+    //      overlap this tile's own exchange work instead of stalling the workgroup ----
+    constexpr int kLookWin = DQ_LOOK_WIN;
+    uint32_t tot = 0, incl = 0;
+    StatusT sw[kLookWin];
+    StatusT *mine = status + tile * kRadixSize + (tid & (kRadixSize - 1));
+    if (tid < kRadixSize) {
 #pragma unroll
-        for (int i = 0; i < kWavesPerBlock; ++i) c[i] = whist[i][tid];
-#pragma unroll
-        for (int i = 0; i < kWavesPerBlock; ++i) { whist[i][tid] = tot; tot += c[i]; }
-
-        StatusT *mine = status + tile * kRadixSize + tid;
+        for (int i = 0; i < kWavesB; ++i) {
+            const uint32_t c = whist[i][tid];
+            whist[i][tid] = tot;
+            tot += c;
+        }
         if (tile == 0) status_store<StatusT>(mine, SB::kPrefix | (StatusT)tot);
         else status_store<StatusT>(mine, SB::kAgg | (StatusT)tot);
-
-        // tile-local exclusive scan over digits
-        uint32_t incl = wave_incl_sum(tot);
-        if (lane == kWave - 1) wtmp[w] = incl;
-        __syncthreads();
-        uint32_t off = 0;
 #pragma unroll
-        for (int i = 0; i < kWavesPerBlock; ++i) if (i < w) off += wtmp[i];
-        const uint32_t excl_tile = off + incl - tot;
-        tile_base[tid] = excl_tile;
-
-        // decoupled look-back: sum predecessors' aggregates until an inclusive prefix shows up
-        StatusT excl = 0;
-        if (tile > 0) {
-            int64_t t = tile - 1;
-            uint32_t spins = 0;
-            for (;;) {
-                const StatusT s = status_load<StatusT>(status + t * kRadixSize + tid);
-                if (s & SB::kPrefix) { excl += s & SB::kMask; break; }
-                if (s & SB::kAgg) { excl += s & SB::kMask; --t; spins = 0; continue; }
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > kSpinLimit) { atomicExch(&ctl->error, 1u); *sticky_error = 1; break; }
-            }
-            status_store<StatusT>(mine, SB::kPrefix | (StatusT)(excl + tot));
-        }
-        gofs[tid] = (IdxT)(digit_offset[tid] + (int64_t)excl) - (IdxT)excl_tile;
+        for (int j = 0; j < kLookWin; ++j)
+            sw[j] = (tile - 1 - j >= 0) ? status_load<StatusT>(status + (tile - 1 - j) * kRadixSize + tid)
+                                        : SB::kPrefix;
+        incl = wave_incl_sum(tot);                             // tile-local scan over digits
+        if (lane == kWave - 1) wtmp[w] = incl;
     }
     __syncthreads();
+    uint32_t excl_tile = 0;
+    if (tid < kRadixSize) {
+        uint32_t off = 0;
+#pragma unroll
+        for (int i = 0; i < kRadixSize / kWave; ++i) if (i < w) off += wtmp[i];
+        excl_tile = off + incl - tot;
+        tile_base[tid] = excl_tile;
+    }
+    __syncthreads();
+    DQ_PHASE(4);
 
-    // ---- stage keys in digit order through LDS, write coalesced runs ----
+    // ---- stage keys, then values, in digit order through LDS; keep the sorted tile in registers ----
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const uint32_t d = digit_of(key[k], shift);
@@ -304,25 +353,70 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void radix_rank_kernel(
         if (valid == kTileN || elem(k) < valid) exch[pos[k]] = key[k];
     }
     __syncthreads();
-    IdxT out[kItems];
+    uint64_t skey[kItems];
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const int q = k * kBlock + tid;
-        const uint64_t kk = exch[q];
-        out[k] = gofs[digit_of(kk, shift)] + (IdxT)q;
-        if (q < valid) kout[out[k]] = kk;
-    }
+    for (int k = 0; k < kItems; ++k) skey[k] = exch[k * kThreads + tid];
     __syncthreads();
     IdxT *exv = reinterpret_cast<IdxT *>(exch);
 #pragma unroll
     for (int k = 0; k < kItems; ++k)
         if (valid == kTileN || elem(k) < valid) exv[pos[k]] = val[k];
     __syncthreads();
+    IdxT sval[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) sval[k] = exv[k * kThreads + tid];
+    DQ_PHASE(5);
+
+    // ---- resolve the look-back: sum aggregates until an inclusive prefix shows up ----
+    if (tid < kRadixSize) {
+        StatusT excl = 0;
+#ifdef DQ_EXPERIMENT_SKIP_LOOKBACK
+        if (false) {
+#else
+        if (tile > 0) {
+#endif
+            int64_t t = tile - 1;
+            uint32_t spins = 0;
+            bool done = false;
+            for (;;) {
+                int used = 0;
+#pragma unroll
+                for (int j = 0; j < kLookWin; ++j) {
+                    if (!done && used == j) {
+                        if (sw[j] & SB::kPrefix) { excl += sw[j] & SB::kMask; done = true; }
+                        else if (sw[j] & SB::kAgg) { excl += sw[j] & SB::kMask; used = j + 1; }
+                    }
+                }
+                if (done) break;
+                t -= used;
+                if (used == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kSpinLimit) { atomicExch(&ctl->error, 1u); *sticky_error = 1; break; }
+                }
+#pragma unroll
+                for (int j = 0; j < kLookWin; ++j)
+                    sw[j] = (t - j >= 0) ? status_load<StatusT>(status + (t - j) * kRadixSize + tid) : SB::kPrefix;
+            }
+            status_store<StatusT>(mine, SB::kPrefix | (StatusT)(excl + tot));
+        }
+#ifdef DQ_EXPERIMENT_SKIP_LOOKBACK
+        excl = (StatusT)tile * (StatusT)tot;     // timing experiment only: plausible, dependency-free offsets
+#endif
+        gofs[tid] = (IdxT)(digit_offset[tid] + (int64_t)excl) - (IdxT)excl_tile;
+    }
+    __syncthreads();
+
+    // ---- coalesced run writes ----
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
-        const int q = k * kBlock + tid;
-        if (q < valid) vout[out[k]] = exv[q];
+        const int q = k * kThreads + tid;
+        if (q < valid) {
+            const IdxT o = gofs[digit_of(skey[k], shift)] + (IdxT)q;
+            kout[o] = skey[k];
+            vout[o] = sval[k];
+        }
     }
+    DQ_PHASE(6);
 }
 
 // ---------------------------------------------------------------------------------

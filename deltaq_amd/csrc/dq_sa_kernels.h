@@ -191,7 +191,7 @@ __global__ __launch_bounds__(1024) void seg_scan_kernel(SegPartials<IdxT> part, 
     if (tid == 0) totals[0] = (int64_t)carry_cnt;
 }
 
-template <typename IdxT, bool kInitial, bool kWriteSA>
+template <typename IdxT, bool kInitial, bool kWriteSA, bool kWriteISA>
 __global__ __launch_bounds__(kBlock) void seg_apply_kernel(
     const uint64_t *__restrict__ keys, const IdxT *__restrict__ vals, int64_t m, int kbits,
     SegPartials<IdxT> part, IdxT *__restrict__ SA, IdxT *__restrict__ ISA,
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void seg_apply_kernel(
         const IdxT p = rank + ((IdxT)j - run_gh);
         const IdxT nr = rank + (run_nh - run_gh);
         if (kWriteSA) SA[p] = suf[i];
-        ISA[suf[i]] = nr;
+        if (kWriteISA) ISA[suf[i]] = nr;
         if (active[i]) {
             act_rank[o] = (uint64_t)nr;
             act_suf[o] = suf[i];
@@ -286,6 +286,50 @@ __global__ __launch_bounds__(kBlock) void gather_key2_kernel(uint64_t *__restric
         const uint64_t k2 = q < n ? (uint64_t)((int64_t)ISA[q] + h) : (uint64_t)(n - 1 - s);
         comp[j] = (comp[j] << kbits) | k2;
     }
+}
+
+// ---------------------------------------------------------------------------------
+// Sparse finishing (few suffixes still tied, e.g. random-like inputs): instead of building
+// the full inverse suffix array, extend the tied suffixes' keys with the next `ebytes` bytes
+// of text:  composite = (rank << kbits) | (bytes, zero padded) << 3 | valid_len,
+// kbits = 8*ebytes + 3.  (padded bytes, valid length) orders a suffix that ends inside the
+// window before one that continues with real zero bytes -- SequenceCompareTo again.
+// ---------------------------------------------------------------------------------
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void gather_text_key_kernel(uint64_t *__restrict__ comp,
+                                                                 const IdxT *__restrict__ suf,
+                                                                 const uint8_t *__restrict__ text,
+                                                                 int64_t m, int64_t n, int64_t h, int ebytes)
+{
+    const int kbits = 8 * ebytes + 3;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < m;
+         j += (int64_t)gridDim.x * kBlock) {
+        const int64_t q = (int64_t)suf[j] + h;
+        int64_t len = n - q;
+        len = len < 0 ? 0 : (len > ebytes ? ebytes : len);
+        uint64_t bytes = 0;
+        for (int b = 0; b < ebytes; ++b) bytes = (bytes << 8) | (b < len ? (uint64_t)text[q + b] : 0ull);
+        comp[j] = (comp[j] << kbits) | (bytes << 3) | (uint64_t)len;
+    }
+}
+
+// ISA[SA[p]] = p : ranks of all singleton groups (switching from sparse to dense doubling)
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void isa_from_sa_kernel(const IdxT *__restrict__ SA,
+                                                             IdxT *__restrict__ ISA, int64_t n)
+{
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock)
+        ISA[SA[p]] = (IdxT)p;
+}
+
+// ISA[suf[j]] = rank[j] for the still-tied suffixes
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void isa_scatter_kernel(const uint64_t *__restrict__ rank,
+                                                             const IdxT *__restrict__ suf,
+                                                             IdxT *__restrict__ ISA, int64_t m)
+{
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < m; j += (int64_t)gridDim.x * kBlock)
+        ISA[suf[j]] = (IdxT)rank[j];
 }
 
 }  // namespace dq

@@ -250,15 +250,18 @@ int radix_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V[2]
 
 // ------------------------------------------------------------------ onesweep driver
 template <typename IdxT> struct RankCfg;
-template <> struct RankCfg<int32_t> { static constexpr int kItems = 20, kMinWaves = 2; };
-template <> struct RankCfg<int64_t> { static constexpr int kItems = 16, kMinWaves = 2; };
+// 512 threads x 16 keys = 8192-key tiles: ~32-key (256 B) runs per digit keep the scattered
+// writes near full lines; 76 KiB of LDS -> 2 workgroups (16 waves) per CU
+template <> struct RankCfg<int32_t> { static constexpr int kItems = 16, kMinWaves = 2, kThreads = 512; };
+template <> struct RankCfg<int64_t> { static constexpr int kItems = 16, kMinWaves = 2, kThreads = 512; };
 
 template <typename IdxT, typename StatusT, int kMode>
 int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin,
                      uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb)
 {
     constexpr int kItems = RankCfg<IdxT>::kItems;
-    constexpr int kTileN = kBlock * kItems;
+    constexpr int kThreads = RankCfg<IdxT>::kThreads;
+    constexpr int kTileN = kThreads * kItems;
     const int64_t ntiles = (m + kTileN - 1) / kTileN;
     const int64_t wb = (int64_t)sizeof(IdxT);
     OnesweepCtl *ctl = reinterpret_cast<OnesweepCtl *>(w.ctl_status);
@@ -267,8 +270,9 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
     if (need > w.ctl_status_bytes) return fail(DQ_ERR_HIP, "status buffer too small");
     HIP_TRY(hipMemsetAsync(w.ctl_status, 0, need, L.st));
     LAUNCH(L, DQ_K_RADIX_RANK_SCATTER, m, kMode == kText ? m * (1 + 8 + wb) : m * 2 * (8 + wb),
-           hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, kItems, kMode, RankCfg<IdxT>::kMinWaves>),
-                              dim3((unsigned)ntiles), dim3(kBlock), 0, L.st, kin, vin, kout, vout, m,
+           hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, kItems, kMode, RankCfg<IdxT>::kMinWaves, kThreads,
+                                                 false, false>),
+                              dim3((unsigned)ntiles), dim3(kThreads), 0, L.st, kin, vin, kout, vout, m,
                               pass * kRadixBits, kb, (const int64_t *)(w.digit_offset + pass * kRadixSize),
                               status, ctl, w.totals + 1));
     return DQ_OK;
@@ -446,10 +450,21 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
         if (active == 0) return flush_profile(c);
         const int64_t nparts = (n + kSegTile - 1) / kSegTile;
         uint64_t *act_rank = K[cur ^ 1];
-        LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb + wb) + active * (8 + wb),
-               hipLaunchKernelGGL((seg_apply_kernel<IdxT, true, false>), dim3((unsigned)nparts),
-                                  dim3(kBlock), 0, st, K[cur], (const IdxT *)d_sa, n, 0, w.part,
-                                  d_sa, w.ISA, act_rank, w.Va));
+        // Few ties (random-like input): finish them by key extension from the text and skip the
+        // n random writes of a full inverse suffix array.  Many ties: build ISA now and double.
+        bool sparse = active * 32 <= n;
+        if (const char *v = getenv("DQ_SPARSE")) sparse = atoi(v) != 0;
+        if (sparse) {
+            LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb) + active * (8 + wb),
+                   hipLaunchKernelGGL((seg_apply_kernel<IdxT, true, false, false>), dim3((unsigned)nparts),
+                                      dim3(kBlock), 0, st, K[cur], (const IdxT *)d_sa, n, 0, w.part,
+                                      d_sa, w.ISA, act_rank, w.Va));
+        } else {
+            LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb + wb) + active * (8 + wb),
+                   hipLaunchKernelGGL((seg_apply_kernel<IdxT, true, false, true>), dim3((unsigned)nparts),
+                                      dim3(kBlock), 0, st, K[cur], (const IdxT *)d_sa, n, 0, w.part,
+                                      d_sa, w.ISA, act_rank, w.Va));
+        }
         // refinement ping-pong: (act_rank buffer, Va) <-> (other key buffer, Vb)
         uint64_t *Kr[2] = {act_rank, K[cur]};
         IdxT *Vr[2] = {w.Va, w.Vb};
@@ -457,14 +472,50 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
         int64_t m = active;
         int64_t h = kb;                  // bytes already compared: the round-0 key width
         const int rbits = bit_length((uint64_t)(n - 1));
+        auto grid_for = [](int64_t items) { return (unsigned)std::min<int64_t>((items + kBlock - 1) / kBlock, 256 * 16); };
+
+        if (sparse) {
+            const int ebytes = std::max(1, std::min(4, (64 - rbits - 3) / 8));
+            const int kbits = 8 * ebytes + 3;
+            for (int r = 0; r < 3 && m > 0; ++r) {
+                t_info[0] += 1;
+                t_info[2] += m;
+                LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + ebytes + 8),
+                       hipLaunchKernelGGL(gather_text_key_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock), 0, st,
+                                          Kr[rcur], (const IdxT *)Vr[rcur], (const uint8_t *)w.text, m, n, h,
+                                          ebytes));
+                rc = sort_engine() == 1 ? onesweep_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, rcur)
+                                        : radix_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, false, rcur);
+                if (rc != DQ_OK) return rc;
+                int64_t m2 = 0;
+                rc = seg_count<IdxT, false>(L, c, w, Kr[rcur], m, kbits, &m2);
+                if (rc != DQ_OK) return rc;
+                const int64_t np = (m + kSegTile - 1) / kSegTile;
+                LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + wb + wb) + m2 * (8 + wb),
+                       hipLaunchKernelGGL((seg_apply_kernel<IdxT, false, true, false>), dim3((unsigned)np),
+                                          dim3(kBlock), 0, st, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits,
+                                          w.part, d_sa, w.ISA, Kr[rcur ^ 1], Vr[rcur ^ 1]));
+                rcur ^= 1;
+                m = m2;
+                h += ebytes;
+            }
+            if (m > 0) {
+                // long repeats after all: materialise the ranks and fall through to doubling
+                LAUNCH(L, DQ_K_SEG_APPLY, n, n * 3 * wb,
+                       hipLaunchKernelGGL(isa_from_sa_kernel<IdxT>, dim3(grid_for(n)), dim3(kBlock), 0, st,
+                                          (const IdxT *)d_sa, w.ISA, n);
+                       hipLaunchKernelGGL(isa_scatter_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock), 0, st,
+                                          (const uint64_t *)Kr[rcur], (const IdxT *)Vr[rcur], w.ISA, m));
+            }
+        }
+
         while (m > 0) {
             t_info[0] += 1;
             t_info[2] += m;
             const int kbits = bit_length((uint64_t)(n - 1) + (uint64_t)h);
             if (kbits + rbits > 64) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
-            const int64_t gblocks = std::min<int64_t>((m + kBlock - 1) / kBlock, 256 * 16);
             LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8),
-                   hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3((unsigned)gblocks), dim3(kBlock),
+                   hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock),
                                       0, st, Kr[rcur], (const IdxT *)Vr[rcur], (const IdxT *)w.ISA, m,
                                       n, h, kbits));
             rc = sort_engine() == 1 ? onesweep_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, rcur)
@@ -475,7 +526,7 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
             if (rc != DQ_OK) return rc;
             const int64_t np = (m + kSegTile - 1) / kSegTile;
             LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + wb + wb + wb) + m2 * (8 + wb),
-                   hipLaunchKernelGGL((seg_apply_kernel<IdxT, false, true>), dim3((unsigned)np),
+                   hipLaunchKernelGGL((seg_apply_kernel<IdxT, false, true, true>), dim3((unsigned)np),
                                       dim3(kBlock), 0, st, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits,
                                       w.part, d_sa, w.ISA, Kr[rcur ^ 1], Vr[rcur ^ 1]));
             rcur ^= 1;

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#define DQ_KERNEL_PHASE_TIMING 1
 #include "../../deltaq_amd/csrc/dq_onesweep.h"
 
 using namespace dq;
@@ -51,27 +52,27 @@ float time_it(F &&f, int reps = 5)
 struct Bufs {
     uint64_t *k0, *k1, *k2; int32_t *v0, *v1, *v2;
     uint32_t *blockhist; int32_t *blockbase; uint32_t *partial; int64_t *digit_offset;
-    uint32_t *status; OnesweepCtl *ctl;
+    uint32_t *status; OnesweepCtl *ctl; int64_t *sticky; uint8_t *text; int64_t *digit_offset_text; int64_t *bytehist;
 };
 
-template <int kItems, int kMinWaves>
+template <int kItems, int kMinWaves, int kThreads = 256, bool kEarly = false, bool kLds = true>
 float run_onesweep(Bufs &B, int64_t m, int shift, bool synth, const char *tag)
 {
-    const int tile = kBlock * kItems;
+    const int tile = kThreads * kItems;
     const int64_t ntiles = (m + tile - 1) / tile;
     auto f = [&]() {
         CK(hipMemsetAsync(B.status, 0, (size_t)ntiles * 256 * 4));
         CK(hipMemsetAsync(B.ctl, 0, sizeof(OnesweepCtl)));
-        if (synth)
-            hipLaunchKernelGGL((onesweep_kernel<int32_t, uint32_t, kItems, true, kMinWaves>), dim3((unsigned)ntiles), dim3(kBlock), 0, 0,
-                               B.k0, (const int32_t *)nullptr, B.k2, B.v2, m, shift, B.digit_offset + (shift / 8) * 256, B.status, B.ctl);
-        else
-            hipLaunchKernelGGL((onesweep_kernel<int32_t, uint32_t, kItems, false, kMinWaves>), dim3((unsigned)ntiles), dim3(kBlock), 0, 0,
-                               B.k0, (const int32_t *)B.v0, B.k2, B.v2, m, shift, B.digit_offset + (shift / 8) * 256, B.status, B.ctl);
+        if constexpr (kItems % 4 == 0) { if (synth)
+            hipLaunchKernelGGL((radix_rank_kernel<int32_t, uint32_t, kItems, kText, kMinWaves, kThreads, kEarly, kLds>), dim3((unsigned)ntiles), dim3(kThreads), 0, 0,
+                               (const uint64_t *)B.text, (const int32_t *)nullptr, B.k2, B.v2, m, 0, 8, B.digit_offset_text, B.status, B.ctl, B.sticky); }
+        if (!synth)
+            hipLaunchKernelGGL((radix_rank_kernel<int32_t, uint32_t, kItems, kPairs, kMinWaves, kThreads, kEarly, kLds>), dim3((unsigned)ntiles), dim3(kThreads), 0, 0,
+                               B.k0, (const int32_t *)B.v0, B.k2, B.v2, m, shift, 8, B.digit_offset + (shift / 8) * 256, B.status, B.ctl, B.sticky);
     };
     float ms = time_it(f);
     OnesweepCtl h; CK(hipMemcpy(&h, B.ctl, sizeof h, hipMemcpyDeviceToHost));
-    printf("%-34s items=%2d minwaves=%d : %8.1f us  %7.1f GB/s alg%s\n", tag, kItems, kMinWaves, ms * 1e3,
+    printf("%-22s thr=%4d items=%2d minw=%d early=%d ldsmatch=%d : %8.1f us  %7.1f GB/s alg%s\n", tag, kThreads, kItems, kMinWaves, (int)kEarly, (int)kLds, ms * 1e3,
            (double)m * (synth ? 20 : 24) / (ms * 1e-3) / 1e9, h.error ? "  LOOKBACK TIMEOUT" : "");
     return ms;
 }
@@ -86,18 +87,27 @@ bool same(const void *a, const void *b, size_t bytes)
 
 int main(int argc, char **argv)
 {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     const int lg = argc > 1 ? atoi(argv[1]) : 26;
     const int skew = argc > 2 ? atoi(argv[2]) : 0;
     const int64_t m = ((int64_t)1 << lg) + (argc > 3 ? atoi(argv[3]) : 0);
     printf("m = %lld  skew=%d\n", (long long)m, skew);
     Bufs B;
-    CK(hipMalloc(&B.k0, m * 8)); CK(hipMalloc(&B.k1, m * 8)); CK(hipMalloc(&B.k2, m * 8));
-    CK(hipMalloc(&B.v0, m * 4)); CK(hipMalloc(&B.v1, m * 4)); CK(hipMalloc(&B.v2, m * 4));
+    CK(hipMalloc(&B.k0, m * 8)); CK(hipMalloc(&B.k1, m * 8)); CK(hipMalloc(&B.k2, (m + (4 << 20)) * 8));
+    CK(hipMalloc(&B.v0, m * 4)); CK(hipMalloc(&B.v1, m * 4)); CK(hipMalloc(&B.v2, (m + (4 << 20)) * 4));
     CK(hipMalloc(&B.blockhist, kMaxSweepBlocks * 256 * 4)); CK(hipMalloc(&B.blockbase, kMaxSweepBlocks * 256 * 4));
     CK(hipMalloc(&B.partial, kHistBlocks * kMaxPasses * 256 * 4)); CK(hipMalloc(&B.digit_offset, kMaxPasses * 256 * 8));
-    CK(hipMalloc(&B.status, ((size_t)m / 2048 + 2) * 256 * 4)); CK(hipMalloc(&B.ctl, sizeof(OnesweepCtl)));
+    CK(hipMalloc(&B.status, ((size_t)m / 2048 + 2) * 256 * 4)); CK(hipMalloc(&B.ctl, sizeof(OnesweepCtl))); CK(hipMalloc(&B.sticky, 64)); CK(hipMalloc(&B.text, m + 64)); CK(hipMemset(B.text, 0, m + 64)); CK(hipMalloc(&B.digit_offset_text, 8 * 256 * 8)); CK(hipMalloc(&B.bytehist, 256 * 8));
     hipLaunchKernelGGL(gen_kernel, dim3(2048), dim3(256), 0, 0, B.k0, B.v0, m, skew);
+    CK(hipMemcpy(B.text, B.k0, m, hipMemcpyDeviceToDevice));   // random bytes as text
     CK(hipDeviceSynchronize());
+    {
+        float t_th = time_it([&]() {
+            hipLaunchKernelGGL(text_hist_kernel, dim3(kHistBlocks), dim3(kBlock), 0, 0, (const uint8_t *)B.text, m, B.partial);
+            hipLaunchKernelGGL(text_hist_reduce_kernel, dim3(1), dim3(kBlock), 0, 0, (const uint32_t *)B.partial, kHistBlocks, B.bytehist);
+            hipLaunchKernelGGL(text_digit_offsets_kernel, dim3(8), dim3(kBlock), 0, 0, (const int64_t *)B.bytehist, (const uint8_t *)B.text, m, 8, B.digit_offset_text); });
+        printf("text hist + reduce + offsets %8.1f us\n", t_th * 1e3);
+    }
 
     const int shift = 8;
     // ---- baseline: upsweep + scan + downsweep
@@ -111,25 +121,38 @@ int main(int argc, char **argv)
     printf("baseline upsweep %8.1f us  scan %6.1f us  downsweep %8.1f us (%.1f GB/s alg)\n", t_up * 1e3, t_sc * 1e3, t_dn * 1e3, (double)m * 24 / (t_dn * 1e-3) / 1e9);
 
     // ---- global histograms
-    float t_h = time_it([&]() { hipLaunchKernelGGL(radix_hist_kernel, dim3(kHistBlocks), dim3(kBlock), 0, 0, B.k0, m, 8, B.partial); });
+    float t_h = time_it([&]() { hipLaunchKernelGGL(radix_hist_kernel<8>, dim3(kHistBlocks), dim3(kBlock), 0, 0, B.k0, m, B.partial); });
     float t_hs = time_it([&]() { hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(8), dim3(kBlock), 0, 0, B.partial, kHistBlocks, B.digit_offset); });
     printf("hist (8 digits, one read) %8.1f us (%.1f GB/s)   hist_scan %6.1f us\n", t_h * 1e3, (double)m * 8 / (t_h * 1e-3) / 1e9, t_hs * 1e3);
 
+    if (argc > 4) {     // profiling target: one variant only
+        if (argv[4][0] == 'p') {      // phase timing
+            const int64_t nt = (m + 5119) / 5120;
+            long long *ts; CK(hipMalloc(&ts, nt * 8 * 8)); CK(hipMemset(ts, 0, nt * 8 * 8));
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ts), &ts, sizeof ts));
+            run_onesweep<20, 2>(B, m, shift, false, "onesweep (phase-timed)");
+            std::vector<long long> h(nt * 8); CK(hipMemcpy(h.data(), ts, nt * 8 * 8, hipMemcpyDeviceToHost));
+            double acc[8] = {0}; long long cnt = 0;
+            for (int64_t t = 0; t < nt - 1; ++t) { bool ok = true; for (int i = 0; i < 7; ++i) ok &= h[t * 8 + i] != 0; if (!ok) continue; ++cnt;
+                for (int i = 1; i < 7; ++i) acc[i] += (double)(h[t * 8 + i] - h[t * 8 + i - 1]); acc[0] += (double)(h[t * 8 + 6] - h[t * 8]); }
+            const char *nm[7] = {"total", "load keys (issue+wait)", "rank loop", "val loads + barrier", "scan+publish+lookback", "key exchange+store", "val exchange+store"};
+            for (int i = 0; i < 7; ++i) printf("  phase %-26s avg %10.0f ticks\n", nm[i], acc[i] / cnt);
+            long long tmin = h[0], tmax = 0; for (int64_t t = 0; t < nt; ++t) { if (h[t*8]) tmin = std::min(tmin, h[t*8]); tmax = std::max(tmax, h[t*8+6]); }
+            printf("  kernel span %lld ticks for %lld tiles\n", tmax - tmin, (long long)nt);
+            return 0;
+        }
+        run_onesweep<20, 2>(B, m, shift, false, "onesweep");
+        return 0;
+    }
     // ---- onesweep variants
-    run_onesweep<16, 1>(B, m, shift, false, "onesweep");
-    printf("   keys %s  vals %s\n", same(B.k1, B.k2, m * 8) ? "MATCH" : "DIFFER", same(B.v1, B.v2, m * 4) ? "MATCH" : "DIFFER");
-    run_onesweep<16, 2>(B, m, shift, false, "onesweep");
-    run_onesweep<16, 3>(B, m, shift, false, "onesweep");
-    run_onesweep<16, 4>(B, m, shift, false, "onesweep");
-    printf("   keys %s  vals %s\n", same(B.k1, B.k2, m * 8) ? "MATCH" : "DIFFER", same(B.v1, B.v2, m * 4) ? "MATCH" : "DIFFER");
-    run_onesweep<8, 1>(B, m, shift, false, "onesweep");
-    run_onesweep<8, 4>(B, m, shift, false, "onesweep");
-    printf("   keys %s  vals %s\n", same(B.k1, B.k2, m * 8) ? "MATCH" : "DIFFER", same(B.v1, B.v2, m * 4) ? "MATCH" : "DIFFER");
-    run_onesweep<12, 3>(B, m, shift, false, "onesweep");
-    run_onesweep<12, 4>(B, m, shift, false, "onesweep");
-    run_onesweep<20, 2>(B, m, shift, false, "onesweep");
-    run_onesweep<24, 2>(B, m, shift, false, "onesweep");
-    printf("   keys %s  vals %s\n", same(B.k1, B.k2, m * 8) ? "MATCH" : "DIFFER", same(B.v1, B.v2, m * 4) ? "MATCH" : "DIFFER");
-    run_onesweep<16, 3>(B, m, shift, true, "onesweep synth-vals");
+#define CHECK() printf("   keys %s  vals %s\n", same(B.k1, B.k2, m * 8) ? "MATCH" : "DIFFER", same(B.v1, B.v2, m * 4) ? "MATCH" : "DIFFER")
+    run_onesweep<20, 2, 256, false, false>(B, m, shift, false, "onesweep"); CHECK();
+    run_onesweep<20, 2, 256, false, true>(B, m, shift, false, "onesweep"); CHECK();
+    run_onesweep<16, 2, 256, false, true>(B, m, shift, false, "onesweep"); CHECK();
+    run_onesweep<16, 2, 512, false, false>(B, m, shift, false, "onesweep"); CHECK();
+    run_onesweep<16, 2, 512, false, true>(B, m, shift, false, "onesweep"); CHECK();
+    run_onesweep<12, 1, 1024, false, true>(B, m, shift, false, "onesweep"); CHECK();
+    run_onesweep<20, 2, 256, false, true>(B, m, shift, true, "onesweep text-pass0");
+    run_onesweep<16, 2, 512, false, true>(B, m, shift, true, "onesweep text-pass0");
     return 0;
 }
