@@ -138,7 +138,13 @@ struct OnesweepCtl {
 #ifndef DQ_LOOK_WIN
 #define DQ_LOOK_WIN 8
 #endif
-enum OnesweepMode { kPairs = 0, kText = 1 };
+// kPairs      (key, suffix) pairs in two arrays
+// kText       round 0, first pass: keys built from the text, suffix index synthesised
+// kTextPacked same, but the suffix index is packed into the low `ib` bits of the key word
+//             (word = key << ib | suffix) and no value array exists
+// kKeys       packed words only
+// kKeysLast   packed words; the last pass also emits SA[o] = word & mask
+enum OnesweepMode { kPairs = 0, kText = 1, kTextPacked = 2, kKeys = 3, kKeysLast = 4 };
 
 // developer instrumentation (tools/kbench): per-tile phase timestamps from thread 0
 #ifdef DQ_KERNEL_PHASE_TIMING
@@ -152,12 +158,14 @@ template <typename IdxT, typename StatusT, int kItems, int kMode, int kMinWaves,
           bool kEarlyVals = false, bool kLdsMatch = true>
 __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     const uint64_t *__restrict__ kin, const IdxT *__restrict__ vin,
-    uint64_t *__restrict__ kout, IdxT *__restrict__ vout, int64_t m, int shift, int kb,
+    uint64_t *__restrict__ kout, IdxT *__restrict__ vout, int64_t m, int shift, int kb, int ib,
     const int64_t *__restrict__ digit_offset /*[256] for this pass*/,
     StatusT *__restrict__ status /*[ntiles][256]*/, OnesweepCtl *__restrict__ ctl,
     int64_t *__restrict__ sticky_error)
 {
-    static_assert(kMode == kPairs || (kItems % 4) == 0, "text mode packs 4 suffixes per lane");
+    constexpr bool kFromText = (kMode == kText || kMode == kTextPacked);
+    constexpr bool kHasVals = (kMode == kPairs || kMode == kText);
+    static_assert(!kFromText || (kItems % 4) == 0, "text mode packs 4 suffixes per lane");
     static_assert(kThreads % kRadixSize == 0, "threads 0..255 own one digit each");
     constexpr int kWavesB = kThreads / kWave;
     constexpr int kTileN = kThreads * kItems;
@@ -191,11 +199,11 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
 
     // element index (inside the tile) of this lane's item k
     auto elem = [&](int k) -> int {
-        return kMode == kText ? ((k >> 2) * kThreads + tid) * 4 + (k & 3) : wbase + k * kWave;
+        return kFromText ? ((k >> 2) * kThreads + tid) * 4 + (k & 3) : wbase + k * kWave;
     };
 
     uint64_t key[kItems];
-    if (kMode == kText) {
+    if (kFromText) {
         const uint32_t *t32 = reinterpret_cast<const uint32_t *>(kin);
         const int kshift = 8 * (8 - kb);
 #pragma unroll
@@ -210,6 +218,11 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
                 key[4 * j + 1] = ((x << 8) | (y >> 56)) >> kshift;
                 key[4 * j + 2] = ((x << 16) | (y >> 48)) >> kshift;
                 key[4 * j + 3] = ((x << 24) | (y >> 40)) >> kshift;
+                if (kMode == kTextPacked) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        key[4 * j + c] = (key[4 * j + c] << ib) | (uint64_t)(base + e0 + c);
+                }
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) key[4 * j + c] = ~0ull;
@@ -230,7 +243,9 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     // registers) or after the ranking loop
     IdxT val[kItems];
     auto load_vals = [&]() {
-        if (kMode == kText) {
+        if (!kHasVals) {
+            // packed words carry their suffix index
+        } else if (kMode == kText) {
 #pragma unroll
             for (int k = 0; k < kItems; ++k) val[k] = (IdxT)(base + elem(k));
         } else if (valid == kTileN) {
@@ -356,15 +371,17 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     uint64_t skey[kItems];
 #pragma unroll
     for (int k = 0; k < kItems; ++k) skey[k] = exch[k * kThreads + tid];
-    __syncthreads();
-    IdxT *exv = reinterpret_cast<IdxT *>(exch);
-#pragma unroll
-    for (int k = 0; k < kItems; ++k)
-        if (valid == kTileN || elem(k) < valid) exv[pos[k]] = val[k];
-    __syncthreads();
     IdxT sval[kItems];
+    if (kHasVals) {
+        __syncthreads();
+        IdxT *exv = reinterpret_cast<IdxT *>(exch);
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) sval[k] = exv[k * kThreads + tid];
+        for (int k = 0; k < kItems; ++k)
+            if (valid == kTileN || elem(k) < valid) exv[pos[k]] = val[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) sval[k] = exv[k * kThreads + tid];
+    }
     DQ_PHASE(5);
 
     // ---- resolve the look-back: sum aggregates until an inclusive prefix shows up ----
@@ -413,7 +430,8 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
         if (q < valid) {
             const IdxT o = gofs[digit_of(skey[k], shift)] + (IdxT)q;
             kout[o] = skey[k];
-            vout[o] = sval[k];
+            if (kHasVals) vout[o] = sval[k];
+            if (kMode == kKeysLast) vout[o] = (IdxT)(skey[k] & ((1ull << ib) - 1));
         }
     }
     DQ_PHASE(6);

@@ -75,27 +75,28 @@ struct SegTileLoader {
     uint64_t ck[kSegItems];
     uint64_t prev, next;
     bool has_prev, has_next;
-    __device__ __forceinline__ void load(const uint64_t *__restrict__ keys, int64_t m, int64_t j0)
+    // kshift > 0: the keys are packed (key << kshift | suffix) words; compare the key part only
+    __device__ __forceinline__ void load(const uint64_t *__restrict__ keys, int64_t m, int64_t j0, int kshift)
     {
 #pragma unroll
-        for (int i = 0; i < kSegItems; ++i) ck[i] = (j0 + i < m) ? keys[j0 + i] : 0;
+        for (int i = 0; i < kSegItems; ++i) ck[i] = (j0 + i < m) ? keys[j0 + i] >> kshift : 0;
         has_prev = j0 > 0 && j0 <= m;
-        prev = has_prev ? keys[j0 - 1] : 0;
+        prev = has_prev ? keys[j0 - 1] >> kshift : 0;
         has_next = j0 + kSegItems < m;
-        next = has_next ? keys[j0 + kSegItems] : 0;
+        next = has_next ? keys[j0 + kSegItems] >> kshift : 0;
     }
 };
 
 template <typename IdxT, bool kInitial>
 __global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const uint64_t *__restrict__ keys,
                                                             int64_t m, int kbits,
-                                                            SegPartials<IdxT> part)
+                                                            SegPartials<IdxT> part, int kshift)
 {
     __shared__ IdxT tmp[3][kWavesPerBlock];
     const int tid = threadIdx.x;
     const int64_t j0 = (int64_t)blockIdx.x * kSegTile + (int64_t)tid * kSegItems;
     SegTileLoader<IdxT, kInitial> t;
-    t.load(keys, m, j0);
+    t.load(keys, m, j0, kshift);
 
     IdxT last_nh = -1, last_gh = -1, cnt = 0;
     bool head[kSegItems + 1];
@@ -195,13 +196,13 @@ template <typename IdxT, bool kInitial, bool kWriteSA, bool kWriteISA>
 __global__ __launch_bounds__(kBlock) void seg_apply_kernel(
     const uint64_t *__restrict__ keys, const IdxT *__restrict__ vals, int64_t m, int kbits,
     SegPartials<IdxT> part, IdxT *__restrict__ SA, IdxT *__restrict__ ISA,
-    uint64_t *__restrict__ act_rank, IdxT *__restrict__ act_suf)
+    uint64_t *__restrict__ act_rank, IdxT *__restrict__ act_suf, int kshift)
 {
     __shared__ IdxT tmp[kWavesPerBlock];
     const int tid = threadIdx.x;
     const int64_t j0 = (int64_t)blockIdx.x * kSegTile + (int64_t)tid * kSegItems;
     SegTileLoader<IdxT, kInitial> t;
-    t.load(keys, m, j0);
+    t.load(keys, m, j0, kshift);
     IdxT suf[kSegItems];
 #pragma unroll
     for (int i = 0; i < kSegItems; ++i) suf[i] = (j0 + i < m) ? vals[j0 + i] : (IdxT)0;
@@ -310,6 +311,120 @@ __global__ __launch_bounds__(kBlock) void gather_text_key_kernel(uint64_t *__res
         uint64_t bytes = 0;
         for (int b = 0; b < ebytes; ++b) bytes = (bytes << 8) | (b < len ? (uint64_t)text[q + b] : 0ull);
         comp[j] = (comp[j] << kbits) | (bytes << 3) | (uint64_t)len;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// small_group_finish: most ties left by round 0 on random-like data are groups of 2-3
+// suffixes that differ a few bytes further on.  One lane per group (first member) sorts a
+// group of <= kMaxG suffixes by direct text comparison from offset h (at most kMaxLen bytes;
+// a suffix that ends first sorts first), writes SA[rank + i] and marks the members resolved.
+// Groups that are larger or still undecided after kMaxLen bytes are left untouched.
+// `resolved` is a zeroed byte-per-entry flag array (nothing this kernel reads is written by
+// it, so neighbouring groups cannot race).
+// ---------------------------------------------------------------------------------
+
+template <typename IdxT, int kMaxG, int kMaxLen>
+__global__ __launch_bounds__(kBlock) void small_group_finish_kernel(const uint64_t *__restrict__ rank,
+                                                                    const IdxT *__restrict__ suf,
+                                                                    const uint8_t *__restrict__ text,
+                                                                    int64_t m, int64_t n, int64_t h,
+                                                                    IdxT *__restrict__ SA,
+                                                                    uint8_t *__restrict__ resolved)
+{
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t r = rank[j];
+    if (j > 0 && rank[j - 1] == r) return;                     // not the first member
+    int g = 1;
+    while (g <= kMaxG && j + g < m && rank[j + g] == r) ++g;
+    if (g > kMaxG) return;
+    int64_t s[kMaxG];
+#pragma unroll
+    for (int i = 0; i < kMaxG; ++i) s[i] = i < g ? (int64_t)suf[j + i] : 0;
+
+    // -1: a < b, +1: a > b, 0: undecided within kMaxLen bytes
+    auto cmp = [&](int64_t a, int64_t b) -> int {
+        const int64_t pa = a + h, pb = b + h;
+        for (int k = 0; k < kMaxLen; ++k) {
+            const bool ea = pa + k >= n, eb = pb + k >= n;
+            if (ea || eb) return ea ? (eb ? (a > b ? -1 : 1) : -1) : 1;   // the shorter suffix first
+            const int ca = text[pa + k], cb = text[pb + k];
+            if (ca != cb) return ca < cb ? -1 : 1;
+        }
+        return 0;
+    };
+    // insertion sort (g <= kMaxG); static indexing via bubble passes keeps s[] in registers
+    bool decided = true;
+#pragma unroll
+    for (int pass = 0; pass < kMaxG - 1; ++pass) {
+#pragma unroll
+        for (int i = 0; i < kMaxG - 1; ++i) {
+            if (i + 1 < g && i < g - 1 - pass) {
+                const int c = cmp(s[i], s[i + 1]);
+                if (c == 0) decided = false;
+                if (c > 0) { const int64_t t = s[i]; s[i] = s[i + 1]; s[i + 1] = t; }
+            }
+        }
+    }
+    if (!decided) return;
+#pragma unroll
+    for (int i = 0; i < kMaxG; ++i) {
+        if (i < g) {
+            SA[(int64_t)r + i] = (IdxT)s[i];
+            resolved[j + i] = 1;
+        }
+    }
+}
+
+// stream compaction of the active list: keep entries whose resolved flag is 0
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void compact_count_kernel(const uint8_t *__restrict__ resolved, int64_t m,
+                                                               SegPartials<IdxT> part)
+{
+    __shared__ IdxT tmp[kWavesPerBlock];
+    const int64_t j0 = (int64_t)blockIdx.x * kSegTile + (int64_t)threadIdx.x * kSegItems;
+    IdxT cnt = 0;
+#pragma unroll
+    for (int i = 0; i < kSegItems; ++i) cnt += (j0 + i < m && resolved[j0 + i] == 0) ? 1 : 0;
+    cnt = wave_sum(cnt);
+    if (lane_id() == 0) tmp[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        IdxT c = 0;
+        for (int i = 0; i < kWavesPerBlock; ++i) c += tmp[i];
+        part.nh[blockIdx.x] = -1;
+        part.gh[blockIdx.x] = -1;
+        part.cnt[blockIdx.x] = c;
+    }
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const uint8_t *__restrict__ resolved,
+                                                                 const uint64_t *__restrict__ rank,
+                                                                 const IdxT *__restrict__ suf, int64_t m,
+                                                                 SegPartials<IdxT> part,
+                                                                 uint64_t *__restrict__ rank_out,
+                                                                 IdxT *__restrict__ suf_out)
+{
+    __shared__ IdxT tmp[kWavesPerBlock];
+    const int64_t j0 = (int64_t)blockIdx.x * kSegTile + (int64_t)threadIdx.x * kSegItems;
+    bool keep[kSegItems];
+    IdxT cnt = 0;
+#pragma unroll
+    for (int i = 0; i < kSegItems; ++i) {
+        keep[i] = (j0 + i < m) && resolved[j0 + i] == 0;
+        cnt += keep[i] ? 1 : 0;
+    }
+    IdxT dummy;
+    int64_t o = (int64_t)part.cnt[blockIdx.x] + (int64_t)block_excl_sum(cnt, tmp, &dummy);
+#pragma unroll
+    for (int i = 0; i < kSegItems; ++i) {
+        if (keep[i]) {
+            rank_out[o] = rank[j0 + i];
+            suf_out[o] = suf[j0 + i];
+            ++o;
+        }
     }
 }
 

@@ -257,7 +257,7 @@ template <> struct RankCfg<int64_t> { static constexpr int kItems = 16, kMinWave
 
 template <typename IdxT, typename StatusT, int kMode>
 int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin,
-                     uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb)
+                     uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb, int ib)
 {
     constexpr int kItems = RankCfg<IdxT>::kItems;
     constexpr int kThreads = RankCfg<IdxT>::kThreads;
@@ -269,21 +269,24 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
     const size_t need = 256 + (size_t)ntiles * kRadixSize * sizeof(StatusT);
     if (need > w.ctl_status_bytes) return fail(DQ_ERR_HIP, "status buffer too small");
     HIP_TRY(hipMemsetAsync(w.ctl_status, 0, need, L.st));
-    LAUNCH(L, DQ_K_RADIX_RANK_SCATTER, m, kMode == kText ? m * (1 + 8 + wb) : m * 2 * (8 + wb),
+    // algorithmic bytes per element: what the pass must read + write
+    const int64_t alg = kMode == kPairs ? 2 * (8 + wb) : kMode == kText ? 1 + 8 + wb
+                      : kMode == kTextPacked ? 1 + 8 : kMode == kKeys ? 16 : 16 + wb;
+    LAUNCH(L, DQ_K_RADIX_RANK_SCATTER, m, m * alg,
            hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, kItems, kMode, RankCfg<IdxT>::kMinWaves, kThreads,
                                                  false, false>),
                               dim3((unsigned)ntiles), dim3(kThreads), 0, L.st, kin, vin, kout, vout, m,
-                              pass * kRadixBits, kb, (const int64_t *)(w.digit_offset + pass * kRadixSize),
-                              status, ctl, w.totals + 1));
+                              pass * kRadixBits + ib, kb, ib,
+                              (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1));
     return DQ_OK;
 }
 
 template <typename IdxT, int kMode>
 int rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin, uint64_t *kout,
-              IdxT *vout, int64_t m, int pass, int kb)
+              IdxT *vout, int64_t m, int pass, int kb, int ib = 0)
 {
-    if (m < (1ll << 30)) return launch_rank_pass<IdxT, uint32_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb);
-    return launch_rank_pass<IdxT, uint64_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb);
+    if (m < (1ll << 30)) return launch_rank_pass<IdxT, uint32_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib);
+    return launch_rank_pass<IdxT, uint64_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib);
 }
 
 template <int kPasses>
@@ -326,7 +329,10 @@ int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V
 
 // Number of leading text bytes worth sorting in round 0: enough bits, under an order-0 model
 // of the text, to make ties among n suffixes rare (~n/1000); text-like inputs get all 8.
-int choose_key_bytes(const int64_t *bytehist, int64_t n)
+// If (almost) that many key bytes fit into one 64-bit word next to the suffix index
+// (ib = bits of n-1), round 0 sorts PACKED words (key << ib | suffix): 16 B per element per
+// pass instead of 24 and no value array; the few extra ties go to the sparse finishing path.
+void choose_key_bytes(const int64_t *bytehist, int64_t n, int *kb_out, bool *packed_out)
 {
     double h0 = 0;
     for (int b = 0; b < 256; ++b) {
@@ -336,14 +342,22 @@ int choose_key_bytes(const int64_t *bytehist, int64_t n)
         }
     }
     const double need = std::log2((double)std::max<int64_t>(n, 2)) + 10.0;
-    if (h0 < 0.25) return 8;
-    int kb = (int)std::ceil(need / h0);
-    return std::min(8, std::max(3, kb));
+    int kb = 8;
+    if (h0 >= 0.25) kb = std::min(8, std::max(3, (int)std::ceil(need / h0)));
+    const int ib = bit_length((uint64_t)(n - 1));
+    const int fit = (64 - ib) / 8;
+    // packed if the bytes that fit still leave at most ~1/8 of the suffixes tied
+    bool packed = fit >= 2 && (kb <= fit || (double)fit * h0 >= std::log2((double)std::max<int64_t>(n, 2)) + 3.0);
+    if (const char *v = getenv("DQ_PACKED")) packed = atoi(v) != 0 && fit >= 2;
+    if (packed) kb = std::min(kb, fit);
+    *kb_out = kb;
+    *packed_out = packed;
 }
 
 // round 0, step 1: byte histogram of the text -> key width kb -> per-digit offsets
 template <typename IdxT>
-int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int *kb_out)
+int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int *kb_out,
+                               bool *packed_out)
 {
     const int blocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 4) + kBlock - 1) / kBlock + 1);
     LAUNCH(L, DQ_K_RADIX_HIST, n, n,
@@ -352,15 +366,17 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
            hipLaunchKernelGGL(text_hist_reduce_kernel, dim3(1), dim3(kBlock), 0, L.st,
                               (const uint32_t *)w.hist_partial, blocks, w.bytehist));
     int kb = 8;
-    const char *force = getenv("DQ_KEY_BYTES");
-    if (force) {
+    bool packed = false;
+    HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, 256 * 8, hipMemcpyDeviceToHost, L.st));
+    HIP_TRY(hipStreamSynchronize(L.st));
+    choose_key_bytes(c.pinned, n, &kb, &packed);
+    if (const char *force = getenv("DQ_KEY_BYTES")) {
         kb = std::min(8, std::max(1, atoi(force)));
-    } else {
-        HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, 256 * 8, hipMemcpyDeviceToHost, L.st));
-        HIP_TRY(hipStreamSynchronize(L.st));
-        kb = choose_key_bytes(c.pinned, n);
+        const int fit = (64 - bit_length((uint64_t)(n - 1))) / 8;
+        if (kb > fit || kb < 2) packed = false;
     }
     *kb_out = kb;
+    *packed_out = packed;
     hipLaunchKernelGGL(text_digit_offsets_kernel, dim3(kb), dim3(kBlock), 0, L.st,
                        (const int64_t *)w.bytehist, (const uint8_t *)w.text, n, kb, w.digit_offset);
     HIP_TRY(hipGetLastError());
@@ -368,13 +384,29 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
 }
 
 // round 0, step 2: kb digit passes; pass 0 builds its keys straight from the text and writes
-// buffer 1, pass p writes buffer (p+1)&1
+// buffer 1, pass p writes buffer (p+1)&1.  Packed: words only, the last pass also emits the SA.
 template <typename IdxT>
 int onesweep_sort_text_passes(Launcher &L, Workspace<IdxT> &w, int64_t n, uint64_t *K[2], IdxT *V[2],
-                              int kb, int &cur)
+                              int kb, bool packed, IdxT *d_sa, int &cur)
 {
-    int rc = rank_pass<IdxT, kText>(L, w, reinterpret_cast<const uint64_t *>(w.text), (const IdxT *)nullptr,
-                                    K[1], V[1], n, 0, kb);
+    const uint64_t *text64 = reinterpret_cast<const uint64_t *>(w.text);
+    int rc;
+    if (packed) {
+        const int ib = bit_length((uint64_t)(n - 1));
+        rc = rank_pass<IdxT, kTextPacked>(L, w, text64, (const IdxT *)nullptr, K[1], (IdxT *)nullptr, n, 0, kb, ib);
+        if (rc != DQ_OK) return rc;
+        cur = 1;
+        for (int p = 1; p < kb; ++p) {
+            if (p == kb - 1)
+                rc = rank_pass<IdxT, kKeysLast>(L, w, K[cur], (const IdxT *)nullptr, K[cur ^ 1], d_sa, n, p, kb, ib);
+            else
+                rc = rank_pass<IdxT, kKeys>(L, w, K[cur], (const IdxT *)nullptr, K[cur ^ 1], (IdxT *)nullptr, n, p, kb, ib);
+            if (rc != DQ_OK) return rc;
+            cur ^= 1;
+        }
+        return DQ_OK;
+    }
+    rc = rank_pass<IdxT, kText>(L, w, text64, (const IdxT *)nullptr, K[1], V[1], n, 0, kb);
     if (rc != DQ_OK) return rc;
     cur = 1;
     for (int p = 1; p < kb; ++p) {
@@ -387,13 +419,13 @@ int onesweep_sort_text_passes(Launcher &L, Workspace<IdxT> &w, int64_t n, uint64
 
 template <typename IdxT, bool kInitial>
 int seg_count(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *keys, int64_t m,
-              int kbits, int64_t *active_out)
+              int kbits, int64_t *active_out, int kshift = 0)
 {
     const int64_t nparts = (m + kSegTile - 1) / kSegTile;
     const int64_t wb = (int64_t)sizeof(IdxT);
     LAUNCH(L, DQ_K_SEG_REDUCE, m, m * 8,
            hipLaunchKernelGGL((seg_reduce_kernel<IdxT, kInitial>), dim3((unsigned)nparts),
-                              dim3(kBlock), 0, L.st, keys, m, kbits, w.part));
+                              dim3(kBlock), 0, L.st, keys, m, kbits, w.part, kshift));
     LAUNCH(L, DQ_K_SEG_SCAN, nparts, nparts * 6 * wb,
            hipLaunchKernelGGL(seg_scan_kernel<IdxT>, dim3(1), dim3(1024), 0, L.st, w.part, nparts,
                               w.totals));
@@ -421,15 +453,16 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
         IdxT *V[2];
         int cur = 0;
         int kb = 8;
+        bool packed = false;
         int rc;
         if (sort_engine() == 1) {
             // pass p writes buffer (p+1)&1, so the last pass (kb-1) writes buffer kb&1: that one
             // must be the caller's SA, which is why the key width is chosen first
-            rc = onesweep_sort_text_prepare<IdxT>(L, c, w, n, &kb);
+            rc = onesweep_sort_text_prepare<IdxT>(L, c, w, n, &kb, &packed);
             if (rc != DQ_OK) return rc;
             V[kb & 1] = d_sa;
             V[(kb & 1) ^ 1] = w.Va;
-            rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, cur);
+            rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur);
             if (rc != DQ_OK) return rc;
         } else {
             const int64_t nquads = (n + 3) / 4;
@@ -443,8 +476,9 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
             rc = radix_sort_pairs<IdxT>(L, w, K, V, n, 64, /*synth_first=*/true, cur);
             if (rc != DQ_OK) return rc;
         }
-        // sorted keys are in K[cur], suffixes in V[cur] == d_sa
-        rc = seg_count<IdxT, true>(L, c, w, K[cur], n, 0, &active);
+        // sorted keys (or packed words) are in K[cur], suffixes in d_sa
+        const int kshift0 = packed ? bit_length((uint64_t)(n - 1)) : 0;
+        rc = seg_count<IdxT, true>(L, c, w, K[cur], n, 0, &active, kshift0);
         if (rc != DQ_OK) return rc;
         t_info[1] = active;
         if (active == 0) return flush_profile(c);
@@ -452,18 +486,18 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
         uint64_t *act_rank = K[cur ^ 1];
         // Few ties (random-like input): finish them by key extension from the text and skip the
         // n random writes of a full inverse suffix array.  Many ties: build ISA now and double.
-        bool sparse = active * 32 <= n;
+        bool sparse = active * 6 <= n;
         if (const char *v = getenv("DQ_SPARSE")) sparse = atoi(v) != 0;
         if (sparse) {
             LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb) + active * (8 + wb),
                    hipLaunchKernelGGL((seg_apply_kernel<IdxT, true, false, false>), dim3((unsigned)nparts),
                                       dim3(kBlock), 0, st, K[cur], (const IdxT *)d_sa, n, 0, w.part,
-                                      d_sa, w.ISA, act_rank, w.Va));
+                                      d_sa, w.ISA, act_rank, w.Va, kshift0));
         } else {
             LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb + wb) + active * (8 + wb),
                    hipLaunchKernelGGL((seg_apply_kernel<IdxT, true, false, true>), dim3((unsigned)nparts),
                                       dim3(kBlock), 0, st, K[cur], (const IdxT *)d_sa, n, 0, w.part,
-                                      d_sa, w.ISA, act_rank, w.Va));
+                                      d_sa, w.ISA, act_rank, w.Va, kshift0));
         }
         // refinement ping-pong: (act_rank buffer, Va) <-> (other key buffer, Vb)
         uint64_t *Kr[2] = {act_rank, K[cur]};
@@ -475,6 +509,35 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
         auto grid_for = [](int64_t items) { return (unsigned)std::min<int64_t>((items + kBlock - 1) / kBlock, 256 * 16); };
 
         if (sparse) {
+            // tiny groups with a short remaining common prefix: finish by direct comparison
+            t_info[0] += 1;
+            t_info[2] += m;
+            uint8_t *resolved = reinterpret_cast<uint8_t *>(w.ISA);     // ISA is unused on the sparse path
+            HIP_TRY(hipMemsetAsync(resolved, 0, (size_t)m, st));
+            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + 16 + wb),
+                   hipLaunchKernelGGL((small_group_finish_kernel<IdxT, 8, 32>), dim3((unsigned)((m + kBlock - 1) / kBlock)),
+                                      dim3(kBlock), 0, st, (const uint64_t *)Kr[rcur], (const IdxT *)Vr[rcur],
+                                      (const uint8_t *)w.text, m, n, h, d_sa, resolved));
+            {
+                const int64_t np = (m + kSegTile - 1) / kSegTile;
+                LAUNCH(L, DQ_K_SEG_REDUCE, m, m * 8,
+                       hipLaunchKernelGGL(compact_count_kernel<IdxT>, dim3((unsigned)np), dim3(kBlock), 0, st,
+                                          (const uint8_t *)resolved, m, w.part));
+                LAUNCH(L, DQ_K_SEG_SCAN, np, np * 6 * wb,
+                       hipLaunchKernelGGL(seg_scan_kernel<IdxT>, dim3(1), dim3(1024), 0, st, w.part, np, w.totals));
+                HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                const int64_t m2 = c.pinned[0];
+                if (m2 > 0) {
+                    LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + wb) + m2 * (8 + wb),
+                           hipLaunchKernelGGL(compact_scatter_kernel<IdxT>, dim3((unsigned)np), dim3(kBlock), 0, st,
+                                              (const uint8_t *)resolved, (const uint64_t *)Kr[rcur],
+                                              (const IdxT *)Vr[rcur], m, w.part,
+                                              Kr[rcur ^ 1], Vr[rcur ^ 1]));
+                    rcur ^= 1;
+                }
+                m = m2;
+            }
             const int ebytes = std::max(1, std::min(4, (64 - rbits - 3) / 8));
             const int kbits = 8 * ebytes + 3;
             for (int r = 0; r < 3 && m > 0; ++r) {
@@ -494,7 +557,7 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
                 LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + wb + wb) + m2 * (8 + wb),
                        hipLaunchKernelGGL((seg_apply_kernel<IdxT, false, true, false>), dim3((unsigned)np),
                                           dim3(kBlock), 0, st, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits,
-                                          w.part, d_sa, w.ISA, Kr[rcur ^ 1], Vr[rcur ^ 1]));
+                                          w.part, d_sa, w.ISA, Kr[rcur ^ 1], Vr[rcur ^ 1], 0));
                 rcur ^= 1;
                 m = m2;
                 h += ebytes;
@@ -528,7 +591,7 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
             LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + wb + wb + wb) + m2 * (8 + wb),
                    hipLaunchKernelGGL((seg_apply_kernel<IdxT, false, true, true>), dim3((unsigned)np),
                                       dim3(kBlock), 0, st, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits,
-                                      w.part, d_sa, w.ISA, Kr[rcur ^ 1], Vr[rcur ^ 1]));
+                                      w.part, d_sa, w.ISA, Kr[rcur ^ 1], Vr[rcur ^ 1], 0));
             rcur ^= 1;
             m = m2;
             h *= 2;
