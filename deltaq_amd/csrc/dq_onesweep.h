@@ -155,7 +155,7 @@ __device__ long long *g_phase_ts = nullptr;          // [ntiles][8]
 #endif
 
 template <typename IdxT, typename StatusT, int kItems, int kMode, int kMinWaves, int kThreads = kBlock,
-          bool kEarlyVals = false, bool kLdsMatch = true>
+          bool kEarlyVals = false, bool kLdsMatch = true, int kExchRounds = 1>
 __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     const uint64_t *__restrict__ kin, const IdxT *__restrict__ vin,
     uint64_t *__restrict__ kout, IdxT *__restrict__ vout, int64_t m, int shift, int kb, int ib,
@@ -172,7 +172,11 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     constexpr int kWaveN = kWave * kItems;
     using SB = StatusBits<StatusT>;
 
-    __shared__ __attribute__((aligned(16))) uint64_t exch[kTileN];
+    // the exchange buffer holds 1/kExchRounds of the tile: the tile is staged through LDS in
+    // kExchRounds position ranges, trading barriers for LDS footprint (= occupancy)
+    static_assert(kItems % kExchRounds == 0, "exchange rounds split the items evenly");
+    constexpr int kExchN = kTileN / kExchRounds;
+    __shared__ __attribute__((aligned(16))) uint64_t exch[kExchN];
     __shared__ uint32_t whist[kWavesB][kRadixSize];
     __shared__ uint32_t tile_base[kRadixSize];
     __shared__ IdxT gofs[kRadixSize];
@@ -183,11 +187,23 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     const int w = tid >> 6;
     const int lane = lane_id();
 
-    if (tid == 0) s_tile = atomicAdd(&ctl->ticket, 1u);
+    if (tid == 0) {
+        // Tiles are handed out by an atomic ticket, so a tile's predecessors are always running.
+        // (Experiment kept behind DQ_XCD_REMAP: permuting ticket -> tile inside groups of 64 so that
+        // the workgroups of one XCD get 8 consecutive tiles and adjacent digit runs meet in one
+        // L2.  It lengthened the look-back waits more than it saved on partial-line writes.)
+        const uint32_t g = atomicAdd(&ctl->ticket, 1u);
+        uint32_t t = g;
+#ifdef DQ_XCD_REMAP   /* measured: -4% on pairs passes, +2% on the text pass; off */
+        const uint32_t ntiles = (uint32_t)((m + kTileN - 1) / kTileN);
+        if ((g | 63u) < ntiles) t = (g & ~63u) | ((g & 7u) << 3) | ((g >> 3) & 7u);
+#endif
+        s_tile = t;
+    }
     for (int i = tid; i < kWavesB * kRadixSize; i += kThreads) (&whist[0][0])[i] = 0;
     if (kLdsMatch) {
         // per-wave digit -> lane-mask tables live in the (not yet used) exchange buffer
-        static_assert(kItems >= kRadixSize / kWave, "exchange buffer must hold the match tables");
+        static_assert(kExchN >= kWavesB * kRadixSize, "exchange buffer must hold the match tables");
         for (int i = tid; i < kWavesB * kRadixSize; i += kThreads) exch[i] = 0;
     }
     __syncthreads();
@@ -279,16 +295,20 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
         }
         return match_digit8(d);
     };
+    (void)lanebit;
     if (valid == kTileN) {
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
             const uint32_t d = digit_of(key[k], shift);
-            const uint64_t peers = peers_of(d);
+            // a digit shared by the whole wave (constant high digits of composite keys, runs of
+            // equal bytes) would be a 64-way same-address LDS atomic: skip the table for it
+            const bool uni = kLdsMatch && __all(d == (uint32_t)__builtin_amdgcn_readfirstlane(d));
+            const uint64_t peers = uni ? ~0ull : peers_of(d);
             const uint32_t before = myhist[d];                 // same value for every peer
             const int r = mask_rank_lt(peers);
             if (r == 0) {
                 myhist[d] = before + (uint32_t)__popcll(peers);
-                if (kLdsMatch) mtab[d] = 0;
+                if (kLdsMatch && !uni) mtab[d] = 0;
             }
             pos[k] = before + (uint32_t)r;
         }
@@ -365,22 +385,45 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     for (int k = 0; k < kItems; ++k) {
         const uint32_t d = digit_of(key[k], shift);
         pos[k] += tile_base[d] + myhist[d];
-        if (valid == kTileN || elem(k) < valid) exch[pos[k]] = key[k];
     }
-    __syncthreads();
-    uint64_t skey[kItems];
-#pragma unroll
-    for (int k = 0; k < kItems; ++k) skey[k] = exch[k * kThreads + tid];
-    IdxT sval[kItems];
-    if (kHasVals) {
-        __syncthreads();
-        IdxT *exv = reinterpret_cast<IdxT *>(exch);
+    if (valid != kTileN) {
 #pragma unroll
         for (int k = 0; k < kItems; ++k)
-            if (valid == kTileN || elem(k) < valid) exv[pos[k]] = val[k];
+            if (elem(k) >= valid) pos[k] = 0xffffffffu;                      // never staged
+    }
+    uint64_t skey[kItems];
+#pragma unroll
+    for (int r = 0; r < kExchRounds; ++r) {
+        if (r > 0) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const uint32_t p = pos[k] - (uint32_t)(r * kExchN);
+            if (p < (uint32_t)kExchN) exch[p] = key[k];
+        }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kItems; ++k) sval[k] = exv[k * kThreads + tid];
+        for (int k = r * (kItems / kExchRounds); k < (r + 1) * (kItems / kExchRounds); ++k)
+            skey[k] = exch[k * kThreads + tid - r * kExchN];
+    }
+    IdxT sval[kItems];
+    if (kHasVals) {
+        constexpr int kValN = kExchN * (int)(sizeof(uint64_t) / sizeof(IdxT));    // values per round
+        constexpr int kValRounds = kTileN / kValN > 0 ? kTileN / kValN : 1;
+        constexpr int kValCap = kTileN / kValRounds;
+        IdxT *exv = reinterpret_cast<IdxT *>(exch);
+#pragma unroll
+        for (int r = 0; r < kValRounds; ++r) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kItems; ++k) {
+                const uint32_t p = pos[k] - (uint32_t)(r * kValCap);
+                if (p < (uint32_t)kValCap) exv[p] = val[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = r * (kItems / kValRounds); k < (r + 1) * (kItems / kValRounds); ++k)
+                sval[k] = exv[k * kThreads + tid - r * kValCap];
+        }
     }
     DQ_PHASE(5);
 
@@ -443,7 +486,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
 // text, corrected for the first / last kb-1 positions.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void text_hist_kernel(const uint8_t *__restrict__ text, int64_t n,
-                                                           uint32_t *__restrict__ partial /*[G][256]*/)
+                                                           unsigned long long *__restrict__ bytehist /*[256], zeroed*/)
 {
     // 4 interleaved sub-histograms (hist[d][lane & 3]) spread equal bytes over 4 banks
     __shared__ uint32_t hist[kRadixSize * 4];
@@ -466,19 +509,8 @@ __global__ __launch_bounds__(kBlock) void text_hist_kernel(const uint8_t *__rest
         for (int64_t i = (chunks << 4) + tid; i < n; i += kBlock) atomicAdd(&hist[((uint32_t)text[i] << 2) | sub], 1u);
     }
     __syncthreads();
-    partial[(int64_t)blockIdx.x * kRadixSize + tid] =
-        hist[tid * 4] + hist[tid * 4 + 1] + hist[tid * 4 + 2] + hist[tid * 4 + 3];
-}
-
-// bytehist[d] = occurrences of byte d in the text (single workgroup)
-__global__ __launch_bounds__(kBlock) void text_hist_reduce_kernel(const uint32_t *__restrict__ partial,
-                                                                  int nblocks, int64_t *__restrict__ bytehist)
-{
-    const int d = threadIdx.x;
-    int64_t sum = 0;
-#pragma unroll 8
-    for (int g = 0; g < nblocks; ++g) sum += partial[(int64_t)g * kRadixSize + d];
-    bytehist[d] = sum;
+    const uint32_t c = hist[tid * 4] + hist[tid * 4 + 1] + hist[tid * 4 + 2] + hist[tid * 4 + 3];
+    if (c) atomicAdd(&bytehist[tid], (unsigned long long)c);
 }
 
 // digit_offset[p][d] for p < kb (one workgroup per digit place p)

@@ -249,18 +249,26 @@ int radix_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V[2]
 }
 
 // ------------------------------------------------------------------ onesweep driver
-template <typename IdxT> struct RankCfg;
-// 512 threads x 16 keys = 8192-key tiles: ~32-key (256 B) runs per digit keep the scattered
-// writes near full lines; 76 KiB of LDS -> 2 workgroups (16 waves) per CU
-template <> struct RankCfg<int32_t> { static constexpr int kItems = 16, kMinWaves = 2, kThreads = 512; };
-template <> struct RankCfg<int64_t> { static constexpr int kItems = 16, kMinWaves = 2, kThreads = 512; };
+// Tile geometry of radix_rank_kernel per (index type, pass kind), from the kbench sweep
+// (tools/kbench, 64 Mi keys, random digits): 512 threads; packed-word passes 24 keys/thread
+// (12288-key tiles, ~48-key runs per digit), LDS match tables; pair passes 20 keys/thread,
+// ballot match; the tile is staged through LDS in 2 position ranges (half the LDS footprint).
+template <typename IdxT, int kMode> struct RankCfg {
+    static constexpr bool kWords = (kMode == kTextPacked || kMode == kKeys || kMode == kKeysLast);
+    static constexpr int kThreads = 512;
+    static constexpr int kItems = kWords ? 24 : (sizeof(IdxT) == 4 ? 20 : 16);
+    static constexpr int kMinWaves = 2;
+    static constexpr int kRounds = 2;
+    static constexpr bool kLdsMatch = kWords;
+};
 
 template <typename IdxT, typename StatusT, int kMode>
 int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin,
                      uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb, int ib)
 {
-    constexpr int kItems = RankCfg<IdxT>::kItems;
-    constexpr int kThreads = RankCfg<IdxT>::kThreads;
+    using Cfg = RankCfg<IdxT, kMode>;
+    constexpr int kItems = Cfg::kItems;
+    constexpr int kThreads = Cfg::kThreads;
     constexpr int kTileN = kThreads * kItems;
     const int64_t ntiles = (m + kTileN - 1) / kTileN;
     const int64_t wb = (int64_t)sizeof(IdxT);
@@ -273,8 +281,8 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
     const int64_t alg = kMode == kPairs ? 2 * (8 + wb) : kMode == kText ? 1 + 8 + wb
                       : kMode == kTextPacked ? 1 + 8 : kMode == kKeys ? 16 : 16 + wb;
     LAUNCH(L, DQ_K_RADIX_RANK_SCATTER, m, m * alg,
-           hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, kItems, kMode, RankCfg<IdxT>::kMinWaves, kThreads,
-                                                 false, false>),
+           hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, kItems, kMode, Cfg::kMinWaves, kThreads,
+                                                 false, Cfg::kLdsMatch, Cfg::kRounds>),
                               dim3((unsigned)ntiles), dim3(kThreads), 0, L.st, kin, vin, kout, vout, m,
                               pass * kRadixBits + ib, kb, ib,
                               (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1));
@@ -360,11 +368,10 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
                                bool *packed_out)
 {
     const int blocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 4) + kBlock - 1) / kBlock + 1);
+    HIP_TRY(hipMemsetAsync(w.bytehist, 0, 256 * 8, L.st));
     LAUNCH(L, DQ_K_RADIX_HIST, n, n,
            hipLaunchKernelGGL(text_hist_kernel, dim3(blocks), dim3(kBlock), 0, L.st,
-                              (const uint8_t *)w.text, n, w.hist_partial);
-           hipLaunchKernelGGL(text_hist_reduce_kernel, dim3(1), dim3(kBlock), 0, L.st,
-                              (const uint32_t *)w.hist_partial, blocks, w.bytehist));
+                              (const uint8_t *)w.text, n, reinterpret_cast<unsigned long long *>(w.bytehist)));
     int kb = 8;
     bool packed = false;
     HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, 256 * 8, hipMemcpyDeviceToHost, L.st));

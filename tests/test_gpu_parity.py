@@ -155,3 +155,56 @@ def test_batch_entry_point(backend_lib, oracle_mod):
     assert rc == 0, backend_lib.dq_last_error()
     for t, s in zip(texts, sas):
         assert np.array_equal(s, oracle_mod.divsufsort(t))
+
+
+FORCED_PATHS = [
+    {},                                                       # defaults (adaptive)
+    {"DQ_PACKED": "1", "DQ_KEY_BYTES": "3", "DQ_SPARSE": "1"},   # packed words, finisher, sparse rounds
+    {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},   # packed words, dense doubling
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "3", "DQ_SPARSE": "1"},   # pairs, sparse + fallback to dense
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "0"},   # pairs, 8-byte keys, dense doubling
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "1"},
+]
+
+
+@pytest.mark.parametrize("env", FORCED_PATHS, ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
+def test_every_code_path_is_bit_exact(ldss, oracle_mod, monkeypatch, env):
+    """The adaptive choices (key width, packed words, sparse/dense finishing) are forced in
+    turn; every combination must produce the same (unique) suffix array."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cases = [
+        load_asset("crash-04dc74e45e66386a3312a5a5825b020bcadc175c"),
+        load_asset("fuzz3"),
+        oracle_mod.gen_uniform(3_000_000, 0x5EED0002),
+        oracle_mod.gen_uniform(200_000, 11) & 3,
+        oracle_mod.gen_enwik_like(500_000, 5, 16384),
+        np.concatenate([oracle_mod.gen_uniform(100_000, 5), oracle_mod.gen_uniform(100_000, 5)[:30_000],
+                        np.zeros(11, np.uint8)]),
+        np.zeros(70_001, np.uint8),
+        oracle_mod.net_random_bytes(8193),
+    ]
+    for T in cases:
+        T = np.ascontiguousarray(T, dtype=np.uint8)
+        SA = ldss.Sort(T)
+        assert np.array_equal(SA, oracle_mod.divsufsort(T)), (env, T.size)
+    T = oracle_mod.gen_uniform(1_000_003, 7)
+    assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
+
+
+def test_legacy_three_kernel_engine_matches(oracle_mod):
+    """DQ_SORT_ENGINE=sweep3 (upsweep/scan/downsweep) is read once per process: run it in a child."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import oracle
+        from deltaq_amd import HipSuffixSort
+        s = HipSuffixSort(0)
+        for T in (oracle.gen_uniform(2_000_000, 3), oracle.gen_enwik_like(300_000, 5, 8192)):
+            assert np.array_equal(s.Sort(T), oracle.divsufsort(T))
+        print("ok")
+    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DQ_SORT_ENGINE="sweep3")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

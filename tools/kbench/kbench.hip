@@ -55,7 +55,7 @@ struct Bufs {
     uint32_t *status; OnesweepCtl *ctl; int64_t *sticky; uint8_t *text; int64_t *digit_offset_text; int64_t *bytehist;
 };
 
-template <int kItems, int kMinWaves, int kThreads = 256, bool kEarly = false, bool kLds = true>
+template <int kItems, int kMinWaves, int kThreads = 256, bool kEarly = false, bool kLds = true, int kRounds = 1, int kPairMode = kPairs>
 float run_onesweep(Bufs &B, int64_t m, int shift, bool synth, const char *tag)
 {
     const int tile = kThreads * kItems;
@@ -64,16 +64,16 @@ float run_onesweep(Bufs &B, int64_t m, int shift, bool synth, const char *tag)
         CK(hipMemsetAsync(B.status, 0, (size_t)ntiles * 256 * 4));
         CK(hipMemsetAsync(B.ctl, 0, sizeof(OnesweepCtl)));
         if constexpr (kItems % 4 == 0) { if (synth)
-            hipLaunchKernelGGL((radix_rank_kernel<int32_t, uint32_t, kItems, kText, kMinWaves, kThreads, kEarly, kLds>), dim3((unsigned)ntiles), dim3(kThreads), 0, 0,
-                               (const uint64_t *)B.text, (const int32_t *)nullptr, B.k2, B.v2, m, 0, 8, B.digit_offset_text, B.status, B.ctl, B.sticky); }
+            hipLaunchKernelGGL((radix_rank_kernel<int32_t, uint32_t, kItems, kText, kMinWaves, kThreads, kEarly, kLds, kRounds>), dim3((unsigned)ntiles), dim3(kThreads), 0, 0,
+                               (const uint64_t *)B.text, (const int32_t *)nullptr, B.k2, B.v2, m, 0, 8, 0, B.digit_offset_text, B.status, B.ctl, B.sticky); }
         if (!synth)
-            hipLaunchKernelGGL((radix_rank_kernel<int32_t, uint32_t, kItems, kPairs, kMinWaves, kThreads, kEarly, kLds>), dim3((unsigned)ntiles), dim3(kThreads), 0, 0,
-                               B.k0, (const int32_t *)B.v0, B.k2, B.v2, m, shift, 8, B.digit_offset + (shift / 8) * 256, B.status, B.ctl, B.sticky);
+            hipLaunchKernelGGL((radix_rank_kernel<int32_t, uint32_t, kItems, kPairMode, kMinWaves, kThreads, kEarly, kLds, kRounds>), dim3((unsigned)ntiles), dim3(kThreads), 0, 0,
+                               B.k0, (const int32_t *)B.v0, B.k2, B.v2, m, shift, 8, 0, B.digit_offset + (shift / 8) * 256, B.status, B.ctl, B.sticky);
     };
     float ms = time_it(f);
     OnesweepCtl h; CK(hipMemcpy(&h, B.ctl, sizeof h, hipMemcpyDeviceToHost));
-    printf("%-22s thr=%4d items=%2d minw=%d early=%d ldsmatch=%d : %8.1f us  %7.1f GB/s alg%s\n", tag, kThreads, kItems, kMinWaves, (int)kEarly, (int)kLds, ms * 1e3,
-           (double)m * (synth ? 20 : 24) / (ms * 1e-3) / 1e9, h.error ? "  LOOKBACK TIMEOUT" : "");
+    printf("%-22s thr=%4d items=%2d minw=%d ldsmatch=%d rounds=%d keysonly=%d : %8.1f us  %7.1f GB/s alg%s\n", tag, kThreads, kItems, kMinWaves, (int)kLds, kRounds, (int)(kPairMode == kKeys), ms * 1e3,
+           (double)m * (synth ? 20 : (kPairMode == kKeys ? 16 : 24)) / (ms * 1e-3) / 1e9, h.error ? "  LOOKBACK TIMEOUT" : "");
     return ms;
 }
 
@@ -103,8 +103,8 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize());
     {
         float t_th = time_it([&]() {
-            hipLaunchKernelGGL(text_hist_kernel, dim3(kHistBlocks), dim3(kBlock), 0, 0, (const uint8_t *)B.text, m, B.partial);
-            hipLaunchKernelGGL(text_hist_reduce_kernel, dim3(1), dim3(kBlock), 0, 0, (const uint32_t *)B.partial, kHistBlocks, B.bytehist);
+            CK(hipMemsetAsync(B.bytehist, 0, 256 * 8));
+            hipLaunchKernelGGL(text_hist_kernel, dim3(kHistBlocks), dim3(kBlock), 0, 0, (const uint8_t *)B.text, m, (unsigned long long *)B.bytehist);
             hipLaunchKernelGGL(text_digit_offsets_kernel, dim3(8), dim3(kBlock), 0, 0, (const int64_t *)B.bytehist, (const uint8_t *)B.text, m, 8, B.digit_offset_text); });
         printf("text hist + reduce + offsets %8.1f us\n", t_th * 1e3);
     }
@@ -146,13 +146,16 @@ int main(int argc, char **argv)
     }
     // ---- onesweep variants
 #define CHECK() printf("   keys %s  vals %s\n", same(B.k1, B.k2, m * 8) ? "MATCH" : "DIFFER", same(B.v1, B.v2, m * 4) ? "MATCH" : "DIFFER")
-    run_onesweep<20, 2, 256, false, false>(B, m, shift, false, "onesweep"); CHECK();
-    run_onesweep<20, 2, 256, false, true>(B, m, shift, false, "onesweep"); CHECK();
-    run_onesweep<16, 2, 256, false, true>(B, m, shift, false, "onesweep"); CHECK();
-    run_onesweep<16, 2, 512, false, false>(B, m, shift, false, "onesweep"); CHECK();
-    run_onesweep<16, 2, 512, false, true>(B, m, shift, false, "onesweep"); CHECK();
-    run_onesweep<12, 1, 1024, false, true>(B, m, shift, false, "onesweep"); CHECK();
-    run_onesweep<20, 2, 256, false, true>(B, m, shift, true, "onesweep text-pass0");
-    run_onesweep<16, 2, 512, false, true>(B, m, shift, true, "onesweep text-pass0");
+#define CHECKK() printf("   keys %s\n", same(B.k1, B.k2, m * 8) ? "MATCH" : "DIFFER")
+#define KV(I, W, T, LM, R) run_onesweep<I, W, T, false, LM, R, kKeys>(B, m, shift, false, "keys"); CHECKK();
+#define PV(I, W, T, LM, R) run_onesweep<I, W, T, false, LM, R, kPairs>(B, m, shift, false, "pairs"); CHECK();
+    KV(16, 2, 512, false, 1) KV(20, 2, 512, false, 2) KV(24, 2, 512, false, 2) KV(24, 2, 512, true, 2)
+    KV(24, 2, 512, false, 1) KV(24, 2, 512, false, 4) KV(28, 2, 512, false, 2) KV(28, 2, 512, true, 4)
+    KV(16, 2, 768, false, 2) KV(16, 2, 768, true, 2) KV(20, 1, 768, false, 2) KV(12, 2, 1024, false, 2) KV(12, 2, 1024, true, 2)
+    PV(16, 2, 512, false, 1) PV(20, 2, 512, false, 2) PV(24, 2, 512, false, 2) PV(24, 2, 512, true, 2) PV(24, 2, 512, false, 4)
+    PV(16, 2, 768, false, 2) PV(16, 2, 768, true, 2) PV(12, 2, 1024, false, 2)
+    run_onesweep<16, 2, 512, false, false, 1>(B, m, shift, true, "text-pass0");
+    run_onesweep<24, 2, 512, false, false, 2>(B, m, shift, true, "text-pass0");
+    run_onesweep<24, 2, 512, false, true, 2>(B, m, shift, true, "text-pass0");
     return 0;
 }
