@@ -27,6 +27,7 @@
 #include "dq_onesweep.h"
 #include "dq_radix.h"
 #include "dq_sa_kernels.h"
+#include "dq_seg_fused.h"
 
 namespace {
 
@@ -178,6 +179,8 @@ struct Workspace {
     int64_t *bytehist;          // [256]
     char *ctl_status;           // OnesweepCtl (256 B) followed by the status words
     size_t ctl_status_bytes;
+    char *seg_status;           // SegCtl (256 B) followed by 3 x ntiles status words
+    size_t seg_status_bytes;
     size_t bytes;
 };
 
@@ -207,6 +210,8 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.bytehist = (int64_t *)take((size_t)kRadixSize * 8);
     w.ctl_status_bytes = 256 + (un / 4096 + 2) * kRadixSize * 8;
     w.ctl_status = take(w.ctl_status_bytes);
+    w.seg_status_bytes = 256 + 3 * (un / kSegTile + 2) * 8;
+    w.seg_status = take(w.seg_status_bytes);
     w.bytes = off;
     return w;
 }
@@ -443,6 +448,42 @@ int seg_count(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *key
     return DQ_OK;
 }
 
+// Rebucket a list sorted by (composite) key: group heads, device-wide scan, SA / ISA
+// scatter, compaction of the still-tied suffixes into (act_rank, act_suf); *active_out = their
+// number.  Engine 1: one fused single-pass kernel; engine 0: the legacy three kernels.
+// kInitial never writes ISA (it is built later, and only on the dense path).
+template <typename IdxT, bool kInitial, bool kWriteSA, bool kWriteISA>
+int rebucket(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *keys, const IdxT *vals,
+             int64_t m, int kbits, int kshift, IdxT *SA, uint64_t *act_rank, IdxT *act_suf,
+             int64_t *active_out)
+{
+    const int64_t wb = (int64_t)sizeof(IdxT);
+    if (sort_engine() == 1) {
+        const int64_t ntiles = (m + kSegFusedTile - 1) / kSegFusedTile;
+        const size_t need = 256 + (size_t)3 * ntiles * 8;
+        if (need > w.seg_status_bytes) return fail(DQ_ERR_HIP, "seg status buffer too small");
+        HIP_TRY(hipMemsetAsync(w.seg_status, 0, need, L.st));
+        LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + (kWriteSA ? 2 * wb : 0) + (kWriteISA ? wb : 0)),
+               hipLaunchKernelGGL((seg_fused_kernel<IdxT, kInitial, kWriteSA, kWriteISA>),
+                                  dim3((unsigned)ntiles), dim3(kSegThreads), 0, L.st, keys, vals, m, kbits, kshift, SA, w.ISA, act_rank,
+                                  act_suf, reinterpret_cast<uint64_t *>(w.seg_status + 256), ntiles,
+                                  reinterpret_cast<SegCtl *>(w.seg_status), w.totals, w.totals + 1));
+        HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, L.st));
+        HIP_TRY(hipStreamSynchronize(L.st));
+        *active_out = c.pinned[0];
+        if (c.pinned[1] != 0) return fail(DQ_ERR_HIP, "device look-back timed out (spin bound hit)");
+        return DQ_OK;
+    }
+    const int64_t ntiles = (m + kSegTile - 1) / kSegTile;
+    int rc = seg_count<IdxT, kInitial>(L, c, w, keys, m, kbits, active_out, kshift);
+    if (rc != DQ_OK) return rc;
+    LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + wb + wb + wb),
+           hipLaunchKernelGGL((seg_apply_kernel<IdxT, kInitial, kWriteSA, kWriteISA>), dim3((unsigned)ntiles),
+                              dim3(kBlock), 0, L.st, keys, vals, m, kbits, w.part, SA, w.ISA, act_rank,
+                              act_suf, kshift));
+    return DQ_OK;
+}
+
 // ------------------------------------------------------------------ the suffix sorter
 // d_text: the workspace's padded copy of the text; d_sa: n entries on the device.
 template <typename IdxT>
@@ -485,26 +526,24 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
         }
         // sorted keys (or packed words) are in K[cur], suffixes in d_sa
         const int kshift0 = packed ? bit_length((uint64_t)(n - 1)) : 0;
-        rc = seg_count<IdxT, true>(L, c, w, K[cur], n, 0, &active, kshift0);
+        uint64_t *act_rank = K[cur ^ 1];
+        rc = rebucket<IdxT, true, false, false>(L, c, w, K[cur], (const IdxT *)d_sa, n, 0, kshift0, d_sa,
+                                                act_rank, w.Va, &active);
         if (rc != DQ_OK) return rc;
         t_info[1] = active;
         if (active == 0) return flush_profile(c);
-        const int64_t nparts = (n + kSegTile - 1) / kSegTile;
-        uint64_t *act_rank = K[cur ^ 1];
-        // Few ties (random-like input): finish them by key extension from the text and skip the
-        // n random writes of a full inverse suffix array.  Many ties: build ISA now and double.
+        // Few ties (random-like input): finish them by direct comparison / key extension from the
+        // text and skip the n random writes of a full inverse suffix array.  Many ties: build the
+        // ISA now (all singletons rank = SA position, tied suffixes = their group rank) and double.
         bool sparse = active * 6 <= n;
         if (const char *v = getenv("DQ_SPARSE")) sparse = atoi(v) != 0;
-        if (sparse) {
-            LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb) + active * (8 + wb),
-                   hipLaunchKernelGGL((seg_apply_kernel<IdxT, true, false, false>), dim3((unsigned)nparts),
-                                      dim3(kBlock), 0, st, K[cur], (const IdxT *)d_sa, n, 0, w.part,
-                                      d_sa, w.ISA, act_rank, w.Va, kshift0));
-        } else {
-            LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb + wb) + active * (8 + wb),
-                   hipLaunchKernelGGL((seg_apply_kernel<IdxT, true, false, true>), dim3((unsigned)nparts),
-                                      dim3(kBlock), 0, st, K[cur], (const IdxT *)d_sa, n, 0, w.part,
-                                      d_sa, w.ISA, act_rank, w.Va, kshift0));
+        auto grid_for = [](int64_t items) { return (unsigned)std::min<int64_t>((items + kBlock - 1) / kBlock, 256 * 16); };
+        if (!sparse) {
+            LAUNCH(L, DQ_K_SEG_APPLY, n, n * 3 * wb,
+                   hipLaunchKernelGGL(isa_from_sa_kernel<IdxT>, dim3(grid_for(n)), dim3(kBlock), 0, st,
+                                      (const IdxT *)d_sa, w.ISA, n);
+                   hipLaunchKernelGGL(isa_scatter_kernel<IdxT>, dim3(grid_for(active)), dim3(kBlock), 0, st,
+                                      (const uint64_t *)act_rank, (const IdxT *)w.Va, w.ISA, active));
         }
         // refinement ping-pong: (act_rank buffer, Va) <-> (other key buffer, Vb)
         uint64_t *Kr[2] = {act_rank, K[cur]};
@@ -513,7 +552,6 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
         int64_t m = active;
         int64_t h = kb;                  // bytes already compared: the round-0 key width
         const int rbits = bit_length((uint64_t)(n - 1));
-        auto grid_for = [](int64_t items) { return (unsigned)std::min<int64_t>((items + kBlock - 1) / kBlock, 256 * 16); };
 
         if (sparse) {
             // tiny groups with a short remaining common prefix: finish by direct comparison
@@ -558,13 +596,9 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
                                         : radix_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, false, rcur);
                 if (rc != DQ_OK) return rc;
                 int64_t m2 = 0;
-                rc = seg_count<IdxT, false>(L, c, w, Kr[rcur], m, kbits, &m2);
+                rc = rebucket<IdxT, false, true, false>(L, c, w, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits, 0,
+                                                        d_sa, Kr[rcur ^ 1], Vr[rcur ^ 1], &m2);
                 if (rc != DQ_OK) return rc;
-                const int64_t np = (m + kSegTile - 1) / kSegTile;
-                LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + wb + wb) + m2 * (8 + wb),
-                       hipLaunchKernelGGL((seg_apply_kernel<IdxT, false, true, false>), dim3((unsigned)np),
-                                          dim3(kBlock), 0, st, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits,
-                                          w.part, d_sa, w.ISA, Kr[rcur ^ 1], Vr[rcur ^ 1], 0));
                 rcur ^= 1;
                 m = m2;
                 h += ebytes;
@@ -592,13 +626,9 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
                                     : radix_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, false, rcur);
             if (rc != DQ_OK) return rc;
             int64_t m2 = 0;
-            rc = seg_count<IdxT, false>(L, c, w, Kr[rcur], m, kbits, &m2);
+            rc = rebucket<IdxT, false, true, true>(L, c, w, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits, 0, d_sa,
+                                                   Kr[rcur ^ 1], Vr[rcur ^ 1], &m2);
             if (rc != DQ_OK) return rc;
-            const int64_t np = (m + kSegTile - 1) / kSegTile;
-            LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + wb + wb + wb) + m2 * (8 + wb),
-                   hipLaunchKernelGGL((seg_apply_kernel<IdxT, false, true, true>), dim3((unsigned)np),
-                                      dim3(kBlock), 0, st, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits,
-                                      w.part, d_sa, w.ISA, Kr[rcur ^ 1], Vr[rcur ^ 1], 0));
             rcur ^= 1;
             m = m2;
             h *= 2;
