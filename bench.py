@@ -40,6 +40,9 @@ def main() -> int:
     ap.add_argument("--workload", choices=["uniform", "enwik"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent timing")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="plumbing test on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -57,10 +60,15 @@ def main() -> int:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the suffix sorter has no CPU path")
     dq_build.build()                       # no-op when the in-tree .so is current
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     n = args.size_mib << 20
     seed = SEED + rank
@@ -98,7 +106,7 @@ def main() -> int:
     info = _abi.last_sort_info()
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
