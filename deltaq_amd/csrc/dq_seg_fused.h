@@ -220,7 +220,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
                 const IdxT rank = kInitial ? (IdxT)0 : (IdxT)(ck[k] >> kbits);
                 const IdxT nr = rank + (IdxT)(rn - rg);
                 if (kWriteSA) SA[rank + (IdxT)(j - rg)] = suf[k];
-                if (kWriteISA) ISA[suf[k]] = nr;
+                // ISA[s] already holds the parent rank: only members whose rank moved need a (random) write
+                if (kWriteISA && nr != rank) ISA[suf[k]] = nr;
                 if (act) {
                     const int64_t o = cc + __popcll(Ak & lt);
                     act_rank[o] = (uint64_t)nr;

@@ -177,8 +177,9 @@ struct Workspace {
     uint32_t *hist_partial;     // [kHistBlocks][8][256]
     int64_t *digit_offset;      // [8][256]
     int64_t *bytehist;          // [256]
-    char *ctl_status;           // OnesweepCtl (256 B) followed by the status words
+    char *ctl_status;           // per digit pass: OnesweepCtl (256 B) + the tiles' status words
     size_t ctl_status_bytes;
+    size_t ctl_status_stride;   // bytes per pass (set by prepare_status)
     char *seg_status;           // SegCtl (256 B) followed by 3 x ntiles status words
     size_t seg_status_bytes;
     size_t bytes;
@@ -208,7 +209,8 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.hist_partial = (uint32_t *)take((size_t)kHistBlocks * kMaxPasses * kRadixSize * 4);
     w.digit_offset = (int64_t *)take((size_t)kMaxPasses * kRadixSize * 8);
     w.bytehist = (int64_t *)take((size_t)kRadixSize * 8);
-    w.ctl_status_bytes = 256 + (un / 4096 + 2) * kRadixSize * 8;
+    // smallest tile is 8192 keys; 8-byte status words once a list reaches 2^30 entries
+    w.ctl_status_bytes = (size_t)kMaxPasses * align_up(256 + (un / 8192 + 2) * kRadixSize * (un >= (1ull << 30) ? 8 : 4));
     w.ctl_status = take(w.ctl_status_bytes);
     w.seg_status_bytes = 256 + 3 * (un / kSegTile + 2) * 8;
     w.seg_status = take(w.seg_status_bytes);
@@ -267,6 +269,19 @@ template <typename IdxT, int kMode> struct RankCfg {
     static constexpr bool kLdsMatch = kWords;
 };
 
+// Zero the look-back state (ticket + status words) of ALL digit passes of one sort with a single
+// memset, so the passes run back to back.
+template <typename IdxT>
+int prepare_status(Launcher &L, Workspace<IdxT> &w, int64_t m, int passes)
+{
+    const size_t word = m < (1ll << 30) ? 4 : 8;
+    const size_t stride = align_up(256 + ((size_t)m / 8192 + 2) * kRadixSize * word);
+    if ((size_t)passes * stride > w.ctl_status_bytes) return fail(DQ_ERR_HIP, "status buffer too small");
+    w.ctl_status_stride = stride;
+    HIP_TRY(hipMemsetAsync(w.ctl_status, 0, (size_t)passes * stride, L.st));
+    return DQ_OK;
+}
+
 template <typename IdxT, typename StatusT, int kMode>
 int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin,
                      uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb, int ib)
@@ -277,11 +292,12 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
     constexpr int kTileN = kThreads * kItems;
     const int64_t ntiles = (m + kTileN - 1) / kTileN;
     const int64_t wb = (int64_t)sizeof(IdxT);
-    OnesweepCtl *ctl = reinterpret_cast<OnesweepCtl *>(w.ctl_status);
-    StatusT *status = reinterpret_cast<StatusT *>(w.ctl_status + 256);
-    const size_t need = 256 + (size_t)ntiles * kRadixSize * sizeof(StatusT);
-    if (need > w.ctl_status_bytes) return fail(DQ_ERR_HIP, "status buffer too small");
-    HIP_TRY(hipMemsetAsync(w.ctl_status, 0, need, L.st));
+    // the status area of every pass of this sort was zeroed by prepare_status()
+    char *area = w.ctl_status + (size_t)pass * w.ctl_status_stride;
+    OnesweepCtl *ctl = reinterpret_cast<OnesweepCtl *>(area);
+    StatusT *status = reinterpret_cast<StatusT *>(area + 256);
+    if (256 + (size_t)ntiles * kRadixSize * sizeof(StatusT) > w.ctl_status_stride)
+        return fail(DQ_ERR_HIP, "status buffer too small");
     // algorithmic bytes per element: what the pass must read + write
     const int64_t alg = kMode == kPairs ? 2 * (8 + wb) : kMode == kText ? 1 + 8 + wb
                       : kMode == kTextPacked ? 1 + 8 : kMode == kKeys ? 16 : 16 + wb;
@@ -331,6 +347,8 @@ int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V
                        (const uint32_t *)w.hist_partial, blocks, w.digit_offset);
     HIP_TRY(hipGetLastError());
     rc = L.end();
+    if (rc != DQ_OK) return rc;
+    rc = prepare_status<IdxT>(L, w, m, passes);
     if (rc != DQ_OK) return rc;
     for (int p = 0; p < passes; ++p) {
         rc = rank_pass<IdxT, kPairs>(L, w, K[cur], V[cur], K[cur ^ 1], V[cur ^ 1], m, p, 8);
@@ -402,7 +420,8 @@ int onesweep_sort_text_passes(Launcher &L, Workspace<IdxT> &w, int64_t n, uint64
                               int kb, bool packed, IdxT *d_sa, int &cur)
 {
     const uint64_t *text64 = reinterpret_cast<const uint64_t *>(w.text);
-    int rc;
+    int rc = prepare_status<IdxT>(L, w, n, kb);
+    if (rc != DQ_OK) return rc;
     if (packed) {
         const int ib = bit_length((uint64_t)(n - 1));
         rc = rank_pass<IdxT, kTextPacked>(L, w, text64, (const IdxT *)nullptr, K[1], (IdxT *)nullptr, n, 0, kb, ib);

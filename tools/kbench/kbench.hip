@@ -149,13 +149,8 @@ int main(int argc, char **argv)
 #define CHECKK() printf("   keys %s\n", same(B.k1, B.k2, m * 8) ? "MATCH" : "DIFFER")
 #define KV(I, W, T, LM, R) run_onesweep<I, W, T, false, LM, R, kKeys>(B, m, shift, false, "keys"); CHECKK();
 #define PV(I, W, T, LM, R) run_onesweep<I, W, T, false, LM, R, kPairs>(B, m, shift, false, "pairs"); CHECK();
-    KV(16, 2, 512, false, 1) KV(20, 2, 512, false, 2) KV(24, 2, 512, false, 2) KV(24, 2, 512, true, 2)
-    KV(24, 2, 512, false, 1) KV(24, 2, 512, false, 4) KV(28, 2, 512, false, 2) KV(28, 2, 512, true, 4)
-    KV(16, 2, 768, false, 2) KV(16, 2, 768, true, 2) KV(20, 1, 768, false, 2) KV(12, 2, 1024, false, 2) KV(12, 2, 1024, true, 2)
-    PV(16, 2, 512, false, 1) PV(20, 2, 512, false, 2) PV(24, 2, 512, false, 2) PV(24, 2, 512, true, 2) PV(24, 2, 512, false, 4)
-    PV(16, 2, 768, false, 2) PV(16, 2, 768, true, 2) PV(12, 2, 1024, false, 2)
-    run_onesweep<16, 2, 512, false, false, 1>(B, m, shift, true, "text-pass0");
-    run_onesweep<24, 2, 512, false, false, 2>(B, m, shift, true, "text-pass0");
-    run_onesweep<24, 2, 512, false, true, 2>(B, m, shift, true, "text-pass0");
+    KV(24, 2, 512, true, 2) KV(28, 2, 512, true, 2) KV(32, 2, 512, true, 2) KV(32, 2, 512, true, 4) KV(40, 1, 512, true, 4)
+    KV(24, 2, 512, false, 2) KV(32, 2, 512, false, 4) KV(16, 2, 1024, true, 2) KV(20, 1, 1024, true, 2) KV(24, 1, 1024, true, 4)
+    PV(20, 2, 512, false, 2) PV(20, 2, 512, true, 2) PV(24, 1, 512, true, 2) PV(16, 1, 1024, false, 2)
     return 0;
 }

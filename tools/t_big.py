@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: 2 GiB uniform random, 64-bit SA, checked by sufcheck_i64 + sampled strict order.
+Also config 3 timing (256 MiB enwik-like) device-resident with the per-kernel profile."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import oracle
+from deltaq_amd import HipSuffixSort, _abi, workload
+from tools import datagen
+
+L = _abi.load(); s = HipSuffixSort(0)
+which = sys.argv[1] if len(sys.argv) > 1 else "enwik"
+if which == "2g":
+    n = 1 << 31
+    t0 = time.time(); T = workload.gen_uniform(n, 0x5EED0004); print("gen", round(time.time() - t0, 1), "s", flush=True)
+    dT = torch.from_numpy(T).cuda()
+    out = torch.empty(n, dtype=torch.int64, device="cuda")
+    print("workspace GiB", L.dq_sufsort_hip_workspace_bytes(n, 8) / 2**30, flush=True)
+    t0 = time.time(); s.Sort(dT, out); torch.cuda.synchronize(); print("sort (first call)", round(time.time() - t0, 3), "s", _abi.last_sort_info(), flush=True)
+    t0 = time.time(); s.Sort(dT, out); torch.cuda.synchronize(); dt = time.time() - t0
+    print(f"2 GiB i64 device-resident: {dt*1e3:.1f} ms = {n/1e6/dt:.0f} MB/s", flush=True)
+    SA = out.cpu().numpy()
+    t0 = time.time(); rc = oracle.sufcheck(T, SA); print("sufcheck_i64", rc, round(time.time() - t0, 1), "s", flush=True)
+    print("sampled strict order (1e6 pairs):", oracle.verify_sampled(T, SA, 1_000_000, 7), flush=True)
+else:
+    n = 256 << 20
+    T = datagen.gen_enwik_like(n, 0xD17A0)
+    dT = torch.from_numpy(T).cuda(); out = torch.empty(n, dtype=torch.int32, device="cuda")
+    s.Sort(dT, out); torch.cuda.synchronize()
+    L.dq_profile_enable(1); L.dq_profile_reset()
+    t0 = time.time(); s.Sort(dT, out); torch.cuda.synchronize(); dt = time.time() - t0
+    L.dq_profile_enable(0)
+    print(f"enwik 256 MiB device-resident: {dt*1e3:.1f} ms = {n/1e6/dt:.0f} MB/s  {_abi.last_sort_info()}")
+    for k, v in _abi.profile_snapshot().items():
+        if v["launches"]:
+            print(f"   {k:24s} launches={v['launches']:4d} total={v['ms']:9.3f} ms  alg={v['alg_bytes']/max(v['ms'],1e-9)/1e6:8.1f} GB/s")
+    SA = out.cpu().numpy()
+    print("sufcheck", oracle.sufcheck(T, SA), "sampled", oracle.verify_sampled(T, SA, 1_000_000, 3))
