@@ -116,13 +116,24 @@ def main() -> int:
         value = total_mb / elapsed
         rs = prof["radix_rank_kernel"]
         roofline = None
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and args.workload == "uniform" and args.size_mib == 64:
+            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+            # separate runs of this same command, tools/profile_gpu.sh): 2*FETCH_SIZE + WRITE_SIZE
+            try:
+                tj = json.load(open(tpath))
+                traffic = int(tj["radix_rank_kernel"]["hbm_bytes_per_launch"])
+                traffic_src = "profiles/traffic.json (rocprofv3 PMC, 2*FETCH_SIZE+WRITE_SIZE per launch)"
+            except Exception:
+                traffic = None
         if rs["launches"]:
             achieved = rs["alg_bytes"] / (rs["ms"] * 1e-3) / 1e9
             roofline = {
                 "kernel": "radix_rank_kernel", "bound": "hbm",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic, "traffic_source": traffic_src,
                 "launches": rs["launches"],
                 "avg_launch_us": round(rs["ms"] / rs["launches"] * 1e3, 2),
                 "alg_bytes_per_launch": rs["alg_bytes"] // rs["launches"],

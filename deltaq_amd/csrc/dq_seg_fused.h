@@ -94,44 +94,57 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
     __syncthreads();
     const int64_t tile = s_tile;
     const int64_t wb = tile * kSegFusedTile + (int64_t)w * kSegWaveN;     // this wave's first entry
+    // everything inside the wave's range is addressed with 32-bit offsets from wb
+    const uint64_t *kp = keys + wb;
+    const IdxT *vp = vals + wb;
+    const int64_t left = m - wb;
+    const int nv = left >= kSegWaveN ? kSegWaveN : (left > 0 ? (int)left : 0);   // entries that exist
+    const IdxT wb_i = (IdxT)wb;
 
     // ---- coalesced, wave-striped load ----
     uint64_t ck[kSegK];
 #pragma unroll
     for (int k = 0; k < kSegK; ++k) {
-        const int64_t j = wb + k * kWave + lane;
-        ck[k] = j < m ? keys[j] >> kshift : 0;
+        const int e = k * kWave + lane;
+        ck[k] = e < nv ? kp[e] >> kshift : 0;
     }
     // one entry of halo on each side of the wave's range (wave-uniform values)
-    const uint64_t halo_prev = (wb > 0 && wb <= m) ? keys[wb - 1] >> kshift : 0;
-    const bool has_after = wb + kSegWaveN < m;
+    const uint64_t halo_prev = (wb > 0 && left >= 0) ? keys[wb - 1] >> kshift : 0;
+    const bool has_after = left > kSegWaveN;
     const uint64_t halo_next = has_after ? keys[wb + kSegWaveN] >> kshift : 0;
 
     // ---- per item: ballot masks of group heads (H), parent-group heads (G) and of the members
     //      of groups of size > 1 (A).  A_k needs H_{k+1}, so it is finished one item later.  The
     //      masks are parked in LDS (wave-uniform 64-bit values x 48 would overflow the SGPR file) ----
     __shared__ uint64_t m_H[kSegWaves][kSegK], m_G[kSegWaves][kSegK], m_A[kSegWaves][kSegK];
-    int64_t wave_nh = -1, wave_gh = -1, wave_cnt = 0;
-    const int64_t nvalid = m - wb;                                   // entries of this wave's range that exist
+    int wave_nh = -1, wave_gh = -1, wave_cnt = 0;                     // local (offset from wb), or -1
     uint64_t Hprev = 0, Vprev = 0;                                   // masks of item k-1
 #pragma unroll
     for (int k = 0; k <= kSegK; ++k) {
         uint64_t Hk = 0, Gk = 0, Vk = 0;
         if (k < kSegK) {
-            const int64_t j = wb + k * kWave + lane;
-            // key of the previous entry: lane-1 of this item, lane 63 of the previous item, or the halo
-            uint64_t pk = __shfl_up(ck[k], 1, kWave);
-            const uint64_t edge = k == 0 ? halo_prev : __shfl(ck[k > 0 ? k - 1 : 0], kWave - 1, kWave);
+            const int e = k * kWave + lane;
+            // key of the previous entry: lane-1 of this item (DPP wave shift), lane 63 of the
+            // previous item, or the halo
+            const uint32_t plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)ck[k], 0x138, 0xf, 0xf, false);
+            const uint32_t phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(ck[k] >> 32), 0x138, 0xf, 0xf, false);
+            uint64_t pk = ((uint64_t)phi << 32) | plo;
+            uint64_t edge = halo_prev;
+            if (k > 0) {
+                const uint64_t q = ck[k > 0 ? k - 1 : 0];
+                edge = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q >> 32), kWave - 1) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q, kWave - 1);
+            }
             if (lane == 0) pk = edge;
-            const bool valid = j < m;
-            const bool first = (j == 0);
+            const bool valid = e < nv;
+            const bool first = (wb == 0 && e == 0);
             Hk = __ballot(valid && (first || ck[k] != pk));
             Gk = kInitial ? (wb == 0 && k == 0 ? 1ull : 0ull)
                           : __ballot(valid && (first || (ck[k] >> kbits) != (pk >> kbits)));
-            const int64_t rem = nvalid - (int64_t)k * kWave;
+            const int rem = nv - k * kWave;
             Vk = rem >= kWave ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1));
-            if (Hk) wave_nh = wb + k * kWave + (63 - __builtin_clzll(Hk));
-            if (Gk) wave_gh = wb + k * kWave + (63 - __builtin_clzll(Gk));
+            if (Hk) wave_nh = k * kWave + (63 - __builtin_clzll(Hk));
+            if (Gk) wave_gh = k * kWave + (63 - __builtin_clzll(Gk));
             if (lane == 0) { m_H[w][k] = Hk; if (!kInitial) m_G[w][k] = Gk; }
         }
         if (k > 0) {
@@ -141,7 +154,10 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
             uint64_t next0;
             if (k < kSegK) next0 = (Hk | ~Vk) & 1ull;
             else {
-                const uint64_t last_key = __shfl(ck[kSegK - 1], kWave - 1, kWave);
+                const uint64_t q = ck[kSegK - 1];
+                const uint64_t last_key =
+                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q >> 32), kWave - 1) << 32) |
+                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q, kWave - 1);
                 next0 = (!has_after || halo_next != last_key) ? 1ull : 0ull;
             }
             const uint64_t Ak = Vprev & ~(Hprev & ((hx >> 1) | (next0 << 63)));
@@ -150,7 +166,11 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
         }
         Hprev = Hk; Vprev = Vk;
     }
-    if (lane == 0) { w_nh[w] = wave_nh; w_gh[w] = wave_gh; w_cnt[w] = wave_cnt; }
+    if (lane == 0) {
+        w_nh[w] = wave_nh >= 0 ? wb + wave_nh : -1;
+        w_gh[w] = wave_gh >= 0 ? wb + wave_gh : -1;
+        w_cnt[w] = wave_cnt;
+    }
     __syncthreads();
 
     // ---- publish the tile's aggregates and look back: wave f handles field f ----
@@ -167,11 +187,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
             __hip_atomic_store(st + tile, (tile == 0 ? kSegPrefix : kSegAgg) | agg, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         uint64_t pf = 0;
-#ifdef DQ_X_NOLB
-        if (false) {
-#else
         if (tile > 0) {
-#endif
             pf = (w == 2) ? seg_lookback<true>(st, tile, ctl, sticky_error)
                           : seg_lookback<false>(st, tile, ctl, sticky_error);
             const uint64_t incl = (w == 2) ? pf + agg : (agg > pf ? agg : pf);
@@ -184,42 +200,40 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
     __syncthreads();
 
     // ---- running values at the start of this wave: tile prefix + earlier waves of the tile ----
-    int64_t cn = (int64_t)s_prefix[0] - 1, cg = (int64_t)s_prefix[1] - 1, cc = (int64_t)s_prefix[2];
+    int64_t cn64 = (int64_t)s_prefix[0] - 1, cg64 = (int64_t)s_prefix[1] - 1, cc = (int64_t)s_prefix[2];
     for (int i = 0; i < w; ++i) {
-        cn = w_nh[i] > cn ? w_nh[i] : cn;
-        cg = w_gh[i] > cg ? w_gh[i] : cg;
+        cn64 = w_nh[i] > cn64 ? w_nh[i] : cn64;
+        cg64 = w_gh[i] > cg64 ? w_gh[i] : cg64;
         cc += w_cnt[i];
     }
+    IdxT cn = (IdxT)cn64, cg = (IdxT)cg64;           // list positions fit the index type
 
-#ifdef DQ_X_NOAPPLY
-    if (cn != -12345) return;
-#endif
     // ---- apply ----
     const uint64_t le = (2ull << lane) - 1;          // bits at or below my lane
     const uint64_t lt = le >> 1;                     // bits strictly below
+    const uint64_t lb = 1ull << lane;
     // issue every suffix load first (independent, in flight together)
     IdxT suf[kSegK];
 #pragma unroll
     for (int k = 0; k < kSegK; ++k) {
-        const int64_t j = wb + k * kWave + lane;
-        const bool need = (kWriteSA || kWriteISA) ? (j < m) : (bool)((m_A[w][k] >> lane) & 1);
-        suf[k] = need ? vals[j] : (IdxT)0;
+        const int e = k * kWave + lane;
+        const bool need = (kWriteSA || kWriteISA) ? (e < nv) : ((m_A[w][k] & lb) != 0);
+        suf[k] = need ? vp[e] : (IdxT)0;
     }
 #pragma unroll
     for (int k = 0; k < kSegK; ++k) {
-        const int64_t jk = wb + k * kWave;
-        const int64_t j = jk + lane;
+        const int e = k * kWave + lane;
         const uint64_t Hk = m_H[w][k], Ak = m_A[w][k];
         const uint64_t Gk = kInitial ? (wb == 0 && k == 0 ? 1ull : 0ull) : m_G[w][k];
-        const bool act = (Ak >> lane) & 1;
-        if ((kWriteSA || kWriteISA) ? (jk < m) : (Ak != 0)) {                 // wave-uniform skip
-            const uint64_t hm = Hk & le, gm = Gk & le;
-            const int64_t rn = hm ? jk + (63 - __builtin_clzll(hm)) : cn;
-            const int64_t rg = gm ? jk + (63 - __builtin_clzll(gm)) : cg;
-            if (j < m) {
+        if ((kWriteSA || kWriteISA) ? (k * kWave < nv) : (Ak != 0)) {          // wave-uniform skip
+            const bool act = (Ak & lb) != 0;
+            if ((kWriteSA || kWriteISA) ? (e < nv) : act) {
+                const uint64_t hm = Hk & le, gm = Gk & le;
+                const IdxT rn = hm ? wb_i + (IdxT)(k * kWave + 63 - __builtin_clzll(hm)) : cn;
+                const IdxT rg = gm ? wb_i + (IdxT)(k * kWave + 63 - __builtin_clzll(gm)) : cg;
                 const IdxT rank = kInitial ? (IdxT)0 : (IdxT)(ck[k] >> kbits);
-                const IdxT nr = rank + (IdxT)(rn - rg);
-                if (kWriteSA) SA[rank + (IdxT)(j - rg)] = suf[k];
+                const IdxT nr = rank + (rn - rg);
+                if (kWriteSA) SA[rank + (wb_i + (IdxT)e - rg)] = suf[k];
                 // ISA[s] already holds the parent rank: only members whose rank moved need a (random) write
                 if (kWriteISA && nr != rank) ISA[suf[k]] = nr;
                 if (act) {
@@ -229,8 +243,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
                 }
             }
         }
-        if (Hk) cn = jk + (63 - __builtin_clzll(Hk));
-        if (Gk) cg = jk + (63 - __builtin_clzll(Gk));
+        if (Hk) cn = wb_i + (IdxT)(k * kWave + 63 - __builtin_clzll(Hk));
+        if (Gk) cg = wb_i + (IdxT)(k * kWave + 63 - __builtin_clzll(Gk));
         cc += __popcll(Ak);
     }
 }

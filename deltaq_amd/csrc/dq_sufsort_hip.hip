@@ -708,6 +708,8 @@ int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device)
     if (rc != DQ_OK) return rc;
     w = carve<IdxT>(c.ws, n, true);
     hipStream_t st = c.stream;
+    // The caller's buffers are ordinary pageable memory; the runtime's staged copies already run
+    // at PCIe rate here (page-locking them per call with hipHostRegister measured no gain).
     HIP_TRY(hipMemcpyAsync(w.text, text, (size_t)n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(w.text + n, 0, 64, st));
     rc = sufsort_device<IdxT>(c, st, w, n, w.SAbuf);
