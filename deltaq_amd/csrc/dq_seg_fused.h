@@ -72,8 +72,8 @@ __device__ __forceinline__ uint64_t seg_lookback(uint64_t *st, int64_t tile, Seg
 }
 
 // kInitial: one parent group [0, m) of rank 0, keys = round-0 keys (>> kshift for packed words);
-//           only compaction is produced (SA already holds the suffixes, ISA is built later
-//           and only if the dense path is taken).
+//           SA already holds the suffixes; ISA is written for every entry only with kWriteISA
+//           (dense path predicted), otherwise it is built later if the dense path is taken.
 // else:     composite keys (rank << kbits | key2); writes SA (kWriteSA) / ISA (kWriteISA).
 // totals[0] receives the number of still-active suffixes.
 template <typename IdxT, bool kInitial, bool kWriteSA, bool kWriteISA>
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
                 const IdxT nr = rank + (rn - rg);
                 if (kWriteSA) SA[rank + (wb_i + (IdxT)e - rg)] = suf[k];
                 // ISA[s] already holds the parent rank: only members whose rank moved need a (random) write
-                if (kWriteISA && nr != rank) ISA[suf[k]] = nr;
+                if (kWriteISA && (kInitial || nr != rank)) ISA[suf[k]] = nr;
                 if (act) {
                     const int64_t o = cc + __popcll(Ak & lt);
                     act_rank[o] = (uint64_t)nr;

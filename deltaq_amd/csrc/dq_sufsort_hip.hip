@@ -182,6 +182,7 @@ struct Workspace {
     size_t ctl_status_stride;   // bytes per pass (set by prepare_status)
     char *seg_status;           // SegCtl (256 B) followed by 3 x ntiles status words
     size_t seg_status_bytes;
+    uint8_t *flags;             // one class byte per tied suffix (small-group rounds)
     size_t bytes;
 };
 
@@ -214,6 +215,7 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.ctl_status = take(w.ctl_status_bytes);
     w.seg_status_bytes = 256 + 3 * (un / kSegTile + 2) * 8;
     w.seg_status = take(w.seg_status_bytes);
+    w.flags = (uint8_t *)take(un + 64);
     w.bytes = off;
     return w;
 }
@@ -503,6 +505,31 @@ int rebucket(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *keys
     return DQ_OK;
 }
 
+// Order-preserving compaction of the (rank, suffix) entries whose class byte == keep_val.
+template <typename IdxT>
+int compact_class(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint8_t *cls, int keep_val,
+                  const uint64_t *rank, const IdxT *suf, int64_t m, uint64_t *rank_out, IdxT *suf_out,
+                  int64_t *count_out)
+{
+    const int64_t wb = (int64_t)sizeof(IdxT);
+    const int64_t np = (m + kSegTile - 1) / kSegTile;
+    LAUNCH(L, DQ_K_SEG_REDUCE, m, m,
+           hipLaunchKernelGGL(compact_count_kernel<IdxT>, dim3((unsigned)np), dim3(kBlock), 0, L.st, cls, m,
+                              w.part, keep_val));
+    LAUNCH(L, DQ_K_SEG_SCAN, np, np * 6 * wb,
+           hipLaunchKernelGGL(seg_scan_kernel<IdxT>, dim3(1), dim3(1024), 0, L.st, w.part, np, w.totals));
+    HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, L.st));
+    HIP_TRY(hipStreamSynchronize(L.st));
+    const int64_t cnt = c.pinned[0];
+    if (cnt > 0) {
+        LAUNCH(L, DQ_K_SEG_APPLY, m, m + cnt * 2 * (8 + wb),
+               hipLaunchKernelGGL(compact_scatter_kernel<IdxT>, dim3((unsigned)np), dim3(kBlock), 0, L.st, cls,
+                                  rank, suf, m, w.part, rank_out, suf_out, keep_val));
+    }
+    *count_out = cnt;
+    return DQ_OK;
+}
+
 // ------------------------------------------------------------------ the suffix sorter
 // d_text: the workspace's padded copy of the text; d_sa: n entries on the device.
 template <typename IdxT>
@@ -546,18 +573,39 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
         // sorted keys (or packed words) are in K[cur], suffixes in d_sa
         const int kshift0 = packed ? bit_length((uint64_t)(n - 1)) : 0;
         uint64_t *act_rank = K[cur ^ 1];
-        rc = rebucket<IdxT, true, false, false>(L, c, w, K[cur], (const IdxT *)d_sa, n, 0, kshift0, d_sa,
-                                                act_rank, w.Va, &active);
+        // Few ties (random-like input): finish them by direct comparison / key extension from the
+        // text and skip the n random writes of a full inverse suffix array.  Many ties: the ISA is
+        // needed (singletons rank = SA position, tied suffixes = their group rank) for doubling.
+        // 4096 sampled adjacent pairs predict which, so that the dense case writes the ISA in the
+        // rebucket pass itself.
+        bool predict_dense = false;
+        // (inputs whose order-0 entropy already promised few ties -- packed words or a short key --
+        // skip the sample and its host round trip)
+        if (sort_engine() == 1 && n >= (1 << 16) && !packed && kb == 8) {
+            constexpr int kSamples = 4096;
+            HIP_TRY(hipMemsetAsync(w.totals + 2, 0, 8, st));
+            hipLaunchKernelGGL(sample_ties_kernel, dim3(kSamples / kBlock), dim3(kBlock), 0, st,
+                               (const uint64_t *)K[cur], n, kshift0, kSamples, w.totals + 2);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(c.pinned, w.totals + 2, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            // a pair ties with probability ~ (tied fraction) * (1 - 1/group size); 1/12 ~ tied fraction 1/6
+            predict_dense = c.pinned[0] * 12 > kSamples;
+        }
+        if (const char *v = getenv("DQ_SPARSE")) predict_dense = atoi(v) == 0;
+        if (predict_dense)
+            rc = rebucket<IdxT, true, false, true>(L, c, w, K[cur], (const IdxT *)d_sa, n, 0, kshift0, d_sa,
+                                                   act_rank, w.Va, &active);
+        else
+            rc = rebucket<IdxT, true, false, false>(L, c, w, K[cur], (const IdxT *)d_sa, n, 0, kshift0, d_sa,
+                                                    act_rank, w.Va, &active);
         if (rc != DQ_OK) return rc;
         t_info[1] = active;
         if (active == 0) return flush_profile(c);
-        // Few ties (random-like input): finish them by direct comparison / key extension from the
-        // text and skip the n random writes of a full inverse suffix array.  Many ties: build the
-        // ISA now (all singletons rank = SA position, tied suffixes = their group rank) and double.
         bool sparse = active * 6 <= n;
         if (const char *v = getenv("DQ_SPARSE")) sparse = atoi(v) != 0;
         auto grid_for = [](int64_t items) { return (unsigned)std::min<int64_t>((items + kBlock - 1) / kBlock, 256 * 16); };
-        if (!sparse) {
+        if (!sparse && !predict_dense) {
             LAUNCH(L, DQ_K_SEG_APPLY, n, n * 3 * wb,
                    hipLaunchKernelGGL(isa_from_sa_kernel<IdxT>, dim3(grid_for(n)), dim3(kBlock), 0, st,
                                       (const IdxT *)d_sa, w.ISA, n);
@@ -632,11 +680,61 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
             }
         }
 
+        const bool no_small = getenv("DQ_NO_SMALL") != nullptr;
         while (m > 0) {
             t_info[0] += 1;
             t_info[2] += m;
             const int kbits = bit_length((uint64_t)(n - 1) + (uint64_t)h);
             if (kbits + rbits > 64) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
+            if (sort_engine() == 1 && !no_small && m * 2 <= n) {
+                // ---- small groups (<= 8) in registers, larger groups through the radix path.
+                //      X = (Ar, As)[0, m) is the list of tied suffixes (members of a group adjacent);
+                //      every buffer has room for n entries and m <= n/2, so the second halves are free.
+                constexpr int kMaxG = 8;
+                uint64_t *Ar = Kr[rcur], *Br = Kr[rcur ^ 1];
+                IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
+                const int64_t half = n / 2;
+                HIP_TRY(hipMemsetAsync(w.flags, 2, (size_t)m, st));
+                LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8 + wb + 1),
+                       hipLaunchKernelGGL((small_group_round_kernel<IdxT, kMaxG>), dim3((unsigned)((m + kBlock - 1) / kBlock)),
+                                          dim3(kBlock), 0, st, (const uint64_t *)Ar, (const IdxT *)As,
+                                          (const IdxT *)w.ISA, m, n, h, Br, Bs, w.flags));
+                int64_t m1 = 0, mL = 0;
+                rc = compact_class<IdxT>(L, c, w, w.flags, 1, Br, Bs, m, Ar + half, As + half, &m1);      // still tied, small
+                if (rc != DQ_OK) return rc;
+                rc = compact_class<IdxT>(L, c, w, w.flags, 2, Ar, As, m, Br + half, Bs + half, &mL);      // large groups
+                if (rc != DQ_OK) return rc;
+                // the large groups' key2 gather must see this round's ISA before anyone updates it
+                if (mL > 0) {
+                    LAUNCH(L, DQ_K_GATHER_KEY2, mL, mL * (8 + wb + wb + 8),
+                           hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3(grid_for(mL)), dim3(kBlock), 0, st,
+                                              Br + half, (const IdxT *)(Bs + half), (const IdxT *)w.ISA, mL, n, h,
+                                              kbits));
+                }
+                LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + 8 + wb + 1 + 2 * wb),
+                       hipLaunchKernelGGL((small_group_apply_kernel<IdxT, kMaxG>), dim3((unsigned)((m + kBlock - 1) / kBlock)),
+                                          dim3(kBlock), 0, st, (const uint64_t *)Ar, (const uint64_t *)Br,
+                                          (const IdxT *)Bs, (const uint8_t *)w.flags, m, d_sa, w.ISA));
+                // next list X' = [small survivors][large survivors] at the front of (Ar, As)
+                if (m1 > 0) {
+                    HIP_TRY(hipMemcpyAsync(Ar, Ar + half, (size_t)m1 * 8, hipMemcpyDeviceToDevice, st));
+                    HIP_TRY(hipMemcpyAsync(As, As + half, (size_t)m1 * sizeof(IdxT), hipMemcpyDeviceToDevice, st));
+                }
+                int64_t mLs = 0;
+                if (mL > 0) {
+                    uint64_t *Kx[2] = {Br + half, Ar + half + m1};
+                    IdxT *Vx[2] = {Bs + half, As + half + m1};
+                    int xcur = 0;
+                    rc = onesweep_sort_pairs<IdxT>(L, w, Kx, Vx, mL, kbits + rbits, xcur);
+                    if (rc != DQ_OK) return rc;
+                    rc = rebucket<IdxT, false, true, true>(L, c, w, Kx[xcur], (const IdxT *)Vx[xcur], mL, kbits, 0,
+                                                           d_sa, Ar + m1, As + m1, &mLs);
+                    if (rc != DQ_OK) return rc;
+                }
+                m = m1 + mLs;
+                h *= 2;
+                continue;
+            }
             LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8),
                    hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock),
                                       0, st, Kr[rcur], (const IdxT *)Vr[rcur], (const IdxT *)w.ISA, m,

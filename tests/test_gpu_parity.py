@@ -164,6 +164,7 @@ FORCED_PATHS = [
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "3", "DQ_SPARSE": "1"},   # pairs, sparse + fallback to dense
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "0"},   # pairs, 8-byte keys, dense doubling
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "1"},
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "4", "DQ_SPARSE": "0", "DQ_NO_SMALL": "1"},   # doubling without the small-group rounds
 ]
 
 
