@@ -93,7 +93,10 @@ def main() -> int:
     for _ in range(args.warmup):
         sorter.Sort(text, sa)
     L.dq_profile_reset()
-    L.dq_profile_enable(0 if args.no_profile else 1)
+    # timed region: hipEvents only around the dominant kernel (mode 2) -- bracketing all ~25
+    # launches of a sort costs ~6 % of the step; the other kernels are profiled in an extra,
+    # untimed pass below
+    L.dq_profile_enable(0 if args.no_profile else 2)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -104,6 +107,15 @@ def main() -> int:
     L.dq_profile_enable(0)
     prof = _abi.profile_snapshot()
     info = _abi.last_sort_info()
+    prof_all, all_steps = {}, 3
+    if not args.no_profile:
+        L.dq_profile_reset()
+        L.dq_profile_enable(1)
+        for _ in range(all_steps):
+            sorter.Sort(text, sa)
+        torch.cuda.synchronize(dev)
+        L.dq_profile_enable(0)
+        prof_all = _abi.profile_snapshot()
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -138,9 +150,9 @@ def main() -> int:
                 "avg_launch_us": round(rs["ms"] / rs["launches"] * 1e3, 2),
                 "alg_bytes_per_launch": rs["alg_bytes"] // rs["launches"],
             }
-        kernels = {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 4),
+        kernels = {k: {"launches_per_step": v["launches"] // all_steps, "ms_per_step": round(v["ms"] / all_steps, 4),
                        "alg_GBps": round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
-                   for k, v in prof.items() if v["launches"]}
+                   for k, v in prof_all.items() if v["launches"]}
         out = {
             "metric": "MB of text suffix-sorted per second (bit-exact SA)",
             "value": round(value, 2), "unit": "MB/s",
@@ -151,7 +163,7 @@ def main() -> int:
             "config": {"workload": wname, "bytes_per_gpu": n, "residency": "text and SA resident in HBM",
                        "rounds_after_initial_sort": info["rounds"], "sharding": f"{world} independent buffers"},
             "roofline": roofline,
-            "kernels": kernels,
+            "kernels_untimed_pass": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host, sa)

@@ -115,10 +115,12 @@ int ensure_ws(DeviceCtx &c, size_t bytes)
 struct Launcher {
     DeviceCtx &c;
     hipStream_t st;
-    bool prof;
+    int prof;                         // 0 off, 1 every kernel, 2 only radix_rank_kernel
+    bool active = false;
     int begin(int cat, int64_t elems, int64_t bytes)
     {
-        if (!prof) return DQ_OK;
+        active = prof == 1 || (prof == 2 && cat == DQ_K_RADIX_RANK_SCATTER);
+        if (!active) return DQ_OK;
         ProfRec r{cat, nullptr, nullptr, elems, bytes};
         for (hipEvent_t *ev : {&r.a, &r.b}) {
             if (!c.pool.empty()) { *ev = c.pool.back(); c.pool.pop_back(); }
@@ -130,7 +132,7 @@ struct Launcher {
     }
     int end()
     {
-        if (!prof) return DQ_OK;
+        if (!active) return DQ_OK;
         HIP_TRY(hipEventRecord(c.pending.back().b, st));
         return DQ_OK;
     }
@@ -535,7 +537,7 @@ int compact_class(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint8_t *
 template <typename IdxT>
 int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, IdxT *d_sa)
 {
-    Launcher L{c, st, g_prof_on.load() != 0};
+    Launcher L{c, st, g_prof_on.load()};
     const int64_t wb = (int64_t)sizeof(IdxT);
     t_info[0] = t_info[1] = t_info[2] = 0;
     HIP_TRY(hipMemsetAsync(w.totals, 0, 64, st));
@@ -944,7 +946,7 @@ void dq_sufsort_hip_release(void)
     }
 }
 
-int32_t dq_profile_enable(int32_t on) { g_prof_on.store(on ? 1 : 0); return DQ_OK; }
+int32_t dq_profile_enable(int32_t on) { g_prof_on.store(on == 2 ? 2 : (on ? 1 : 0)); return DQ_OK; }
 
 void dq_profile_reset(void)
 {

@@ -86,7 +86,7 @@ void dq_sufsort_hip_release(void);
 #define DQ_K_RADIX_HIST          8   /* text / key digit histograms + offset scans */
 #define DQ_K_COUNT               9
 
-int32_t dq_profile_enable(int32_t on);
+int32_t dq_profile_enable(int32_t on);   /* 0 off, 1 every kernel, 2 only radix_rank_kernel (cheapest) */
 void    dq_profile_reset(void);
 /* launches, summed milliseconds, summed elements processed, summed algorithmic bytes */
 int32_t dq_profile_get(int32_t category, int64_t *launches, double *total_ms, int64_t *elements,

@@ -209,3 +209,29 @@ def test_legacy_three_kernel_engine_matches(oracle_mod):
     env = dict(os.environ, DQ_SORT_ENGINE="sweep3")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_shared_provider_from_many_threads(ldss, oracle_mod):
+    """Providers are shared singletons in the reference's benchmark (SuffixSortingBenchmarks.cs:59-61):
+    every entry point must be re-entrant.  8 threads, one shared instance, different inputs."""
+    import threading
+    inputs = [oracle_mod.gen_uniform(300_000 + 1111 * i, 100 + i) if i % 2 == 0
+              else oracle_mod.gen_enwik_like(150_000 + 777 * i, 200 + i, 4096) for i in range(8)]
+    outs = [None] * len(inputs)
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                outs[i] = ldss.Sort(inputs[i])
+        except Exception as e:            # pragma: no cover
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(inputs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for T, SA in zip(inputs, outs):
+        assert np.array_equal(SA, oracle_mod.divsufsort(T))
