@@ -533,24 +533,59 @@ int compact_class(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint8_t *
 }
 
 // ------------------------------------------------------------------ the suffix sorter
-// d_text: the workspace's padded copy of the text; d_sa: n entries on the device.
+// One sort = one SuffixSorter.  State that survives between phases: the list of still-tied
+// suffixes X = (Kr[rcur], Vr[rcur])[0, m) as (group rank, suffix) with the members of a group
+// adjacent, and h = bytes already compared.
 template <typename IdxT>
-int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, IdxT *d_sa)
-{
-    Launcher L{c, st, g_prof_on.load()};
-    const int64_t wb = (int64_t)sizeof(IdxT);
-    t_info[0] = t_info[1] = t_info[2] = 0;
-    HIP_TRY(hipMemsetAsync(w.totals, 0, 64, st));
+struct SuffixSorter {
+    DeviceCtx &c;
+    hipStream_t st;
+    Workspace<IdxT> &w;        // w.text holds the padded text
+    int64_t n;
+    IdxT *d_sa;                // n entries on the device
+    Launcher L;
 
-    // ---- round 0: leading kb bytes of every suffix as a key, full radix ranking
-    int64_t active = 0;
+    static constexpr int64_t wb = (int64_t)sizeof(IdxT);
+    uint64_t *Kr[2] = {nullptr, nullptr};
+    IdxT *Vr[2] = {nullptr, nullptr};
+    int rcur = 0;
+    int64_t m = 0, h = 0;
+    int rbits = 0;
+
+    SuffixSorter(DeviceCtx &c_, hipStream_t st_, Workspace<IdxT> &w_, int64_t n_, IdxT *sa_)
+        : c(c_), st(st_), w(w_), n(n_), d_sa(sa_), L{c_, st_, g_prof_on.load()} {}
+
+    static unsigned grid_for(int64_t items)
+    {
+        return (unsigned)std::min<int64_t>((items + kBlock - 1) / kBlock, 256 * 16);
+    }
+
+    int sort_pairs(uint64_t *K[2], IdxT *V[2], int64_t cnt, int bits, int &cur)
+    {
+        return sort_engine() == 1 ? onesweep_sort_pairs<IdxT>(L, w, K, V, cnt, bits, cur)
+                                  : radix_sort_pairs<IdxT>(L, w, K, V, cnt, bits, false, cur);
+    }
+
+    // ISA[SA[p]] = p for everybody, then the tied suffixes get their group rank
+    int build_isa(const uint64_t *rank, const IdxT *suf, int64_t cnt)
+    {
+        LAUNCH(L, DQ_K_SEG_APPLY, n, n * 3 * wb,
+               hipLaunchKernelGGL(isa_from_sa_kernel<IdxT>, dim3(grid_for(n)), dim3(kBlock), 0, st,
+                                  (const IdxT *)d_sa, w.ISA, n);
+               hipLaunchKernelGGL(isa_scatter_kernel<IdxT>, dim3(grid_for(cnt)), dim3(kBlock), 0, st, rank, suf,
+                                  w.ISA, cnt));
+        return DQ_OK;
+    }
+
+    // ---- round 0: leading kb bytes of every suffix as a key (or packed word), full radix ranking,
+    //      then the first rebucket: X = members of groups of size > 1.  *dense_built tells whether
+    //      the rebucket pass already wrote the inverse suffix array.
+    int round0(bool *dense_built)
     {
         uint64_t *K[2] = {w.K0, w.K1};
         IdxT *V[2];
-        int cur = 0;
-        int kb = 8;
+        int cur = 0, kb = 8, rc;
         bool packed = false;
-        int rc;
         if (sort_engine() == 1) {
             // pass p writes buffer (p+1)&1, so the last pass (kb-1) writes buffer kb&1: that one
             // must be the caller's SA, which is why the key width is chosen first
@@ -564,8 +599,7 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
             const int64_t nquads = (n + 3) / 4;
             const int64_t blocks = std::min<int64_t>((nquads + kBlock - 1) / kBlock, 256 * 8);
             LAUNCH(L, DQ_K_PACK_KEYS, n, n * 9,
-                   hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st,
-                                      w.text, n, w.K0));
+                   hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, w.text, n, w.K0));
             const int passes = 64 / kRadixBits;
             V[passes & 1] = d_sa;            // the last pass must land in the caller's SA buffer
             V[(passes & 1) ^ 1] = w.Va;
@@ -575,14 +609,13 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
         // sorted keys (or packed words) are in K[cur], suffixes in d_sa
         const int kshift0 = packed ? bit_length((uint64_t)(n - 1)) : 0;
         uint64_t *act_rank = K[cur ^ 1];
-        // Few ties (random-like input): finish them by direct comparison / key extension from the
-        // text and skip the n random writes of a full inverse suffix array.  Many ties: the ISA is
-        // needed (singletons rank = SA position, tied suffixes = their group rank) for doubling.
-        // 4096 sampled adjacent pairs predict which, so that the dense case writes the ISA in the
-        // rebucket pass itself.
+
+        // Few ties (random-like input): they are finished by direct comparison / key extension from
+        // the text, without the n random writes of a full inverse suffix array.  Many ties: the ISA
+        // is needed for doubling.  4096 sampled adjacent pairs predict which, so that the dense case
+        // writes the ISA in the rebucket pass itself.  (Inputs whose order-0 entropy already promised
+        // few ties -- packed words or a short key -- skip the sample and its host round trip.)
         bool predict_dense = false;
-        // (inputs whose order-0 entropy already promised few ties -- packed words or a short key --
-        // skip the sample and its host round trip)
         if (sort_engine() == 1 && n >= (1 << 16) && !packed && kb == 8) {
             constexpr int kSamples = 4096;
             HIP_TRY(hipMemsetAsync(w.totals + 2, 0, 8, st));
@@ -596,91 +629,145 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
         }
         if (const char *v = getenv("DQ_SPARSE")) predict_dense = atoi(v) == 0;
         if (predict_dense)
-            rc = rebucket<IdxT, true, false, true>(L, c, w, K[cur], (const IdxT *)d_sa, n, 0, kshift0, d_sa,
-                                                   act_rank, w.Va, &active);
+            rc = rebucket<IdxT, true, false, true>(L, c, w, K[cur], (const IdxT *)d_sa, n, 0, kshift0, d_sa, act_rank,
+                                                   w.Va, &m);
         else
-            rc = rebucket<IdxT, true, false, false>(L, c, w, K[cur], (const IdxT *)d_sa, n, 0, kshift0, d_sa,
-                                                    act_rank, w.Va, &active);
+            rc = rebucket<IdxT, true, false, false>(L, c, w, K[cur], (const IdxT *)d_sa, n, 0, kshift0, d_sa, act_rank,
+                                                    w.Va, &m);
         if (rc != DQ_OK) return rc;
-        t_info[1] = active;
-        if (active == 0) return flush_profile(c);
-        bool sparse = active * 6 <= n;
-        if (const char *v = getenv("DQ_SPARSE")) sparse = atoi(v) != 0;
-        auto grid_for = [](int64_t items) { return (unsigned)std::min<int64_t>((items + kBlock - 1) / kBlock, 256 * 16); };
-        if (!sparse && !predict_dense) {
-            LAUNCH(L, DQ_K_SEG_APPLY, n, n * 3 * wb,
-                   hipLaunchKernelGGL(isa_from_sa_kernel<IdxT>, dim3(grid_for(n)), dim3(kBlock), 0, st,
-                                      (const IdxT *)d_sa, w.ISA, n);
-                   hipLaunchKernelGGL(isa_scatter_kernel<IdxT>, dim3(grid_for(active)), dim3(kBlock), 0, st,
-                                      (const uint64_t *)act_rank, (const IdxT *)w.Va, w.ISA, active));
-        }
-        // refinement ping-pong: (act_rank buffer, Va) <-> (other key buffer, Vb)
-        uint64_t *Kr[2] = {act_rank, K[cur]};
-        IdxT *Vr[2] = {w.Va, w.Vb};
-        int rcur = 0;
-        int64_t m = active;
-        int64_t h = kb;                  // bytes already compared: the round-0 key width
-        const int rbits = bit_length((uint64_t)(n - 1));
+        *dense_built = predict_dense;
+        // ping-pong buffers of the tied list: (act_rank buffer, Va) <-> (other key buffer, Vb)
+        Kr[0] = act_rank; Kr[1] = K[cur];
+        Vr[0] = w.Va; Vr[1] = w.Vb;
+        rcur = 0;
+        h = kb;                          // bytes already compared: the round-0 key width
+        rbits = bit_length((uint64_t)(n - 1));
+        return DQ_OK;
+    }
 
-        if (sparse) {
-            // tiny groups with a short remaining common prefix: finish by direct comparison
+    // ---- sparse finishing: direct comparison of tiny groups, then up to 3 rounds of key extension
+    //      from the text; whatever is still tied afterwards (long repeats) goes to doubling.
+    int finish_sparse()
+    {
+        int rc;
+        // tiny groups with a short remaining common prefix
+        t_info[0] += 1;
+        t_info[2] += m;
+        uint8_t *resolved = reinterpret_cast<uint8_t *>(w.ISA);         // ISA is unused on the sparse path
+        HIP_TRY(hipMemsetAsync(resolved, 0, (size_t)m, st));
+        LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + 16 + wb),
+               hipLaunchKernelGGL((small_group_finish_kernel<IdxT, 8, 32>), dim3((unsigned)((m + kBlock - 1) / kBlock)),
+                                  dim3(kBlock), 0, st, (const uint64_t *)Kr[rcur], (const IdxT *)Vr[rcur],
+                                  (const uint8_t *)w.text, m, n, h, d_sa, resolved));
+        int64_t m2 = 0;
+        rc = compact_class<IdxT>(L, c, w, resolved, 0, Kr[rcur], Vr[rcur], m, Kr[rcur ^ 1], Vr[rcur ^ 1], &m2);
+        if (rc != DQ_OK) return rc;
+        if (m2 > 0) rcur ^= 1;
+        m = m2;
+
+        const int ebytes = std::max(1, std::min(4, (64 - rbits - 3) / 8));
+        const int kbits = 8 * ebytes + 3;
+        for (int r = 0; r < 3 && m > 0; ++r) {
             t_info[0] += 1;
             t_info[2] += m;
-            uint8_t *resolved = reinterpret_cast<uint8_t *>(w.ISA);     // ISA is unused on the sparse path
-            HIP_TRY(hipMemsetAsync(resolved, 0, (size_t)m, st));
-            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + 16 + wb),
-                   hipLaunchKernelGGL((small_group_finish_kernel<IdxT, 8, 32>), dim3((unsigned)((m + kBlock - 1) / kBlock)),
-                                      dim3(kBlock), 0, st, (const uint64_t *)Kr[rcur], (const IdxT *)Vr[rcur],
-                                      (const uint8_t *)w.text, m, n, h, d_sa, resolved));
-            {
-                const int64_t np = (m + kSegTile - 1) / kSegTile;
-                LAUNCH(L, DQ_K_SEG_REDUCE, m, m * 8,
-                       hipLaunchKernelGGL(compact_count_kernel<IdxT>, dim3((unsigned)np), dim3(kBlock), 0, st,
-                                          (const uint8_t *)resolved, m, w.part));
-                LAUNCH(L, DQ_K_SEG_SCAN, np, np * 6 * wb,
-                       hipLaunchKernelGGL(seg_scan_kernel<IdxT>, dim3(1), dim3(1024), 0, st, w.part, np, w.totals));
-                HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                const int64_t m2 = c.pinned[0];
-                if (m2 > 0) {
-                    LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + wb) + m2 * (8 + wb),
-                           hipLaunchKernelGGL(compact_scatter_kernel<IdxT>, dim3((unsigned)np), dim3(kBlock), 0, st,
-                                              (const uint8_t *)resolved, (const uint64_t *)Kr[rcur],
-                                              (const IdxT *)Vr[rcur], m, w.part,
-                                              Kr[rcur ^ 1], Vr[rcur ^ 1]));
-                    rcur ^= 1;
-                }
-                m = m2;
-            }
-            const int ebytes = std::max(1, std::min(4, (64 - rbits - 3) / 8));
-            const int kbits = 8 * ebytes + 3;
-            for (int r = 0; r < 3 && m > 0; ++r) {
-                t_info[0] += 1;
-                t_info[2] += m;
-                LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + ebytes + 8),
-                       hipLaunchKernelGGL(gather_text_key_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock), 0, st,
-                                          Kr[rcur], (const IdxT *)Vr[rcur], (const uint8_t *)w.text, m, n, h,
-                                          ebytes));
-                rc = sort_engine() == 1 ? onesweep_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, rcur)
-                                        : radix_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, false, rcur);
-                if (rc != DQ_OK) return rc;
-                int64_t m2 = 0;
-                rc = rebucket<IdxT, false, true, false>(L, c, w, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits, 0,
-                                                        d_sa, Kr[rcur ^ 1], Vr[rcur ^ 1], &m2);
-                if (rc != DQ_OK) return rc;
-                rcur ^= 1;
-                m = m2;
-                h += ebytes;
-            }
-            if (m > 0) {
-                // long repeats after all: materialise the ranks and fall through to doubling
-                LAUNCH(L, DQ_K_SEG_APPLY, n, n * 3 * wb,
-                       hipLaunchKernelGGL(isa_from_sa_kernel<IdxT>, dim3(grid_for(n)), dim3(kBlock), 0, st,
-                                          (const IdxT *)d_sa, w.ISA, n);
-                       hipLaunchKernelGGL(isa_scatter_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock), 0, st,
-                                          (const uint64_t *)Kr[rcur], (const IdxT *)Vr[rcur], w.ISA, m));
-            }
+            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + ebytes + 8),
+                   hipLaunchKernelGGL(gather_text_key_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock), 0, st, Kr[rcur],
+                                      (const IdxT *)Vr[rcur], (const uint8_t *)w.text, m, n, h, ebytes));
+            rc = sort_pairs(Kr, Vr, m, kbits + rbits, rcur);
+            if (rc != DQ_OK) return rc;
+            rc = rebucket<IdxT, false, true, false>(L, c, w, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits, 0, d_sa,
+                                                    Kr[rcur ^ 1], Vr[rcur ^ 1], &m2);
+            if (rc != DQ_OK) return rc;
+            rcur ^= 1;
+            m = m2;
+            h += ebytes;
         }
+        // long repeats after all: materialise the ranks for the doubling rounds
+        return m > 0 ? build_isa(Kr[rcur], Vr[rcur], m) : DQ_OK;
+    }
+
+    // ---- one doubling round, everything through the radix path
+    int doubling_round_radix(int kbits)
+    {
+        LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8),
+               hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock), 0, st, Kr[rcur],
+                                  (const IdxT *)Vr[rcur], (const IdxT *)w.ISA, m, n, h, kbits));
+        int rc = sort_pairs(Kr, Vr, m, kbits + rbits, rcur);
+        if (rc != DQ_OK) return rc;
+        int64_t m2 = 0;
+        rc = rebucket<IdxT, false, true, true>(L, c, w, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits, 0, d_sa,
+                                               Kr[rcur ^ 1], Vr[rcur ^ 1], &m2);
+        if (rc != DQ_OK) return rc;
+        rcur ^= 1;
+        m = m2;
+        return DQ_OK;
+    }
+
+    // ---- one doubling round with the groups of <= 8 sorted in registers and only the larger groups
+    //      through the radix path.  Needs m <= n/2: every buffer has room for n entries, so with
+    //      X in the first halves the second halves are free for the two compactions.
+    int doubling_round_small(int kbits)
+    {
+        constexpr int kMaxG = 8;
+        uint64_t *Ar = Kr[rcur], *Br = Kr[rcur ^ 1];
+        IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
+        const int64_t half = n / 2;
+        int rc;
+        HIP_TRY(hipMemsetAsync(w.flags, 2, (size_t)m, st));
+        LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8 + wb + 1),
+               hipLaunchKernelGGL((small_group_round_kernel<IdxT, kMaxG>), dim3((unsigned)((m + kBlock - 1) / kBlock)),
+                                  dim3(kBlock), 0, st, (const uint64_t *)Ar, (const IdxT *)As, (const IdxT *)w.ISA, m,
+                                  n, h, Br, Bs, w.flags));
+        int64_t m1 = 0, mL = 0;
+        rc = compact_class<IdxT>(L, c, w, w.flags, 1, Br, Bs, m, Ar + half, As + half, &m1);      // still tied, small
+        if (rc != DQ_OK) return rc;
+        rc = compact_class<IdxT>(L, c, w, w.flags, 2, Ar, As, m, Br + half, Bs + half, &mL);      // large groups
+        if (rc != DQ_OK) return rc;
+        // the large groups' key2 gather must see this round's ISA before anyone updates it
+        if (mL > 0) {
+            LAUNCH(L, DQ_K_GATHER_KEY2, mL, mL * (8 + wb + wb + 8),
+                   hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3(grid_for(mL)), dim3(kBlock), 0, st, Br + half,
+                                      (const IdxT *)(Bs + half), (const IdxT *)w.ISA, mL, n, h, kbits));
+        }
+        LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + 8 + wb + 1 + 2 * wb),
+               hipLaunchKernelGGL((small_group_apply_kernel<IdxT, kMaxG>), dim3((unsigned)((m + kBlock - 1) / kBlock)),
+                                  dim3(kBlock), 0, st, (const uint64_t *)Ar, (const uint64_t *)Br, (const IdxT *)Bs,
+                                  (const uint8_t *)w.flags, m, d_sa, w.ISA));
+        // next list X' = [small survivors][large survivors] at the front of (Ar, As)
+        if (m1 > 0) {
+            HIP_TRY(hipMemcpyAsync(Ar, Ar + half, (size_t)m1 * 8, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(As, As + half, (size_t)m1 * sizeof(IdxT), hipMemcpyDeviceToDevice, st));
+        }
+        int64_t mLs = 0;
+        if (mL > 0) {
+            uint64_t *Kx[2] = {Br + half, Ar + half + m1};
+            IdxT *Vx[2] = {Bs + half, As + half + m1};
+            int xcur = 0;
+            rc = onesweep_sort_pairs<IdxT>(L, w, Kx, Vx, mL, kbits + rbits, xcur);
+            if (rc != DQ_OK) return rc;
+            rc = rebucket<IdxT, false, true, true>(L, c, w, Kx[xcur], (const IdxT *)Vx[xcur], mL, kbits, 0, d_sa,
+                                                   Ar + m1, As + m1, &mLs);
+            if (rc != DQ_OK) return rc;
+        }
+        m = m1 + mLs;
+        return DQ_OK;
+    }
+
+    int run()
+    {
+        t_info[0] = t_info[1] = t_info[2] = 0;
+        HIP_TRY(hipMemsetAsync(w.totals, 0, 64, st));
+        bool dense_built = false;
+        int rc = round0(&dense_built);
+        if (rc != DQ_OK) return rc;
+        t_info[1] = m;
+        if (m == 0) return flush_profile(c);
+
+        bool sparse = m * 6 <= n;
+        if (const char *v = getenv("DQ_SPARSE")) sparse = atoi(v) != 0;
+        if (sparse) rc = finish_sparse();
+        else if (!dense_built) rc = build_isa(Kr[rcur], Vr[rcur], m);
+        if (rc != DQ_OK) return rc;
 
         const bool no_small = getenv("DQ_NO_SMALL") != nullptr;
         while (m > 0) {
@@ -688,73 +775,21 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
             t_info[2] += m;
             const int kbits = bit_length((uint64_t)(n - 1) + (uint64_t)h);
             if (kbits + rbits > 64) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
-            if (sort_engine() == 1 && !no_small && m * 2 <= n) {
-                // ---- small groups (<= 8) in registers, larger groups through the radix path.
-                //      X = (Ar, As)[0, m) is the list of tied suffixes (members of a group adjacent);
-                //      every buffer has room for n entries and m <= n/2, so the second halves are free.
-                constexpr int kMaxG = 8;
-                uint64_t *Ar = Kr[rcur], *Br = Kr[rcur ^ 1];
-                IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
-                const int64_t half = n / 2;
-                HIP_TRY(hipMemsetAsync(w.flags, 2, (size_t)m, st));
-                LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8 + wb + 1),
-                       hipLaunchKernelGGL((small_group_round_kernel<IdxT, kMaxG>), dim3((unsigned)((m + kBlock - 1) / kBlock)),
-                                          dim3(kBlock), 0, st, (const uint64_t *)Ar, (const IdxT *)As,
-                                          (const IdxT *)w.ISA, m, n, h, Br, Bs, w.flags));
-                int64_t m1 = 0, mL = 0;
-                rc = compact_class<IdxT>(L, c, w, w.flags, 1, Br, Bs, m, Ar + half, As + half, &m1);      // still tied, small
-                if (rc != DQ_OK) return rc;
-                rc = compact_class<IdxT>(L, c, w, w.flags, 2, Ar, As, m, Br + half, Bs + half, &mL);      // large groups
-                if (rc != DQ_OK) return rc;
-                // the large groups' key2 gather must see this round's ISA before anyone updates it
-                if (mL > 0) {
-                    LAUNCH(L, DQ_K_GATHER_KEY2, mL, mL * (8 + wb + wb + 8),
-                           hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3(grid_for(mL)), dim3(kBlock), 0, st,
-                                              Br + half, (const IdxT *)(Bs + half), (const IdxT *)w.ISA, mL, n, h,
-                                              kbits));
-                }
-                LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + 8 + wb + 1 + 2 * wb),
-                       hipLaunchKernelGGL((small_group_apply_kernel<IdxT, kMaxG>), dim3((unsigned)((m + kBlock - 1) / kBlock)),
-                                          dim3(kBlock), 0, st, (const uint64_t *)Ar, (const uint64_t *)Br,
-                                          (const IdxT *)Bs, (const uint8_t *)w.flags, m, d_sa, w.ISA));
-                // next list X' = [small survivors][large survivors] at the front of (Ar, As)
-                if (m1 > 0) {
-                    HIP_TRY(hipMemcpyAsync(Ar, Ar + half, (size_t)m1 * 8, hipMemcpyDeviceToDevice, st));
-                    HIP_TRY(hipMemcpyAsync(As, As + half, (size_t)m1 * sizeof(IdxT), hipMemcpyDeviceToDevice, st));
-                }
-                int64_t mLs = 0;
-                if (mL > 0) {
-                    uint64_t *Kx[2] = {Br + half, Ar + half + m1};
-                    IdxT *Vx[2] = {Bs + half, As + half + m1};
-                    int xcur = 0;
-                    rc = onesweep_sort_pairs<IdxT>(L, w, Kx, Vx, mL, kbits + rbits, xcur);
-                    if (rc != DQ_OK) return rc;
-                    rc = rebucket<IdxT, false, true, true>(L, c, w, Kx[xcur], (const IdxT *)Vx[xcur], mL, kbits, 0,
-                                                           d_sa, Ar + m1, As + m1, &mLs);
-                    if (rc != DQ_OK) return rc;
-                }
-                m = m1 + mLs;
-                h *= 2;
-                continue;
-            }
-            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8),
-                   hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock),
-                                      0, st, Kr[rcur], (const IdxT *)Vr[rcur], (const IdxT *)w.ISA, m,
-                                      n, h, kbits));
-            rc = sort_engine() == 1 ? onesweep_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, rcur)
-                                    : radix_sort_pairs<IdxT>(L, w, Kr, Vr, m, kbits + rbits, false, rcur);
+            rc = (sort_engine() == 1 && !no_small && m * 2 <= n) ? doubling_round_small(kbits)
+                                                                  : doubling_round_radix(kbits);
             if (rc != DQ_OK) return rc;
-            int64_t m2 = 0;
-            rc = rebucket<IdxT, false, true, true>(L, c, w, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits, 0, d_sa,
-                                                   Kr[rcur ^ 1], Vr[rcur ^ 1], &m2);
-            if (rc != DQ_OK) return rc;
-            rcur ^= 1;
-            m = m2;
             h *= 2;
         }
+        HIP_TRY(hipStreamSynchronize(st));
+        return flush_profile(c);
     }
-    HIP_TRY(hipStreamSynchronize(st));
-    return flush_profile(c);
+};
+
+template <typename IdxT>
+int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, IdxT *d_sa)
+{
+    SuffixSorter<IdxT> sorter(c, st, w, n, d_sa);
+    return sorter.run();
 }
 
 int resolve_device(int32_t device, int *out)
