@@ -18,7 +18,7 @@ DQ_ERR_HIP = -3
 DQ_ERR_TOO_LARGE = -4
 DQ_ERR_NO_DEVICE = -5
 
-KERNEL_CATEGORIES = 9
+KERNEL_CATEGORIES = 10
 K_RADIX_RANK_SCATTER = 3
 
 # every symbol include/dq_sufsort.h declares

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libdq_sufsort_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 SOURCES = ["dq_sufsort_hip.hip"]
-HEADERS = ["dq_device_utils.h", "dq_radix.h", "dq_sa_kernels.h", os.path.join("..", "..", "include", "dq_sufsort.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "dq_sufsort.h")]
 ARCH = "gfx950"
 
 

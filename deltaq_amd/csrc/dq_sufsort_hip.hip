@@ -28,6 +28,7 @@
 #include "dq_radix.h"
 #include "dq_sa_kernels.h"
 #include "dq_seg_fused.h"
+#include "dq_small.h"
 
 namespace {
 
@@ -64,7 +65,7 @@ std::atomic<int> g_prof_on{0};
 const char *const kKernelNames[DQ_K_COUNT] = {
     "pack_keys_kernel", "radix_upsweep_kernel", "radix_scan_kernel", "radix_rank_kernel",
     "seg_reduce_kernel", "seg_scan_kernel", "seg_apply_kernel", "gather_key2_kernel",
-    "radix_hist_kernels"};
+    "radix_hist_kernels", "small_sufsort_kernel"};
 
 // sort engine: 1 = onesweep (default), 0 = legacy upsweep/scan/downsweep (DQ_SORT_ENGINE=sweep3)
 int sort_engine()
@@ -86,10 +87,13 @@ struct DeviceCtx {
     char *ws = nullptr;
     size_t ws_bytes = 0;
     int64_t *pinned = nullptr;          // 4 KiB pinned readback area
+    uint8_t *pinned_io = nullptr;       // short texts: text in / SA out, read and written by the kernel itself
     std::vector<ProfRec> pending;
     std::vector<hipEvent_t> pool;
 };
 constexpr int kMaxDevices = 64;
+constexpr size_t kSmallTextArea = kSmallMaxN + 64;
+constexpr size_t kSmallIoBytes = kSmallTextArea + (size_t)kSmallMaxN * 8;
 DeviceCtx g_ctx[kMaxDevices];
 
 int init_ctx(DeviceCtx &c, int dev)
@@ -99,6 +103,7 @@ int init_ctx(DeviceCtx &c, int dev)
     c.dev = dev;
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc((void **)&c.pinned, 4096, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c.pinned_io, kSmallIoBytes, hipHostMallocDefault));
     return DQ_OK;
 }
 
@@ -792,6 +797,26 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
     return sorter.run();
 }
 
+// ------------------------------------------------------------------ short texts: one launch
+// Largest n the single-workgroup sorter takes (DQ_SMALL_N=0 sends everything down the
+// device-wide pipeline; the tests use that to keep the pipeline covered on the fixtures).
+int64_t small_limit()
+{
+    if (const char *v = getenv("DQ_SMALL_N")) return std::min<int64_t>(std::max(0, atoi(v)), kSmallMaxN);
+    return sort_engine() == 1 ? kSmallMaxN : 0;
+}
+
+template <typename IdxT>
+int sufsort_small(DeviceCtx &c, hipStream_t st, const uint8_t *text, int64_t n, IdxT *sa)
+{
+    Launcher L{c, st, g_prof_on.load()};
+    t_info[0] = t_info[1] = t_info[2] = 0;
+    LAUNCH(L, DQ_K_SMALL_SORT, n, n * (1 + (int64_t)sizeof(IdxT)),
+           hipLaunchKernelGGL(small_sufsort_kernel<IdxT>, dim3(1), dim3(kSmallThreads), 0, st, text, (int)n, sa));
+    HIP_TRY(hipStreamSynchronize(st));
+    return flush_profile(c);
+}
+
 int resolve_device(int32_t device, int *out)
 {
     int count = 0;
@@ -838,6 +863,15 @@ int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device)
     std::lock_guard<std::mutex> lk(c.mu);
     rc = init_ctx(c, dev);
     if (rc != DQ_OK) return rc;
+    if (n <= small_limit()) {
+        // the kernel reads the text from, and writes the SA to, pinned host memory: one launch, no copies
+        IdxT *io_sa = reinterpret_cast<IdxT *>(c.pinned_io + kSmallTextArea);
+        memcpy(c.pinned_io, text, (size_t)n);
+        rc = sufsort_small<IdxT>(c, c.stream, c.pinned_io, n, io_sa);
+        if (rc != DQ_OK) { c.pending.clear(); return rc; }
+        memcpy(sa, io_sa, (size_t)n * sizeof(IdxT));
+        return DQ_OK;
+    }
     Workspace<IdxT> w = carve<IdxT>(nullptr, n, true);
     rc = ensure_ws(c, w.bytes);
     if (rc != DQ_OK) return rc;
@@ -868,6 +902,11 @@ int sufsort_dev(const void *d_text, int64_t n, void *d_sa, int32_t device, void 
     std::lock_guard<std::mutex> lk(c.mu);
     rc = init_ctx(c, dev);
     if (rc != DQ_OK) return rc;
+    if (n <= small_limit()) {
+        rc = sufsort_small<IdxT>(c, stream ? (hipStream_t)stream : c.stream, (const uint8_t *)d_text, n, (IdxT *)d_sa);
+        if (rc != DQ_OK) c.pending.clear();
+        return rc;
+    }
     Workspace<IdxT> w = carve<IdxT>(nullptr, n, false);
     rc = ensure_ws(c, w.bytes);
     if (rc != DQ_OK) return rc;
@@ -975,6 +1014,8 @@ void dq_sufsort_hip_release(void)
         c.pool.clear();
         if (c.pinned) (void)hipHostFree(c.pinned);
         c.pinned = nullptr;
+        if (c.pinned_io) (void)hipHostFree(c.pinned_io);
+        c.pinned_io = nullptr;
         if (c.stream) (void)hipStreamDestroy(c.stream);
         c.stream = nullptr;
         c.dev = -1;

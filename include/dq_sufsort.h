@@ -84,7 +84,8 @@ void dq_sufsort_hip_release(void);
 #define DQ_K_SEG_APPLY           6
 #define DQ_K_GATHER_KEY2         7
 #define DQ_K_RADIX_HIST          8   /* text / key digit histograms + offset scans */
-#define DQ_K_COUNT               9
+#define DQ_K_SMALL_SORT          9   /* small_sufsort_kernel: a whole short text (n <= 8192) in one workgroup */
+#define DQ_K_COUNT               10
 
 int32_t dq_profile_enable(int32_t on);   /* 0 off, 1 every kernel, 2 only radix_rank_kernel (cheapest) */
 void    dq_profile_reset(void);

@@ -3,7 +3,7 @@
 results table of BASELINE.md section 4.  CPU numbers: oracle/divsufsort.c, 1 thread, same host."""
 import ctypes, json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import oracle

@@ -3,7 +3,7 @@
 Also config 3 timing (256 MiB enwik-like) device-resident with the per-kernel profile."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import oracle

@@ -25,12 +25,21 @@ def ldss(backend_lib):
     return HipSuffixSort(0)
 
 
+@pytest.fixture(params=["auto", "device-wide"])
+def pipeline(request, monkeypatch):
+    """Texts of n <= 8192 bytes are sorted by the single-workgroup kernel (dq_small.h); DQ_SMALL_N=0
+    sends them down the device-wide pipeline instead.  The fixture-scale tests run both ways."""
+    if request.param == "device-wide":
+        monkeypatch.setenv("DQ_SMALL_N", "0")
+    return request.param
+
+
 def Verify(oracle_mod, T, SA):
     """LibDivSufSortTests.Verify (cs:43-64)."""
     oracle_mod.verify(T, np.asarray(SA))
 
 
-def test_CheckShruggy(ldss, oracle_mod):
+def test_CheckShruggy(ldss, oracle_mod, pipeline):
     T = "¯\\_(ツ)_/¯".encode("utf-8")
     SA = ldss.Sort(T)
     Verify(oracle_mod, T, SA)
@@ -38,7 +47,7 @@ def test_CheckShruggy(ldss, oracle_mod):
 
 
 @pytest.mark.parametrize("name", asset_names())
-def test_CheckFile(ldss, oracle_mod, golden, name):
+def test_CheckFile(ldss, oracle_mod, golden, name, pipeline):
     T = load_asset(name)
     SA = ldss.Sort(T)
     Verify(oracle_mod, T, SA)
@@ -47,7 +56,7 @@ def test_CheckFile(ldss, oracle_mod, golden, name):
 
 
 @pytest.mark.parametrize("size", [0, 1, 2, 4, 8, 16, 32, 51, 0x1000, 0x8000, 0x8000 - 1])
-def test_CheckRandomBuffer(ldss, oracle_mod, golden, size):
+def test_CheckRandomBuffer(ldss, oracle_mod, golden, size, pipeline):
     T = oracle_mod.net_random_bytes(size)
     SA = np.zeros(size, dtype=np.int32)             # AllocationMode.Clear, cs:143
     ldss.Sort(T, SA)
@@ -85,12 +94,40 @@ def pathological_cases(oracle_mod):
     return out
 
 
-def test_pathological_inputs(ldss, oracle_mod):
+def test_pathological_inputs(ldss, oracle_mod, pipeline):
     for name, T in pathological_cases(oracle_mod).items():
         T = np.ascontiguousarray(T, dtype=np.uint8)
         SA = ldss.Sort(T)
         ref = oracle_mod.divsufsort(T)
         assert np.array_equal(SA, ref), name
+
+
+def test_single_workgroup_sorter_every_small_size(ldss, oracle_mod, backend_lib):
+    """dq_small.h: every length 1..300 plus the sizes around each elements-per-thread step and the
+    8192 limit, on alphabets of 1, 2, 4 and 256 symbols, host and device entry points, both index widths."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(20261001)
+    sizes = list(range(1, 301)) + [1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 7000, 8191, 8192, 8193]
+    for n in sizes:
+        sigma = (1, 2, 4, 256)[n % 4]
+        T = rng.integers(0, sigma, size=n, dtype=np.uint8) if sigma > 1 else np.full(n, 7, np.uint8)
+        if n % 5 == 0:
+            T[-min(n, 9):] = 0                    # genuine zero tail against the zero padding
+        ref = oracle_mod.divsufsort(T)
+        assert np.array_equal(ldss.Sort(T), ref), n
+        if n % 7 == 0 or n > 300:
+            assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), ref.astype(np.int64)), n
+            dSA = ldss.Sort(torch.from_numpy(T).cuda())
+            assert np.array_equal(dSA.cpu().numpy(), ref), n
+    # the kernel really ran for these sizes: its profile category counts the launches
+    backend_lib.dq_profile_enable(1)
+    backend_lib.dq_profile_reset()
+    ldss.Sort(oracle_mod.net_random_bytes(5000))
+    launches = ctypes.c_int64()
+    backend_lib.dq_profile_get(9, ctypes.byref(launches), None, None, None)
+    backend_lib.dq_profile_enable(0)
+    assert launches.value == 1
 
 
 @pytest.mark.parametrize("n", [1 << 16, (1 << 20) + 3, 5_000_000])
@@ -172,6 +209,7 @@ FORCED_PATHS = [
 def test_every_code_path_is_bit_exact(ldss, oracle_mod, monkeypatch, env):
     """The adaptive choices (key width, packed words, sparse/dense finishing) are forced in
     turn; every combination must produce the same (unique) suffix array."""
+    monkeypatch.setenv("DQ_SMALL_N", "0")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     cases = [
