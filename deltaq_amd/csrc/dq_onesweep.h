@@ -80,21 +80,38 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t *__re
     }
 }
 
-// digit_offset[p][d] = number of keys whose digit p is < d   (one workgroup per digit place)
-__global__ __launch_bounds__(kBlock) void radix_hist_scan_kernel(const uint32_t *__restrict__ partial,
-                                                                 int nblocks,
-                                                                 int64_t *__restrict__ digit_offset)
+// digit_offset[p][d] = number of keys whose digit p is < d   (one workgroup per digit place).
+// The partial sums are a latency chain (nblocks dependent-free but serial loads per digit), so
+// 4 slices of the workgroups are summed side by side and combined through LDS.
+constexpr int kHistScanThreads = 1024;
+__global__ __launch_bounds__(kHistScanThreads) void radix_hist_scan_kernel(const uint32_t *__restrict__ partial,
+                                                                           int nblocks,
+                                                                           int64_t *__restrict__ digit_offset)
 {
+    __shared__ int64_t slice[kHistScanThreads / kRadixSize][kRadixSize];
     __shared__ int64_t tmp[kWavesPerBlock];
     const int p = blockIdx.x;
-    const int d = threadIdx.x;
+    const int d = threadIdx.x & (kRadixSize - 1);
+    const int q = threadIdx.x / kRadixSize;
     int64_t sum = 0;
-#pragma unroll 8
-    for (int g = 0; g < nblocks; ++g)
+#pragma unroll 16
+    for (int g = q; g < nblocks; g += kHistScanThreads / kRadixSize)
         sum += partial[(int64_t)g * (kMaxPasses * kRadixSize) + p * kRadixSize + d];
-    int64_t total;
-    const int64_t excl = block_excl_sum(sum, tmp, &total);
-    digit_offset[p * kRadixSize + d] = excl;
+    slice[q][d] = sum;
+    __syncthreads();
+    const int w = threadIdx.x >> 6;
+    int64_t incl = 0;
+    if (threadIdx.x < kRadixSize) {
+        sum = slice[0][d] + slice[1][d] + slice[2][d] + slice[3][d];
+        incl = wave_incl_sum(sum);
+        if (lane_id() == kWave - 1) tmp[w] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < kRadixSize) {
+        int64_t off = 0;
+        for (int i = 0; i < w; ++i) off += tmp[i];
+        digit_offset[p * kRadixSize + d] = off + incl - sum;
+    }
 }
 
 // ---------------------------------------------------------------------------------

@@ -428,80 +428,6 @@ __global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const uint8_t *
     }
 }
 
-// ---------------------------------------------------------------------------------
-// Small-group doubling round (dense path).  After a couple of rounds nearly every still-tied
-// suffix of text-like data sits in a group of 2..8 (measured 80-100 % from
-// h = 16 on).  Sorting those with 8 radix passes over composite keys is wasteful: one lane
-// per group gathers key2 = rank of the suffix h further on, sorts <= 8 (key2, suffix) pairs in
-// registers and emits the new ranks.
-//   round kernel : reads ISA only (no writes: other groups read the same ISA in this round)
-//                  class[j] = 0 resolved, 1 still tied (nrank/nsuf valid); larger groups keep
-//                  the preset class 2 and go through the radix path
-//   apply kernel : SA[rank + i] = nsuf, ISA[nsuf] = nrank (where it moved), after every reader
-// ---------------------------------------------------------------------------------
-template <typename IdxT, int kMaxG>
-__global__ __launch_bounds__(kBlock) void small_group_round_kernel(
-    const uint64_t *__restrict__ rank, const IdxT *__restrict__ suf, const IdxT *__restrict__ ISA,
-    int64_t m, int64_t n, int64_t h, uint64_t *__restrict__ nrank, IdxT *__restrict__ nsuf,
-    uint8_t *__restrict__ cls /* preset to 2 */)
-{
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= m) return;
-    const uint64_t r = rank[j];
-    if (j > 0 && rank[j - 1] == r) return;                     // not the first member
-    int g = 1;
-    while (g <= kMaxG && j + g < m && rank[j + g] == r) ++g;
-    if (g > kMaxG) return;
-    int64_t s[kMaxG], k2[kMaxG];
-#pragma unroll
-    for (int i = 0; i < kMaxG; ++i) {
-        s[i] = 0; k2[i] = 0;
-        if (i < g) {
-            s[i] = (int64_t)suf[j + i];
-            const int64_t q = s[i] + h;
-            k2[i] = q < n ? (int64_t)ISA[q] + h : n - 1 - s[i];       // same rule as gather_key2_kernel
-        }
-    }
-    // bubble network with static indices keeps everything in registers
-#pragma unroll
-    for (int pass = 0; pass < kMaxG - 1; ++pass) {
-#pragma unroll
-        for (int i = 0; i < kMaxG - 1; ++i) {
-            if (i + 1 < g && i < g - 1 - pass && k2[i] > k2[i + 1]) {
-                const int64_t a = k2[i]; k2[i] = k2[i + 1]; k2[i + 1] = a;
-                const int64_t b = s[i]; s[i] = s[i + 1]; s[i + 1] = b;
-            }
-        }
-    }
-    uint64_t nr = r;
-#pragma unroll
-    for (int i = 0; i < kMaxG; ++i) {
-        if (i < g) {
-            if (i > 0 && k2[i] != k2[i - 1]) nr = r + (uint64_t)i;
-            const bool tied = (i > 0 && k2[i] == k2[i - 1]) || (i + 1 < g && k2[i + 1] == k2[i]);
-            nrank[j + i] = nr;
-            nsuf[j + i] = (IdxT)s[i];
-            cls[j + i] = tied ? 1 : 0;
-        }
-    }
-}
-
-template <typename IdxT, int kMaxG>
-__global__ __launch_bounds__(kBlock) void small_group_apply_kernel(
-    const uint64_t *__restrict__ rank, const uint64_t *__restrict__ nrank, const IdxT *__restrict__ nsuf,
-    const uint8_t *__restrict__ cls, int64_t m, IdxT *__restrict__ SA, IdxT *__restrict__ ISA)
-{
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= m || cls[j] == 2) return;
-    const uint64_t r = rank[j];
-    int i = 0;                                                   // position inside the group
-    while (i < kMaxG - 1 && j - i > 0 && rank[j - i - 1] == r) ++i;
-    const IdxT s = nsuf[j];
-    SA[(int64_t)r + i] = s;
-    const uint64_t nr = nrank[j];
-    if (nr != r) ISA[s] = (IdxT)nr;
-}
-
 // Estimate of the tie fraction after round 0: kSamples evenly spaced adjacent pairs of the
 // sorted key list; *count = pairs with equal keys.  Decides whether the rebucket pass should
 // write the full inverse suffix array right away (dense doubling expected).

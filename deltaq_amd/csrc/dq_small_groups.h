@@ -1,0 +1,223 @@
+// dq_small_groups.h -- one doubling round for the tie groups of <= 8 suffixes, in a single pass.
+//
+// After the first rounds most tie groups are tiny (pairs inside long repeats), and the round
+// is nothing but random rank gathers and scatters; pushing those elements through 6-8 radix
+// passes wastes ~200 B of traffic per element.  small_group_round_kernel instead finishes a
+// round for every group of <= kSgMaxG members in one pass over the tied list X:
+//
+//   load      one lane per element: (rank, suffix) coalesced, key2 = ISA[s+h]+h | n-1-s gathered
+//             by the lane itself (one outstanding random read per lane), parked in LDS
+//   classify  each lane scans <= 8 LDS neighbours on both sides for its group's extent
+//   sort      a lane's place inside its group = #(members with a smaller key2) + #(equal ones
+//             before it): <= 8 LDS reads, no divergent sorting network
+//   exchange  the record moves to the LDS slot of its sorted position, so the workgroup now
+//             holds its part of X in final order: SA writes are contiguous runs and the
+//             survivors of one subgroup are adjacent
+//   emit      SA[rank + place] = s                                  (final for resolved ones)
+//             still tied  -> appended to the next list T as (new rank, s)
+//             rank moved  -> appended to the update list U as (s, new rank)
+//             group > 8   -> appended to L as (rank << kbits | key2, s) for the radix path
+//
+// The inverse suffix array must not change while other workgroups still gather from it, so
+// rank updates are deferred to isa_update_kernel (the next launch).  Lists are appended with
+// one atomic per workgroup and list: their order across workgroups is arbitrary, which is
+// fine -- the only invariant the next round needs is "members of a group are adjacent", and
+// a group is always emitted by the one workgroup that owns its first member.
+#pragma once
+#include <type_traits>
+#include "dq_device_utils.h"
+
+namespace dq {
+
+constexpr int kSgMaxG = 8;
+constexpr int kSgThreads = 512;
+constexpr int kSgItems = 8;
+constexpr int kSgWaves = kSgThreads / kWave;
+constexpr int kSgSpan = kSgThreads * kSgItems;      // list positions a workgroup looks at
+constexpr int kSgTile = kSgSpan - kSgMaxG;          // ... of which it owns the groups starting in the first kSgTile
+
+// Appended-entry counters.  One same-address atomic costs ~11 ns on MI355X (they serialise in
+// one L2 channel), so a workgroup reserves its T and U space with ONE packed atomic
+// (T count in the low half, U count in the high half); L is touched only where large groups exist.
+struct SmallGroupCounters {
+    unsigned long long tied_moved;  // low 32 bits: entries appended to T, high 32 bits: to U
+    unsigned long long large;       // entries appended to L
+};
+
+template <typename IdxT>
+__global__ __launch_bounds__(kSgThreads) void small_group_round_kernel(
+    const uint64_t *__restrict__ rank, const IdxT *__restrict__ suf, const IdxT *__restrict__ ISA,
+    int64_t m, int64_t n, int64_t h, int kbits, IdxT *__restrict__ SA,
+    uint64_t *__restrict__ t_rank, IdxT *__restrict__ t_suf,
+    uint64_t *__restrict__ l_key, IdxT *__restrict__ l_suf,
+    uint64_t *__restrict__ u_rank_end, IdxT *__restrict__ u_suf_end,      // U grows DOWNWARD from these
+    SmallGroupCounters *__restrict__ ctr)
+{
+    // ranks and key2 values are < n + h <= 2n: unsigned 32 bits are enough for the int32 index type
+    using ElemT = typename std::make_unsigned<IdxT>::type;
+    constexpr int kHalo = kSgMaxG;
+    constexpr ElemT kNone = ~(ElemT)0;
+    __shared__ ElemT s_rank[kSgSpan + 2 * kHalo];      // phase 2 on: slot_dest
+    __shared__ ElemT s_key2[kSgSpan + 2 * kHalo];      // phase 2 on: slot_rank
+    __shared__ IdxT slot_suf[kSgSpan];
+    __shared__ uint8_t slot_flag[kSgSpan];             // 0 empty, bit0 present, bit1 tied, bit2 moved
+    __shared__ uint32_t wave_cnt[3][kSgItems][kSgWaves];
+    __shared__ unsigned long long base[3];
+    ElemT *slot_dest = s_rank;
+    ElemT *slot_rank = s_key2;
+
+    const int t = threadIdx.x;
+    const int lane = lane_id();
+    const int wv = t >> 6;
+    const int64_t j0 = (int64_t)blockIdx.x * kSgTile;
+
+    ElemT r[kSgItems], k2[kSgItems];
+    IdxT s[kSgItems];
+#pragma unroll
+    for (int k = 0; k < kSgItems; ++k) {
+        const int e = k * kSgThreads + t;
+        const int64_t j = j0 + e;
+        r[k] = kNone; s[k] = 0;
+        if (j < m) { r[k] = (ElemT)rank[j]; s[k] = suf[j]; }
+    }
+#pragma unroll
+    for (int k = 0; k < kSgItems; ++k) {
+        const int64_t q = (int64_t)s[k] + h;
+        k2[k] = 0;
+        if (r[k] != kNone)
+            k2[k] = q < n ? (ElemT)((int64_t)ISA[q] + h) : (ElemT)(n - 1 - (int64_t)s[k]);   // as gather_key2_kernel
+    }
+#pragma unroll
+    for (int k = 0; k < kSgItems; ++k) {
+        const int e = k * kSgThreads + t;
+        s_rank[kHalo + e] = r[k];
+        s_key2[kHalo + e] = k2[k];
+        slot_flag[e] = 0;
+    }
+    if (t < kHalo) {
+        const int64_t jl = j0 - kHalo + t;
+        s_rank[t] = jl >= 0 ? (ElemT)rank[jl] : kNone;
+        const int64_t jr = j0 + kSgSpan + t;
+        s_rank[kHalo + kSgSpan + t] = jr < m ? (ElemT)rank[jr] : kNone;
+    }
+    __syncthreads();
+
+    int slot[kSgItems];                                 // -1: not a small-group element this workgroup owns
+    uint8_t flag[kSgItems];
+    ElemT nrank[kSgItems], dest[kSgItems];
+    bool own_large[kSgItems];
+#pragma unroll
+    for (int k = 0; k < kSgItems; ++k) {
+        const int e = k * kSgThreads + t;
+        const bool valid = r[k] != kNone;
+        // extent of the group: equal ranks to the left / right, each capped at kSgMaxG
+        int left = 0, right = 0;
+#pragma unroll
+        for (int i = 1; i <= kSgMaxG; ++i)
+            if (left == i - 1 && s_rank[kHalo + e - i] == r[k]) left = i;
+#pragma unroll
+        for (int i = 1; i <= kSgMaxG; ++i)
+            if (right == i - 1 && s_rank[kHalo + e + i] == r[k]) right = i;
+        const bool large = valid && (left + right + 1 > kSgMaxG);
+        const int head = e - left;                      // span index of the group's first member
+        const bool own_small = valid && !large && head >= 0 && head < kSgTile;
+        own_large[k] = large && e < kSgTile;
+        slot[k] = -1; flag[k] = 0; nrank[k] = 0; dest[k] = 0;
+        if (own_small) {
+            int less = 0, eq = 0, eq_before = 0;
+#pragma unroll
+            for (int i = -kSgMaxG + 1; i < kSgMaxG; ++i) {
+                if (i >= -left && i <= right) {
+                    const ElemT o = s_key2[kHalo + e + i];
+                    less += o < k2[k];
+                    eq += o == k2[k];
+                    eq_before += (o == k2[k]) && i < 0;
+                }
+            }
+            slot[k] = head + less + eq_before;          // <= kSgTile - 1 + kSgMaxG - 1 < kSgSpan
+            nrank[k] = r[k] + (ElemT)less;
+            dest[k] = r[k] + (ElemT)(less + eq_before);
+            flag[k] = (uint8_t)(1 | (eq > 1 ? 2 : 0) | (less != 0 ? 4 : 0));
+        }
+    }
+    __syncthreads();                                    // every reader of s_rank / s_key2 is done
+#pragma unroll
+    for (int k = 0; k < kSgItems; ++k) {
+        if (slot[k] >= 0) {
+            slot_dest[slot[k]] = dest[k];
+            slot_rank[slot[k]] = nrank[k];
+            slot_suf[slot[k]] = s[k];
+            slot_flag[slot[k]] = flag[k];
+        }
+    }
+    __syncthreads();
+
+    // from here on item k of lane t speaks for the record in sorted slot k*kSgThreads + t
+    uint32_t f[kSgItems];
+    uint64_t bt[kSgItems], bl[kSgItems], bu[kSgItems];
+#pragma unroll
+    for (int k = 0; k < kSgItems; ++k) {
+        const int e = k * kSgThreads + t;
+        f[k] = slot_flag[e];
+        if (f[k] & 1) SA[slot_dest[e]] = slot_suf[e];
+        bt[k] = __ballot((f[k] & 2) != 0);
+        bl[k] = __ballot(own_large[k]);
+        bu[k] = __ballot((f[k] & 4) != 0);
+        if (lane == 0) {
+            wave_cnt[0][k][wv] = (uint32_t)__popcll(bt[k]);
+            wave_cnt[1][k][wv] = (uint32_t)__popcll(bl[k]);
+            wave_cnt[2][k][wv] = (uint32_t)__popcll(bu[k]);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the 3 x 64 (item, wave) counts in emission order: one wave per list
+    if (wv < 3) {
+        uint32_t *cnts = &wave_cnt[wv][0][0];
+        const uint32_t c = cnts[lane];
+        const uint32_t incl = wave_incl_sum(c);
+        cnts[lane] = incl - c;
+        const uint32_t tot = __shfl(incl, kWave - 1, kWave);
+        if (lane == 0) base[wv] = tot;                 // totals first; bases below
+    }
+    __syncthreads();
+    if (t == 0) {
+        const unsigned long long nt = base[0], nl = base[1], nu = base[2];
+        unsigned long long tu = 0;
+        if (nt | nu) tu = atomicAdd(&ctr->tied_moved, nt | (nu << 32));
+        base[0] = tu & 0xffffffffull;
+        base[2] = tu >> 32;
+        base[1] = nl ? atomicAdd(&ctr->large, nl) : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSgItems; ++k) {
+        const int e = k * kSgThreads + t;
+        if (f[k] & 2) {
+            const int64_t p = (int64_t)base[0] + wave_cnt[0][k][wv] + mask_rank_lt(bt[k]);
+            t_rank[p] = (uint64_t)slot_rank[e];
+            t_suf[p] = slot_suf[e];
+        }
+        if (own_large[k]) {
+            const int64_t p = (int64_t)base[1] + wave_cnt[1][k][wv] + mask_rank_lt(bl[k]);
+            l_key[p] = ((uint64_t)r[k] << kbits) | (uint64_t)k2[k];
+            l_suf[p] = s[k];
+        }
+        if (f[k] & 4) {
+            const int64_t p = (int64_t)base[2] + wave_cnt[2][k][wv] + mask_rank_lt(bu[k]);
+            u_rank_end[-1 - p] = (uint64_t)slot_rank[e];
+            u_suf_end[-1 - p] = slot_suf[e];
+        }
+    }
+}
+
+// ISA[s] = new rank for the entries of the update list (stored downward from the *_end pointers)
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void isa_update_kernel(const uint64_t *__restrict__ u_rank_end,
+                                                            const IdxT *__restrict__ u_suf_end, int64_t count,
+                                                            IdxT *__restrict__ ISA)
+{
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < count; p += (int64_t)gridDim.x * kBlock)
+        ISA[u_suf_end[-1 - p]] = (IdxT)u_rank_end[-1 - p];
+}
+
+}  // namespace dq

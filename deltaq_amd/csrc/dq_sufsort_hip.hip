@@ -29,6 +29,7 @@
 #include "dq_sa_kernels.h"
 #include "dq_seg_fused.h"
 #include "dq_small.h"
+#include "dq_small_groups.h"
 
 namespace {
 
@@ -189,7 +190,6 @@ struct Workspace {
     size_t ctl_status_stride;   // bytes per pass (set by prepare_status)
     char *seg_status;           // SegCtl (256 B) followed by 3 x ntiles status words
     size_t seg_status_bytes;
-    uint8_t *flags;             // one class byte per tied suffix (small-group rounds)
     size_t bytes;
 };
 
@@ -222,7 +222,6 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.ctl_status = take(w.ctl_status_bytes);
     w.seg_status_bytes = 256 + 3 * (un / kSegTile + 2) * 8;
     w.seg_status = take(w.seg_status_bytes);
-    w.flags = (uint8_t *)take(un + 64);
     w.bytes = off;
     return w;
 }
@@ -352,7 +351,7 @@ int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V
         case 7: launch_hist<7>(L.st, blocks, K[cur], m, w.hist_partial); break;
         default: launch_hist<8>(L.st, blocks, K[cur], m, w.hist_partial); break;
     }
-    hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(passes), dim3(kBlock), 0, L.st,
+    hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(passes), dim3(kHistScanThreads), 0, L.st,
                        (const uint32_t *)w.hist_partial, blocks, w.digit_offset);
     HIP_TRY(hipGetLastError());
     rc = L.end();
@@ -708,52 +707,43 @@ struct SuffixSorter {
         return DQ_OK;
     }
 
-    // ---- one doubling round with the groups of <= 8 sorted in registers and only the larger groups
-    //      through the radix path.  Needs m <= n/2: every buffer has room for n entries, so with
-    //      X in the first halves the second halves are free for the two compactions.
+    // ---- one doubling round with the groups of <= 8 finished in a single pass (dq_small_groups.h)
+    //      and only the larger groups through the radix path.  Needs m <= n/2: every buffer has room
+    //      for n entries, X sits in the first half of (A, As), and the other buffer pair receives
+    //      T (next list, from 0), L (large groups, from n/2) and U (rank updates, downward from n).
     int doubling_round_small(int kbits)
     {
-        constexpr int kMaxG = 8;
-        uint64_t *Ar = Kr[rcur], *Br = Kr[rcur ^ 1];
+        uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
         IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
         const int64_t half = n / 2;
-        int rc;
-        HIP_TRY(hipMemsetAsync(w.flags, 2, (size_t)m, st));
-        LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8 + wb + 1),
-               hipLaunchKernelGGL((small_group_round_kernel<IdxT, kMaxG>), dim3((unsigned)((m + kBlock - 1) / kBlock)),
-                                  dim3(kBlock), 0, st, (const uint64_t *)Ar, (const IdxT *)As, (const IdxT *)w.ISA, m,
-                                  n, h, Br, Bs, w.flags));
-        int64_t m1 = 0, mL = 0;
-        rc = compact_class<IdxT>(L, c, w, w.flags, 1, Br, Bs, m, Ar + half, As + half, &m1);      // still tied, small
-        if (rc != DQ_OK) return rc;
-        rc = compact_class<IdxT>(L, c, w, w.flags, 2, Ar, As, m, Br + half, Bs + half, &mL);      // large groups
-        if (rc != DQ_OK) return rc;
-        // the large groups' key2 gather must see this round's ISA before anyone updates it
-        if (mL > 0) {
-            LAUNCH(L, DQ_K_GATHER_KEY2, mL, mL * (8 + wb + wb + 8),
-                   hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3(grid_for(mL)), dim3(kBlock), 0, st, Br + half,
-                                      (const IdxT *)(Bs + half), (const IdxT *)w.ISA, mL, n, h, kbits));
-        }
-        LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + 8 + wb + 1 + 2 * wb),
-               hipLaunchKernelGGL((small_group_apply_kernel<IdxT, kMaxG>), dim3((unsigned)((m + kBlock - 1) / kBlock)),
-                                  dim3(kBlock), 0, st, (const uint64_t *)Ar, (const uint64_t *)Br, (const IdxT *)Bs,
-                                  (const uint8_t *)w.flags, m, d_sa, w.ISA));
-        // next list X' = [small survivors][large survivors] at the front of (Ar, As)
-        if (m1 > 0) {
-            HIP_TRY(hipMemcpyAsync(Ar, Ar + half, (size_t)m1 * 8, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(As, As + half, (size_t)m1 * sizeof(IdxT), hipMemcpyDeviceToDevice, st));
+        SmallGroupCounters *ctr = reinterpret_cast<SmallGroupCounters *>(w.totals + 4);
+        HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(SmallGroupCounters), st));
+        LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + wb + 8 + wb),
+               hipLaunchKernelGGL(small_group_round_kernel<IdxT>, dim3((unsigned)((m + kSgTile - 1) / kSgTile)),
+                                  dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
+                                  (const IdxT *)w.ISA, m, n, h, kbits, d_sa, B, Bs, B + half, Bs + half, B + n,
+                                  Bs + n, ctr));
+        HIP_TRY(hipMemcpyAsync(c.pinned, ctr, sizeof(SmallGroupCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const int64_t m1 = c.pinned[0] & 0xffffffffll, mU = (int64_t)((uint64_t)c.pinned[0] >> 32), mL = c.pinned[1];
+        if (mU > 0) {
+            LAUNCH(L, DQ_K_SEG_APPLY, mU, mU * (8 + wb + wb),
+                   hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(mU)), dim3(kBlock), 0, st,
+                                      (const uint64_t *)(B + n), (const IdxT *)(Bs + n), mU, w.ISA));
         }
         int64_t mLs = 0;
         if (mL > 0) {
-            uint64_t *Kx[2] = {Br + half, Ar + half + m1};
-            IdxT *Vx[2] = {Bs + half, As + half + m1};
+            // radix ping-pong partner: the unused second half of X's own buffers
+            uint64_t *Kx[2] = {B + half, A + half};
+            IdxT *Vx[2] = {Bs + half, As + half};
             int xcur = 0;
-            rc = onesweep_sort_pairs<IdxT>(L, w, Kx, Vx, mL, kbits + rbits, xcur);
+            int rc = onesweep_sort_pairs<IdxT>(L, w, Kx, Vx, mL, kbits + rbits, xcur);
             if (rc != DQ_OK) return rc;
             rc = rebucket<IdxT, false, true, true>(L, c, w, Kx[xcur], (const IdxT *)Vx[xcur], mL, kbits, 0, d_sa,
-                                                   Ar + m1, As + m1, &mLs);
+                                                   B + m1, Bs + m1, &mLs);
             if (rc != DQ_OK) return rc;
         }
+        rcur ^= 1;
         m = m1 + mLs;
         return DQ_OK;
     }
@@ -780,7 +770,7 @@ struct SuffixSorter {
             t_info[2] += m;
             const int kbits = bit_length((uint64_t)(n - 1) + (uint64_t)h);
             if (kbits + rbits > 64) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
-            rc = (sort_engine() == 1 && !no_small && m * 2 <= n) ? doubling_round_small(kbits)
+            rc = (sort_engine() == 1 && !no_small && m * 2 <= n && n < (1ll << 32)) ? doubling_round_small(kbits)
                                                                   : doubling_round_radix(kbits);
             if (rc != DQ_OK) return rc;
             h *= 2;
