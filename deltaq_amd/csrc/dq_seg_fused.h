@@ -233,7 +233,9 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
                 const IdxT rg = gm ? wb_i + (IdxT)(k * kWave + 63 - __builtin_clzll(gm)) : cg;
                 const IdxT rank = kInitial ? (IdxT)0 : (IdxT)(ck[k] >> kbits);
                 const IdxT nr = rank + (rn - rg);
-                if (kWriteSA) SA[rank + (wb_i + (IdxT)e - rg)] = suf[k];
+                // dense doubling (ISA maintained) never reads SA again: a still-tied member's slot is
+                // written once, in the round that resolves it
+                if (kWriteSA && !(kWriteISA && act)) SA[rank + (wb_i + (IdxT)e - rg)] = suf[k];
                 // ISA[s] already holds the parent rank: only members whose rank moved need a (random) write
                 if (kWriteISA && (kInitial || nr != rank)) ISA[suf[k]] = nr;
                 if (act) {

@@ -13,7 +13,7 @@
 //   exchange  the record moves to the LDS slot of its sorted position, so the workgroup now
 //             holds its part of X in final order: SA writes are contiguous runs and the
 //             survivors of one subgroup are adjacent
-//   emit      SA[rank + place] = s                                  (final for resolved ones)
+//   emit      resolved    -> SA[rank + place] = s (final)
 //             still tied  -> appended to the next list T as (new rank, s)
 //             rank moved  -> appended to the update list U as (s, new rank)
 //             group > 8   -> appended to L as (rank << kbits | key2, s) for the radix path
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kSgThreads) void small_group_round_kernel(
     for (int k = 0; k < kSgItems; ++k) {
         const int e = k * kSgThreads + t;
         f[k] = slot_flag[e];
-        if (f[k] & 1) SA[slot_dest[e]] = slot_suf[e];
+        if ((f[k] & 3) == 1) SA[slot_dest[e]] = slot_suf[e];      // resolved now; tied ones are written when they resolve
         bt[k] = __ballot((f[k] & 2) != 0);
         bl[k] = __ballot(own_large[k]);
         bu[k] = __ballot((f[k] & 4) != 0);
