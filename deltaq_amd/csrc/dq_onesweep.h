@@ -161,7 +161,14 @@ struct OnesweepCtl {
 //             (word = key << ib | suffix) and no value array exists
 // kKeys       packed words only
 // kKeysLast   packed words; the last pass also emits SA[o] = word & mask
-enum OnesweepMode { kPairs = 0, kText = 1, kTextPacked = 2, kKeys = 3, kKeysLast = 4 };
+// kKeysLastTies  last pass of a packed sort that is expected to leave few ties: emits ONLY the SA
+//             (no sorted words) and, from the sorted tile it already holds, the tie structure:
+//             ebits bit o = 1 iff the keys at output positions o-1 and o are equal, for every
+//             pair inside one digit run of the tile (atomic OR of the few set bits), plus the
+//             first and last word of each of the tile's digit runs in seam_tab so that
+//             tie_seam_kernel (dq_ties.h) can decide the pairs that straddle two tiles
+enum OnesweepMode { kPairs = 0, kText = 1, kTextPacked = 2, kKeys = 3, kKeysLast = 4, kKeysLastTies = 5 };
+constexpr uint64_t kSeamEmpty = ~0ull;          // seam_tab marker: the tile has no key with this digit
 
 // developer instrumentation (tools/kbench): per-tile phase timestamps from thread 0
 #ifdef DQ_KERNEL_PHASE_TIMING
@@ -178,9 +185,11 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     uint64_t *__restrict__ kout, IdxT *__restrict__ vout, int64_t m, int shift, int kb, int ib,
     const int64_t *__restrict__ digit_offset /*[256] for this pass*/,
     StatusT *__restrict__ status /*[ntiles][256]*/, OnesweepCtl *__restrict__ ctl,
-    int64_t *__restrict__ sticky_error)
+    int64_t *__restrict__ sticky_error, uint32_t *__restrict__ ebits = nullptr,
+    uint64_t *__restrict__ seam_tab /*[ntiles][256][2]*/ = nullptr)
 {
     constexpr bool kFromText = (kMode == kText || kMode == kTextPacked);
+    constexpr bool kTies = (kMode == kKeysLastTies);
     constexpr bool kHasVals = (kMode == kPairs || kMode == kText);
     static_assert(!kFromText || (kItems % 4) == 0, "text mode packs 4 suffixes per lane");
     static_assert(kThreads % kRadixSize == 0, "threads 0..255 own one digit each");
@@ -482,7 +491,62 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
         gofs[tid] = (IdxT)(digit_offset[tid] + (int64_t)excl) - (IdxT)excl_tile;
     }
     __syncthreads();
+    DQ_PHASE(6);
 
+    if (kTies) {
+        // ---- tie structure of the sorted tile.  q = k*kThreads + tid is the position in the sorted
+        //      tile; the predecessor q-1 sits in lane-1 (DPP), in the previous wave's lane 63 or, for
+        //      tid 0, in the last lane of item k-1: those come through LDS (the exchange buffer is idle) ----
+        uint64_t *edge = exch;                                   // [kItems][kWavesB]
+        uint64_t *run_first = exch + kItems * kWavesB;           // [256] first / last word of each digit run,
+        uint64_t *run_last = run_first + kRadixSize;             // staged here and written out coalesced
+        static_assert(kExchN >= kItems * kWavesB + 2 * kRadixSize, "exchange buffer holds the seam staging");
+        if (lane == kWave - 1) {
+#pragma unroll
+            for (int k = 0; k < kItems; ++k) edge[k * kWavesB + w] = skey[k];
+        }
+        if (tid < kRadixSize) { run_first[tid] = kSeamEmpty; run_last[tid] = kSeamEmpty; }
+        __syncthreads();
+        const uint64_t smask = (1ull << ib) - 1;
+        // lane 0's predecessors for all items, fetched with ONE LDS read (lane k holds item k's) and
+        // handed over by readlane inside the loop: no LDS round trip per item
+        static_assert(kItems <= kWave, "one lane per item");
+        uint64_t eprev = 0;
+        if (lane < kItems) {
+            if (w > 0) eprev = edge[lane * kWavesB + w - 1];
+            else if (lane > 0) eprev = edge[(lane - 1) * kWavesB + kWavesB - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const int q = k * kThreads + tid;
+            const uint32_t plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)skey[k], 0x138, 0xf, 0xf, false);
+            const uint32_t phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(skey[k] >> 32), 0x138, 0xf, 0xf, false);
+            uint64_t prev = ((uint64_t)phi << 32) | plo;
+            const uint64_t e0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(eprev >> 32), k) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)eprev, k);
+            if (lane == 0) prev = e0;
+            if (q < valid) {
+                const uint32_t d = digit_of(skey[k], shift);
+                const IdxT o = gofs[d] + (IdxT)q;
+                const bool hasprev = q > 0;
+                // equal keys imply equal digits, so a tie never crosses a run boundary
+                if (hasprev && ((skey[k] ^ prev) >> ib) == 0)
+                    atomicOr(&ebits[(uint64_t)o >> 5], 1u << ((uint32_t)o & 31u));
+                const uint32_t dp = digit_of(prev, shift);
+                if (!hasprev || dp != d) {
+                    run_first[d] = skey[k];
+                    if (hasprev) run_last[dp] = prev;
+                }
+                if (q == valid - 1) run_last[d] = skey[k];
+                vout[o] = (IdxT)(skey[k] & smask);
+            }
+        }
+        __syncthreads();
+        if (tid < kRadixSize) {
+            seam_tab[(tile * kRadixSize + tid) * 2] = run_first[tid];
+            seam_tab[(tile * kRadixSize + tid) * 2 + 1] = run_last[tid];
+        }
+    } else {
     // ---- coalesced run writes ----
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
@@ -494,7 +558,8 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
             if (kMode == kKeysLast) vout[o] = (IdxT)(skey[k] & ((1ull << ib) - 1));
         }
     }
-    DQ_PHASE(6);
+    }
+    DQ_PHASE(7);
 }
 
 // ---------------------------------------------------------------------------------

@@ -316,115 +316,100 @@ __global__ __launch_bounds__(kBlock) void gather_text_key_kernel(uint64_t *__res
 
 // ---------------------------------------------------------------------------------
 // small_group_finish: most ties left by round 0 on random-like data are groups of 2-3
-// suffixes that differ a few bytes further on.  One lane per group (first member) sorts a
-// group of <= kMaxG suffixes by direct text comparison from offset h (at most kMaxLen bytes;
-// a suffix that ends first sorts first), writes SA[rank + i] and marks the members resolved.
-// Groups that are larger or still undecided after kMaxLen bytes are left untouched.
-// `resolved` is a zeroed byte-per-entry flag array (nothing this kernel reads is written by
-// it, so neighbouring groups cannot race).
+// suffixes that differ a few bytes further on.  The first member's lane sorts a group of
+// <= kMaxG suffixes by direct text comparison from offset h (at most kMaxLen bytes; a suffix
+// that ends first sorts first) and writes SA[rank + i].  What it cannot finish -- groups that
+// are larger, or still undecided after kMaxLen bytes -- is appended to the list (out_rank,
+// out_suf) for the key-extension rounds: one atomic per workgroup that has leftovers, order
+// arbitrary (the next step radix-sorts the list anyway).  *out_count must be zero on entry.
 // ---------------------------------------------------------------------------------
+constexpr int kFinishThreads = 256;
 
 template <typename IdxT, int kMaxG, int kMaxLen>
-__global__ __launch_bounds__(kBlock) void small_group_finish_kernel(const uint64_t *__restrict__ rank,
-                                                                    const IdxT *__restrict__ suf,
-                                                                    const uint8_t *__restrict__ text,
-                                                                    int64_t m, int64_t n, int64_t h,
-                                                                    IdxT *__restrict__ SA,
-                                                                    uint8_t *__restrict__ resolved)
+__global__ __launch_bounds__(kFinishThreads) void small_group_finish_kernel(
+    const uint64_t *__restrict__ rank, const IdxT *__restrict__ suf, const uint8_t *__restrict__ text,
+    int64_t m, int64_t n, int64_t h, IdxT *__restrict__ SA, uint64_t *__restrict__ out_rank,
+    IdxT *__restrict__ out_suf, unsigned long long *__restrict__ out_count)
 {
-    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= m) return;
-    const uint64_t r = rank[j];
-    if (j > 0 && rank[j - 1] == r) return;                     // not the first member
-    int g = 1;
-    while (g <= kMaxG && j + g < m && rank[j + g] == r) ++g;
-    if (g > kMaxG) return;
-    int64_t s[kMaxG];
-#pragma unroll
-    for (int i = 0; i < kMaxG; ++i) s[i] = i < g ? (int64_t)suf[j + i] : 0;
+    __shared__ uint32_t wave_tot[kFinishThreads / kWave];
+    __shared__ unsigned long long s_base;
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * kFinishThreads + threadIdx.x;
 
-    // -1: a < b, +1: a > b, 0: undecided within kMaxLen bytes
-    auto cmp = [&](int64_t a, int64_t b) -> int {
-        const int64_t pa = a + h, pb = b + h;
-        for (int k = 0; k < kMaxLen; ++k) {
-            const bool ea = pa + k >= n, eb = pb + k >= n;
-            if (ea || eb) return ea ? (eb ? (a > b ? -1 : 1) : -1) : 1;   // the shorter suffix first
-            const int ca = text[pa + k], cb = text[pb + k];
-            if (ca != cb) return ca < cb ? -1 : 1;
-        }
-        return 0;
-    };
-    // insertion sort (g <= kMaxG); static indexing via bubble passes keeps s[] in registers
-    bool decided = true;
+    uint32_t emit = 0;                 // entries this lane appends: itself (large group) or its whole undecided group
+    uint64_t r = 0;
+    int g = 1;
+    bool head = false;
+    if (j < m) {
+        r = rank[j];
+        int left = 0, right = 0;
 #pragma unroll
-    for (int pass = 0; pass < kMaxG - 1; ++pass) {
+        for (int i = 1; i <= kMaxG; ++i)
+            if (left == i - 1 && j - i >= 0 && rank[j - i] == r) left = i;
 #pragma unroll
-        for (int i = 0; i < kMaxG - 1; ++i) {
-            if (i + 1 < g && i < g - 1 - pass) {
-                const int c = cmp(s[i], s[i + 1]);
-                if (c == 0) decided = false;
-                if (c > 0) { const int64_t t = s[i]; s[i] = s[i + 1]; s[i + 1] = t; }
+        for (int i = 1; i <= kMaxG; ++i)
+            if (right == i - 1 && j + i < m && rank[j + i] == r) right = i;
+        g = left + right + 1;
+        if (g > kMaxG) emit = 1;
+        else head = left == 0;
+    }
+    int64_t s[kMaxG];
+    if (head) {
+#pragma unroll
+        for (int i = 0; i < kMaxG; ++i) s[i] = i < g ? (int64_t)suf[j + i] : 0;
+        // -1: a < b, +1: a > b, 0: undecided within kMaxLen bytes
+        auto cmp = [&](int64_t a, int64_t b) -> int {
+            const int64_t pa = a + h, pb = b + h;
+            for (int k = 0; k < kMaxLen; ++k) {
+                const bool ea = pa + k >= n, eb = pb + k >= n;
+                if (ea || eb) return ea ? (eb ? (a > b ? -1 : 1) : -1) : 1;   // the shorter suffix first
+                const int ca = text[pa + k], cb = text[pb + k];
+                if (ca != cb) return ca < cb ? -1 : 1;
+            }
+            return 0;
+        };
+        // bubble passes with static indices keep s[] in registers
+        bool decided = true;
+#pragma unroll
+        for (int pass = 0; pass < kMaxG - 1; ++pass) {
+#pragma unroll
+            for (int i = 0; i < kMaxG - 1; ++i) {
+                if (i + 1 < g && i < g - 1 - pass) {
+                    const int c = cmp(s[i], s[i + 1]);
+                    if (c == 0) decided = false;
+                    if (c > 0) { const int64_t t = s[i]; s[i] = s[i + 1]; s[i + 1] = t; }
+                }
             }
         }
-    }
-    if (!decided) return;
+        if (decided) {
 #pragma unroll
-    for (int i = 0; i < kMaxG; ++i) {
-        if (i < g) {
-            SA[(int64_t)r + i] = (IdxT)s[i];
-            resolved[j + i] = 1;
+            for (int i = 0; i < kMaxG; ++i)
+                if (i < g) SA[(int64_t)r + i] = (IdxT)s[i];
+        } else {
+            emit = (uint32_t)g;
         }
     }
-}
-
-// stream compaction of the active list: keep entries whose flag byte equals keep_val
-template <typename IdxT>
-__global__ __launch_bounds__(kBlock) void compact_count_kernel(const uint8_t *__restrict__ resolved, int64_t m,
-                                                               SegPartials<IdxT> part, int keep_val = 0)
-{
-    __shared__ IdxT tmp[kWavesPerBlock];
-    const int64_t j0 = (int64_t)blockIdx.x * kSegTile + (int64_t)threadIdx.x * kSegItems;
-    IdxT cnt = 0;
-#pragma unroll
-    for (int i = 0; i < kSegItems; ++i) cnt += (j0 + i < m && resolved[j0 + i] == keep_val) ? 1 : 0;
-    cnt = wave_sum(cnt);
-    if (lane_id() == 0) tmp[threadIdx.x >> 6] = cnt;
+    const uint32_t incl = wave_incl_sum(emit);
+    if (lane == kWave - 1) wave_tot[w] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        IdxT c = 0;
-        for (int i = 0; i < kWavesPerBlock; ++i) c += tmp[i];
-        part.nh[blockIdx.x] = -1;
-        part.gh[blockIdx.x] = -1;
-        part.cnt[blockIdx.x] = c;
-    }
-}
-
-template <typename IdxT>
-__global__ __launch_bounds__(kBlock) void compact_scatter_kernel(const uint8_t *__restrict__ resolved,
-                                                                 const uint64_t *__restrict__ rank,
-                                                                 const IdxT *__restrict__ suf, int64_t m,
-                                                                 SegPartials<IdxT> part,
-                                                                 uint64_t *__restrict__ rank_out,
-                                                                 IdxT *__restrict__ suf_out, int keep_val = 0)
-{
-    __shared__ IdxT tmp[kWavesPerBlock];
-    const int64_t j0 = (int64_t)blockIdx.x * kSegTile + (int64_t)threadIdx.x * kSegItems;
-    bool keep[kSegItems];
-    IdxT cnt = 0;
+    uint32_t off = incl - emit, tot = 0;
 #pragma unroll
-    for (int i = 0; i < kSegItems; ++i) {
-        keep[i] = (j0 + i < m) && resolved[j0 + i] == keep_val;
-        cnt += keep[i] ? 1 : 0;
+    for (int k = 0; k < kFinishThreads / kWave; ++k) {
+        const uint32_t c = wave_tot[k];
+        if (k < w) off += c;
+        tot += c;
     }
-    IdxT dummy;
-    int64_t o = (int64_t)part.cnt[blockIdx.x] + (int64_t)block_excl_sum(cnt, tmp, &dummy);
-#pragma unroll
-    for (int i = 0; i < kSegItems; ++i) {
-        if (keep[i]) {
-            rank_out[o] = rank[j0 + i];
-            suf_out[o] = suf[j0 + i];
-            ++o;
-        }
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(out_count, (unsigned long long)tot) : 0ull;
+    __syncthreads();
+    if (emit == 0) return;
+    const int64_t o = (int64_t)s_base + off;
+    if (head) {
+        // undecided small group: its members as they stand in the list
+        for (int i = 0; i < g; ++i) { out_rank[o + i] = r; out_suf[o + i] = suf[j + i]; }
+    } else {
+        out_rank[o] = r;
+        out_suf[o] = suf[j];
     }
 }
 

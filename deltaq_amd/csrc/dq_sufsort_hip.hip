@@ -30,6 +30,7 @@
 #include "dq_seg_fused.h"
 #include "dq_small.h"
 #include "dq_small_groups.h"
+#include "dq_ties.h"
 
 namespace {
 
@@ -268,12 +269,17 @@ int radix_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V[2]
 // (tools/kbench, 64 Mi keys, random digits): 512 threads; packed-word passes 24 keys/thread
 // (12288-key tiles, ~48-key runs per digit), LDS match tables; pair passes 20 keys/thread,
 // ballot match; the tile is staged through LDS in 2 position ranges (half the LDS footprint).
+#ifndef DQ_TIES_BIG_TILE
+#define DQ_TIES_BIG_TILE 0
+#endif
 template <typename IdxT, int kMode> struct RankCfg {
-    static constexpr bool kWords = (kMode == kTextPacked || kMode == kKeys || kMode == kKeysLast);
-    static constexpr int kThreads = 512;
+    static constexpr bool kWords = (kMode == kTextPacked || kMode == kKeys || kMode == kKeysLast || kMode == kKeysLastTies);
+    // the tie-recording last pass writes 4- or 8-byte SA entries only: a 1024-thread tile doubles its runs
+    static constexpr bool kBig = (kMode == kKeysLastTies) && DQ_TIES_BIG_TILE;
+    static constexpr int kThreads = kBig ? 1024 : 512;
     static constexpr int kItems = kWords ? 24 : (sizeof(IdxT) == 4 ? 20 : 16);
-    static constexpr int kMinWaves = 2;
-    static constexpr int kRounds = 2;
+    static constexpr int kMinWaves = kBig ? 4 : 2;
+    static constexpr int kRounds = kBig ? 4 : 2;
     static constexpr bool kLdsMatch = kWords;
 };
 
@@ -292,7 +298,8 @@ int prepare_status(Launcher &L, Workspace<IdxT> &w, int64_t m, int passes)
 
 template <typename IdxT, typename StatusT, int kMode>
 int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin,
-                     uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb, int ib)
+                     uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb, int ib,
+                     uint32_t *ebits = nullptr, uint64_t *seam_tab = nullptr)
 {
     using Cfg = RankCfg<IdxT, kMode>;
     constexpr int kItems = Cfg::kItems;
@@ -308,22 +315,27 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
         return fail(DQ_ERR_HIP, "status buffer too small");
     // algorithmic bytes per element: what the pass must read + write
     const int64_t alg = kMode == kPairs ? 2 * (8 + wb) : kMode == kText ? 1 + 8 + wb
-                      : kMode == kTextPacked ? 1 + 8 : kMode == kKeys ? 16 : 16 + wb;
-    LAUNCH(L, DQ_K_RADIX_RANK_SCATTER, m, m * alg,
+                      : kMode == kTextPacked ? 1 + 8 : kMode == kKeys ? 16 : kMode == kKeysLastTies ? 8 + wb : 16 + wb;
+    // the tie-recording pass also writes 1 bit per element and 2 words per (tile, digit)
+    const int64_t alg_extra = kMode == kKeysLastTies ? m / 8 + ntiles * kRadixSize * 16 : 0;
+    LAUNCH(L, DQ_K_RADIX_RANK_SCATTER, m, m * alg + alg_extra,
            hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, kItems, kMode, Cfg::kMinWaves, kThreads,
                                                  false, Cfg::kLdsMatch, Cfg::kRounds>),
                               dim3((unsigned)ntiles), dim3(kThreads), 0, L.st, kin, vin, kout, vout, m,
                               pass * kRadixBits + ib, kb, ib,
-                              (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1));
+                              (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1,
+                              ebits, seam_tab));
     return DQ_OK;
 }
 
 template <typename IdxT, int kMode>
 int rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin, uint64_t *kout,
-              IdxT *vout, int64_t m, int pass, int kb, int ib = 0)
+              IdxT *vout, int64_t m, int pass, int kb, int ib = 0, uint32_t *ebits = nullptr,
+              uint64_t *seam_tab = nullptr)
 {
-    if (m < (1ll << 30)) return launch_rank_pass<IdxT, uint32_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib);
-    return launch_rank_pass<IdxT, uint64_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib);
+    if (m < (1ll << 30))
+        return launch_rank_pass<IdxT, uint32_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits, seam_tab);
+    return launch_rank_pass<IdxT, uint64_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits, seam_tab);
 }
 
 template <int kPasses>
@@ -425,7 +437,8 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
 // buffer 1, pass p writes buffer (p+1)&1.  Packed: words only, the last pass also emits the SA.
 template <typename IdxT>
 int onesweep_sort_text_passes(Launcher &L, Workspace<IdxT> &w, int64_t n, uint64_t *K[2], IdxT *V[2],
-                              int kb, bool packed, IdxT *d_sa, int &cur)
+                              int kb, bool packed, IdxT *d_sa, int &cur, uint32_t *ebits = nullptr,
+                              uint64_t *seam_tab = nullptr)
 {
     const uint64_t *text64 = reinterpret_cast<const uint64_t *>(w.text);
     int rc = prepare_status<IdxT>(L, w, n, kb);
@@ -436,7 +449,10 @@ int onesweep_sort_text_passes(Launcher &L, Workspace<IdxT> &w, int64_t n, uint64
         if (rc != DQ_OK) return rc;
         cur = 1;
         for (int p = 1; p < kb; ++p) {
-            if (p == kb - 1)
+            if (p == kb - 1 && ebits)
+                rc = rank_pass<IdxT, kKeysLastTies>(L, w, K[cur], (const IdxT *)nullptr, (uint64_t *)nullptr, d_sa, n, p,
+                                                    kb, ib, ebits, seam_tab);
+            else if (p == kb - 1)
                 rc = rank_pass<IdxT, kKeysLast>(L, w, K[cur], (const IdxT *)nullptr, K[cur ^ 1], d_sa, n, p, kb, ib);
             else
                 rc = rank_pass<IdxT, kKeys>(L, w, K[cur], (const IdxT *)nullptr, K[cur ^ 1], (IdxT *)nullptr, n, p, kb, ib);
@@ -453,6 +469,46 @@ int onesweep_sort_text_passes(Launcher &L, Workspace<IdxT> &w, int64_t n, uint64
         if (rc != DQ_OK) return rc;
         cur ^= 1;
     }
+    return DQ_OK;
+}
+
+// After a packed sort whose last pass ran in kKeysLastTies mode: decide the cross-tile pairs, then
+// turn the tie bits into the list of tied suffixes.  *overflow: a run of equal keys too long for
+// the per-thread walk was met and the caller must take the general rebucket pass instead.
+template <typename IdxT>
+int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int kb, int ib, uint32_t *ebits,
+                 const uint64_t *seam_tab, const IdxT *d_sa, uint64_t *act_rank, IdxT *act_suf, int64_t *count,
+                 bool *overflow)
+{
+    using Cfg = RankCfg<IdxT, kKeysLastTies>;
+    const int64_t ntiles = (n + Cfg::kThreads * Cfg::kItems - 1) / (Cfg::kThreads * Cfg::kItems);
+    const int pass = kb - 1;
+    char *area = w.ctl_status + (size_t)pass * w.ctl_status_stride;
+    const int64_t *dofs = w.digit_offset + pass * kRadixSize;
+    const int64_t nwords = (n + 63) / 64;
+    TieCounters *ctr = reinterpret_cast<TieCounters *>(w.totals + 6);
+    const int64_t wb = (int64_t)sizeof(IdxT);
+    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(TieCounters), L.st));
+    const unsigned sg = (unsigned)((ntiles * kRadixSize + kBlock - 1) / kBlock);
+    if (n < (1ll << 30)) {
+        LAUNCH(L, DQ_K_SEG_REDUCE, ntiles * kRadixSize, ntiles * kRadixSize * 16,
+               hipLaunchKernelGGL(tie_seam_kernel<uint32_t>, dim3(sg), dim3(kBlock), 0, L.st, seam_tab, ntiles, ib, dofs,
+                                  reinterpret_cast<const uint32_t *>(area + 256), ebits));
+    } else {
+        LAUNCH(L, DQ_K_SEG_REDUCE, ntiles * kRadixSize, ntiles * kRadixSize * 16,
+               hipLaunchKernelGGL(tie_seam_kernel<uint64_t>, dim3(sg), dim3(kBlock), 0, L.st, seam_tab, ntiles, ib, dofs,
+                                  reinterpret_cast<const uint64_t *>(area + 256), ebits));
+    }
+    LAUNCH(L, DQ_K_SEG_APPLY, n, n / 8,
+           hipLaunchKernelGGL(tie_collect_kernel<IdxT>, dim3((unsigned)((nwords + kTieThreads - 1) / kTieThreads)),
+                              dim3(kTieThreads), 0, L.st, reinterpret_cast<const uint64_t *>(ebits), nwords, n, d_sa,
+                              act_rank, act_suf, ctr));
+    HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 64, hipMemcpyDeviceToHost, L.st));     // [1] sticky flag, [6..7] counters
+    HIP_TRY(hipStreamSynchronize(L.st));
+    if (c.pinned[1] != 0) return fail(DQ_ERR_HIP, "radix look-back timed out (device spin bound hit)");
+    *count = c.pinned[6];
+    *overflow = c.pinned[7] != 0;
+    (void)wb;
     return DQ_OK;
 }
 
@@ -508,31 +564,6 @@ int rebucket(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *keys
            hipLaunchKernelGGL((seg_apply_kernel<IdxT, kInitial, kWriteSA, kWriteISA>), dim3((unsigned)ntiles),
                               dim3(kBlock), 0, L.st, keys, vals, m, kbits, w.part, SA, w.ISA, act_rank,
                               act_suf, kshift));
-    return DQ_OK;
-}
-
-// Order-preserving compaction of the (rank, suffix) entries whose class byte == keep_val.
-template <typename IdxT>
-int compact_class(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint8_t *cls, int keep_val,
-                  const uint64_t *rank, const IdxT *suf, int64_t m, uint64_t *rank_out, IdxT *suf_out,
-                  int64_t *count_out)
-{
-    const int64_t wb = (int64_t)sizeof(IdxT);
-    const int64_t np = (m + kSegTile - 1) / kSegTile;
-    LAUNCH(L, DQ_K_SEG_REDUCE, m, m,
-           hipLaunchKernelGGL(compact_count_kernel<IdxT>, dim3((unsigned)np), dim3(kBlock), 0, L.st, cls, m,
-                              w.part, keep_val));
-    LAUNCH(L, DQ_K_SEG_SCAN, np, np * 6 * wb,
-           hipLaunchKernelGGL(seg_scan_kernel<IdxT>, dim3(1), dim3(1024), 0, L.st, w.part, np, w.totals));
-    HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, L.st));
-    HIP_TRY(hipStreamSynchronize(L.st));
-    const int64_t cnt = c.pinned[0];
-    if (cnt > 0) {
-        LAUNCH(L, DQ_K_SEG_APPLY, m, m + cnt * 2 * (8 + wb),
-               hipLaunchKernelGGL(compact_scatter_kernel<IdxT>, dim3((unsigned)np), dim3(kBlock), 0, L.st, cls,
-                                  rank, suf, m, w.part, rank_out, suf_out, keep_val));
-    }
-    *count_out = cnt;
     return DQ_OK;
 }
 
@@ -597,8 +628,44 @@ struct SuffixSorter {
             if (rc != DQ_OK) return rc;
             V[kb & 1] = d_sa;
             V[(kb & 1) ^ 1] = w.Va;
-            rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur);
-            if (rc != DQ_OK) return rc;
+            // Packed words were chosen because few ties are expected: the last pass then records the tie
+            // structure itself (1 bit per suffix + 2 words per tile and digit, in the idle Vb buffer)
+            // instead of writing the sorted words for a rebucket pass to read back.
+            const bool fused_ties = packed && kb >= 2 && n >= (1 << 16) && !getenv("DQ_NO_FUSED_TIES") &&
+                                    !getenv("DQ_SPARSE");
+            if (fused_ties) {
+                const int ib = bit_length((uint64_t)(n - 1));
+                const int64_t nwords = (n + 63) / 64;
+                uint32_t *ebits = reinterpret_cast<uint32_t *>(w.Vb);
+                uint64_t *seam_tab = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(w.Vb) +
+                                                                  align_up((size_t)(nwords + 1) * 8));
+                HIP_TRY(hipMemsetAsync(ebits, 0, (size_t)(nwords + 1) * 8, st));
+                rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur, ebits, seam_tab);
+                if (rc != DQ_OK) return rc;
+                // cur names the buffer the last pass would have written: it is free, the pass's input
+                // K[cur ^ 1] stays intact for the fallback
+                bool overflow = false;
+                rc = collect_ties<IdxT>(L, c, w, n, kb, ib, ebits, seam_tab, (const IdxT *)d_sa, K[cur], w.Va, &m,
+                                        &overflow);
+                if (rc != DQ_OK) return rc;
+                if (!overflow) {
+                    *dense_built = false;
+                    Kr[0] = K[cur]; Kr[1] = K[cur ^ 1];
+                    Vr[0] = w.Va; Vr[1] = w.Vb;
+                    rcur = 0;
+                    h = kb;
+                    rbits = ib;
+                    return DQ_OK;
+                }
+                // a long run of equal keys: redo the last pass with the sorted words as output and take
+                // the general rebucket pass below
+                HIP_TRY(hipMemsetAsync(w.ctl_status + (size_t)(kb - 1) * w.ctl_status_stride, 0, w.ctl_status_stride, st));
+                rc = rank_pass<IdxT, kKeysLast>(L, w, K[cur ^ 1], (const IdxT *)nullptr, K[cur], d_sa, n, kb - 1, kb, ib);
+                if (rc != DQ_OK) return rc;
+            } else {
+                rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur);
+                if (rc != DQ_OK) return rc;
+            }
         } else {
             const int64_t nquads = (n + 3) / 4;
             const int64_t blocks = std::min<int64_t>((nquads + kBlock - 1) / kBlock, 256 * 8);
@@ -654,18 +721,19 @@ struct SuffixSorter {
     int finish_sparse()
     {
         int rc;
-        // tiny groups with a short remaining common prefix
+        // tiny groups with a short remaining common prefix; the leftovers come back as a new list
         t_info[0] += 1;
         t_info[2] += m;
-        uint8_t *resolved = reinterpret_cast<uint8_t *>(w.ISA);         // ISA is unused on the sparse path
-        HIP_TRY(hipMemsetAsync(resolved, 0, (size_t)m, st));
+        unsigned long long *left_over = reinterpret_cast<unsigned long long *>(w.totals + 3);
+        HIP_TRY(hipMemsetAsync(left_over, 0, 8, st));
         LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + 16 + wb),
-               hipLaunchKernelGGL((small_group_finish_kernel<IdxT, 8, 32>), dim3((unsigned)((m + kBlock - 1) / kBlock)),
-                                  dim3(kBlock), 0, st, (const uint64_t *)Kr[rcur], (const IdxT *)Vr[rcur],
-                                  (const uint8_t *)w.text, m, n, h, d_sa, resolved));
-        int64_t m2 = 0;
-        rc = compact_class<IdxT>(L, c, w, resolved, 0, Kr[rcur], Vr[rcur], m, Kr[rcur ^ 1], Vr[rcur ^ 1], &m2);
-        if (rc != DQ_OK) return rc;
+               hipLaunchKernelGGL((small_group_finish_kernel<IdxT, 8, 32>),
+                                  dim3((unsigned)((m + kFinishThreads - 1) / kFinishThreads)), dim3(kFinishThreads), 0,
+                                  st, (const uint64_t *)Kr[rcur], (const IdxT *)Vr[rcur], (const uint8_t *)w.text, m, n,
+                                  h, d_sa, Kr[rcur ^ 1], Vr[rcur ^ 1], left_over));
+        HIP_TRY(hipMemcpyAsync(c.pinned, left_over, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        int64_t m2 = c.pinned[0];
         if (m2 > 0) rcur ^= 1;
         m = m2;
 

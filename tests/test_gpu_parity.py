@@ -130,6 +130,27 @@ def test_single_workgroup_sorter_every_small_size(ldss, oracle_mod, backend_lib)
     assert launches.value == 1
 
 
+def test_tie_bits_of_the_last_pass(ldss, oracle_mod, backend_lib):
+    """Packed sorts record ties in the last digit pass (dq_ties.h): pairs inside a tile, pairs that
+    straddle tiles (any n > one tile has them), runs continuing over several 64-bit words, and the
+    fallback when a run of equal keys is too long for the per-thread walk."""
+    rnd = oracle_mod.gen_uniform
+    cases = {
+        "random 3M": rnd(3_000_000, 21),
+        "run of 1000 zeros": np.concatenate([rnd(700_000, 22), np.zeros(1000, np.uint8), rnd(400_000, 23)]),
+        "run of 60000 x 0x41 (fallback)": np.concatenate([rnd(2_000_000, 24), np.full(60_000, 0x41, np.uint8),
+                                                          rnd(1_000_000, 25)]),
+        "repeat of 5000 bytes": np.concatenate([rnd(900_000, 26), rnd(900_000, 26)[1000:6000], rnd(300_000, 27)]),
+        "exactly one tile": rnd(12288, 28), "one tile + 1": rnd(12289, 29), "64 KiB": rnd(1 << 16, 30),
+        "zero tail": np.concatenate([rnd(500_000, 31), np.zeros(9, np.uint8)]),
+    }
+    for name, T in cases.items():
+        T = np.ascontiguousarray(T, dtype=np.uint8)
+        assert np.array_equal(ldss.Sort(T), oracle_mod.divsufsort(T)), name
+    T = cases["random 3M"]
+    assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
+
+
 @pytest.mark.parametrize("n", [1 << 16, (1 << 20) + 3, 5_000_000])
 def test_uniform_random_matches_oracle(ldss, oracle_mod, n):
     T = oracle_mod.gen_uniform(n, 0x5EED0002)
@@ -202,6 +223,8 @@ FORCED_PATHS = [
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "0"},   # pairs, 8-byte keys, dense doubling
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "1"},
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "4", "DQ_SPARSE": "0", "DQ_NO_SMALL": "1"},   # doubling without the small-group rounds
+    {"DQ_NO_FUSED_TIES": "1"},                                   # packed sort + general rebucket pass instead of tie bits
+    {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2"},                     # tie bits with MANY ties (dense doubling after them)
 ]
 
 
