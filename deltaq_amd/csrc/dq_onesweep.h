@@ -155,6 +155,9 @@ struct OnesweepCtl {
 #ifndef DQ_LOOK_WIN
 #define DQ_LOOK_WIN 8
 #endif
+#ifndef DQ_LOOK_WIN2
+#define DQ_LOOK_WIN2 8
+#endif
 // kPairs      (key, suffix) pairs in two arrays
 // kText       round 0, first pass: keys built from the text, suffix index synthesised
 // kTextPacked same, but the suffix index is packed into the low `ib` bits of the key word
@@ -464,7 +467,8 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
             int64_t t = tile - 1;
             uint32_t spins = 0;
             bool done = false;
-            for (;;) {
+            // the window prefetched at publish time first ...
+            {
                 int used = 0;
 #pragma unroll
                 for (int j = 0; j < kLookWin; ++j) {
@@ -473,15 +477,28 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
                         else if (sw[j] & SB::kAgg) { excl += sw[j] & SB::kMask; used = j + 1; }
                     }
                 }
-                if (done) break;
                 t -= used;
-                if (used == 0) {
+            }
+            // ... then kLookWin2 status words per round trip until an inclusive prefix shows up
+            constexpr int kLookWin2 = DQ_LOOK_WIN2;
+            while (!done) {
+                StatusT s2[kLookWin2];
+#pragma unroll
+                for (int j = 0; j < kLookWin2; ++j)
+                    s2[j] = (t - j >= 0) ? status_load<StatusT>(status + (t - j) * kRadixSize + tid) : SB::kPrefix;
+                int used = 0;
+#pragma unroll
+                for (int j = 0; j < kLookWin2; ++j) {
+                    if (!done && used == j) {
+                        if (s2[j] & SB::kPrefix) { excl += s2[j] & SB::kMask; done = true; }
+                        else if (s2[j] & SB::kAgg) { excl += s2[j] & SB::kMask; used = j + 1; }
+                    }
+                }
+                t -= used;
+                if (!done && used == 0) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > kSpinLimit) { atomicExch(&ctl->error, 1u); *sticky_error = 1; break; }
                 }
-#pragma unroll
-                for (int j = 0; j < kLookWin; ++j)
-                    sw[j] = (t - j >= 0) ? status_load<StatusT>(status + (t - j) * kRadixSize + tid) : SB::kPrefix;
             }
             status_store<StatusT>(mine, SB::kPrefix | (StatusT)(excl + tot));
         }
