@@ -280,7 +280,9 @@ template <typename IdxT, int kMode> struct RankCfg {
     static constexpr int kItems = kWords ? 24 : (sizeof(IdxT) == 4 ? 20 : 16);
     static constexpr int kMinWaves = kBig ? 4 : 2;
     static constexpr int kRounds = kBig ? 4 : 2;
-    static constexpr bool kLdsMatch = true;      // kbench: LDS match tables beat 8 ballots for words (-6%) and pairs (-2%)
+    // LDS match tables beat 8 ballots on near-uniform digits (words: -6%), but equal digits in a wave are
+    // same-address LDS atomics: pair passes run on text-like (skewed) data and keep the ballots
+    static constexpr bool kLdsMatch = kWords;
 };
 
 // Zero the look-back state (ticket + status words) of ALL digit passes of one sort with a single
