@@ -36,6 +36,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into deltaq_amd/libdq_sufsort_hip.so."""
     if not force and not is_stale():
         return LIB_PATH
+    # one builder at a time (bench.py ranks, pytest-xdist workers): the others wait, then find it current
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not is_stale():
+            return LIB_PATH
+        return _build_locked(verbose)
+
+
+def _build_locked(verbose: bool) -> str:
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-pthread"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
