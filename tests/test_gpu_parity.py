@@ -151,6 +151,64 @@ def test_tie_bits_of_the_last_pass(ldss, oracle_mod, backend_lib):
     assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
 
 
+def structured_text(rng, n):
+    """Random text with the structure suffix sorters are sensitive to: a random alphabet size, runs of
+    one byte, copies of earlier pieces (long repeats), periodic stretches and zero tails."""
+    sigma = int(rng.choice([1, 2, 3, 4, 16, 64, 256]))
+    out = []
+    total = 0
+    while total < n:
+        kind = rng.integers(0, 6)
+        ln = int(min(n - total, rng.integers(1, max(2, n // 3))))
+        if kind == 0 or not out:
+            piece = rng.integers(0, sigma, size=ln, dtype=np.uint8)
+        elif kind == 1:
+            piece = np.full(ln, rng.integers(0, sigma), dtype=np.uint8)
+        elif kind == 2:                                         # copy of something earlier
+            src = np.concatenate(out)
+            a = int(rng.integers(0, src.size))
+            piece = np.resize(src[a:a + ln], ln) if src[a:a + ln].size else src[:1]
+        elif kind == 3:                                         # short period
+            per = rng.integers(0, sigma, size=int(rng.integers(1, 9)), dtype=np.uint8)
+            piece = np.resize(per, ln)
+        elif kind == 4:
+            piece = np.zeros(ln, dtype=np.uint8)
+        else:
+            piece = rng.integers(0, 256, size=ln, dtype=np.uint8)
+        out.append(np.ascontiguousarray(piece, dtype=np.uint8))
+        total += out[-1].size
+    return np.concatenate(out)[:n]
+
+
+FUZZ_ENVS = [
+    {},
+    {"DQ_SMALL_N": "0"},                                   # everything through the device-wide pipeline
+    {"DQ_NO_FUSED_TIES": "1", "DQ_NO_SMALL": "1"},         # general rebucket pass, radix-only doubling rounds
+    {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2", "DQ_SMALL_N": "0"},   # tie bits with most suffixes tied
+    {"DQ_SPARSE": "1", "DQ_SMALL_N": "0"},                 # finisher + key extension + fallback on dense inputs
+]
+
+
+@pytest.mark.parametrize("env", FUZZ_ENVS, ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
+def test_randomised_structured_inputs(ldss, oracle_mod, monkeypatch, env):
+    """Differential test over ~400 structured inputs of 1 .. 2 000 000 bytes (sizes on both sides of every
+    path switch: single-workgroup sorter, packed / pair keys, tie bits, sparse / dense finishing), under
+    the default adaptive choices and with the alternatives forced."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(0xD17A + len(env))
+    sizes = [int(x) for x in rng.integers(1, 2000, 120)] + [int(x) for x in rng.integers(2000, 20000, 120)] + \
+            [int(x) for x in rng.integers(20000, 100000, 100)] + [int(x) for x in rng.integers(100000, 300000, 50)] + \
+            [int(x) for x in rng.integers(300000, 2000000, 10)]
+    for i, n in enumerate(sizes):
+        T = structured_text(rng, n)
+        ref = oracle_mod.divsufsort(T)
+        if i % 9 == 0:
+            assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), ref.astype(np.int64)), (env, i, n, "i64")
+        else:
+            assert np.array_equal(ldss.Sort(T), ref), (env, i, n)
+
+
 @pytest.mark.parametrize("n", [1 << 16, (1 << 20) + 3, 5_000_000])
 def test_uniform_random_matches_oracle(ldss, oracle_mod, n):
     T = oracle_mod.gen_uniform(n, 0x5EED0002)
