@@ -24,6 +24,22 @@ if which == "2g":
     SA = out.cpu().numpy()
     t0 = time.time(); rc = oracle.sufcheck(T, SA); print("sufcheck_i64", rc, round(time.time() - t0, 1), "s", flush=True)
     print("sampled strict order (1e6 pairs):", oracle.verify_sampled(T, SA, 1_000_000, 7), flush=True)
+elif which == "i32max":
+    # the largest texts the int32 interface takes: 64-bit status words (n >= 2^30) with 32-bit indices,
+    # packed words with ib = 31
+    for n in ((3 << 29) + 12345, (1 << 31) - 1):
+        t0 = time.time(); T = workload.gen_uniform(n, 0x5EED0007); print("gen", n, round(time.time() - t0, 1), "s", flush=True)
+        if n == (1 << 31) - 1:
+            T[1000:200_000] = T[5_000_000:5_199_000]          # a long repeat: dense rounds at this size too
+        dT = torch.from_numpy(T).cuda()
+        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        t0 = time.time(); s.Sort(dT, out); torch.cuda.synchronize(); print("sort (first call)", round(time.time() - t0, 3), "s", _abi.last_sort_info(), flush=True)
+        t0 = time.time(); s.Sort(dT, out); torch.cuda.synchronize(); dt = time.time() - t0
+        print(f"n={n} i32 device-resident: {dt*1e3:.1f} ms = {n/1e6/dt:.0f} MB/s", flush=True)
+        SA = out.cpu().numpy(); del dT, out
+        t0 = time.time(); rc = oracle.sufcheck(T, SA); print("sufcheck", rc, round(time.time() - t0, 1), "s", flush=True)
+        print("sampled strict order (1e6 pairs):", oracle.verify_sampled(T, SA, 1_000_000, 7), flush=True)
+        del SA, T
 else:
     n = 256 << 20
     T = datagen.gen_enwik_like(n, 0xD17A0)
