@@ -22,6 +22,7 @@
 namespace dq {
 
 constexpr int kHistBlocks = 512;
+constexpr int kHistThreads = 1024;   // 16 waves share one set of sub-histograms: 512 workgroups fill the 256 CUs
 constexpr int kMaxPasses = 8;
 
 constexpr uint32_t kSpinLimit = 1u << 24;
@@ -33,22 +34,22 @@ constexpr uint32_t kSpinLimit = 1u << 24;
 // a wave whose 64 keys share a digit (constant high digits of composite keys) adds once.
 // ---------------------------------------------------------------------------------
 template <int kPasses>
-__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t *__restrict__ keys,
+__global__ __launch_bounds__(kHistThreads) void radix_hist_kernel(const uint64_t *__restrict__ keys,
                                                             int64_t m, uint32_t *__restrict__ partial)
 {
     __shared__ uint32_t hist[kPasses][kRadixSize * 4];     // kPasses * 4 KiB
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int sub = tid & 3;
-    for (int i = tid; i < kPasses * kRadixSize * 4; i += kBlock) (&hist[0][0])[i] = 0;
+    for (int i = tid; i < kPasses * kRadixSize * 4; i += kHistThreads) (&hist[0][0])[i] = 0;
     __syncthreads();
 
     const int64_t pairs = m >> 1;
     const ulonglong2 *k2 = reinterpret_cast<const ulonglong2 *>(keys);
     // i0 is wave-uniform, so a wave enters/leaves the loop as a whole and the wave-uniform
     // shortcut below always sees 64 lanes; out-of-range lanes contribute nothing
-    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + (tid & ~(kWave - 1)); i0 < pairs;
-         i0 += (int64_t)gridDim.x * kBlock) {
+    for (int64_t i0 = (int64_t)blockIdx.x * kHistThreads + (tid & ~(kWave - 1)); i0 < pairs;
+         i0 += (int64_t)gridDim.x * kHistThreads) {
         const int64_t i = i0 + lane;
         const bool ok = i < pairs;
         const bool full = (i0 + kWave) <= pairs;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint64_t *__re
         for (int p = 0; p < kPasses; ++p) atomicAdd(&hist[p][digit_of(k, p * kRadixBits) << 2], 1u);
     }
     __syncthreads();
-    for (int i = tid; i < kPasses * kRadixSize; i += kBlock) {
+    for (int i = tid; i < kPasses * kRadixSize; i += kHistThreads) {
         const uint32_t *h4 = &(&hist[0][0])[i * 4];
         partial[(int64_t)blockIdx.x * (kMaxPasses * kRadixSize) + i] = h4[0] + h4[1] + h4[2] + h4[3];
     }

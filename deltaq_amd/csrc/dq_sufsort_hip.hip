@@ -343,7 +343,7 @@ int rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *
 template <int kPasses>
 void launch_hist(hipStream_t st, int blocks, const uint64_t *keys, int64_t m, uint32_t *partial)
 {
-    hipLaunchKernelGGL(radix_hist_kernel<kPasses>, dim3(blocks), dim3(kBlock), 0, st, keys, m, partial);
+    hipLaunchKernelGGL(radix_hist_kernel<kPasses>, dim3(blocks), dim3(kHistThreads), 0, st, keys, m, partial);
 }
 
 // generic pairs: all digit histograms in one read, then one radix_rank_kernel per digit
@@ -352,7 +352,7 @@ int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V
                         int total_bits, int &cur)
 {
     const int passes = (total_bits + kRadixBits - 1) / kRadixBits;
-    const int blocks = (int)std::min<int64_t>(kHistBlocks, ((m >> 1) + kBlock - 1) / kBlock + 1);
+    const int blocks = (int)std::min<int64_t>(kHistBlocks, ((m >> 1) + kHistThreads - 1) / kHistThreads + 1);
     int rc = L.begin(DQ_K_RADIX_HIST, m, m * 8);
     if (rc != DQ_OK) return rc;
     switch (passes) {

@@ -121,7 +121,7 @@ int main(int argc, char **argv)
     printf("baseline upsweep %8.1f us  scan %6.1f us  downsweep %8.1f us (%.1f GB/s alg)\n", t_up * 1e3, t_sc * 1e3, t_dn * 1e3, (double)m * 24 / (t_dn * 1e-3) / 1e9);
 
     // ---- global histograms
-    float t_h = time_it([&]() { hipLaunchKernelGGL(radix_hist_kernel<8>, dim3(kHistBlocks), dim3(kBlock), 0, 0, B.k0, m, B.partial); });
+    float t_h = time_it([&]() { hipLaunchKernelGGL(radix_hist_kernel<8>, dim3(kHistBlocks), dim3(kHistThreads), 0, 0, B.k0, m, B.partial); });
     float t_hs = time_it([&]() { hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(8), dim3(kHistScanThreads), 0, 0, B.partial, kHistBlocks, B.digit_offset); });
     printf("hist (8 digits, one read) %8.1f us (%.1f GB/s)   hist_scan %6.1f us\n", t_h * 1e3, (double)m * 8 / (t_h * 1e-3) / 1e9, t_hs * 1e3);
 
