@@ -322,6 +322,7 @@ __global__ __launch_bounds__(kBlock) void gather_text_key_kernel(uint64_t *__res
 // are larger, or still undecided after kMaxLen bytes -- is appended to the list (out_rank,
 // out_suf) for the key-extension rounds: one atomic per workgroup that has leftovers, order
 // arbitrary (the next step radix-sorts the list anyway).  *out_count must be zero on entry.
+// With m_dev the list length is read on the device (launch without a host round trip).
 // ---------------------------------------------------------------------------------
 constexpr int kFinishThreads = 256;
 
@@ -329,13 +330,23 @@ template <typename IdxT, int kMaxG, int kMaxLen>
 __global__ __launch_bounds__(kFinishThreads) void small_group_finish_kernel(
     const uint64_t *__restrict__ rank, const IdxT *__restrict__ suf, const uint8_t *__restrict__ text,
     int64_t m, int64_t n, int64_t h, IdxT *__restrict__ SA, uint64_t *__restrict__ out_rank,
-    IdxT *__restrict__ out_suf, unsigned long long *__restrict__ out_count)
+    IdxT *__restrict__ out_suf, unsigned long long *__restrict__ out_count,
+    const unsigned long long *__restrict__ m_dev = nullptr)
 {
+    // speculative launch (the list length is still on the device): m is the capacity the grid was
+    // sized for; a longer list makes the host redo the step, so nothing is done for it here
+    if (m_dev) {
+        const unsigned long long real = m_dev[0];
+        if (real > (unsigned long long)m || m_dev[1] != 0) return;      // m_dev[1]: the producer gave up (TieCounters)
+        m = (int64_t)real;
+    }
     __shared__ uint32_t wave_tot[kFinishThreads / kWave];
     __shared__ unsigned long long s_base;
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
-    const int64_t j = (int64_t)blockIdx.x * kFinishThreads + threadIdx.x;
+    // grid-stride over tiles of kFinishThreads entries (the trip count is uniform per workgroup)
+    for (int64_t j0 = (int64_t)blockIdx.x * kFinishThreads; j0 < m; j0 += (int64_t)gridDim.x * kFinishThreads) {
+    const int64_t j = j0 + threadIdx.x;
 
     uint32_t emit = 0;                 // entries this lane appends: itself (large group) or its whole undecided group
     uint64_t r = 0;
@@ -402,14 +413,17 @@ __global__ __launch_bounds__(kFinishThreads) void small_group_finish_kernel(
     }
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(out_count, (unsigned long long)tot) : 0ull;
     __syncthreads();
-    if (emit == 0) return;
-    const int64_t o = (int64_t)s_base + off;
-    if (head) {
-        // undecided small group: its members as they stand in the list
-        for (int i = 0; i < g; ++i) { out_rank[o + i] = r; out_suf[o + i] = suf[j + i]; }
-    } else {
-        out_rank[o] = r;
-        out_suf[o] = suf[j];
+    if (emit != 0) {
+        const int64_t o = (int64_t)s_base + off;
+        if (head) {
+            // undecided small group: its members as they stand in the list
+            for (int i = 0; i < g; ++i) { out_rank[o + i] = r; out_suf[o + i] = suf[j + i]; }
+        } else {
+            out_rank[o] = r;
+            out_suf[o] = suf[j];
+        }
+    }
+    __syncthreads();                   // wave_tot / s_base are reused by the next tile
     }
 }
 

@@ -480,7 +480,7 @@ int onesweep_sort_text_passes(Launcher &L, Workspace<IdxT> &w, int64_t n, uint64
 template <typename IdxT>
 int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int kb, int ib, uint32_t *ebits,
                  const uint64_t *seam_tab, const IdxT *d_sa, uint64_t *act_rank, IdxT *act_suf, int64_t *count,
-                 bool *overflow)
+                 bool *overflow, int64_t fin_cap, uint64_t *fin_rank, IdxT *fin_suf, int64_t *fin_left)
 {
     using Cfg = RankCfg<IdxT, kKeysLastTies>;
     const int64_t ntiles = (n + Cfg::kThreads * Cfg::kItems - 1) / (Cfg::kThreads * Cfg::kItems);
@@ -505,11 +505,24 @@ int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int k
            hipLaunchKernelGGL(tie_collect_kernel<IdxT>, dim3((unsigned)((nwords + kTieThreads - 1) / kTieThreads)),
                               dim3(kTieThreads), 0, L.st, reinterpret_cast<const uint64_t *>(ebits), nwords, n, d_sa,
                               act_rank, act_suf, ctr));
-    HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 64, hipMemcpyDeviceToHost, L.st));     // [1] sticky flag, [6..7] counters
+    // Few ties are expected here, so the direct-comparison finisher is launched right away on the list
+    // whose length is still on the device (capacity fin_cap), saving a host round trip; its result is
+    // used only if the list fits and the sparse path is taken.
+    unsigned long long *left_over = reinterpret_cast<unsigned long long *>(w.totals + 3);     // zero since run()
+    if (fin_cap > 0) {
+        LAUNCH(L, DQ_K_GATHER_KEY2, fin_cap, 0,
+               hipLaunchKernelGGL((small_group_finish_kernel<IdxT, 8, 32>),
+                                  dim3((unsigned)std::min<int64_t>((fin_cap + kFinishThreads - 1) / kFinishThreads, 256 * 16)),
+                                  dim3(kFinishThreads), 0, L.st, (const uint64_t *)act_rank, (const IdxT *)act_suf, (const uint8_t *)w.text,
+                                  fin_cap, n, (int64_t)kb, const_cast<IdxT *>(d_sa), fin_rank, fin_suf, left_over,
+                                  (const unsigned long long *)&ctr->count));
+    }
+    HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 64, hipMemcpyDeviceToHost, L.st));     // [1] sticky flag, [3] leftovers, [6..7] counters
     HIP_TRY(hipStreamSynchronize(L.st));
     if (c.pinned[1] != 0) return fail(DQ_ERR_HIP, "radix look-back timed out (device spin bound hit)");
     *count = c.pinned[6];
     *overflow = c.pinned[7] != 0;
+    *fin_left = c.pinned[3];
     (void)wb;
     return DQ_OK;
 }
@@ -588,6 +601,9 @@ struct SuffixSorter {
     int rcur = 0;
     int64_t m = 0, h = 0;
     int rbits = 0;
+    // the finisher already ran (speculatively, right after the tie bits were collected)
+    bool fin_done = false;
+    int64_t fin_cap = 0, fin_left = 0;
 
     SuffixSorter(DeviceCtx &c_, hipStream_t st_, Workspace<IdxT> &w_, int64_t n_, IdxT *sa_)
         : c(c_), st(st_), w(w_), n(n_), d_sa(sa_), L{c_, st_, g_prof_on.load()} {}
@@ -647,9 +663,11 @@ struct SuffixSorter {
                 // cur names the buffer the last pass would have written: it is free, the pass's input
                 // K[cur ^ 1] stays intact for the fallback
                 bool overflow = false;
+                fin_cap = n / 8;
                 rc = collect_ties<IdxT>(L, c, w, n, kb, ib, ebits, seam_tab, (const IdxT *)d_sa, K[cur], w.Va, &m,
-                                        &overflow);
+                                        &overflow, fin_cap, K[cur ^ 1], w.Vb, &fin_left);
                 if (rc != DQ_OK) return rc;
+                fin_done = !overflow && m <= fin_cap;
                 if (!overflow) {
                     *dense_built = false;
                     Kr[0] = K[cur]; Kr[1] = K[cur ^ 1];
@@ -726,16 +744,19 @@ struct SuffixSorter {
         // tiny groups with a short remaining common prefix; the leftovers come back as a new list
         t_info[0] += 1;
         t_info[2] += m;
-        unsigned long long *left_over = reinterpret_cast<unsigned long long *>(w.totals + 3);
-        HIP_TRY(hipMemsetAsync(left_over, 0, 8, st));
-        LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + 16 + wb),
-               hipLaunchKernelGGL((small_group_finish_kernel<IdxT, 8, 32>),
-                                  dim3((unsigned)((m + kFinishThreads - 1) / kFinishThreads)), dim3(kFinishThreads), 0,
-                                  st, (const uint64_t *)Kr[rcur], (const IdxT *)Vr[rcur], (const uint8_t *)w.text, m, n,
-                                  h, d_sa, Kr[rcur ^ 1], Vr[rcur ^ 1], left_over));
-        HIP_TRY(hipMemcpyAsync(c.pinned, left_over, 8, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        int64_t m2 = c.pinned[0];
+        int64_t m2 = fin_left;
+        if (!fin_done) {
+            unsigned long long *left_over = reinterpret_cast<unsigned long long *>(w.totals + 3);
+            HIP_TRY(hipMemsetAsync(left_over, 0, 8, st));
+            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + 16 + wb),
+                   hipLaunchKernelGGL((small_group_finish_kernel<IdxT, 8, 32>),
+                                      dim3((unsigned)((m + kFinishThreads - 1) / kFinishThreads)), dim3(kFinishThreads),
+                                      0, st, (const uint64_t *)Kr[rcur], (const IdxT *)Vr[rcur],
+                                      (const uint8_t *)w.text, m, n, h, d_sa, Kr[rcur ^ 1], Vr[rcur ^ 1], left_over));
+            HIP_TRY(hipMemcpyAsync(c.pinned, left_over, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            m2 = c.pinned[0];
+        }
         if (m2 > 0) rcur ^= 1;
         m = m2;
 
