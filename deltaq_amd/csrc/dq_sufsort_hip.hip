@@ -90,6 +90,7 @@ struct DeviceCtx {
     size_t ws_bytes = 0;
     int64_t *pinned = nullptr;          // 4 KiB pinned readback area
     uint8_t *pinned_io = nullptr;       // short texts: text in / SA out, read and written by the kernel itself
+    hipEvent_t readback = nullptr;      // "the pinned readback has landed" (work queued behind it keeps running)
     std::vector<ProfRec> pending;
     std::vector<hipEvent_t> pool;
 };
@@ -106,6 +107,7 @@ int init_ctx(DeviceCtx &c, int dev)
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc((void **)&c.pinned, 4096, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&c.pinned_io, kSmallIoBytes, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&c.readback, hipEventDisableTiming));
     return DQ_OK;
 }
 
@@ -420,7 +422,13 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
     int kb = 8;
     bool packed = false;
     HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, 256 * 8, hipMemcpyDeviceToHost, L.st));
-    HIP_TRY(hipStreamSynchronize(L.st));
+    HIP_TRY(hipEventRecord(c.readback, L.st));
+    // While the host waits for the histogram and picks the key width, the device zeroes what the passes
+    // need whatever that choice is: the look-back state of all 8 possible passes and the tie bits.
+    int rc = prepare_status<IdxT>(L, w, n, kMaxPasses);
+    if (rc != DQ_OK) return rc;
+    if (n >= (1 << 16)) HIP_TRY(hipMemsetAsync(w.Vb, 0, (size_t)((n + 63) / 64 + 1) * 8, L.st));
+    HIP_TRY(hipEventSynchronize(c.readback));
     choose_key_bytes(c.pinned, n, &kb, &packed);
     if (const char *force = getenv("DQ_KEY_BYTES")) {
         kb = std::min(8, std::max(1, atoi(force)));
@@ -443,8 +451,7 @@ int onesweep_sort_text_passes(Launcher &L, Workspace<IdxT> &w, int64_t n, uint64
                               uint64_t *seam_tab = nullptr)
 {
     const uint64_t *text64 = reinterpret_cast<const uint64_t *>(w.text);
-    int rc = prepare_status<IdxT>(L, w, n, kb);
-    if (rc != DQ_OK) return rc;
+    int rc = DQ_OK;                 // look-back state zeroed by onesweep_sort_text_prepare()
     if (packed) {
         const int ib = bit_length((uint64_t)(n - 1));
         rc = rank_pass<IdxT, kTextPacked>(L, w, text64, (const IdxT *)nullptr, K[1], (IdxT *)nullptr, n, 0, kb, ib);
@@ -657,7 +664,7 @@ struct SuffixSorter {
                 uint32_t *ebits = reinterpret_cast<uint32_t *>(w.Vb);
                 uint64_t *seam_tab = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(w.Vb) +
                                                                   align_up((size_t)(nwords + 1) * 8));
-                HIP_TRY(hipMemsetAsync(ebits, 0, (size_t)(nwords + 1) * 8, st));
+                // (the tie bits were zeroed by onesweep_sort_text_prepare while the key width was chosen)
                 rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur, ebits, seam_tab);
                 if (rc != DQ_OK) return rc;
                 // cur names the buffer the last pass would have written: it is free, the pass's input
@@ -1097,6 +1104,8 @@ void dq_sufsort_hip_release(void)
         c.pinned = nullptr;
         if (c.pinned_io) (void)hipHostFree(c.pinned_io);
         c.pinned_io = nullptr;
+        if (c.readback) (void)hipEventDestroy(c.readback);
+        c.readback = nullptr;
         if (c.stream) (void)hipStreamDestroy(c.stream);
         c.stream = nullptr;
         c.dev = -1;
