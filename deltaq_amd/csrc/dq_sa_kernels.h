@@ -380,8 +380,14 @@ __global__ __launch_bounds__(kFinishThreads) void small_group_finish_kernel(
             }
             return 0;
         };
-        // bubble passes with static indices keep s[] in registers
+        // bubble passes with static indices keep s[] in registers.  Nearly every group on random-like
+        // data is a pair: it gets its own single comparison instead of walking the 28-site network.
         bool decided = true;
+        if (g == 2) {
+            const int c = cmp(s[0], s[1]);
+            if (c == 0) decided = false;
+            if (c > 0) { const int64_t t = s[0]; s[0] = s[1]; s[1] = t; }
+        } else
 #pragma unroll
         for (int pass = 0; pass < kMaxG - 1; ++pass) {
 #pragma unroll
