@@ -75,8 +75,10 @@ __device__ __forceinline__ uint64_t seg_lookback(uint64_t *st, int64_t tile, Seg
 //           SA already holds the suffixes; ISA is written for every entry only with kWriteISA
 //           (dense path predicted), otherwise it is built later if the dense path is taken.
 // else:     composite keys (rank << kbits | key2); writes SA (kWriteSA) / ISA (kWriteISA).
+// kEmitPairs (with kInitial): instead of the ISA scatter and the list of tied suffixes, one word per entry
+//           (tied? << 63 | rank << kbits | suffix, kbits = bits of n-1) goes to act_rank in list order.
 // totals[0] receives the number of still-active suffixes.
-template <typename IdxT, bool kInitial, bool kWriteSA, bool kWriteISA>
+template <typename IdxT, bool kInitial, bool kWriteSA, bool kWriteISA, bool kEmitPairs = false>
 __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
     const uint64_t *__restrict__ keys, const IdxT *__restrict__ vals, int64_t m, int kbits, int kshift,
     IdxT *__restrict__ SA, IdxT *__restrict__ ISA, uint64_t *__restrict__ act_rank,
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
 #pragma unroll
     for (int k = 0; k < kSegK; ++k) {
         const int e = k * kWave + lane;
-        const bool need = (kWriteSA || kWriteISA) ? (e < nv) : ((m_A[w][k] & lb) != 0);
+        const bool need = (kWriteSA || kWriteISA || kEmitPairs) ? (e < nv) : ((m_A[w][k] & lb) != 0);
         suf[k] = need ? vp[e] : (IdxT)0;
     }
 #pragma unroll
@@ -225,23 +227,29 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
         const int e = k * kWave + lane;
         const uint64_t Hk = m_H[w][k], Ak = m_A[w][k];
         const uint64_t Gk = kInitial ? (wb == 0 && k == 0 ? 1ull : 0ull) : m_G[w][k];
-        if ((kWriteSA || kWriteISA) ? (k * kWave < nv) : (Ak != 0)) {          // wave-uniform skip
+        if ((kWriteSA || kWriteISA || kEmitPairs) ? (k * kWave < nv) : (Ak != 0)) {          // wave-uniform skip
             const bool act = (Ak & lb) != 0;
-            if ((kWriteSA || kWriteISA) ? (e < nv) : act) {
+            if ((kWriteSA || kWriteISA || kEmitPairs) ? (e < nv) : act) {
                 const uint64_t hm = Hk & le, gm = Gk & le;
                 const IdxT rn = hm ? wb_i + (IdxT)(k * kWave + 63 - __builtin_clzll(hm)) : cn;
                 const IdxT rg = gm ? wb_i + (IdxT)(k * kWave + 63 - __builtin_clzll(gm)) : cg;
                 const IdxT rank = kInitial ? (IdxT)0 : (IdxT)(ck[k] >> kbits);
                 const IdxT nr = rank + (rn - rg);
-                // dense doubling (ISA maintained) never reads SA again: a still-tied member's slot is
-                // written once, in the round that resolves it
-                if (kWriteSA && !(kWriteISA && act)) SA[rank + (wb_i + (IdxT)e - rg)] = suf[k];
-                // ISA[s] already holds the parent rank: only members whose rank moved need a (random) write
-                if (kWriteISA && (kInitial || nr != rank)) ISA[suf[k]] = nr;
-                if (act) {
-                    const int64_t o = cc + __popcll(Ak & lt);
-                    act_rank[o] = (uint64_t)nr;
-                    act_suf[o] = suf[k];
+                if (kEmitPairs) {
+                    // (tied?, rank, suffix) in list order, coalesced: the inverse suffix array is built from
+                    // these words after they have been binned by suffix (dq_isa_pairs.h); kbits = bits of n-1
+                    act_rank[wb + e] = ((uint64_t)(act ? 1 : 0) << 63) | ((uint64_t)nr << kbits) | (uint64_t)suf[k];
+                } else {
+                    // dense doubling (ISA maintained) never reads SA again: a still-tied member's slot is
+                    // written once, in the round that resolves it
+                    if (kWriteSA && !(kWriteISA && act)) SA[rank + (wb_i + (IdxT)e - rg)] = suf[k];
+                    // ISA[s] already holds the parent rank: only members whose rank moved need a (random) write
+                    if (kWriteISA && (kInitial || nr != rank)) ISA[suf[k]] = nr;
+                    if (act) {
+                        const int64_t o = cc + __popcll(Ak & lt);
+                        act_rank[o] = (uint64_t)nr;
+                        act_suf[o] = suf[k];
+                    }
                 }
             }
         }

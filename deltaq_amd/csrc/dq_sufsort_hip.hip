@@ -31,6 +31,7 @@
 #include "dq_small.h"
 #include "dq_small_groups.h"
 #include "dq_ties.h"
+#include "dq_isa_pairs.h"
 
 namespace {
 
@@ -303,7 +304,7 @@ int prepare_status(Launcher &L, Workspace<IdxT> &w, int64_t m, int passes)
 template <typename IdxT, typename StatusT, int kMode>
 int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin,
                      uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb, int ib,
-                     uint32_t *ebits = nullptr, uint64_t *seam_tab = nullptr)
+                     uint32_t *ebits = nullptr, uint64_t *seam_tab = nullptr, int shift_override = -1)
 {
     using Cfg = RankCfg<IdxT, kMode>;
     constexpr int kItems = Cfg::kItems;
@@ -326,7 +327,7 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
            hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, kItems, kMode, Cfg::kMinWaves, kThreads,
                                                  false, Cfg::kLdsMatch, Cfg::kRounds>),
                               dim3((unsigned)ntiles), dim3(kThreads), 0, L.st, kin, vin, kout, vout, m,
-                              pass * kRadixBits + ib, kb, ib,
+                              shift_override >= 0 ? shift_override : pass * kRadixBits + ib, kb, ib,
                               (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1,
                               ebits, seam_tab));
     return DQ_OK;
@@ -335,11 +336,13 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
 template <typename IdxT, int kMode>
 int rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin, uint64_t *kout,
               IdxT *vout, int64_t m, int pass, int kb, int ib = 0, uint32_t *ebits = nullptr,
-              uint64_t *seam_tab = nullptr)
+              uint64_t *seam_tab = nullptr, int shift_override = -1)
 {
     if (m < (1ll << 30))
-        return launch_rank_pass<IdxT, uint32_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits, seam_tab);
-    return launch_rank_pass<IdxT, uint64_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits, seam_tab);
+        return launch_rank_pass<IdxT, uint32_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits, seam_tab,
+                                                       shift_override);
+    return launch_rank_pass<IdxT, uint64_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits, seam_tab,
+                                                   shift_override);
 }
 
 template <int kPasses>
@@ -608,6 +611,8 @@ struct SuffixSorter {
     int rcur = 0;
     int64_t m = 0, h = 0;
     int rbits = 0;
+    // the list already holds composite keys (rank << kbits | key2) for the next doubling round
+    bool keys_ready = false;
     // the finisher already ran (speculatively, right after the tie bits were collected)
     bool fin_done = false;
     int64_t fin_cap = 0, fin_left = 0;
@@ -634,6 +639,72 @@ struct SuffixSorter {
                                   (const IdxT *)d_sa, w.ISA, n);
                hipLaunchKernelGGL(isa_scatter_kernel<IdxT>, dim3(grid_for(cnt)), dim3(kBlock), 0, st, rank, suf,
                                   w.ISA, cnt));
+        return DQ_OK;
+    }
+
+    // ---- dense inputs: first ISA + first key2 gather through suffix-binned words (dq_isa_pairs.h).
+    //      keys = the sorted round-0 keys (buffer P1), P0 = the other key buffer (free).  On return the
+    //      tied list is (P1, Va) and m its length.
+    bool uses_small_round(int64_t mm) const
+    {
+        return sort_engine() == 1 && !getenv("DQ_NO_SMALL") && mm * 2 <= n && n < (1ll << 32);
+    }
+
+    int build_isa_binned(uint64_t *keys, uint64_t *P0, int kb, int kshift0)
+    {
+        const int ib = bit_length((uint64_t)(n - 1));
+        const int64_t ntiles = (n + kSegFusedTile - 1) / kSegFusedTile;
+        const size_t need = 256 + (size_t)3 * ntiles * 8;
+        if (need > w.seg_status_bytes) return fail(DQ_ERR_HIP, "seg status buffer too small");
+        HIP_TRY(hipMemsetAsync(w.seg_status, 0, need, st));
+        LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb + 8),
+               hipLaunchKernelGGL((seg_fused_kernel<IdxT, true, false, false, true>), dim3((unsigned)ntiles),
+                                  dim3(kSegThreads), 0, st, (const uint64_t *)keys, (const IdxT *)d_sa, n, ib, kshift0,
+                                  d_sa, w.ISA, P0, w.Va, reinterpret_cast<uint64_t *>(w.seg_status + 256), ntiles,
+                                  reinterpret_cast<SegCtl *>(w.seg_status), w.totals, w.totals + 1));
+        // digit offsets of the two binning passes in closed form: every suffix 0..n-1 occurs once
+        const int sh[2] = {ib - 16, ib - 8};
+        HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        m = c.pinned[0];
+        if (c.pinned[1] != 0) return fail(DQ_ERR_HIP, "device look-back timed out (spin bound hit)");
+        for (int p = 0; p < 2; ++p) {
+            const int64_t unit = 1ll << sh[p];                       // suffixes per digit value inside one cycle
+            const int64_t full = n >> (sh[p] + 8), rem = n & ((unit << 8) - 1);
+            int64_t acc = 0;
+            for (int d = 0; d < 256; ++d) {
+                c.pinned[p * 256 + d] = acc;
+                acc += full * unit + std::min<int64_t>(std::max<int64_t>(rem - d * unit, 0), unit);
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(w.digit_offset, c.pinned, 2 * 256 * 8, hipMemcpyHostToDevice, st));
+        int rc = prepare_status<IdxT>(L, w, n, 2);
+        if (rc != DQ_OK) return rc;
+        rc = rank_pass<IdxT, kKeys>(L, w, P0, (const IdxT *)nullptr, keys, (IdxT *)nullptr, n, 0, kb, ib, nullptr, nullptr, sh[0]);
+        if (rc != DQ_OK) return rc;
+        rc = rank_pass<IdxT, kKeys>(L, w, keys, (const IdxT *)nullptr, P0, (IdxT *)nullptr, n, 1, kb, ib, nullptr, nullptr, sh[1]);
+        if (rc != DQ_OK) return rc;
+        if (ib - 16 <= 12) {
+            LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb),
+                   hipLaunchKernelGGL((isa_from_pairs_kernel<IdxT, 4096>), dim3((unsigned)((n + 4095) / 4096)),
+                                      dim3(kPairThreads), 0, st, (const uint64_t *)P0, n, ib, w.ISA));
+        } else {
+            LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb),
+                   hipLaunchKernelGGL((isa_from_pairs_kernel<IdxT, 32768>), dim3((unsigned)((n + 32767) / 32768)),
+                                      dim3(kPairThreads), 0, st, (const uint64_t *)P0, n, ib, w.ISA));
+        }
+        // The list comes out in suffix order, not with the members of a group adjacent, so the first
+        // doubling round always takes the radix path (which sorts it); key2 is gathered here for it.
+        const bool with_key2 = true;
+        const int kbits = bit_length((uint64_t)(n - 1) + (uint64_t)kb);
+        unsigned long long *cnt = reinterpret_cast<unsigned long long *>(w.totals + 3);
+        HIP_TRY(hipMemsetAsync(cnt, 0, 8, st));
+        const int64_t per = (int64_t)kPairThreads * kPairItems;
+        LAUNCH(L, DQ_K_GATHER_KEY2, n, n * 8 + m * (wb + 8 + wb),
+               hipLaunchKernelGGL(key2_from_pairs_kernel<IdxT>, dim3((unsigned)((n + per - 1) / per)), dim3(kPairThreads),
+                                  0, st, (const uint64_t *)P0, n, ib, (const IdxT *)w.ISA, (int64_t)kb, kbits, with_key2,
+                                  keys, w.Va, cnt));
+        keys_ready = with_key2;
         return DQ_OK;
     }
 
@@ -726,6 +797,19 @@ struct SuffixSorter {
             predict_dense = c.pinned[0] * 12 > kSamples;
         }
         if (const char *v = getenv("DQ_SPARSE")) predict_dense = atoi(v) == 0;
+        const bool binned = predict_dense && sort_engine() == 1 && n >= (1 << 16) &&
+                            2 * bit_length((uint64_t)(n - 1)) <= 63 && !getenv("DQ_NO_BINNED_ISA");
+        if (binned) {
+            rc = build_isa_binned(K[cur], K[cur ^ 1], kb, kshift0);
+            if (rc != DQ_OK) return rc;
+            *dense_built = true;
+            Kr[0] = K[cur]; Kr[1] = K[cur ^ 1];
+            Vr[0] = w.Va; Vr[1] = w.Vb;
+            rcur = 0;
+            h = kb;
+            rbits = bit_length((uint64_t)(n - 1));
+            return DQ_OK;
+        }
         if (predict_dense)
             rc = rebucket<IdxT, true, false, true>(L, c, w, K[cur], (const IdxT *)d_sa, n, 0, kshift0, d_sa, act_rank,
                                                    w.Va, &m);
@@ -791,9 +875,13 @@ struct SuffixSorter {
     // ---- one doubling round, everything through the radix path
     int doubling_round_radix(int kbits)
     {
-        LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8),
-               hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock), 0, st, Kr[rcur],
-                                  (const IdxT *)Vr[rcur], (const IdxT *)w.ISA, m, n, h, kbits));
+        if (keys_ready) {
+            keys_ready = false;          // build_isa_binned() gathered key2 while the ranks were still local
+        } else {
+            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8),
+                   hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock), 0, st, Kr[rcur],
+                                      (const IdxT *)Vr[rcur], (const IdxT *)w.ISA, m, n, h, kbits));
+        }
         int rc = sort_pairs(Kr, Vr, m, kbits + rbits, rcur);
         if (rc != DQ_OK) return rc;
         int64_t m2 = 0;
@@ -858,18 +946,17 @@ struct SuffixSorter {
 
         bool sparse = m * 6 <= n;
         if (const char *v = getenv("DQ_SPARSE")) sparse = atoi(v) != 0;
+        if (keys_ready) sparse = false;      // the ISA exists and the list is already keyed for a doubling round
         if (sparse) rc = finish_sparse();
         else if (!dense_built) rc = build_isa(Kr[rcur], Vr[rcur], m);
         if (rc != DQ_OK) return rc;
 
-        const bool no_small = getenv("DQ_NO_SMALL") != nullptr;
         while (m > 0) {
             t_info[0] += 1;
             t_info[2] += m;
             const int kbits = bit_length((uint64_t)(n - 1) + (uint64_t)h);
             if (kbits + rbits > 64) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
-            rc = (sort_engine() == 1 && !no_small && m * 2 <= n && n < (1ll << 32)) ? doubling_round_small(kbits)
-                                                                  : doubling_round_radix(kbits);
+            rc = (uses_small_round(m) && !keys_ready) ? doubling_round_small(kbits) : doubling_round_radix(kbits);
             if (rc != DQ_OK) return rc;
             h *= 2;
         }
