@@ -40,6 +40,16 @@ elif which == "i32max":
         t0 = time.time(); rc = oracle.sufcheck(T, SA); print("sufcheck", rc, round(time.time() - t0, 1), "s", flush=True)
         print("sampled strict order (1e6 pairs):", oracle.verify_sampled(T, SA, 1_000_000, 7), flush=True)
         del SA, T
+elif which == "enwik320":
+    # text-like input with bits(n-1) = 29: the suffix-binned ISA build with 32768-entry spans
+    n = 320 << 20
+    T = datagen.gen_enwik_like(n, 0xD17A1)
+    dT = torch.from_numpy(T).cuda(); out = torch.empty(n, dtype=torch.int32, device="cuda")
+    s.Sort(dT, out); torch.cuda.synchronize()
+    t0 = time.time(); s.Sort(dT, out); torch.cuda.synchronize(); dt = time.time() - t0
+    print(f"enwik 320 MiB device-resident: {dt*1e3:.1f} ms = {n/1e6/dt:.0f} MB/s  {_abi.last_sort_info()}", flush=True)
+    SA = out.cpu().numpy()
+    print("sufcheck", oracle.sufcheck(T, SA), "sampled", oracle.verify_sampled(T, SA, 1_000_000, 3), flush=True)
 else:
     n = 256 << 20
     T = datagen.gen_enwik_like(n, 0xD17A0)
