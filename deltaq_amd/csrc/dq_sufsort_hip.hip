@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1095,6 +1096,125 @@ int sufsort_dev(const void *d_text, int64_t n, void *d_sa, int32_t device, void 
     return DQ_OK;
 }
 
+// ------------------------------------------------------------------ batch: one device's share, pipelined
+// Three stages on three host threads and three streams, kBatchSlots device buffers in flight:
+//   copy-in   text j -> slot          (pageable host memory: the copy blocks its thread, not the others)
+//   sort      slot's text -> slot's SA (device-resident sorter; one sort at a time per device anyway)
+//   copy-out  slot's SA -> sas[j]
+// so the PCIe transfers of neighbouring inputs overlap the sort.  Inputs that need the
+// short-text path or that are larger than the slot size go through the plain host entry point.
+constexpr int kBatchSlots = 3;
+
+int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *const *texts, const int64_t *lens,
+                    int32_t *const *sas, std::string *err)
+{
+    auto plain = [&](int j) -> int {
+        int rc = sufsort_host<int32_t>(texts[j], lens[j], sas[j], device);
+        if (rc != DQ_OK) *err = t_err;
+        return rc;
+    };
+    const int64_t direct = std::max<int64_t>(small_limit(), 2);             // these bypass the pipeline
+    int64_t cap = 0;
+    int big = 0;
+    for (int j : jobs)
+        if (lens[j] > direct) { cap = std::max(cap, lens[j]); ++big; }
+    if (big < 3 || cap > (1ll << 30)) {                       // nothing to overlap / slots would be huge
+        for (int j : jobs) { int rc = plain(j); if (rc != DQ_OK) return rc; }
+        return DQ_OK;
+    }
+    if (hipSetDevice(device) != hipSuccess) { *err = "hipSetDevice failed"; return DQ_ERR_HIP; }
+    struct Slot { uint8_t *text = nullptr; int32_t *sa = nullptr; int job = -1; };
+    Slot slots[kBatchSlots];
+    hipStream_t s_in = nullptr, s_sort = nullptr, s_out = nullptr;
+    auto cleanup = [&]() {
+        for (Slot &sl : slots) { if (sl.text) (void)hipFree(sl.text); if (sl.sa) (void)hipFree(sl.sa); }
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_sort) (void)hipStreamDestroy(s_sort);
+        if (s_out) (void)hipStreamDestroy(s_out);
+    };
+    bool ok = hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&s_sort, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking) == hipSuccess;
+    for (Slot &sl : slots)
+        ok = ok && hipMalloc((void **)&sl.text, (size_t)cap + 64) == hipSuccess &&
+             hipMalloc((void **)&sl.sa, (size_t)cap * sizeof(int32_t)) == hipSuccess;
+    if (!ok) { cleanup(); *err = "batch slot allocation failed"; return DQ_ERR_OOM; }
+
+    // slot hand-over: free -> filled (text on the device) -> sorted (SA on the device) -> free
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> filled, sorted, freeq;
+    for (int k = 0; k < kBatchSlots; ++k) freeq.push_back(k);
+    bool in_done = false, sort_done = false;
+    std::atomic<int> failed{DQ_OK};
+    std::string errs[3];
+    auto take = [&](std::vector<int> &q, const bool *producer_done) -> int {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !q.empty() || (producer_done && *producer_done) || failed.load() != DQ_OK; });
+        if (q.empty()) return -1;
+        const int k = q.front();
+        q.erase(q.begin());
+        return k;
+    };
+    auto give = [&](std::vector<int> &q, int k) { { std::lock_guard<std::mutex> lk(mu); q.push_back(k); } cv.notify_all(); };
+    auto fail_stage = [&](int stage, int rc, const std::string &what) {
+        errs[stage] = what;
+        int expect = DQ_OK;
+        failed.compare_exchange_strong(expect, rc);
+        cv.notify_all();
+    };
+
+    std::thread t_in([&]() {
+        (void)hipSetDevice(device);
+        for (int j : jobs) {
+            if (lens[j] <= direct) continue;                                // handled after the pipeline
+            const int k = take(freeq, nullptr);
+            if (k < 0 || failed.load() != DQ_OK) break;
+            slots[k].job = j;
+            hipError_t e = hipMemcpyAsync(slots[k].text, texts[j], (size_t)lens[j], hipMemcpyHostToDevice, s_in);
+            if (e == hipSuccess) e = hipStreamSynchronize(s_in);
+            if (e != hipSuccess) { fail_stage(0, DQ_ERR_HIP, std::string("batch copy-in: ") + hipGetErrorString(e)); break; }
+            give(filled, k);
+        }
+        { std::lock_guard<std::mutex> lk(mu); in_done = true; }
+        cv.notify_all();
+    });
+    std::thread t_sort([&]() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            const int k = take(filled, &in_done);
+            if (k < 0 || failed.load() != DQ_OK) break;
+            const int j = slots[k].job;
+            int rc = sufsort_dev<int32_t>(slots[k].text, lens[j], slots[k].sa, device, s_sort);
+            if (rc != DQ_OK) { fail_stage(1, rc, t_err); break; }
+            give(sorted, k);
+        }
+        { std::lock_guard<std::mutex> lk(mu); sort_done = true; }
+        cv.notify_all();
+    });
+    std::thread t_out([&]() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            const int k = take(sorted, &sort_done);
+            if (k < 0 || failed.load() != DQ_OK) break;
+            const int j = slots[k].job;
+            hipError_t e = hipMemcpyAsync(sas[j], slots[k].sa, (size_t)lens[j] * sizeof(int32_t), hipMemcpyDeviceToHost, s_out);
+            if (e == hipSuccess) e = hipStreamSynchronize(s_out);
+            if (e != hipSuccess) { fail_stage(2, DQ_ERR_HIP, std::string("batch copy-out: ") + hipGetErrorString(e)); break; }
+            give(freeq, k);
+        }
+    });
+    t_in.join(); t_sort.join(); t_out.join();
+    cleanup();
+    if (failed.load() != DQ_OK) {
+        for (const std::string &e : errs) if (!e.empty()) { *err = e; break; }
+        return failed.load();
+    }
+    for (int j : jobs)
+        if (lens[j] <= direct) { int rc = plain(j); if (rc != DQ_OK) return rc; }
+    return DQ_OK;
+}
+
 }  // namespace
 
 // ====================================================================== C ABI
@@ -1156,10 +1276,7 @@ int32_t dq_sufsort_hip_batch_i32(int32_t count, const uint8_t *const *texts, con
     for (int d = 0; d < ndev; ++d) {
         threads.emplace_back([&, d]() {
             const int device = devs ? devs[d] : d;
-            for (int j : share[d]) {
-                int rc = sufsort_host<int32_t>(texts[j], lens[j], sas[j], device);
-                if (rc != DQ_OK) { rcs[d] = rc; errs[d] = t_err; return; }
-            }
+            rcs[d] = batch_on_device(device, share[d], texts, lens, sas, &errs[d]);
         });
     }
     for (auto &t : threads) t.join();

@@ -61,7 +61,7 @@ if "--2g" in sys.argv:
     run("4: 2 GiB uniform, i64", workload.gen_uniform(1 << 31, 0x5EED0004), dtype=np.int64, cpu="--2g-cpu" in sys.argv)
 # 5: 128 x 16 MiB on ONE GPU (batch entry point, host buffers) + device-resident loop
 texts = [workload.gen_uniform(16 << 20, 0x5EED0500 + j) for j in range(128)]
-sas = [np.empty(t.size, np.int32) for t in texts]
+sas = [np.ones(t.size, np.int32) for t in texts]           # pre-touched output pages (np.zeros would stay untouched)
 cnt = len(texts)
 tp = (ctypes.c_void_p * cnt)(*[t.ctypes.data for t in texts]); sp = (ctypes.c_void_p * cnt)(*[a.ctypes.data for a in sas])
 ln = (ctypes.c_int64 * cnt)(*[t.size for t in texts])

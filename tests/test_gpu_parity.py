@@ -259,9 +259,15 @@ def test_full_size_config_by_properties(ldss, oracle_mod):
 
 def test_batch_entry_point(backend_lib, oracle_mod):
     import ctypes
-    texts = [oracle_mod.gen_uniform(100_000 + 1000 * j, 0x5EED0500 + j) for j in range(5)]
+    # more inputs than pipeline slots (copy-in / sort / copy-out overlap, slots reused), of mixed sizes,
+    # plus the ones that bypass the pipeline: empty, 1 and 2 bytes, short texts
+    texts = [oracle_mod.gen_uniform(100_000 + 37_000 * (j % 5), 0x5EED0500 + j) for j in range(17)]
     texts.append(np.zeros(0, np.uint8))
     texts.append(oracle_mod.gen_enwik_like(50_000, 9, 4096))
+    texts.append(np.array([7], np.uint8))
+    texts.append(np.array([9, 3], np.uint8))
+    texts.append(oracle_mod.net_random_bytes(4096))
+    texts.append(oracle_mod.gen_enwik_like(700_000, 11, 16384))
     sas = [np.empty(t.size, np.int32) for t in texts]
     cnt = len(texts)
     tp = (ctypes.c_void_p * cnt)(*[t.ctypes.data if t.size else None for t in texts])
