@@ -273,17 +273,13 @@ int radix_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V[2]
 // (tools/kbench, 64 Mi keys, random digits): 512 threads; packed-word passes 24 keys/thread
 // (12288-key tiles, ~48-key runs per digit), LDS match tables; pair passes 20 keys/thread,
 // ballot match; the tile is staged through LDS in 2 position ranges (half the LDS footprint).
-#ifndef DQ_TIES_BIG_TILE
-#define DQ_TIES_BIG_TILE 0
-#endif
 template <typename IdxT, int kMode> struct RankCfg {
     static constexpr bool kWords = (kMode == kTextPacked || kMode == kKeys || kMode == kKeysLast || kMode == kKeysLastTies);
-    // the tie-recording last pass writes 4- or 8-byte SA entries only: a 1024-thread tile doubles its runs
-    static constexpr bool kBig = (kMode == kKeysLastTies) && DQ_TIES_BIG_TILE;
-    static constexpr int kThreads = kBig ? 1024 : 512;
+    // (a 1024-thread tile for the tie-recording last pass, whose runs are 4-byte SA entries, measured +18 %)
+    static constexpr int kThreads = 512;
     static constexpr int kItems = kWords ? 24 : (sizeof(IdxT) == 4 ? 20 : 16);
-    static constexpr int kMinWaves = kBig ? 4 : 2;
-    static constexpr int kRounds = kBig ? 4 : 2;
+    static constexpr int kMinWaves = 2;
+    static constexpr int kRounds = 2;
     // LDS match tables beat 8 ballots on near-uniform digits (words: -6%), but equal digits in a wave are
     // same-address LDS atomics: pair passes run on text-like (skewed) data and keep the ballots
     static constexpr bool kLdsMatch = kWords;
