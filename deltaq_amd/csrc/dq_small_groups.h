@@ -51,8 +51,15 @@ __global__ __launch_bounds__(kSgThreads) void small_group_round_kernel(
     uint64_t *__restrict__ t_rank, IdxT *__restrict__ t_suf,
     uint64_t *__restrict__ l_key, IdxT *__restrict__ l_suf,
     uint64_t *__restrict__ u_rank_end, IdxT *__restrict__ u_suf_end,      // U grows DOWNWARD from these
-    SmallGroupCounters *__restrict__ ctr)
+    SmallGroupCounters *__restrict__ ctr, const SmallGroupCounters *__restrict__ prev = nullptr)
 {
+    // chained rounds (no host round trip in between): the list length is what the previous round appended
+    // to T; m is then only the bound the grid was sized for
+    if (prev) {
+        const int64_t real = (int64_t)(prev->tied_moved & 0xffffffffull);
+        m = real < m ? real : m;
+    }
+    if ((int64_t)blockIdx.x * kSgTile >= m) return;
     // ranks and key2 values are < n + h <= 2n: unsigned 32 bits are enough for the int32 index type
     using ElemT = typename std::make_unsigned<IdxT>::type;
     constexpr int kHalo = kSgMaxG;
@@ -214,8 +221,10 @@ __global__ __launch_bounds__(kSgThreads) void small_group_round_kernel(
 template <typename IdxT>
 __global__ __launch_bounds__(kBlock) void isa_update_kernel(const uint64_t *__restrict__ u_rank_end,
                                                             const IdxT *__restrict__ u_suf_end, int64_t count,
-                                                            IdxT *__restrict__ ISA)
+                                                            IdxT *__restrict__ ISA,
+                                                            const SmallGroupCounters *__restrict__ cnt_dev = nullptr)
 {
+    if (cnt_dev) count = (int64_t)(cnt_dev->tied_moved >> 32);            // chained rounds: length from the device
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < count; p += (int64_t)gridDim.x * kBlock)
         ISA[u_suf_end[-1 - p]] = (IdxT)u_rank_end[-1 - p];
 }

@@ -175,6 +175,8 @@ int flush_profile(DeviceCtx &c)
         if (rc_ != DQ_OK) return rc_;                     \
     } while (0)
 
+constexpr int kSgChain = 4;       // small-group rounds chained without a host round trip
+
 // ------------------------------------------------------------------ workspace carving
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -187,6 +189,7 @@ struct Workspace {
     IdxT *blockbase;
     SegPartials<IdxT> part;
     int64_t *totals;            // [0] active count, [1] sticky look-back timeout flag
+    SmallGroupCounters *sg_ctr; // one per chained small-group round
     uint32_t *hist_partial;     // [kHistBlocks][8][256]
     int64_t *digit_offset;      // [8][256]
     int64_t *bytehist;          // [256]
@@ -219,6 +222,7 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.part.gh = (IdxT *)take(nparts * sizeof(IdxT));
     w.part.cnt = (IdxT *)take(nparts * sizeof(IdxT));
     w.totals = (int64_t *)take(64);
+    w.sg_ctr = (SmallGroupCounters *)take(kSgChain * sizeof(SmallGroupCounters));
     w.hist_partial = (uint32_t *)take((size_t)kHistBlocks * kMaxPasses * kRadixSize * 4);
     w.digit_offset = (int64_t *)take((size_t)kMaxPasses * kRadixSize * 8);
     w.bytehist = (int64_t *)take((size_t)kRadixSize * 8);
@@ -610,6 +614,8 @@ struct SuffixSorter {
     int rbits = 0;
     // the list already holds composite keys (rank << kbits | key2) for the next doubling round
     bool keys_ready = false;
+    // the last small-group round sent nothing to the radix list: every group has <= 8 members
+    bool only_small_groups = false;
     // the finisher already ran (speculatively, right after the tie bits were collected)
     bool fin_done = false;
     int64_t fin_cap = 0, fin_left = 0;
@@ -928,6 +934,45 @@ struct SuffixSorter {
         }
         rcur ^= 1;
         m = m1 + mLs;
+        only_small_groups = mL == 0;      // groups only ever split: from now on every group has <= 8 members
+        return DQ_OK;
+    }
+
+    // ---- kSgChain small-group rounds back to back, lengths handed over on the device.  Only valid once
+    //      every group has <= 8 members (nothing goes to the radix list any more); the grids are sized for
+    //      the current m, which is an upper bound for all later rounds.
+    int doubling_rounds_small_chain()
+    {
+        const int64_t half = n / 2;
+        const int64_t m_in = m;
+        HIP_TRY(hipMemsetAsync(w.sg_ctr, 0, kSgChain * sizeof(SmallGroupCounters), st));
+        int64_t hr = h;
+        for (int r = 0; r < kSgChain; ++r) {
+            uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
+            IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
+            const int kbits = std::min(bit_length((uint64_t)(n - 1) + (uint64_t)hr), 64 - rbits);   // (no radix keys are made)
+            LAUNCH(L, DQ_K_GATHER_KEY2, m_in, 0,
+                   hipLaunchKernelGGL(small_group_round_kernel<IdxT>, dim3((unsigned)((m_in + kSgTile - 1) / kSgTile)),
+                                      dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
+                                      (const IdxT *)w.ISA, m_in, n, hr, kbits, d_sa, B, Bs, B + half, Bs + half, B + n,
+                                      Bs + n, w.sg_ctr + r, r == 0 ? (const SmallGroupCounters *)nullptr : w.sg_ctr + r - 1));
+            LAUNCH(L, DQ_K_SEG_APPLY, m_in, 0,
+                   hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(m_in)), dim3(kBlock), 0, st,
+                                      (const uint64_t *)(B + n), (const IdxT *)(Bs + n), (int64_t)0, w.ISA,
+                                      (const SmallGroupCounters *)(w.sg_ctr + r)));
+            rcur ^= 1;
+            hr *= 2;
+        }
+        HIP_TRY(hipMemcpyAsync(c.pinned, w.sg_ctr, kSgChain * sizeof(SmallGroupCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        int64_t cur_m = m_in;
+        for (int r = 0; r < kSgChain; ++r) {
+            if (c.pinned[2 * r + 1] != 0) return fail(DQ_ERR_HIP, "chained small-group round met a large group");
+            if (cur_m > 0) { t_info[0] += 1; t_info[2] += cur_m; }
+            cur_m = c.pinned[2 * r] & 0xffffffffll;
+        }
+        m = cur_m;
+        h = hr;
         return DQ_OK;
     }
 
@@ -949,6 +994,11 @@ struct SuffixSorter {
         if (rc != DQ_OK) return rc;
 
         while (m > 0) {
+            if (only_small_groups && uses_small_round(m) && !keys_ready && !getenv("DQ_NO_CHAIN")) {
+                rc = doubling_rounds_small_chain();           // several rounds, one host round trip; updates h
+                if (rc != DQ_OK) return rc;
+                continue;
+            }
             t_info[0] += 1;
             t_info[2] += m;
             const int kbits = bit_length((uint64_t)(n - 1) + (uint64_t)h);
