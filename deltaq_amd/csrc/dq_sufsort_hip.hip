@@ -225,7 +225,7 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.sg_ctr = (SmallGroupCounters *)take(kSgChain * sizeof(SmallGroupCounters));
     w.hist_partial = (uint32_t *)take((size_t)kHistBlocks * kMaxPasses * kRadixSize * 4);
     w.digit_offset = (int64_t *)take((size_t)kMaxPasses * kRadixSize * 8);
-    w.bytehist = (int64_t *)take((size_t)kRadixSize * 8);
+    w.bytehist = (int64_t *)take((size_t)(kRadixSize + 8) * 8);        // + the 8 k-gram sample counters
     // smallest tile is 8192 keys; 8-byte status words once a list reaches 2^30 entries
     w.ctl_status_bytes = (size_t)kMaxPasses * align_up(256 + (un / 8192 + 2) * kRadixSize * (un >= (1ull << 30) ? 8 : 4));
     w.ctl_status = take(w.ctl_status_bytes);
@@ -391,7 +391,7 @@ int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V
 // If (almost) that many key bytes fit into one 64-bit word next to the suffix index
 // (ib = bits of n-1), round 0 sorts PACKED words (key << ib | suffix): 16 B per element per
 // pass instead of 24 and no value array; the few extra ties go to the sparse finishing path.
-void choose_key_bytes(const int64_t *bytehist, int64_t n, int *kb_out, bool *packed_out)
+void choose_key_bytes(const int64_t *bytehist, const int64_t *kgram_coll, int64_t n, int *kb_out, bool *packed_out)
 {
     double h0 = 0;
     for (int b = 0; b < 256; ++b) {
@@ -407,6 +407,17 @@ void choose_key_bytes(const int64_t *bytehist, int64_t n, int *kb_out, bool *pac
     const int fit = (64 - ib) / 8;
     // packed if the bytes that fit still leave at most ~1/8 of the suffixes tied
     bool packed = fit >= 2 && (kb <= fit || (double)fit * h0 >= std::log2((double)std::max<int64_t>(n, 2)) + 3.0);
+    // Veto from the k-gram sample: an order-0 model cannot see repetition.  With S sampled suffixes and C
+    // adjacent sorted pairs agreeing on L bytes, a suffix expects about n * 2C / S^2 twins under an L-byte
+    // key.  Repetitive (text-like) data takes the 8-byte pair path, which is built for many ties.
+    // (It takes 1 sample in 16 with a twin among the samples: a few repeated regions in otherwise random data
+    // are what the packed sort and its sparse finishing are good at.)
+    if (kgram_coll) {
+        const int L = packed ? std::min(kb, fit) : kb;
+        const int64_t C = kgram_coll[std::max(L, 1) - 1];
+        const double twins = (double)n * 2.0 * (double)C / ((double)kKgramSamples * (double)kKgramSamples);
+        if (C >= kKgramSamples / 16 && twins > 0.25) { packed = false; kb = 8; }
+    }
     if (const char *v = getenv("DQ_PACKED")) packed = atoi(v) != 0 && fit >= 2;
     if (packed) kb = std::min(kb, fit);
     *kb_out = kb;
@@ -425,7 +436,11 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
                               (const uint8_t *)w.text, n, reinterpret_cast<unsigned long long *>(w.bytehist)));
     int kb = 8;
     bool packed = false;
-    HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, 256 * 8, hipMemcpyDeviceToHost, L.st));
+    // (the 8 k-gram counters sit right behind the byte histogram: one readback)
+    hipLaunchKernelGGL(sample_kgrams_kernel, dim3(1), dim3(kKgramSamples), 0, L.st, (const uint8_t *)w.text, n,
+                       w.bytehist + 256);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, (256 + 8) * 8, hipMemcpyDeviceToHost, L.st));
     HIP_TRY(hipEventRecord(c.readback, L.st));
     // While the host waits for the histogram and picks the key width, the device zeroes what the passes
     // need whatever that choice is: the look-back state of all 8 possible passes and the tie bits.
@@ -433,7 +448,7 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
     if (rc != DQ_OK) return rc;
     if (n >= (1 << 16)) HIP_TRY(hipMemsetAsync(w.Vb, 0, (size_t)((n + 63) / 64 + 1) * 8, L.st));
     HIP_TRY(hipEventSynchronize(c.readback));
-    choose_key_bytes(c.pinned, n, &kb, &packed);
+    choose_key_bytes(c.pinned, n >= kKgramSamples * 8 ? c.pinned + 256 : nullptr, n, &kb, &packed);
     if (const char *force = getenv("DQ_KEY_BYTES")) {
         kb = std::min(8, std::max(1, atoi(force)));
         const int fit = (64 - bit_length((uint64_t)(n - 1))) / 8;
