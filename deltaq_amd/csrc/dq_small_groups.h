@@ -29,12 +29,14 @@
 
 namespace dq {
 
-constexpr int kSgMaxG = 8;
+constexpr int kSgMaxG = 8;                          // long lists: the LDS work per entry grows with the group cap
+constexpr int kSgMaxGShort = 32;                    // short lists are launch-bound: take larger groups too, so that
+                                                    // the radix side path (7 launches + a host round trip) dies out sooner
 constexpr int kSgThreads = 512;
 constexpr int kSgItems = 8;
 constexpr int kSgWaves = kSgThreads / kWave;
 constexpr int kSgSpan = kSgThreads * kSgItems;      // list positions a workgroup looks at
-constexpr int kSgTile = kSgSpan - kSgMaxG;          // ... of which it owns the groups starting in the first kSgTile
+template <int kMaxG> constexpr int sg_tile() { return kSgSpan - kMaxG; }   // ... of which it owns the groups starting there
 
 // Appended-entry counters.  One same-address atomic costs ~11 ns on MI355X (they serialise in
 // one L2 channel), so a workgroup reserves its T and U space with ONE packed atomic
@@ -44,7 +46,7 @@ struct SmallGroupCounters {
     unsigned long long large;       // entries appended to L
 };
 
-template <typename IdxT>
+template <typename IdxT, int kMaxG = kSgMaxG>
 __global__ __launch_bounds__(kSgThreads) void small_group_round_kernel(
     const uint64_t *__restrict__ rank, const IdxT *__restrict__ suf, const IdxT *__restrict__ ISA,
     int64_t m, int64_t n, int64_t h, int kbits, IdxT *__restrict__ SA,
@@ -59,10 +61,11 @@ __global__ __launch_bounds__(kSgThreads) void small_group_round_kernel(
         const int64_t real = (int64_t)(prev->tied_moved & 0xffffffffull);
         m = real < m ? real : m;
     }
-    if ((int64_t)blockIdx.x * kSgTile >= m) return;
+    constexpr int kTile = sg_tile<kMaxG>();
+    if ((int64_t)blockIdx.x * kTile >= m) return;
     // ranks and key2 values are < n + h <= 2n: unsigned 32 bits are enough for the int32 index type
     using ElemT = typename std::make_unsigned<IdxT>::type;
-    constexpr int kHalo = kSgMaxG;
+    constexpr int kHalo = kMaxG;
     constexpr ElemT kNone = ~(ElemT)0;
     __shared__ ElemT s_rank[kSgSpan + 2 * kHalo];      // phase 2 on: slot_dest
     __shared__ ElemT s_key2[kSgSpan + 2 * kHalo];      // phase 2 on: slot_rank
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(kSgThreads) void small_group_round_kernel(
     const int t = threadIdx.x;
     const int lane = lane_id();
     const int wv = t >> 6;
-    const int64_t j0 = (int64_t)blockIdx.x * kSgTile;
+    const int64_t j0 = (int64_t)blockIdx.x * kTile;
 
     ElemT r[kSgItems], k2[kSgItems];
     IdxT s[kSgItems];
@@ -117,23 +120,23 @@ __global__ __launch_bounds__(kSgThreads) void small_group_round_kernel(
     for (int k = 0; k < kSgItems; ++k) {
         const int e = k * kSgThreads + t;
         const bool valid = r[k] != kNone;
-        // extent of the group: equal ranks to the left / right, each capped at kSgMaxG
+        // extent of the group: equal ranks to the left / right, each capped at kMaxG
         int left = 0, right = 0;
 #pragma unroll
-        for (int i = 1; i <= kSgMaxG; ++i)
+        for (int i = 1; i <= kMaxG; ++i)
             if (left == i - 1 && s_rank[kHalo + e - i] == r[k]) left = i;
 #pragma unroll
-        for (int i = 1; i <= kSgMaxG; ++i)
+        for (int i = 1; i <= kMaxG; ++i)
             if (right == i - 1 && s_rank[kHalo + e + i] == r[k]) right = i;
-        const bool large = valid && (left + right + 1 > kSgMaxG);
+        const bool large = valid && (left + right + 1 > kMaxG);
         const int head = e - left;                      // span index of the group's first member
-        const bool own_small = valid && !large && head >= 0 && head < kSgTile;
-        own_large[k] = large && e < kSgTile;
+        const bool own_small = valid && !large && head >= 0 && head < kTile;
+        own_large[k] = large && e < kTile;
         slot[k] = -1; flag[k] = 0; nrank[k] = 0; dest[k] = 0;
         if (own_small) {
             int less = 0, eq = 0, eq_before = 0;
 #pragma unroll
-            for (int i = -kSgMaxG + 1; i < kSgMaxG; ++i) {
+            for (int i = -kMaxG + 1; i < kMaxG; ++i) {
                 if (i >= -left && i <= right) {
                     const ElemT o = s_key2[kHalo + e + i];
                     less += o < k2[k];
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(kSgThreads) void small_group_round_kernel(
                     eq_before += (o == k2[k]) && i < 0;
                 }
             }
-            slot[k] = head + less + eq_before;          // <= kSgTile - 1 + kSgMaxG - 1 < kSgSpan
+            slot[k] = head + less + eq_before;          // <= kTile - 1 + kMaxG - 1 < kSgSpan
             nrank[k] = r[k] + (ElemT)less;
             dest[k] = r[k] + (ElemT)(less + eq_before);
             flag[k] = (uint8_t)(1 | (eq > 1 ? 2 : 0) | (less != 0 ? 4 : 0));

@@ -176,6 +176,7 @@ int flush_profile(DeviceCtx &c)
     } while (0)
 
 constexpr int kSgChain = 4;       // small-group rounds chained without a host round trip
+constexpr int64_t kSgShortList = 1 << 20;     // below this many tied suffixes a round is launch-bound
 
 // ------------------------------------------------------------------ workspace carving
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -629,8 +630,9 @@ struct SuffixSorter {
     int rbits = 0;
     // the list already holds composite keys (rank << kbits | key2) for the next doubling round
     bool keys_ready = false;
-    // the last small-group round sent nothing to the radix list: every group has <= 8 members
+    // the last small-group round sent nothing to the radix list: every group has <= small_cap members
     bool only_small_groups = false;
+    int small_cap = kSgMaxG;
     // the finisher already ran (speculatively, right after the tie bits were collected)
     bool fin_done = false;
     int64_t fin_cap = 0, fin_left = 0;
@@ -922,14 +924,28 @@ struct SuffixSorter {
         const int64_t half = n / 2;
         SmallGroupCounters *ctr = reinterpret_cast<SmallGroupCounters *>(w.totals + 4);
         HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(SmallGroupCounters), st));
-        LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + wb + 8 + wb),
-               hipLaunchKernelGGL(small_group_round_kernel<IdxT>, dim3((unsigned)((m + kSgTile - 1) / kSgTile)),
-                                  dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
-                                  (const IdxT *)w.ISA, m, n, h, kbits, d_sa, B, Bs, B + half, Bs + half, B + n,
-                                  Bs + n, ctr));
+        const int64_t m_before = m;
+        if (m < kSgShortList) {
+            constexpr int kTile = sg_tile<kSgMaxGShort>();
+            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + wb + 8 + wb),
+                   hipLaunchKernelGGL((small_group_round_kernel<IdxT, kSgMaxGShort>), dim3((unsigned)((m + kTile - 1) / kTile)),
+                                      dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
+                                      (const IdxT *)w.ISA, m, n, h, kbits, d_sa, B, Bs, B + half, Bs + half, B + n,
+                                      Bs + n, ctr, (const SmallGroupCounters *)nullptr));
+        } else {
+            constexpr int kTile = sg_tile<kSgMaxG>();
+            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + wb + 8 + wb),
+                   hipLaunchKernelGGL((small_group_round_kernel<IdxT, kSgMaxG>), dim3((unsigned)((m + kTile - 1) / kTile)),
+                                      dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
+                                      (const IdxT *)w.ISA, m, n, h, kbits, d_sa, B, Bs, B + half, Bs + half, B + n,
+                                      Bs + n, ctr, (const SmallGroupCounters *)nullptr));
+        }
         HIP_TRY(hipMemcpyAsync(c.pinned, ctr, sizeof(SmallGroupCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const int64_t m1 = c.pinned[0] & 0xffffffffll, mU = (int64_t)((uint64_t)c.pinned[0] >> 32), mL = c.pinned[1];
+        if (getenv("DQ_TRACE"))
+            fprintf(stderr, "[dq] small round h=%lld m=%lld -> tied %lld, to radix %lld, moved %lld\n", (long long)h,
+                    (long long)m, (long long)m1, (long long)mL, (long long)mU);
         if (mU > 0) {
             LAUNCH(L, DQ_K_SEG_APPLY, mU, mU * (8 + wb + wb),
                    hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(mU)), dim3(kBlock), 0, st,
@@ -949,14 +965,22 @@ struct SuffixSorter {
         }
         rcur ^= 1;
         m = m1 + mLs;
-        only_small_groups = mL == 0;      // groups only ever split: from now on every group has <= 8 members
+        // groups only ever split: once nothing went to the radix list, every group fits this round's cap
+        if (mL == 0) small_cap = m_before < kSgShortList ? kSgMaxGShort : kSgMaxG;
+        only_small_groups = mL == 0;
         return DQ_OK;
     }
 
     // ---- kSgChain small-group rounds back to back, lengths handed over on the device.  Only valid once
-    //      every group has <= 8 members (nothing goes to the radix list any more); the grids are sized for
+    //      every group has <= small_cap members (nothing goes to the radix list any more); the grids are sized for
     //      the current m, which is an upper bound for all later rounds.
     int doubling_rounds_small_chain()
+    {
+        return small_cap == kSgMaxGShort ? small_chain<kSgMaxGShort>() : small_chain<kSgMaxG>();
+    }
+
+    template <int kCap>
+    int small_chain()
     {
         const int64_t half = n / 2;
         const int64_t m_in = m;
@@ -966,8 +990,9 @@ struct SuffixSorter {
             uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
             IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
             const int kbits = std::min(bit_length((uint64_t)(n - 1) + (uint64_t)hr), 64 - rbits);   // (no radix keys are made)
+            constexpr int kTile = sg_tile<kCap>();                           // (every group has <= kCap members here)
             LAUNCH(L, DQ_K_GATHER_KEY2, m_in, 0,
-                   hipLaunchKernelGGL(small_group_round_kernel<IdxT>, dim3((unsigned)((m_in + kSgTile - 1) / kSgTile)),
+                   hipLaunchKernelGGL((small_group_round_kernel<IdxT, kCap>), dim3((unsigned)((m_in + kTile - 1) / kTile)),
                                       dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
                                       (const IdxT *)w.ISA, m_in, n, hr, kbits, d_sa, B, Bs, B + half, Bs + half, B + n,
                                       Bs + n, w.sg_ctr + r, r == 0 ? (const SmallGroupCounters *)nullptr : w.sg_ctr + r - 1));
