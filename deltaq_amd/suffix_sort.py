@@ -103,7 +103,12 @@ class HipSuffixSort:
         fn = (self._lib.dq_sufsort_hip_dev_i32 if suffixes.dtype == torch.int32
               else self._lib.dq_sufsort_hip_dev_i64)
         dev = text.device.index if text.device.index is not None else torch.cuda.current_device()
-        stream = torch.cuda.current_stream(text.device).cuda_stream
+        cur = torch.cuda.current_stream(text.device)
+        stream = cur.cuda_stream
+        if not stream:
+            # torch's default stream is the legacy null stream: the library then works on its own
+            # (non-blocking) stream, so whatever produced `text` has to be finished first
+            cur.synchronize()
         _abi.check(fn(text.data_ptr() if n else None, n, suffixes.data_ptr() if n else None, dev, stream))
         return ret
 
