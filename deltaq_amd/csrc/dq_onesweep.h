@@ -585,18 +585,71 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
 // T[i + kb-1-p] (zero past the end), so every digit place shares ONE byte histogram of the
 // text, corrected for the first / last kb-1 positions.
 // ---------------------------------------------------------------------------------
+//
+// Workgroup 0 of the grid does something else (kgram_coll != nullptr): the byte histogram says nothing
+// about repetition (text has ~4.5 bits of order-0 entropy per byte and ~2 bits of real entropy), so it
+// samples kKgramSamples evenly spaced suffixes and counts, for every prefix length L = 1..8, the samples
+// whose first L bytes were already seen in an earlier sample (one hashed bit set per length in LDS; a
+// ~1.6 % full table gives ~16 false hits, far below the threshold the host applies).  With C such samples
+// out of S, a suffix expects about n * 2C / S^2 twins under an L-byte key.  kgram_coll[L-1] = C for L.
+// It runs beside the histogram workgroups, so the sample costs no time of its own.
+constexpr int kKgramSamples = 1024;
+constexpr int kKgramBits = 32768;                    // bits per length in the seen-set
+
+__device__ __forceinline__ void sample_kgrams(const uint8_t *__restrict__ text, int64_t n,
+                                              unsigned long long *__restrict__ coll, uint32_t *seen /*[8][kKgramBits/32]*/,
+                                              uint32_t *cnt)
+{
+    constexpr int kPer = kKgramSamples / kBlock;
+    const int t = threadIdx.x;
+    for (int i = t; i < 8 * kKgramBits / 32; i += kBlock) seen[i] = 0;
+    if (t < 8) cnt[t] = 0;
+    uint64_t key[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const int64_t p = (int64_t)((__int128)(q * kBlock + t) * n / kKgramSamples);
+        uint64_t k = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) k = (k << 8) | (p + b < n ? (uint64_t)text[p + b] : 0ull);
+        key[q] = k;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+#pragma unroll
+        for (int L = 1; L <= 8; ++L) {
+            uint64_t x = (key[q] >> (64 - 8 * L)) + 0x9E3779B97F4A7C15ull * (uint64_t)L;
+            x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+            x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+            const uint32_t bit = (uint32_t)(x >> 40) & (kKgramBits - 1);
+            const uint32_t old = atomicOr(&seen[(L - 1) * (kKgramBits / 32) + (bit >> 5)], 1u << (bit & 31));
+            if (old & (1u << (bit & 31))) atomicAdd(&cnt[L - 1], 1u);
+        }
+    }
+    __syncthreads();
+    if (t < 8) coll[t] = (unsigned long long)cnt[t];
+}
+
 __global__ __launch_bounds__(kBlock) void text_hist_kernel(const uint8_t *__restrict__ text, int64_t n,
-                                                           unsigned long long *__restrict__ bytehist /*[256], zeroed*/)
+                                                           unsigned long long *__restrict__ bytehist /*[256], zeroed*/,
+                                                           unsigned long long *__restrict__ kgram_coll = nullptr)
 {
     // 4 interleaved sub-histograms (hist[d][lane & 3]) spread equal bytes over 4 banks
     __shared__ uint32_t hist[kRadixSize * 4];
+    if (kgram_coll && blockIdx.x == 0) {
+        __shared__ uint32_t s_seen[8 * kKgramBits / 32];
+        sample_kgrams(text, n, kgram_coll, s_seen, hist);
+        return;
+    }
     const int tid = threadIdx.x;
     const int sub = tid & 3;
+    const int64_t nblocks = (int64_t)gridDim.x - (kgram_coll ? 1 : 0);          // workgroups that build the histogram
+    const int64_t hblock = (int64_t)blockIdx.x - (kgram_coll ? 1 : 0);
     for (int i = tid; i < kRadixSize * 4; i += kBlock) hist[i] = 0;
     __syncthreads();
     const uint4 *t16 = reinterpret_cast<const uint4 *>(text);      // text is 16-byte aligned
     const int64_t chunks = n >> 4;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + tid; i < chunks; i += (int64_t)gridDim.x * kBlock) {
+    for (int64_t i = hblock * kBlock + tid; i < chunks; i += nblocks * kBlock) {
         const uint4 v = t16[i];
         const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -605,7 +658,7 @@ __global__ __launch_bounds__(kBlock) void text_hist_kernel(const uint8_t *__rest
             for (int b = 0; b < 4; ++b) atomicAdd(&hist[(((wds[j] >> (8 * b)) & 0xff) << 2) | sub], 1u);
         }
     }
-    if (blockIdx.x == 0) {
+    if (hblock == 0) {
         for (int64_t i = (chunks << 4) + tid; i < n; i += kBlock) atomicAdd(&hist[((uint32_t)text[i] << 2) | sub], 1u);
     }
     __syncthreads();

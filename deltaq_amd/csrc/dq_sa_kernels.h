@@ -433,50 +433,6 @@ __global__ __launch_bounds__(kFinishThreads) void small_group_finish_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------
-// sample_kgrams: the byte histogram says nothing about repetition (text has ~4.5 bits of order-0
-// entropy per byte and ~2 bits of real entropy), so before the key width is chosen one workgroup
-// samples kKgramSamples evenly spaced suffixes, sorts their 8-byte keys (bitonic, LDS) and counts,
-// for every prefix length L = 1..8, the adjacent sorted pairs that agree on L bytes.  A pair of
-// random suffixes colliding on L bytes with probability q shows up ~S^2 q / 2 times; n q is the
-// expected number of twins of a suffix, i.e. how tied an L-byte sort will leave the text.
-// coll[L-1] receives the count for length L.
-// ---------------------------------------------------------------------------------
-constexpr int kKgramSamples = 1024;
-
-__global__ __launch_bounds__(kKgramSamples) void sample_kgrams_kernel(const uint8_t *__restrict__ text, int64_t n,
-                                                                    int64_t *__restrict__ coll /*[8]*/)
-{
-    __shared__ uint64_t key[kKgramSamples];
-    __shared__ uint32_t cnt[8];
-    const int t = threadIdx.x;
-    if (t < 8) cnt[t] = 0;
-    const int64_t p = (int64_t)((__int128)t * n / kKgramSamples);
-    uint64_t k = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) k = (k << 8) | (p + i < n ? (uint64_t)text[p + i] : 0ull);
-    key[t] = k;
-    __syncthreads();
-    for (int size = 2; size <= kKgramSamples; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int partner = t ^ stride;
-            if (partner > t) {
-                const uint64_t a = key[t], b = key[partner];
-                const bool up = (t & size) == 0;
-                if ((a > b) == up) { key[t] = b; key[partner] = a; }
-            }
-            __syncthreads();
-        }
-    }
-    if (t > 0) {
-        const uint64_t x = key[t] ^ key[t - 1];
-        const int same = x == 0 ? 8 : (__builtin_clzll(x) >> 3);          // leading bytes in common
-        for (int L = 1; L <= same; ++L) atomicAdd(&cnt[L - 1], 1u);
-    }
-    __syncthreads();
-    if (t < 8) coll[t] = (int64_t)cnt[t];
-}
-
 // Estimate of the tie fraction after round 0: kSamples evenly spaced adjacent pairs of the
 // sorted key list; *count = pairs with equal keys.  Decides whether the rebucket pass should
 // write the full inverse suffix array right away (dense doubling expected).

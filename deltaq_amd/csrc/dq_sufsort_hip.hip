@@ -432,15 +432,13 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
 {
     const int blocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 4) + kBlock - 1) / kBlock + 1);
     HIP_TRY(hipMemsetAsync(w.bytehist, 0, 256 * 8, L.st));
+    // (+1 workgroup: the k-gram sample, whose 8 counters sit right behind the byte histogram: one readback)
     LAUNCH(L, DQ_K_RADIX_HIST, n, n,
-           hipLaunchKernelGGL(text_hist_kernel, dim3(blocks), dim3(kBlock), 0, L.st,
-                              (const uint8_t *)w.text, n, reinterpret_cast<unsigned long long *>(w.bytehist)));
+           hipLaunchKernelGGL(text_hist_kernel, dim3(blocks + 1), dim3(kBlock), 0, L.st,
+                              (const uint8_t *)w.text, n, reinterpret_cast<unsigned long long *>(w.bytehist),
+                              reinterpret_cast<unsigned long long *>(w.bytehist + 256)));
     int kb = 8;
     bool packed = false;
-    // (the 8 k-gram counters sit right behind the byte histogram: one readback)
-    hipLaunchKernelGGL(sample_kgrams_kernel, dim3(1), dim3(kKgramSamples), 0, L.st, (const uint8_t *)w.text, n,
-                       w.bytehist + 256);
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, (256 + 8) * 8, hipMemcpyDeviceToHost, L.st));
     HIP_TRY(hipEventRecord(c.readback, L.st));
     // While the host waits for the histogram and picks the key width, the device zeroes what the passes
