@@ -186,6 +186,7 @@ FUZZ_ENVS = [
     {"DQ_NO_FUSED_TIES": "1", "DQ_NO_SMALL": "1"},         # general rebucket pass, radix-only doubling rounds
     {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2", "DQ_SMALL_N": "0"},   # tie bits with most suffixes tied
     {"DQ_SPARSE": "1", "DQ_SMALL_N": "0"},                 # finisher + key extension + fallback on dense inputs
+    {"DQ_NO_BINNED_ISA": "1", "DQ_NO_CHAIN": "1"},         # first ISA by scatter, one host round trip per small-group round
 ]
 
 
