@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Long randomised differential run on a GPU box (not collected by pytest):
+    python tests/manual/stress.py [seconds] [seed]
+Structured random inputs of 1 B .. 24 MB (tests/test_gpu_parity.py::structured_text), random forced-path
+environments, int32 / int64, host and device entry points; every SA is bit-compared with the oracle."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import oracle
+from deltaq_amd import HipSuffixSort
+src = open(os.path.join(ROOT, "tests", "test_gpu_parity.py")).read()
+ns = {}
+exec(src[src.index("def structured_text"):src.index("FUZZ_ENVS = [")], {"np": np}, ns)
+structured_text = ns["structured_text"]
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ENVS = [{}, {}, {}, {"DQ_SMALL_N": "0"}, {"DQ_NO_FUSED_TIES": "1"}, {"DQ_NO_SMALL": "1"}, {"DQ_NO_BINNED_ISA": "1"},
+        {"DQ_NO_CHAIN": "1"}, {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2"}, {"DQ_PACKED": "1", "DQ_KEY_BYTES": "3"},
+        {"DQ_PACKED": "0", "DQ_KEY_BYTES": "4"}, {"DQ_SPARSE": "1"}, {"DQ_SPARSE": "0"}]
+KEYS = sorted({k for e in ENVS for k in e})
+s = HipSuffixSort(0)
+t_end = time.time() + budget
+count = 0; total = 0
+while time.time() < t_end:
+    u = rng.random()
+    n = int(rng.integers(1, 3000)) if u < 0.25 else int(rng.integers(3000, 200_000)) if u < 0.7 else \
+        int(rng.integers(200_000, 3_000_000)) if u < 0.95 else int(rng.integers(3_000_000, 24_000_000))
+    T = structured_text(rng, n)
+    env = ENVS[int(rng.integers(0, len(ENVS)))]
+    for k in KEYS: os.environ.pop(k, None)
+    os.environ.update(env)
+    ref = oracle.divsufsort(T)
+    mode = int(rng.integers(0, 4))
+    if mode == 0:   got = s.Sort(T)
+    elif mode == 1: got = s.Sort(T, index_dtype=np.int64)
+    elif mode == 2: got = s.Sort(torch.from_numpy(T).cuda()).cpu().numpy()
+    else:           got = s.Sort(torch.from_numpy(T).cuda(), index_dtype=np.int64).cpu().numpy()
+    if not np.array_equal(got.astype(np.int64), ref.astype(np.int64)):
+        np.save(os.path.join(ROOT, "gpurun_out", f"stress_fail_{seed}_{count}.npy"), T)
+        print("MISMATCH", dict(count=count, n=n, env=env, mode=mode), flush=True)
+        sys.exit(1)
+    count += 1; total += n
+print(f"stress OK: {count} inputs, {total/1e6:.1f} MB, seed {seed}", flush=True)
