@@ -1,0 +1,126 @@
+"""numpy models of the device algorithms added on top of plain prefix doubling, checked against direct
+definitions.  They pin the LOGIC (what the kernels in dq_ties.h / dq_isa_pairs.h / dq_small_groups.h are
+specified to compute) on the CPU; the kernels themselves are checked bit-exact on the GPU (test_gpu_parity.py)."""
+import numpy as np
+import pytest
+
+
+def sorted_keys(rng, n, distinct):
+    return np.sort(rng.integers(0, distinct, size=n, dtype=np.uint64))
+
+
+# ---------------------------------------------------------------- tie bits of the last digit pass (dq_ties.h)
+def tie_bits_model(keys_in, tile, top_shift):
+    """keys_in: the last pass's INPUT order (sorted by the low digits, arbitrary top digit).  Emulates the pass:
+    per tile, a stable split by the top digit; E bits for neighbours inside one (tile, digit) run; the first /
+    last key of every run in a seam table; then the seam decision.  Returns (sorted keys, E)."""
+    n = keys_in.size
+    digit = (keys_in >> np.uint64(top_shift)).astype(np.int64)
+    ntiles = (n + tile - 1) // tile
+    counts = np.zeros((ntiles, 256), np.int64)
+    for t in range(ntiles):
+        counts[t] = np.bincount(digit[t * tile:(t + 1) * tile], minlength=256)
+    dig_tot = counts.sum(axis=0)
+    dig_off = np.concatenate([[0], np.cumsum(dig_tot)[:-1]])
+    excl = np.cumsum(counts, axis=0) - counts                      # keys with digit d in tiles before t
+    out = np.zeros(n, np.uint64)
+    E = np.zeros(n, bool)
+    first = np.full((ntiles, 256), -1, np.int64); last = np.full((ntiles, 256), -1, np.int64)
+    for t in range(ntiles):
+        k = keys_in[t * tile:(t + 1) * tile]; d = digit[t * tile:(t + 1) * tile]
+        order = np.argsort(d, kind="stable")
+        ks, ds = k[order], d[order]
+        pos = np.arange(ks.size)
+        run_start = np.concatenate([[0], np.cumsum(counts[t])[:-1]])
+        o = dig_off[ds] + excl[t, ds] + (pos - run_start[ds])
+        out[o] = ks
+        same_run = np.concatenate([[False], ds[1:] == ds[:-1]])
+        eq = np.concatenate([[False], ks[1:] == ks[:-1]]) & same_run
+        E[o[eq]] = True
+        for dd in np.unique(ds):
+            idx = np.nonzero(ds == dd)[0]
+            first[t, dd] = idx[0]; last[t, dd] = idx[-1]
+            first[t, dd] = int(ks[idx[0]]); last[t, dd] = int(ks[idx[-1]])
+    # seam kernel: first key of run (t, d) against the last key of the nearest earlier tile that has digit d
+    for t in range(1, ntiles):
+        for dd in range(256):
+            if counts[t, dd] == 0:
+                continue
+            tp = t - 1
+            while tp >= 0 and counts[tp, dd] == 0:
+                tp -= 1
+            if tp >= 0 and last[tp, dd] == first[t, dd]:
+                E[dig_off[dd] + excl[t, dd]] = True
+    return out, E
+
+
+def collect_model(E):
+    """tie_collect_kernel: members of groups of size > 1 as (rank = position of the first member, position)."""
+    n = E.size
+    active = E | np.concatenate([E[1:], [False]])
+    head = np.maximum.accumulate(np.where(~E, np.arange(n), 0))
+    p = np.nonzero(active)[0]
+    return head[p], p
+
+
+@pytest.mark.parametrize("n,distinct,tile", [(5000, 3000, 512), (4096, 40, 256), (3000, 1, 128), (7777, 10**9, 1024),
+                                              (2048, 600, 2048), (1, 5, 64), (257, 2, 64)])
+def test_tie_bits_and_seams_equal_the_direct_definition(n, distinct, tile):
+    rng = np.random.default_rng(n + distinct)
+    keys = rng.integers(0, distinct, size=n, dtype=np.uint64) | (rng.integers(0, 7, size=n, dtype=np.uint64) << np.uint64(56))
+    low_sorted = keys[np.argsort(keys & np.uint64((1 << 56) - 1), kind="stable")]          # LSD: low digits done
+    out, E = tie_bits_model(low_sorted, tile, 56)
+    assert np.array_equal(out, np.sort(keys))
+    direct = np.concatenate([[False], out[1:] == out[:-1]])
+    assert np.array_equal(E, direct)
+    rank, pos = collect_model(E)
+    # every tied position appears once, with the position of its group's first member as rank
+    _, first_idx, inv, cnt = np.unique(out, return_index=True, return_inverse=True, return_counts=True)
+    tied = np.nonzero(cnt[inv] > 1)[0]
+    assert np.array_equal(pos, tied)
+    assert np.array_equal(rank, first_idx[inv][tied])
+
+
+# ---------------------------------------------------------------- suffix-binned first ISA (dq_isa_pairs.h)
+@pytest.mark.parametrize("n", [1 << 16, (1 << 16) + 1, 100_003, 1 << 17])
+def test_binned_words_put_consecutive_suffixes_in_consecutive_positions(n):
+    rng = np.random.default_rng(n)
+    ib = int(n - 1).bit_length()
+    sa = rng.permutation(n).astype(np.uint64)
+    rank = np.sort(rng.integers(0, n, size=n)).astype(np.uint64)       # any non-decreasing rank array
+    words = (rank << np.uint64(ib)) | sa
+    # closed-form digit offsets of the two binning passes: every suffix occurs exactly once
+    for sh in (ib - 16, ib - 8):
+        unit = 1 << sh
+        full, rem = n >> (sh + 8), n & ((unit << 8) - 1)
+        cnt = np.array([full * unit + min(max(rem - d * unit, 0), unit) for d in range(256)])
+        d = ((words & np.uint64((1 << ib) - 1)) >> np.uint64(sh)) & np.uint64(255)
+        assert np.array_equal(cnt, np.bincount(d.astype(np.int64), minlength=256))
+        words = words[np.argsort(d, kind="stable")]
+    suf = (words & np.uint64((1 << ib) - 1)).astype(np.int64)
+    span = 4096
+    isa = np.zeros(n, np.int64)
+    for base in range(0, n, span):
+        s = suf[base:base + span]
+        assert s.min() == base and s.max() == min(base + span, n) - 1          # the LDS image covers exactly its span
+        image = np.zeros(span, np.int64)
+        image[s - base] = (words[base:base + span] >> np.uint64(ib)).astype(np.int64)
+        isa[base:base + s.size] = image[:s.size]
+    direct = np.zeros(n, np.int64); direct[sa.astype(np.int64)] = rank.astype(np.int64)
+    assert np.array_equal(isa, direct)
+
+
+# ---------------------------------------------------------------- place inside a small group (dq_small_groups.h)
+def test_place_by_counting_is_a_stable_sort_and_finds_the_ties():
+    rng = np.random.default_rng(5)
+    for g in range(1, 33):
+        k2 = rng.integers(0, max(2, g // 2), size=g)
+        less = np.array([(k2 < x).sum() for x in k2])
+        eq_before = np.array([(k2[:i] == k2[i]).sum() for i in range(g)])
+        place = less + eq_before
+        assert sorted(place.tolist()) == list(range(g))
+        assert np.array_equal(k2[np.argsort(place)], np.sort(k2))
+        tied = np.array([(k2 == x).sum() > 1 for x in k2])
+        new_rank = less                                             # rank offset of the subgroup
+        for i in range(g):
+            assert tied[i] == ((new_rank == new_rank[i]).sum() > 1)
