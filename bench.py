@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- MB of text suffix-sorted per second (bit-exact SA) on N MI355X.
 
-One "step" = one ISuffixSort.Sort of the workload buffer, text already resident in HBM,
-SA left in HBM (dq_sufsort_hip_dev_i32).  Workload at every N: BASELINE.json configs[1],
-a 64 MiB uniform-random byte buffer per GPU (splitmix64, seed 0x5EED0002 + rank); the
-path shards across independent inputs with no data-path collective, so N GPUs = N
-buffers (weak scaling) and value = total MB sorted / max-over-ranks time.
+One "step" = one ISuffixSort.Sort of the workload buffer with the text already resident in HBM
+and the SA left in HBM (dq_sufsort_hip_dev_i32).  Workload: the north-star run of BASELINE.json,
+a 256 MiB uniform-random byte buffer per GPU (splitmix64, seed 0x5EED0003 + rank), int32 SA.
+A single suffix array does not shard; independent inputs do, with no
+data-path collective, so N GPUs = N buffers (weak scaling) and
+value = total MB sorted / max-over-ranks time.
 
     python bench.py [--gpus 1] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live: every radix_rank_kernel
-launch in the timed region is bracketed by hipEvents on its launch stream (library-side,
-dq_profile_*).  `cpu_baseline` times the oracle's single-threaded restatement of the
-reference's LibDivSufSort on this host (rank 0, N=1 only) and bit-compares its SA with the
-GPU's.  oracle/ is used here ONLY as that baseline/checker.
+Prints ONE JSON line (rank 0).  Beside the contract's fields it carries
+  roofline      the dominant kernel, measured live: every launch of it inside the timed region is
+                bracketed by hipEvents on its launch stream (library side, dq_profile_*)
+  through_abi   the same buffer through the interface the reference exposes (host pointers in and
+                out, dq_sufsort_hip_i32 == ISuffixSort.Sort(text, suffixes)): PCIe-inclusive, never `value`
+  configs       one short record per other BASELINE.json configuration (64 MiB uniform, 256 MiB
+                enwik-style text, and 128 x 16 MiB through the batch entry point on this rank's GPU)
+  batch         (every N) BASELINE configs[4] as named: 128 x 16 MiB buffers (seeds 0x5EED0500 + j),
+                LPT-sharded over the N ranks, host buffers in/out, MB/s = 2 GiB / max-over-ranks wall;
+                for N > 1 the scatter/sort/gather layer also runs once over RCCL and rank 0 checks
+                the gathered suffix arrays
+  cpu_baseline  the oracle's single-threaded restatement of the reference's LibDivSufSort on this
+                host (rank 0, N = 1 only), timed on the same 256 MiB buffer and bit-compared with the GPU's SA
+oracle/ is used here ONLY as that baseline / checker.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -28,18 +39,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
-SEED = 0x5EED0002
+SEED_TARGET = 0x5EED0003       # 256 MiB uniform, the north-star run
+SEED_CONFIG1 = 0x5EED0002      # 64 MiB uniform
+SEED_ENWIK = 0xD17A0           # 256 MiB enwik-style text
+SEED_BATCH = 0x5EED0500        # + j, 128 x 16 MiB
+BATCH_COUNT, BATCH_BYTES = 128, 16 << 20
 
 
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size-mib", type=int, default=64, help="bytes of text per GPU (MiB)")
+    ap.add_argument("--size-mib", type=int, default=256, help="bytes of text per GPU (MiB)")
     ap.add_argument("--workload", choices=["uniform", "enwik"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel hipEvent timing")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed region (profiling runs): no through_abi / configs / batch records")
+    ap.add_argument("--no-build", action="store_true",
+                    help="never spawn a compiler (runs under rocprofv3, where the GPU is up before main())")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
@@ -50,16 +69,27 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+    # Native builds first, before anything initialises the GPU runtime (compilers are child processes;
+    # under rocprofv3 the GPU is already up, so a stale library there is an error, not a rebuild).
+    from deltaq_amd import build as dq_build
+    import oracle
+    from tools import datagen
+    if args.no_build:
+        if dq_build.is_stale():
+            raise SystemExit("libdq_sufsort_hip.so is stale: run __graft_entry__.build() first")
+    else:
+        dq_build.build()                   # no-op when the in-tree .so is current
+        oracle.build()
+        datagen.build()
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    from deltaq_amd import HipSuffixSort, _abi, build as dq_build
-    from deltaq_amd import workload as wl
+    from deltaq_amd import HipSuffixSort, _abi
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the suffix sorter has no CPU path")
-    dq_build.build()                       # no-op when the in-tree .so is current
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -71,13 +101,12 @@ def main() -> int:
             dist.init_process_group(args.backend)
 
     n = args.size_mib << 20
-    seed = SEED + rank
     if args.workload == "uniform":
-        host = wl.gen_uniform(n, seed)
-        wname = f"{args.size_mib} MiB uniform-random bytes per GPU (splitmix64 seed 0x{SEED:X}+rank), int32 SA"
+        seed = (SEED_TARGET if args.size_mib == 256 else SEED_CONFIG1) + rank
+        host = datagen.gen_uniform(n, seed)
+        wname = f"{args.size_mib} MiB uniform-random bytes per GPU (splitmix64 seed 0x{seed - rank:X}+rank), int32 SA"
     else:
-        from tools import datagen
-        host = datagen.gen_enwik_like(n, 0xD17A0 + rank)
+        host = datagen.gen_enwik_like(n, SEED_ENWIK + rank)
         wname = f"{args.size_mib} MiB enwik8-style skewed text per GPU (seed 0xD17A0+rank, R=256 KiB), int32 SA"
     text = torch.from_numpy(host).to(dev)
     sa = torch.empty(n, dtype=torch.int32, device=dev)
@@ -90,13 +119,21 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # which kernel dominates?  one profiled sort decides (its category is then the only one bracketed
+    # by hipEvents inside the timed region: bracketing all ~25 launches of a sort costs ~6 % of the step)
     for _ in range(args.warmup):
         sorter.Sort(text, sa)
+    dominant = "radix_rank_kernel"
+    if not args.no_profile:
+        L.dq_profile_reset()
+        L.dq_profile_enable(1)
+        sorter.Sort(text, sa)
+        torch.cuda.synchronize(dev)
+        L.dq_profile_enable(0)
+        snap = _abi.profile_snapshot()
+        dominant = max(snap, key=lambda k: snap[k]["ms"])
     L.dq_profile_reset()
-    # timed region: hipEvents only around the dominant kernel (mode 2) -- bracketing all ~25
-    # launches of a sort costs ~6 % of the step; the other kernels are profiled in an extra,
-    # untimed pass below
-    L.dq_profile_enable(0 if args.no_profile else 2)
+    L.dq_profile_enable(0 if args.no_profile else 100 + _abi.category_of(dominant))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -122,27 +159,27 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    extras = not args.no_extras
+    through_abi = configs = None
+    if extras and rank == 0:
+        through_abi = time_through_abi(sorter, host, sa, reps=3)
+    # the named configs[4] workload: every rank takes part
+    batch = batch_config4(world, rank, local_rank, dev, args.backend, sorter) if extras else None
+    if extras and rank == 0 and world == 1:
+        del text
+        configs = other_configs(sorter, dev)
+
     out = None
     if rank == 0:
         total_mb = world * n * args.steps / 1e6
         value = total_mb / elapsed
-        rs = prof["radix_rank_kernel"]
+        rs = prof[dominant]
         roofline = None
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.workload == "uniform" and args.size_mib == 64:
-            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-            # separate runs of this same command, tools/profile_gpu.sh): 2*FETCH_SIZE + WRITE_SIZE
-            try:
-                tj = json.load(open(tpath))
-                traffic = int(tj["radix_rank_kernel"]["hbm_bytes_per_launch"])
-                traffic_src = "profiles/traffic.json (rocprofv3 PMC, 2*FETCH_SIZE+WRITE_SIZE per launch)"
-            except Exception:
-                traffic = None
         if rs["launches"]:
             achieved = rs["alg_bytes"] / (rs["ms"] * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(dominant, args)
             roofline = {
-                "kernel": "radix_rank_kernel", "bound": "hbm",
+                "kernel": dominant, "bound": "hbm",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
@@ -150,7 +187,7 @@ def main() -> int:
                 "avg_launch_us": round(rs["ms"] / rs["launches"] * 1e3, 2),
                 "alg_bytes_per_launch": rs["alg_bytes"] // rs["launches"],
             }
-        kernels = {k: {"launches_per_step": v["launches"] // all_steps, "ms_per_step": round(v["ms"] / all_steps, 4),
+        kernels = {k: {"launches_per_step": v["launches"] / all_steps, "ms_per_step": round(v["ms"] / all_steps, 4),
                        "alg_GBps": round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
                    for k, v in prof_all.items() if v["launches"]}
         out = {
@@ -165,8 +202,18 @@ def main() -> int:
             "roofline": roofline,
             "kernels_untimed_pass": kernels,
         }
+        if through_abi is not None:
+            out["through_abi"] = through_abi
+        if configs is not None:
+            out["configs"] = configs
+        if batch is not None:
+            out["batch"] = batch
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host, sa)
+            cb = cpu_baseline(host, sa)
+            out["cpu_baseline"] = cb
+            if through_abi is not None:
+                through_abi["speedup_vs_cpu"] = round(through_abi["MBps"] / cb["value"], 1)
+            out["speedup_vs_cpu_device_resident"] = round(value / cb["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -174,15 +221,145 @@ def main() -> int:
     return 0
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, tools/profile_gpu.sh):
+    2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, None
+    try:
+        tj = json.load(open(tpath))
+        if tj.get("workload") != f"{args.workload}-{args.size_mib}MiB":
+            return None, None
+        return int(tj[kernel]["hbm_bytes_per_launch"]), \
+            "profiles/traffic.json (rocprofv3 PMC, 2*FETCH_SIZE+WRITE_SIZE per launch)"
+    except Exception:
+        return None, None
+
+
+def time_device(sorter, host, dev, reps):
+    import torch
+    text = torch.from_numpy(host).to(dev)
+    sa = torch.empty(host.size, dtype=torch.int32, device=dev)
+    sorter.Sort(text, sa)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sorter.Sort(text, sa)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def time_through_abi(sorter, host, sa_dev=None, reps=3):
+    """ISuffixSort.Sort(text, suffixes) as the reference's caller sees it: pageable host memory in and out."""
+    import numpy as np
+    n = host.size
+    out = np.ones(n, dtype=np.int32)            # touched pages, like a pooled MemoryOwner<int>
+    sorter.Sort(host, out)                      # first call grows the workspace
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        sorter.Sort(host, out)
+        ts.append(time.perf_counter() - t0)
+    best = min(ts)
+    rec = {"entry": "dq_sufsort_hip_i32 (host pointers in/out, PCIe-inclusive)", "ms": round(best * 1e3, 3),
+           "MBps": round(n / 1e6 / best, 1), "reps": reps}
+    if sa_dev is not None:
+        rec["sa_equals_device_resident"] = bool(np.array_equal(out, sa_dev.cpu().numpy()))
+    return rec
+
+
+def other_configs(sorter, dev):
+    """One short record per BASELINE.json configuration that is not the timed workload."""
+    from deltaq_amd import _abi
+    from tools import datagen
+    recs = []
+    for name, gen, reps in (
+            ("configs[1]: 64 MiB uniform random", lambda: datagen.gen_uniform(64 << 20, SEED_CONFIG1), 10),
+            ("configs[2]: 256 MiB enwik8-style text", lambda: datagen.gen_enwik_like(256 << 20, SEED_ENWIK), 3)):
+        host = gen()
+        ms = time_device(sorter, host, dev, reps)
+        rounds = _abi.last_sort_info()["rounds"]
+        abi = time_through_abi(sorter, host, None, reps=2)
+        recs.append({"config": name, "device_resident_ms": round(ms, 3), "device_resident_MBps": round(host.size / 1e3 / ms, 1),
+                     "through_abi_ms": abi["ms"], "through_abi_MBps": abi["MBps"], "rounds": rounds})
+        del host
+    return recs
+
+
+def batch_config4(world, rank, local_rank, dev, backend, sorter):
+    """BASELINE configs[4]: 128 x 16 MiB independent buffers, LPT-sharded over the ranks, host buffers in
+    and out through dq_sufsort_hip_batch_i32 on each rank's GPU; no data-path collective.  Then, for
+    N > 1, once through the scatter / sort / gather layer over RCCL with a small batch, checked on rank 0."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from deltaq_amd import _abi
+    from deltaq_amd.batch import plan_shards, sort_batch_distributed
+    from tools import datagen
+    L = _abi.load()
+    plan = plan_shards([BATCH_BYTES] * BATCH_COUNT, world)
+    mine = plan[rank]
+    texts = [datagen.gen_uniform(BATCH_BYTES, SEED_BATCH + j) for j in mine]
+    sas = [np.ones(BATCH_BYTES, np.int32) for _ in mine]           # pre-touched output pages
+    cnt = len(mine)
+    tp = (ctypes.c_void_p * cnt)(*[t.ctypes.data for t in texts])
+    sp = (ctypes.c_void_p * cnt)(*[a.ctypes.data for a in sas])
+    ln = (ctypes.c_int64 * cnt)(*[BATCH_BYTES] * cnt)
+    devs = (ctypes.c_int32 * 1)(local_rank)
+    # warm the pipeline's slots and the workspace with two buffers
+    _abi.check(L.dq_sufsort_hip_batch_i32(min(cnt, 3), tp, ln, sp, 1, devs))
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    _abi.check(L.dq_sufsort_hip_batch_i32(cnt, tp, ln, sp, 1, devs))
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    # device-resident rate of the same buffers (what `value` would be for this shape)
+    dms = time_device(sorter, texts[0], dev, 8) if cnt else 0.0
+    rec = None
+    if rank == 0:
+        import oracle
+        ok = all(oracle.sufcheck_mt(texts[k], sas[k]) == 0 for k in range(min(cnt, 4)))
+        rec = {"workload": "BASELINE configs[4]: 128 x 16 MiB uniform random (seeds 0x5EED0500+j), int32 SA",
+               "entry": "dq_sufsort_hip_batch_i32 per rank (host pointers in/out, PCIe-inclusive)",
+               "sharding": {"policy": "LPT over ranks (deltaq_amd.batch.plan_shards)",
+                            "buffers_per_rank": [len(p) for p in plan]},
+               "wall_ms": round(wall * 1e3, 2), "MBps": round(BATCH_COUNT * BATCH_BYTES / 1e6 / wall, 1),
+               "device_resident_ms_per_buffer": round(dms, 3),
+               "device_resident_MBps_per_gpu": round(BATCH_BYTES / 1e3 / dms, 1) if dms else None,
+               "sufcheck_first_buffers": bool(ok)}
+    del texts, sas
+    if world > 1:
+        # the gather layer over RCCL (torch.distributed "nccl"): 2 small buffers per rank, SAs to rank 0
+        small = None
+        if rank == 0:
+            small = [datagen.gen_uniform((1 << 20) + 4099 * j, SEED_BATCH + 1000 + j) for j in range(2 * world)]
+        try:
+            got = sort_batch_distributed(small, gather_to_root=True)
+            if rank == 0:
+                import oracle
+                good = all(oracle.sufcheck_mt(t, np.ascontiguousarray(s)) == 0 for t, s in zip(small, got))
+                rec["rccl_scatter_sort_gather"] = {"backend": backend, "buffers": len(small), "sufcheck": bool(good)}
+        except Exception as e:                      # report, do not lose the bench line
+            if rank == 0:
+                rec["rccl_scatter_sort_gather"] = {"backend": backend, "error": repr(e)[:300]}
+    return rec
+
+
 def cpu_baseline(host, sa_dev):
     """Single-threaded restatement of the reference's LibDivSufSort on this host, timed on the
-    SAME buffer the GPU sorted (one run: ~8 s for 64 MiB), then bit-compared with the GPU SA."""
+    SAME buffer the GPU sorted (one run: ~12 s for 256 MiB), then bit-compared with the GPU SA."""
     import numpy as np
     import oracle
     n = host.size
-    sample = host
     t0 = time.perf_counter()
-    ref = oracle.divsufsort(sample)
+    ref = oracle.divsufsort(host)
     dt = time.perf_counter() - t0
     gpu = sa_dev.cpu().numpy()
     return {

@@ -18,8 +18,7 @@ DQ_ERR_HIP = -3
 DQ_ERR_TOO_LARGE = -4
 DQ_ERR_NO_DEVICE = -5
 
-KERNEL_CATEGORIES = 10
-K_RADIX_RANK_SCATTER = 3
+K_RADIX_RANK = 2          # DQ_K_RADIX_RANK: the dominant kernel's profile category
 
 # every symbol include/dq_sufsort.h declares
 EXPORTS = (
@@ -29,6 +28,7 @@ EXPORTS = (
     "dq_sufsort_hip_batch_i32",
     "dq_sufsort_hip_workspace_bytes", "dq_sufsort_hip_release",
     "dq_profile_enable", "dq_profile_reset", "dq_profile_get", "dq_profile_kernel_name",
+    "dq_profile_category_count",
     "dq_last_sort_info",
 )
 
@@ -105,6 +105,8 @@ def load() -> ctypes.CDLL:
                                  ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.dq_profile_kernel_name.restype = ctypes.c_char_p
     L.dq_profile_kernel_name.argtypes = [i32]
+    L.dq_profile_category_count.restype = i32
+    L.dq_profile_category_count.argtypes = []
     L.dq_last_sort_info.restype = i32
     L.dq_last_sort_info.argtypes = [ctypes.POINTER(i64)] * 3
     _lib = L
@@ -130,12 +132,21 @@ def profile_snapshot() -> dict:
     """{kernel name: {launches, ms, elements, alg_bytes}} accumulated since dq_profile_reset."""
     L = load()
     out = {}
-    for cat in range(KERNEL_CATEGORIES):
+    for cat in range(L.dq_profile_category_count()):
         n, ms, el, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
         L.dq_profile_get(cat, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(el), ctypes.byref(by))
         out[L.dq_profile_kernel_name(cat).decode()] = {
             "launches": n.value, "ms": ms.value, "elements": el.value, "alg_bytes": by.value}
     return out
+
+
+def category_of(kernel_name: str) -> int:
+    """Profile category (DQ_K_*) of a kernel name."""
+    L = load()
+    for cat in range(L.dq_profile_category_count()):
+        if L.dq_profile_kernel_name(cat).decode() == kernel_name:
+            return cat
+    raise KeyError(kernel_name)
 
 
 def last_sort_info() -> dict:

@@ -1,9 +1,8 @@
 // dq_sa_kernels.h -- suffix-array specific kernels around the radix engine:
-//   pack_keys        text -> 8-byte big-endian keys (zero padded past the end)
-//   seg_reduce/scan/apply   "rank rebucketing": group heads, device-wide
-//                    (max, max, sum) scan, SA / ISA scatter, compaction of the
-//                    suffixes that are still in groups of size > 1
 //   gather_key2      composite (rank, ISA[s + h]) keys for the next doubling round
+//   gather_text_key  composite (rank, next bytes of text) keys for the sparse finishing rounds
+//   small_group_finish   groups of <= 8 tied suffixes sorted by direct text comparison
+//   sample_ties, isa_from_sa, isa_scatter
 //
 // Order contract (reference: LibDivSufSortTests.cs:43-59 -- unsigned bytes,
 // a proper prefix sorts first): suffixes that run off the end of the text are
@@ -12,259 +11,6 @@
 #include "dq_device_utils.h"
 
 namespace dq {
-
-constexpr int kSegItems = 8;
-constexpr int kSegTile = kBlock * kSegItems;    // 2048 elements per workgroup
-
-// ---------------------------------------------------------------------------------
-// pack_keys: key[i] = T[i] T[i+1] ... T[i+7] as a big-endian u64.
-// `text` is the library's own padded copy: >= 16 zero bytes follow T[n-1] and the
-// base is 16-byte aligned, so 4-byte loads at i, i+4, i+8 are always in bounds.
-// Each lane packs 4 consecutive suffixes (one dword of text + 2 dwords of halo).
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void pack_keys_kernel(const uint8_t *__restrict__ text,
-                                                           int64_t n, uint64_t *__restrict__ keys)
-{
-    const uint32_t *t32 = reinterpret_cast<const uint32_t *>(text);
-    const int64_t nquads = (n + 3) >> 2;
-    for (int64_t qd = (int64_t)blockIdx.x * kBlock + threadIdx.x; qd < nquads;
-         qd += (int64_t)gridDim.x * kBlock) {
-        const uint32_t w0 = t32[qd], w1 = t32[qd + 1], w2 = t32[qd + 2];
-        const uint64_t x = __builtin_bswap64((uint64_t)w0 | ((uint64_t)w1 << 32));   // b0..b7
-        const uint64_t y = (uint64_t)__builtin_bswap32(w2) << 32;                    // b8..b11
-        uint64_t k[4];
-        k[0] = x;
-        k[1] = (x << 8) | (y >> 56);
-        k[2] = (x << 16) | (y >> 48);
-        k[3] = (x << 24) | (y >> 40);
-        const int64_t i = qd << 2;
-        if (i + 4 <= n) {
-            ulonglong2 a, b;
-            a.x = k[0]; a.y = k[1]; b.x = k[2]; b.y = k[3];
-            *reinterpret_cast<ulonglong2 *>(keys + i) = a;
-            *reinterpret_cast<ulonglong2 *>(keys + i + 2) = b;
-        } else {
-            for (int j = 0; j < 4; ++j)
-                if (i + j < n) keys[i + j] = k[j];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// Rebucketing over a list of m (composite key, suffix) pairs sorted by composite key.
-//   kInitial: the list is the whole suffix array sorted by its 8-byte text key; there
-//             is one parent group [0, n) with rank 0.
-//   else:     composite key = (parent rank << kbits) | key2; parent groups are runs of
-//             equal rank, and the parent rank IS the SA position of the group's first
-//             member, so member j lands at SA[rank + (j - first j of its group)].
-// For element j:  nh(j) = last new-group head <= j,  gh(j) = last parent-group head <= j
-//   SA position p = rank + (j - gh),  new rank = rank + (nh - gh).
-// A suffix stays active iff its new group has more than one member.
-// ---------------------------------------------------------------------------------
-template <typename IdxT>
-struct SegPartials {
-    IdxT *nh;    // per-workgroup: last new head index in the tile, or -1
-    IdxT *gh;    // per-workgroup: last parent-group head index in the tile, or -1
-    IdxT *cnt;   // per-workgroup: number of still-active elements
-};
-
-template <typename IdxT, bool kInitial>
-struct SegTileLoader {
-    // loads this thread's kSegItems consecutive composite keys plus the neighbours
-    // needed for head / activity tests
-    uint64_t ck[kSegItems];
-    uint64_t prev, next;
-    bool has_prev, has_next;
-    // kshift > 0: the keys are packed (key << kshift | suffix) words; compare the key part only
-    __device__ __forceinline__ void load(const uint64_t *__restrict__ keys, int64_t m, int64_t j0, int kshift)
-    {
-#pragma unroll
-        for (int i = 0; i < kSegItems; ++i) ck[i] = (j0 + i < m) ? keys[j0 + i] >> kshift : 0;
-        has_prev = j0 > 0 && j0 <= m;
-        prev = has_prev ? keys[j0 - 1] >> kshift : 0;
-        has_next = j0 + kSegItems < m;
-        next = has_next ? keys[j0 + kSegItems] >> kshift : 0;
-    }
-};
-
-template <typename IdxT, bool kInitial>
-__global__ __launch_bounds__(kBlock) void seg_reduce_kernel(const uint64_t *__restrict__ keys,
-                                                            int64_t m, int kbits,
-                                                            SegPartials<IdxT> part, int kshift)
-{
-    __shared__ IdxT tmp[3][kWavesPerBlock];
-    const int tid = threadIdx.x;
-    const int64_t j0 = (int64_t)blockIdx.x * kSegTile + (int64_t)tid * kSegItems;
-    SegTileLoader<IdxT, kInitial> t;
-    t.load(keys, m, j0, kshift);
-
-    IdxT last_nh = -1, last_gh = -1, cnt = 0;
-    bool head[kSegItems + 1];
-#pragma unroll
-    for (int i = 0; i < kSegItems; ++i) {
-        const int64_t j = j0 + i;
-        const uint64_t p = i == 0 ? t.prev : t.ck[i - 1];
-        const bool first = (j == 0);
-        head[i] = first || t.ck[i] != p;
-        const bool ghead = kInitial ? first : (first || (t.ck[i] >> kbits) != (p >> kbits));
-        if (j < m) {
-            if (head[i]) last_nh = (IdxT)j;
-            if (ghead) last_gh = (IdxT)j;
-        }
-    }
-    head[kSegItems] = !t.has_next || t.next != t.ck[kSegItems - 1];
-#pragma unroll
-    for (int i = 0; i < kSegItems; ++i) {
-        const int64_t j = j0 + i;
-        const bool next_head = (j + 1 >= m) ? true : head[i + 1];
-        if (j < m && !(head[i] && next_head)) ++cnt;
-    }
-    last_nh = wave_max(last_nh);
-    last_gh = wave_max(last_gh);
-    cnt = wave_sum(cnt);
-    const int w = tid >> 6;
-    if (lane_id() == 0) { tmp[0][w] = last_nh; tmp[1][w] = last_gh; tmp[2][w] = cnt; }
-    __syncthreads();
-    if (tid == 0) {
-        IdxT a = tmp[0][0], b = tmp[1][0], c = tmp[2][0];
-        for (int i = 1; i < kWavesPerBlock; ++i) {
-            a = tmp[0][i] > a ? tmp[0][i] : a;
-            b = tmp[1][i] > b ? tmp[1][i] : b;
-            c += tmp[2][i];
-        }
-        part.nh[blockIdx.x] = a;
-        part.gh[blockIdx.x] = b;
-        part.cnt[blockIdx.x] = c;
-    }
-}
-
-// Exclusive scan of the per-workgroup partials by ONE workgroup of 1024 threads
-// (prefix max, prefix max, prefix sum), in coalesced chunks of 4096 entries with a running
-// carry.  totals[0] receives the active count.
-template <typename IdxT>
-__global__ __launch_bounds__(1024) void seg_scan_kernel(SegPartials<IdxT> part, int64_t nparts,
-                                                        int64_t *__restrict__ totals)
-{
-    constexpr int kPer = 4;
-    constexpr int kWaves = 1024 / kWave;
-    __shared__ IdxT s_nh[kWaves], s_gh[kWaves], s_cnt[kWaves];
-    const int tid = threadIdx.x;
-    const int lane = lane_id();
-    const int w = tid >> 6;
-    IdxT carry_nh = -1, carry_gh = -1, carry_cnt = 0;
-    for (int64_t c0 = 0; c0 < nparts; c0 += 1024 * kPer) {
-        const int64_t i0 = c0 + (int64_t)tid * kPer;
-        IdxT x[kPer], y[kPer], z[kPer];
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const bool ok = i0 + k < nparts;
-            x[k] = ok ? part.nh[i0 + k] : (IdxT)-1;
-            y[k] = ok ? part.gh[i0 + k] : (IdxT)-1;
-            z[k] = ok ? part.cnt[i0 + k] : (IdxT)0;
-        }
-        IdxT a = x[0], b = y[0], c = z[0];
-#pragma unroll
-        for (int k = 1; k < kPer; ++k) { a = x[k] > a ? x[k] : a; b = y[k] > b ? y[k] : b; c += z[k]; }
-        // inclusive scans across the 1024 threads
-        IdxT ia = wave_incl_max(a), ib = wave_incl_max(b), ic = wave_incl_sum(c);
-        if (lane == kWave - 1) { s_nh[w] = ia; s_gh[w] = ib; s_cnt[w] = ic; }
-        __syncthreads();
-        IdxT pa = carry_nh, pb = carry_gh, pc = carry_cnt;       // prefix of earlier waves + chunks
-        IdxT ta = carry_nh, tb = carry_gh, tc = carry_cnt;       // ... including this whole chunk
-#pragma unroll
-        for (int i = 0; i < kWaves; ++i) {
-            const IdxT u = s_nh[i], v = s_gh[i], q = s_cnt[i];
-            if (i < w) { pa = u > pa ? u : pa; pb = v > pb ? v : pb; pc += q; }
-            ta = u > ta ? u : ta; tb = v > tb ? v : tb; tc += q;
-        }
-        // exclusive value for this thread = earlier waves/chunks + earlier lanes of this wave
-        IdxT ea = __shfl_up(ia, 1, kWave), eb = __shfl_up(ib, 1, kWave), ec = __shfl_up(ic, 1, kWave);
-        if (lane == 0) { ea = -1; eb = -1; ec = 0; }
-        pa = ea > pa ? ea : pa; pb = eb > pb ? eb : pb; pc += ec;
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            if (i0 + k < nparts) { part.nh[i0 + k] = pa; part.gh[i0 + k] = pb; part.cnt[i0 + k] = pc; }
-            pa = x[k] > pa ? x[k] : pa; pb = y[k] > pb ? y[k] : pb; pc += z[k];
-        }
-        carry_nh = ta; carry_gh = tb; carry_cnt = tc;
-        __syncthreads();
-    }
-    if (tid == 0) totals[0] = (int64_t)carry_cnt;
-}
-
-template <typename IdxT, bool kInitial, bool kWriteSA, bool kWriteISA>
-__global__ __launch_bounds__(kBlock) void seg_apply_kernel(
-    const uint64_t *__restrict__ keys, const IdxT *__restrict__ vals, int64_t m, int kbits,
-    SegPartials<IdxT> part, IdxT *__restrict__ SA, IdxT *__restrict__ ISA,
-    uint64_t *__restrict__ act_rank, IdxT *__restrict__ act_suf, int kshift)
-{
-    __shared__ IdxT tmp[kWavesPerBlock];
-    const int tid = threadIdx.x;
-    const int64_t j0 = (int64_t)blockIdx.x * kSegTile + (int64_t)tid * kSegItems;
-    SegTileLoader<IdxT, kInitial> t;
-    t.load(keys, m, j0, kshift);
-    IdxT suf[kSegItems];
-#pragma unroll
-    for (int i = 0; i < kSegItems; ++i) suf[i] = (j0 + i < m) ? vals[j0 + i] : (IdxT)0;
-
-    bool head[kSegItems + 1];
-    bool ghead[kSegItems];
-    IdxT last_nh = -1, last_gh = -1;
-#pragma unroll
-    for (int i = 0; i < kSegItems; ++i) {
-        const int64_t j = j0 + i;
-        const uint64_t p = i == 0 ? t.prev : t.ck[i - 1];
-        const bool first = (j == 0);
-        head[i] = first || t.ck[i] != p;
-        ghead[i] = kInitial ? first : (first || (t.ck[i] >> kbits) != (p >> kbits));
-        if (j < m) {
-            if (head[i]) last_nh = (IdxT)j;
-            if (ghead[i]) last_gh = (IdxT)j;
-        }
-    }
-    head[kSegItems] = !t.has_next || t.next != t.ck[kSegItems - 1];
-    bool active[kSegItems];
-    IdxT cnt = 0;
-#pragma unroll
-    for (int i = 0; i < kSegItems; ++i) {
-        const int64_t j = j0 + i;
-        const bool next_head = (j + 1 >= m) ? true : head[i + 1];
-        active[i] = j < m && !(head[i] && next_head);
-        cnt += active[i] ? 1 : 0;
-    }
-
-    // workgroup-wide exclusive scans over the threads: running last-head indices
-    // (max) and the running active count (sum)
-    IdxT run_nh = block_excl_max(last_nh, tmp);
-    __syncthreads();
-    IdxT run_gh = block_excl_max(last_gh, tmp);
-    __syncthreads();
-    IdxT dummy;
-    const IdxT cnt_excl = block_excl_sum(cnt, tmp, &dummy);
-
-    const IdxT blk_nh = part.nh[blockIdx.x], blk_gh = part.gh[blockIdx.x];
-    run_nh = blk_nh > run_nh ? blk_nh : run_nh;
-    run_gh = blk_gh > run_gh ? blk_gh : run_gh;
-    int64_t o = (int64_t)part.cnt[blockIdx.x] + (int64_t)cnt_excl;
-
-#pragma unroll
-    for (int i = 0; i < kSegItems; ++i) {
-        const int64_t j = j0 + i;
-        if (j >= m) break;
-        if (head[i]) run_nh = (IdxT)j;
-        if (ghead[i]) run_gh = (IdxT)j;
-        const IdxT rank = kInitial ? (IdxT)0 : (IdxT)(t.ck[i] >> kbits);
-        const IdxT p = rank + ((IdxT)j - run_gh);
-        const IdxT nr = rank + (run_nh - run_gh);
-        if (kWriteSA) SA[p] = suf[i];
-        if (kWriteISA) ISA[suf[i]] = nr;
-        if (active[i]) {
-            act_rank[o] = (uint64_t)nr;
-            act_suf[o] = suf[i];
-            ++o;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------
 // gather_key2: composite[j] = (rank_j << kbits) | key2_j in place, where
@@ -278,14 +24,15 @@ template <typename IdxT>
 __global__ __launch_bounds__(kBlock) void gather_key2_kernel(uint64_t *__restrict__ comp,
                                                              const IdxT *__restrict__ suf,
                                                              const IdxT *__restrict__ ISA,
-                                                             int64_t m, int64_t n, int64_t h, int kbits)
+                                                             int64_t m, int64_t n, int64_t h, int kbits,
+                                                             int rshift = 0)
 {
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < m;
          j += (int64_t)gridDim.x * kBlock) {
         const int64_t s = (int64_t)suf[j];
         const int64_t q = s + h;
         const uint64_t k2 = q < n ? (uint64_t)((int64_t)ISA[q] + h) : (uint64_t)(n - 1 - s);
-        comp[j] = (comp[j] << kbits) | k2;
+        comp[j] = ((comp[j] >> rshift) << kbits) | k2;        // rshift = 1: see seg_fused_kernel's rank_from_isa
     }
 }
 

@@ -78,12 +78,16 @@ __device__ __forceinline__ uint64_t seg_lookback(uint64_t *st, int64_t tile, Seg
 // kEmitPairs (with kInitial): instead of the ISA scatter and the list of tied suffixes, one word per entry
 //           (tied? << 63 | rank << kbits | suffix, kbits = bits of n-1) goes to act_rank in list order.
 // totals[0] receives the number of still-active suffixes.
+// rank_from_isa (doubling rounds only): the rank part of the composite keys is rank >> 1 -- still unique
+// per group and order preserving, because groups in the tied list have >= 2 members -- and the
+// true parent rank of an entry is read from ISA[suffix].
 template <typename IdxT, bool kInitial, bool kWriteSA, bool kWriteISA, bool kEmitPairs = false>
 __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
     const uint64_t *__restrict__ keys, const IdxT *__restrict__ vals, int64_t m, int kbits, int kshift,
     IdxT *__restrict__ SA, IdxT *__restrict__ ISA, uint64_t *__restrict__ act_rank,
     IdxT *__restrict__ act_suf, uint64_t *__restrict__ status /*[3][ntiles]*/, int64_t ntiles,
-    SegCtl *__restrict__ ctl, int64_t *__restrict__ totals, int64_t *__restrict__ sticky_error)
+    SegCtl *__restrict__ ctl, int64_t *__restrict__ totals, int64_t *__restrict__ sticky_error,
+    int rank_from_isa = 0)
 {
     __shared__ int64_t w_nh[kSegWaves], w_gh[kSegWaves], w_cnt[kSegWaves];
     __shared__ uint64_t s_prefix[3];
@@ -233,7 +237,9 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
                 const uint64_t hm = Hk & le, gm = Gk & le;
                 const IdxT rn = hm ? wb_i + (IdxT)(k * kWave + 63 - __builtin_clzll(hm)) : cn;
                 const IdxT rg = gm ? wb_i + (IdxT)(k * kWave + 63 - __builtin_clzll(gm)) : cg;
-                const IdxT rank = kInitial ? (IdxT)0 : (IdxT)(ck[k] >> kbits);
+                // rank_from_isa: the composite key carries rank >> 1 (n close to 2^32, dq_sufsort_hip.hip::run);
+                // a tied suffix's own ISA entry is its parent rank
+                const IdxT rank = kInitial ? (IdxT)0 : (kWriteISA && rank_from_isa) ? ISA[suf[k]] : (IdxT)(ck[k] >> kbits);
                 const IdxT nr = rank + (rn - rg);
                 if (kEmitPairs) {
                     // (tied?, rank, suffix) in list order, coalesced: the inverse suffix array is built from

@@ -1,12 +1,17 @@
 // dq_sufsort_hip.hip -- host runtime + C ABI of libdq_sufsort_hip.so.
 //
-// Suffix-array construction for byte text on one MI355X (gfx950):
-//   round 0   pack 8-byte keys, stable LSD radix ranking of (key, suffix) pairs
-//             (8 digit passes), mark group heads, device-wide scan -> ranks
+// Suffix-array construction for byte text on one MI355X (gfx950), prefix doubling on ranks:
+//   round 0   byte histogram of the text -> key width kb (3..8 bytes); kb stable LSD digit passes
+//             (radix_rank_kernel) over packed words (key << ib | suffix) or (key, suffix) pairs,
+//             the first pass building its keys from the text, the last one emitting the SA and
+//             (packed) the tie bits; group heads / device-wide scan -> ranks (seg_fused_kernel)
+//   few ties  groups of <= 8 sorted by direct text comparison, key extension from the text
 //   round r   for the suffixes still tied: key2 = rank of the suffix h bytes further on,
-//             sort by (rank, key2), rebucket, h *= 2   (prefix doubling; only the active
-//             suffixes are touched), until no group has more than one member.
-// The result is the unique suffix array, hence bit-identical to the reference's
+//             sort by (rank, key2), rebucket, h *= 2 (only the tied suffixes are touched;
+//             groups of <= 8..32 members are finished in one pass per round), until no group
+//             has more than one member.
+// DESIGN.md section 2 has the whole map.  The result is the unique suffix array, hence
+// bit-identical to the reference's
 // LibDivSufSort.Sort() (LibDivSufSort.cs:12-29; order = LibDivSufSortTests.cs:43-59).
 //
 // This file contains no CPU sorting path: if HIP is unusable the entry points fail.
@@ -67,19 +72,10 @@ KernelStat g_prof[DQ_K_COUNT];
 std::atomic<int> g_prof_on{0};
 
 const char *const kKernelNames[DQ_K_COUNT] = {
-    "pack_keys_kernel", "radix_upsweep_kernel", "radix_scan_kernel", "radix_rank_kernel",
-    "seg_reduce_kernel", "seg_scan_kernel", "seg_apply_kernel", "gather_key2_kernel",
-    "radix_hist_kernels", "small_sufsort_kernel"};
-
-// sort engine: 1 = onesweep (default), 0 = legacy upsweep/scan/downsweep (DQ_SORT_ENGINE=sweep3)
-int sort_engine()
-{
-    static int e = [] {
-        const char *v = getenv("DQ_SORT_ENGINE");
-        return (v && strcmp(v, "sweep3") == 0) ? 0 : 1;
-    }();
-    return e;
-}
+    "text_hist_kernel", "radix_hist_kernel", "radix_rank_kernel", "seg_fused_kernel",
+    "tie_seam_kernel", "tie_collect_kernel", "small_group_finish_kernel", "small_group_round_kernel",
+    "isa_update_kernel", "isa_from_pairs_kernel", "key2_from_pairs_kernel", "gather_key2_kernel",
+    "gather_text_key_kernel", "isa_from_sa_kernel", "small_sufsort_kernel"};
 
 struct ProfRec { int cat; hipEvent_t a, b; int64_t elems, bytes; };
 
@@ -95,6 +91,12 @@ struct DeviceCtx {
     hipEvent_t readback = nullptr;      // "the pinned readback has landed" (work queued behind it keeps running)
     std::vector<ProfRec> pending;
     std::vector<hipEvent_t> pool;
+    // batch pipeline (dq_sufsort_hip_batch_i32): device slots and streams, kept between calls
+    std::mutex batch_mu;                // one batch at a time per device
+    uint8_t *bslot_text[3] = {nullptr, nullptr, nullptr};
+    int32_t *bslot_sa[3] = {nullptr, nullptr, nullptr};
+    size_t bslot_cap = 0;               // bytes of text each slot holds
+    hipStream_t b_in = nullptr, b_sort = nullptr, b_out = nullptr;
 };
 constexpr int kMaxDevices = 64;
 constexpr size_t kSmallTextArea = kSmallMaxN + 64;
@@ -105,12 +107,34 @@ int init_ctx(DeviceCtx &c, int dev)
 {
     HIP_TRY(hipSetDevice(dev));
     if (c.dev == dev) return DQ_OK;
+    // c.dev is published only once every resource exists: a failure half way (e.g. pinned memory
+    // exhausted) frees what was made and leaves the context unbuilt, so the next call retries
+    hipError_t e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c.pinned, 4096, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c.pinned_io, kSmallIoBytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c.readback, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (c.readback) (void)hipEventDestroy(c.readback);
+        if (c.pinned_io) (void)hipHostFree(c.pinned_io);
+        if (c.pinned) (void)hipHostFree(c.pinned);
+        if (c.stream) (void)hipStreamDestroy(c.stream);
+        c.readback = nullptr; c.pinned_io = nullptr; c.pinned = nullptr; c.stream = nullptr;
+        return fail(e == hipErrorOutOfMemory ? DQ_ERR_OOM : DQ_ERR_HIP, "device context setup", e);
+    }
     c.dev = dev;
-    HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    HIP_TRY(hipHostMalloc((void **)&c.pinned, 4096, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&c.pinned_io, kSmallIoBytes, hipHostMallocDefault));
-    HIP_TRY(hipEventCreateWithFlags(&c.readback, hipEventDisableTiming));
     return DQ_OK;
+}
+
+// A sort that failed half way leaves timing events queued in c.pending: hand them back to the pool
+// (after the stream has drained, so none is still being recorded).
+void drop_pending(DeviceCtx &c, hipStream_t st)
+{
+    (void)hipStreamSynchronize(st);
+    for (ProfRec &r : c.pending) {
+        if (r.a) c.pool.push_back(r.a);
+        if (r.b) c.pool.push_back(r.b);
+    }
+    c.pending.clear();
 }
 
 int ensure_ws(DeviceCtx &c, size_t bytes)
@@ -126,19 +150,19 @@ int ensure_ws(DeviceCtx &c, size_t bytes)
 struct Launcher {
     DeviceCtx &c;
     hipStream_t st;
-    int prof;                         // 0 off, 1 every kernel, 2 only radix_rank_kernel
+    int prof;                         // 0 off, 1 every kernel, 2 only radix_rank_kernel, 100 + c only category c
     bool active = false;
     int begin(int cat, int64_t elems, int64_t bytes)
     {
-        active = prof == 1 || (prof == 2 && cat == DQ_K_RADIX_RANK_SCATTER);
+        active = prof == 1 || (prof == 2 && cat == DQ_K_RADIX_RANK) || prof == 100 + cat;
         if (!active) return DQ_OK;
-        ProfRec r{cat, nullptr, nullptr, elems, bytes};
+        c.pending.push_back(ProfRec{cat, nullptr, nullptr, elems, bytes});      // queued first: an error below leaks nothing
+        ProfRec &r = c.pending.back();
         for (hipEvent_t *ev : {&r.a, &r.b}) {
             if (!c.pool.empty()) { *ev = c.pool.back(); c.pool.pop_back(); }
             else HIP_TRY(hipEventCreate(ev));
         }
         HIP_TRY(hipEventRecord(r.a, st));
-        c.pending.push_back(r);
         return DQ_OK;
     }
     int end()
@@ -186,9 +210,6 @@ struct Workspace {
     uint8_t *text;
     uint64_t *K0, *K1;
     IdxT *Va, *Vb, *ISA, *SAbuf;
-    uint32_t *blockhist;
-    IdxT *blockbase;
-    SegPartials<IdxT> part;
     int64_t *totals;            // [0] active count, [1] sticky look-back timeout flag
     SmallGroupCounters *sg_ctr; // one per chained small-group round
     uint32_t *hist_partial;     // [kHistBlocks][8][256]
@@ -210,18 +231,13 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     auto take = [&](size_t b) { char *p = base ? base + off : nullptr; off += align_up(b); return p; };
     const size_t un = (size_t)n;
     w.text = (uint8_t *)take(un + 64);
-    w.K0 = (uint64_t *)take(un * 8);
-    w.K1 = (uint64_t *)take(un * 8);
-    w.Va = (IdxT *)take(un * sizeof(IdxT));
-    w.Vb = (IdxT *)take(un * sizeof(IdxT));
+    // (+2: the lists of a small-group round start their L region on an even entry, see sg_half())
+    w.K0 = (uint64_t *)take((un + 2) * 8);
+    w.K1 = (uint64_t *)take((un + 2) * 8);
+    w.Va = (IdxT *)take((un + 2) * sizeof(IdxT));
+    w.Vb = (IdxT *)take((un + 2) * sizeof(IdxT));
     w.ISA = (IdxT *)take(un * sizeof(IdxT));
     w.SAbuf = with_sa ? (IdxT *)take(un * sizeof(IdxT)) : nullptr;
-    w.blockhist = (uint32_t *)take((size_t)kMaxSweepBlocks * kRadixSize * 4);
-    w.blockbase = (IdxT *)take((size_t)kMaxSweepBlocks * kRadixSize * sizeof(IdxT));
-    const size_t nparts = (un + kSegTile - 1) / kSegTile + 1;
-    w.part.nh = (IdxT *)take(nparts * sizeof(IdxT));
-    w.part.gh = (IdxT *)take(nparts * sizeof(IdxT));
-    w.part.cnt = (IdxT *)take(nparts * sizeof(IdxT));
     w.totals = (int64_t *)take(64);
     w.sg_ctr = (SmallGroupCounters *)take(kSgChain * sizeof(SmallGroupCounters));
     w.hist_partial = (uint32_t *)take((size_t)kHistBlocks * kMaxPasses * kRadixSize * 4);
@@ -230,48 +246,13 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     // smallest tile is 8192 keys; 8-byte status words once a list reaches 2^30 entries
     w.ctl_status_bytes = (size_t)kMaxPasses * align_up(256 + (un / 8192 + 2) * kRadixSize * (un >= (1ull << 30) ? 8 : 4));
     w.ctl_status = take(w.ctl_status_bytes);
-    w.seg_status_bytes = 256 + 3 * (un / kSegTile + 2) * 8;
+    w.seg_status_bytes = 256 + 3 * (un / kSegFusedTile + 2) * 8;
     w.seg_status = take(w.seg_status_bytes);
     w.bytes = off;
     return w;
 }
 
 inline int bit_length(uint64_t x) { return x == 0 ? 1 : 64 - __builtin_clzll(x); }
-
-// ------------------------------------------------------------------ radix sort driver
-template <typename IdxT>
-int radix_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V[2], int64_t m,
-                     int total_bits, bool synth_first, int &cur)
-{
-    const int passes = (total_bits + kRadixBits - 1) / kRadixBits;
-    const int64_t ntiles = (m + kTile - 1) / kTile;
-    int64_t G = std::min<int64_t>(ntiles, kMaxSweepBlocks);
-    const int tpb = (int)((ntiles + G - 1) / G);
-    G = (ntiles + tpb - 1) / tpb;
-    const int64_t wb = (int64_t)sizeof(IdxT);
-    for (int p = 0; p < passes; ++p) {
-        const int shift = p * kRadixBits;
-        LAUNCH(L, DQ_K_RADIX_UPSWEEP, m, m * 8,
-               hipLaunchKernelGGL(radix_upsweep_kernel, dim3((unsigned)G), dim3(kBlock), 0, L.st,
-                                  K[cur], m, shift, tpb, w.blockhist));
-        LAUNCH(L, DQ_K_RADIX_SCAN, G * kRadixSize, G * kRadixSize * (4 + wb),
-               hipLaunchKernelGGL(radix_scan_kernel<IdxT>, dim3(1), dim3(1024), 0, L.st,
-                                  w.blockhist, (int)G, w.blockbase));
-        if (synth_first && p == 0) {
-            LAUNCH(L, DQ_K_RADIX_RANK_SCATTER, m, m * (8 + 8 + wb),
-                   hipLaunchKernelGGL((radix_rank_scatter_kernel<IdxT, true>), dim3((unsigned)G),
-                                      dim3(kBlock), 0, L.st, K[cur], (const IdxT *)nullptr,
-                                      K[cur ^ 1], V[cur ^ 1], m, shift, tpb, w.blockbase));
-        } else {
-            LAUNCH(L, DQ_K_RADIX_RANK_SCATTER, m, m * 2 * (8 + wb),
-                   hipLaunchKernelGGL((radix_rank_scatter_kernel<IdxT, false>), dim3((unsigned)G),
-                                      dim3(kBlock), 0, L.st, K[cur], V[cur], K[cur ^ 1], V[cur ^ 1],
-                                      m, shift, tpb, w.blockbase));
-        }
-        cur ^= 1;
-    }
-    return DQ_OK;
-}
 
 // ------------------------------------------------------------------ onesweep driver
 // Tile geometry of radix_rank_kernel per (index type, pass kind), from the kbench sweep
@@ -325,7 +306,7 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
                       : kMode == kTextPacked ? 1 + 8 : kMode == kKeys ? 16 : kMode == kKeysLastTies ? 8 + wb : 16 + wb;
     // the tie-recording pass also writes 1 bit per element and 2 words per (tile, digit)
     const int64_t alg_extra = kMode == kKeysLastTies ? m / 8 + ntiles * kRadixSize * 16 : 0;
-    LAUNCH(L, DQ_K_RADIX_RANK_SCATTER, m, m * alg + alg_extra,
+    LAUNCH(L, DQ_K_RADIX_RANK, m, m * alg + alg_extra,
            hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, kItems, kMode, Cfg::kMinWaves, kThreads,
                                                  false, Cfg::kLdsMatch, Cfg::kRounds>),
                               dim3((unsigned)ntiles), dim3(kThreads), 0, L.st, kin, vin, kout, vout, m,
@@ -433,7 +414,7 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
     const int blocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 4) + kBlock - 1) / kBlock + 1);
     HIP_TRY(hipMemsetAsync(w.bytehist, 0, 256 * 8, L.st));
     // (+1 workgroup: the k-gram sample, whose 8 counters sit right behind the byte histogram: one readback)
-    LAUNCH(L, DQ_K_RADIX_HIST, n, n,
+    LAUNCH(L, DQ_K_TEXT_HIST, n, n,
            hipLaunchKernelGGL(text_hist_kernel, dim3(blocks + 1), dim3(kBlock), 0, L.st,
                               (const uint8_t *)w.text, n, reinterpret_cast<unsigned long long *>(w.bytehist),
                               reinterpret_cast<unsigned long long *>(w.bytehist + 256)));
@@ -518,15 +499,15 @@ int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int k
     HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(TieCounters), L.st));
     const unsigned sg = (unsigned)((ntiles * kRadixSize + kBlock - 1) / kBlock);
     if (n < (1ll << 30)) {
-        LAUNCH(L, DQ_K_SEG_REDUCE, ntiles * kRadixSize, ntiles * kRadixSize * 16,
+        LAUNCH(L, DQ_K_TIE_SEAM, ntiles * kRadixSize, ntiles * kRadixSize * (16 + (int64_t)sizeof(uint64_t)),
                hipLaunchKernelGGL(tie_seam_kernel<uint32_t>, dim3(sg), dim3(kBlock), 0, L.st, seam_tab, ntiles, ib, dofs,
                                   reinterpret_cast<const uint32_t *>(area + 256), ebits));
     } else {
-        LAUNCH(L, DQ_K_SEG_REDUCE, ntiles * kRadixSize, ntiles * kRadixSize * 16,
+        LAUNCH(L, DQ_K_TIE_SEAM, ntiles * kRadixSize, ntiles * kRadixSize * (16 + (int64_t)sizeof(uint64_t)),
                hipLaunchKernelGGL(tie_seam_kernel<uint64_t>, dim3(sg), dim3(kBlock), 0, L.st, seam_tab, ntiles, ib, dofs,
                                   reinterpret_cast<const uint64_t *>(area + 256), ebits));
     }
-    LAUNCH(L, DQ_K_SEG_APPLY, n, n / 8,
+    LAUNCH(L, DQ_K_TIE_COLLECT, n, n / 8,
            hipLaunchKernelGGL(tie_collect_kernel<IdxT>, dim3((unsigned)((nwords + kTieThreads - 1) / kTieThreads)),
                               dim3(kTieThreads), 0, L.st, reinterpret_cast<const uint64_t *>(ebits), nwords, n, d_sa,
                               act_rank, act_suf, ctr));
@@ -535,7 +516,7 @@ int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int k
     // used only if the list fits and the sparse path is taken.
     unsigned long long *left_over = reinterpret_cast<unsigned long long *>(w.totals + 3);     // zero since run()
     if (fin_cap > 0) {
-        LAUNCH(L, DQ_K_GATHER_KEY2, fin_cap, 0,
+        LAUNCH(L, DQ_K_SMALL_FINISH, fin_cap, 0,
                hipLaunchKernelGGL((small_group_finish_kernel<IdxT, 8, 32>),
                                   dim3((unsigned)std::min<int64_t>((fin_cap + kFinishThreads - 1) / kFinishThreads, 256 * 16)),
                                   dim3(kFinishThreads), 0, L.st, (const uint64_t *)act_rank, (const IdxT *)act_suf, (const uint8_t *)w.text,
@@ -552,25 +533,6 @@ int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int k
     return DQ_OK;
 }
 
-template <typename IdxT, bool kInitial>
-int seg_count(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *keys, int64_t m,
-              int kbits, int64_t *active_out, int kshift = 0)
-{
-    const int64_t nparts = (m + kSegTile - 1) / kSegTile;
-    const int64_t wb = (int64_t)sizeof(IdxT);
-    LAUNCH(L, DQ_K_SEG_REDUCE, m, m * 8,
-           hipLaunchKernelGGL((seg_reduce_kernel<IdxT, kInitial>), dim3((unsigned)nparts),
-                              dim3(kBlock), 0, L.st, keys, m, kbits, w.part, kshift));
-    LAUNCH(L, DQ_K_SEG_SCAN, nparts, nparts * 6 * wb,
-           hipLaunchKernelGGL(seg_scan_kernel<IdxT>, dim3(1), dim3(1024), 0, L.st, w.part, nparts,
-                              w.totals));
-    HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, L.st));
-    HIP_TRY(hipStreamSynchronize(L.st));
-    *active_out = c.pinned[0];
-    if (c.pinned[1] != 0) return fail(DQ_ERR_HIP, "radix look-back timed out (device spin bound hit)");
-    return DQ_OK;
-}
-
 // Rebucket a list sorted by (composite) key: group heads, device-wide scan, SA / ISA
 // scatter, compaction of the still-tied suffixes into (act_rank, act_suf); *active_out = their
 // number.  Engine 1: one fused single-pass kernel; engine 0: the legacy three kernels.
@@ -578,32 +540,22 @@ int seg_count(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *key
 template <typename IdxT, bool kInitial, bool kWriteSA, bool kWriteISA>
 int rebucket(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *keys, const IdxT *vals,
              int64_t m, int kbits, int kshift, IdxT *SA, uint64_t *act_rank, IdxT *act_suf,
-             int64_t *active_out)
+             int64_t *active_out, int rank_from_isa = 0)
 {
     const int64_t wb = (int64_t)sizeof(IdxT);
-    if (sort_engine() == 1) {
-        const int64_t ntiles = (m + kSegFusedTile - 1) / kSegFusedTile;
-        const size_t need = 256 + (size_t)3 * ntiles * 8;
-        if (need > w.seg_status_bytes) return fail(DQ_ERR_HIP, "seg status buffer too small");
-        HIP_TRY(hipMemsetAsync(w.seg_status, 0, need, L.st));
-        LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + (kWriteSA ? 2 * wb : 0) + (kWriteISA ? wb : 0)),
-               hipLaunchKernelGGL((seg_fused_kernel<IdxT, kInitial, kWriteSA, kWriteISA>),
-                                  dim3((unsigned)ntiles), dim3(kSegThreads), 0, L.st, keys, vals, m, kbits, kshift, SA, w.ISA, act_rank,
-                                  act_suf, reinterpret_cast<uint64_t *>(w.seg_status + 256), ntiles,
-                                  reinterpret_cast<SegCtl *>(w.seg_status), w.totals, w.totals + 1));
-        HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, L.st));
-        HIP_TRY(hipStreamSynchronize(L.st));
-        *active_out = c.pinned[0];
-        if (c.pinned[1] != 0) return fail(DQ_ERR_HIP, "device look-back timed out (spin bound hit)");
-        return DQ_OK;
-    }
-    const int64_t ntiles = (m + kSegTile - 1) / kSegTile;
-    int rc = seg_count<IdxT, kInitial>(L, c, w, keys, m, kbits, active_out, kshift);
-    if (rc != DQ_OK) return rc;
-    LAUNCH(L, DQ_K_SEG_APPLY, m, m * (8 + wb + wb + wb),
-           hipLaunchKernelGGL((seg_apply_kernel<IdxT, kInitial, kWriteSA, kWriteISA>), dim3((unsigned)ntiles),
-                              dim3(kBlock), 0, L.st, keys, vals, m, kbits, w.part, SA, w.ISA, act_rank,
-                              act_suf, kshift));
+    const int64_t ntiles = (m + kSegFusedTile - 1) / kSegFusedTile;
+    const size_t need = 256 + (size_t)3 * ntiles * 8;
+    if (need > w.seg_status_bytes) return fail(DQ_ERR_HIP, "seg status buffer too small");
+    HIP_TRY(hipMemsetAsync(w.seg_status, 0, need, L.st));
+    LAUNCH(L, DQ_K_SEG_FUSED, m, m * (8 + (kWriteSA ? 2 * wb : 0) + (kWriteISA ? wb : 0)),
+           hipLaunchKernelGGL((seg_fused_kernel<IdxT, kInitial, kWriteSA, kWriteISA>),
+                              dim3((unsigned)ntiles), dim3(kSegThreads), 0, L.st, keys, vals, m, kbits, kshift, SA, w.ISA, act_rank,
+                              act_suf, reinterpret_cast<uint64_t *>(w.seg_status + 256), ntiles,
+                              reinterpret_cast<SegCtl *>(w.seg_status), w.totals, w.totals + 1, rank_from_isa));
+    HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, L.st));
+    HIP_TRY(hipStreamSynchronize(L.st));
+    *active_out = c.pinned[0];
+    if (c.pinned[1] != 0) return fail(DQ_ERR_HIP, "device look-back timed out (spin bound hit)");
     return DQ_OK;
 }
 
@@ -645,14 +597,13 @@ struct SuffixSorter {
 
     int sort_pairs(uint64_t *K[2], IdxT *V[2], int64_t cnt, int bits, int &cur)
     {
-        return sort_engine() == 1 ? onesweep_sort_pairs<IdxT>(L, w, K, V, cnt, bits, cur)
-                                  : radix_sort_pairs<IdxT>(L, w, K, V, cnt, bits, false, cur);
+        return onesweep_sort_pairs<IdxT>(L, w, K, V, cnt, bits, cur);
     }
 
     // ISA[SA[p]] = p for everybody, then the tied suffixes get their group rank
     int build_isa(const uint64_t *rank, const IdxT *suf, int64_t cnt)
     {
-        LAUNCH(L, DQ_K_SEG_APPLY, n, n * 3 * wb,
+        LAUNCH(L, DQ_K_ISA_FROM_SA, n, n * 3 * wb,
                hipLaunchKernelGGL(isa_from_sa_kernel<IdxT>, dim3(grid_for(n)), dim3(kBlock), 0, st,
                                   (const IdxT *)d_sa, w.ISA, n);
                hipLaunchKernelGGL(isa_scatter_kernel<IdxT>, dim3(grid_for(cnt)), dim3(kBlock), 0, st, rank, suf,
@@ -665,7 +616,7 @@ struct SuffixSorter {
     //      tied list is (P1, Va) and m its length.
     bool uses_small_round(int64_t mm) const
     {
-        return sort_engine() == 1 && !getenv("DQ_NO_SMALL") && mm * 2 <= n && n < (1ll << 32);
+        return !getenv("DQ_NO_SMALL") && mm * 2 <= n && n < (1ll << 32);
     }
 
     int build_isa_binned(uint64_t *keys, uint64_t *P0, int kb, int kshift0)
@@ -675,7 +626,7 @@ struct SuffixSorter {
         const size_t need = 256 + (size_t)3 * ntiles * 8;
         if (need > w.seg_status_bytes) return fail(DQ_ERR_HIP, "seg status buffer too small");
         HIP_TRY(hipMemsetAsync(w.seg_status, 0, need, st));
-        LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb + 8),
+        LAUNCH(L, DQ_K_SEG_FUSED, n, n * (8 + wb + 8),
                hipLaunchKernelGGL((seg_fused_kernel<IdxT, true, false, false, true>), dim3((unsigned)ntiles),
                                   dim3(kSegThreads), 0, st, (const uint64_t *)keys, (const IdxT *)d_sa, n, ib, kshift0,
                                   d_sa, w.ISA, P0, w.Va, reinterpret_cast<uint64_t *>(w.seg_status + 256), ntiles,
@@ -703,11 +654,11 @@ struct SuffixSorter {
         rc = rank_pass<IdxT, kKeys>(L, w, keys, (const IdxT *)nullptr, P0, (IdxT *)nullptr, n, 1, kb, ib, nullptr, nullptr, sh[1]);
         if (rc != DQ_OK) return rc;
         if (ib - 16 <= 12) {
-            LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb),
+            LAUNCH(L, DQ_K_ISA_FROM_PAIRS, n, n * (8 + wb),
                    hipLaunchKernelGGL((isa_from_pairs_kernel<IdxT, 4096>), dim3((unsigned)((n + 4095) / 4096)),
                                       dim3(kPairThreads), 0, st, (const uint64_t *)P0, n, ib, w.ISA));
         } else {
-            LAUNCH(L, DQ_K_SEG_APPLY, n, n * (8 + wb),
+            LAUNCH(L, DQ_K_ISA_FROM_PAIRS, n, n * (8 + wb),
                    hipLaunchKernelGGL((isa_from_pairs_kernel<IdxT, 32768>), dim3((unsigned)((n + 32767) / 32768)),
                                       dim3(kPairThreads), 0, st, (const uint64_t *)P0, n, ib, w.ISA));
         }
@@ -718,7 +669,7 @@ struct SuffixSorter {
         unsigned long long *cnt = reinterpret_cast<unsigned long long *>(w.totals + 3);
         HIP_TRY(hipMemsetAsync(cnt, 0, 8, st));
         const int64_t per = (int64_t)kPairThreads * kPairItems;
-        LAUNCH(L, DQ_K_GATHER_KEY2, n, n * 8 + m * (wb + 8 + wb),
+        LAUNCH(L, DQ_K_KEY2_FROM_PAIRS, n, n * 8 + m * (wb + 8 + wb),
                hipLaunchKernelGGL(key2_from_pairs_kernel<IdxT>, dim3((unsigned)((n + per - 1) / per)), dim3(kPairThreads),
                                   0, st, (const uint64_t *)P0, n, ib, (const IdxT *)w.ISA, (int64_t)kb, kbits, with_key2,
                                   keys, w.Va, cnt));
@@ -735,62 +686,50 @@ struct SuffixSorter {
         IdxT *V[2];
         int cur = 0, kb = 8, rc;
         bool packed = false;
-        if (sort_engine() == 1) {
-            // pass p writes buffer (p+1)&1, so the last pass (kb-1) writes buffer kb&1: that one
-            // must be the caller's SA, which is why the key width is chosen first
-            rc = onesweep_sort_text_prepare<IdxT>(L, c, w, n, &kb, &packed);
+        // pass p writes buffer (p+1)&1, so the last pass (kb-1) writes buffer kb&1: that one
+        // must be the caller's SA, which is why the key width is chosen first
+        rc = onesweep_sort_text_prepare<IdxT>(L, c, w, n, &kb, &packed);
+        if (rc != DQ_OK) return rc;
+        V[kb & 1] = d_sa;
+        V[(kb & 1) ^ 1] = w.Va;
+        // Packed words were chosen because few ties are expected: the last pass then records the tie
+        // structure itself (1 bit per suffix + 2 words per tile and digit, in the idle Vb buffer)
+        // instead of writing the sorted words for a rebucket pass to read back.
+        const bool fused_ties = packed && kb >= 2 && n >= (1 << 16) && !getenv("DQ_NO_FUSED_TIES") &&
+                                !getenv("DQ_SPARSE");
+        if (fused_ties) {
+            const int ib = bit_length((uint64_t)(n - 1));
+            const int64_t nwords = (n + 63) / 64;
+            uint32_t *ebits = reinterpret_cast<uint32_t *>(w.Vb);
+            uint64_t *seam_tab = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(w.Vb) +
+                                                              align_up((size_t)(nwords + 1) * 8));
+            // (the tie bits were zeroed by onesweep_sort_text_prepare while the key width was chosen)
+            rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur, ebits, seam_tab);
             if (rc != DQ_OK) return rc;
-            V[kb & 1] = d_sa;
-            V[(kb & 1) ^ 1] = w.Va;
-            // Packed words were chosen because few ties are expected: the last pass then records the tie
-            // structure itself (1 bit per suffix + 2 words per tile and digit, in the idle Vb buffer)
-            // instead of writing the sorted words for a rebucket pass to read back.
-            const bool fused_ties = packed && kb >= 2 && n >= (1 << 16) && !getenv("DQ_NO_FUSED_TIES") &&
-                                    !getenv("DQ_SPARSE");
-            if (fused_ties) {
-                const int ib = bit_length((uint64_t)(n - 1));
-                const int64_t nwords = (n + 63) / 64;
-                uint32_t *ebits = reinterpret_cast<uint32_t *>(w.Vb);
-                uint64_t *seam_tab = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(w.Vb) +
-                                                                  align_up((size_t)(nwords + 1) * 8));
-                // (the tie bits were zeroed by onesweep_sort_text_prepare while the key width was chosen)
-                rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur, ebits, seam_tab);
-                if (rc != DQ_OK) return rc;
-                // cur names the buffer the last pass would have written: it is free, the pass's input
-                // K[cur ^ 1] stays intact for the fallback
-                bool overflow = false;
-                fin_cap = n / 8;
-                rc = collect_ties<IdxT>(L, c, w, n, kb, ib, ebits, seam_tab, (const IdxT *)d_sa, K[cur], w.Va, &m,
-                                        &overflow, fin_cap, K[cur ^ 1], w.Vb, &fin_left);
-                if (rc != DQ_OK) return rc;
-                fin_done = !overflow && m <= fin_cap;
-                if (!overflow) {
-                    *dense_built = false;
-                    Kr[0] = K[cur]; Kr[1] = K[cur ^ 1];
-                    Vr[0] = w.Va; Vr[1] = w.Vb;
-                    rcur = 0;
-                    h = kb;
-                    rbits = ib;
-                    return DQ_OK;
-                }
-                // a long run of equal keys: redo the last pass with the sorted words as output and take
-                // the general rebucket pass below
-                HIP_TRY(hipMemsetAsync(w.ctl_status + (size_t)(kb - 1) * w.ctl_status_stride, 0, w.ctl_status_stride, st));
-                rc = rank_pass<IdxT, kKeysLast>(L, w, K[cur ^ 1], (const IdxT *)nullptr, K[cur], d_sa, n, kb - 1, kb, ib);
-                if (rc != DQ_OK) return rc;
-            } else {
-                rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur);
-                if (rc != DQ_OK) return rc;
+            // cur names the buffer the last pass would have written: it is free, the pass's input
+            // K[cur ^ 1] stays intact for the fallback
+            bool overflow = false;
+            fin_cap = n / 8;
+            rc = collect_ties<IdxT>(L, c, w, n, kb, ib, ebits, seam_tab, (const IdxT *)d_sa, K[cur], w.Va, &m,
+                                    &overflow, fin_cap, K[cur ^ 1], w.Vb, &fin_left);
+            if (rc != DQ_OK) return rc;
+            fin_done = !overflow && m <= fin_cap;
+            if (!overflow) {
+                *dense_built = false;
+                Kr[0] = K[cur]; Kr[1] = K[cur ^ 1];
+                Vr[0] = w.Va; Vr[1] = w.Vb;
+                rcur = 0;
+                h = kb;
+                rbits = ib;
+                return DQ_OK;
             }
+            // a long run of equal keys: redo the last pass with the sorted words as output and take
+            // the general rebucket pass below
+            HIP_TRY(hipMemsetAsync(w.ctl_status + (size_t)(kb - 1) * w.ctl_status_stride, 0, w.ctl_status_stride, st));
+            rc = rank_pass<IdxT, kKeysLast>(L, w, K[cur ^ 1], (const IdxT *)nullptr, K[cur], d_sa, n, kb - 1, kb, ib);
+            if (rc != DQ_OK) return rc;
         } else {
-            const int64_t nquads = (n + 3) / 4;
-            const int64_t blocks = std::min<int64_t>((nquads + kBlock - 1) / kBlock, 256 * 8);
-            LAUNCH(L, DQ_K_PACK_KEYS, n, n * 9,
-                   hipLaunchKernelGGL(pack_keys_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, w.text, n, w.K0));
-            const int passes = 64 / kRadixBits;
-            V[passes & 1] = d_sa;            // the last pass must land in the caller's SA buffer
-            V[(passes & 1) ^ 1] = w.Va;
-            rc = radix_sort_pairs<IdxT>(L, w, K, V, n, 64, /*synth_first=*/true, cur);
+            rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur);
             if (rc != DQ_OK) return rc;
         }
         // sorted keys (or packed words) are in K[cur], suffixes in d_sa
@@ -803,7 +742,7 @@ struct SuffixSorter {
         // writes the ISA in the rebucket pass itself.  (Inputs whose order-0 entropy already promised
         // few ties -- packed words or a short key -- skip the sample and its host round trip.)
         bool predict_dense = false;
-        if (sort_engine() == 1 && n >= (1 << 16) && !packed && kb == 8) {
+        if (n >= (1 << 16) && !packed && kb == 8) {
             constexpr int kSamples = 4096;
             HIP_TRY(hipMemsetAsync(w.totals + 2, 0, 8, st));
             hipLaunchKernelGGL(sample_ties_kernel, dim3(kSamples / kBlock), dim3(kBlock), 0, st,
@@ -815,7 +754,7 @@ struct SuffixSorter {
             predict_dense = c.pinned[0] * 12 > kSamples;
         }
         if (const char *v = getenv("DQ_SPARSE")) predict_dense = atoi(v) == 0;
-        const bool binned = predict_dense && sort_engine() == 1 && n >= (1 << 16) &&
+        const bool binned = predict_dense && n >= (1 << 16) &&
                             2 * bit_length((uint64_t)(n - 1)) <= 63 && !getenv("DQ_NO_BINNED_ISA");
         if (binned) {
             rc = build_isa_binned(K[cur], K[cur ^ 1], kb, kshift0);
@@ -857,7 +796,7 @@ struct SuffixSorter {
         if (!fin_done) {
             unsigned long long *left_over = reinterpret_cast<unsigned long long *>(w.totals + 3);
             HIP_TRY(hipMemsetAsync(left_over, 0, 8, st));
-            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + 16 + wb),
+            LAUNCH(L, DQ_K_SMALL_FINISH, m, m * (8 + wb + 16 + wb),
                    hipLaunchKernelGGL((small_group_finish_kernel<IdxT, 8, 32>),
                                       dim3((unsigned)((m + kFinishThreads - 1) / kFinishThreads)), dim3(kFinishThreads),
                                       0, st, (const uint64_t *)Kr[rcur], (const IdxT *)Vr[rcur],
@@ -874,7 +813,7 @@ struct SuffixSorter {
         for (int r = 0; r < 3 && m > 0; ++r) {
             t_info[0] += 1;
             t_info[2] += m;
-            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + ebytes + 8),
+            LAUNCH(L, DQ_K_GATHER_TEXT_KEY, m, m * (8 + wb + ebytes + 8),
                    hipLaunchKernelGGL(gather_text_key_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock), 0, st, Kr[rcur],
                                       (const IdxT *)Vr[rcur], (const uint8_t *)w.text, m, n, h, ebytes));
             rc = sort_pairs(Kr, Vr, m, kbits + rbits, rcur);
@@ -891,20 +830,20 @@ struct SuffixSorter {
     }
 
     // ---- one doubling round, everything through the radix path
-    int doubling_round_radix(int kbits)
+    int doubling_round_radix(int kbits, int rshift = 0)
     {
         if (keys_ready) {
             keys_ready = false;          // build_isa_binned() gathered key2 while the ranks were still local
         } else {
             LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8),
                    hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock), 0, st, Kr[rcur],
-                                      (const IdxT *)Vr[rcur], (const IdxT *)w.ISA, m, n, h, kbits));
+                                      (const IdxT *)Vr[rcur], (const IdxT *)w.ISA, m, n, h, kbits, rshift));
         }
-        int rc = sort_pairs(Kr, Vr, m, kbits + rbits, rcur);
+        int rc = sort_pairs(Kr, Vr, m, kbits + rbits - rshift, rcur);
         if (rc != DQ_OK) return rc;
         int64_t m2 = 0;
         rc = rebucket<IdxT, false, true, true>(L, c, w, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits, 0, d_sa,
-                                               Kr[rcur ^ 1], Vr[rcur ^ 1], &m2);
+                                               Kr[rcur ^ 1], Vr[rcur ^ 1], &m2, rshift);
         if (rc != DQ_OK) return rc;
         rcur ^= 1;
         m = m2;
@@ -915,28 +854,33 @@ struct SuffixSorter {
     //      and only the larger groups through the radix path.  Needs m <= n/2: every buffer has room
     //      for n entries, X sits in the first half of (A, As), and the other buffer pair receives
     //      T (next list, from 0), L (large groups, from n/2) and U (rank updates, downward from n).
+    // L region of a small-group round: first even entry at or after n/2, so that the 16-byte key loads of
+    // the radix histogram over it are aligned; U then grows downward from n + 2 (the buffers have the slack)
+    int64_t sg_half() const { return (n / 2 + 1) & ~(int64_t)1; }
+    int64_t sg_top() const { return n + 2; }
+
     int doubling_round_small(int kbits)
     {
         uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
         IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
-        const int64_t half = n / 2;
+        const int64_t half = sg_half(), top = sg_top();
         SmallGroupCounters *ctr = reinterpret_cast<SmallGroupCounters *>(w.totals + 4);
         HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(SmallGroupCounters), st));
         const int64_t m_before = m;
         if (m < kSgShortList) {
             constexpr int kTile = sg_tile<kSgMaxGShort>();
-            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + wb + 8 + wb),
+            LAUNCH(L, DQ_K_SMALL_ROUND, m, m * (8 + wb + wb + wb + 8 + wb),
                    hipLaunchKernelGGL((small_group_round_kernel<IdxT, kSgMaxGShort>), dim3((unsigned)((m + kTile - 1) / kTile)),
                                       dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
-                                      (const IdxT *)w.ISA, m, n, h, kbits, d_sa, B, Bs, B + half, Bs + half, B + n,
-                                      Bs + n, ctr, (const SmallGroupCounters *)nullptr));
+                                      (const IdxT *)w.ISA, m, n, h, kbits, d_sa, B, Bs, B + half, Bs + half, B + top,
+                                      Bs + top, ctr, (const SmallGroupCounters *)nullptr));
         } else {
             constexpr int kTile = sg_tile<kSgMaxG>();
-            LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + wb + 8 + wb),
+            LAUNCH(L, DQ_K_SMALL_ROUND, m, m * (8 + wb + wb + wb + 8 + wb),
                    hipLaunchKernelGGL((small_group_round_kernel<IdxT, kSgMaxG>), dim3((unsigned)((m + kTile - 1) / kTile)),
                                       dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
-                                      (const IdxT *)w.ISA, m, n, h, kbits, d_sa, B, Bs, B + half, Bs + half, B + n,
-                                      Bs + n, ctr, (const SmallGroupCounters *)nullptr));
+                                      (const IdxT *)w.ISA, m, n, h, kbits, d_sa, B, Bs, B + half, Bs + half, B + top,
+                                      Bs + top, ctr, (const SmallGroupCounters *)nullptr));
         }
         HIP_TRY(hipMemcpyAsync(c.pinned, ctr, sizeof(SmallGroupCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -945,9 +889,9 @@ struct SuffixSorter {
             fprintf(stderr, "[dq] small round h=%lld m=%lld -> tied %lld, to radix %lld, moved %lld\n", (long long)h,
                     (long long)m, (long long)m1, (long long)mL, (long long)mU);
         if (mU > 0) {
-            LAUNCH(L, DQ_K_SEG_APPLY, mU, mU * (8 + wb + wb),
+            LAUNCH(L, DQ_K_ISA_UPDATE, mU, mU * (8 + wb + wb),
                    hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(mU)), dim3(kBlock), 0, st,
-                                      (const uint64_t *)(B + n), (const IdxT *)(Bs + n), mU, w.ISA));
+                                      (const uint64_t *)(B + top), (const IdxT *)(Bs + top), mU, w.ISA));
         }
         int64_t mLs = 0;
         if (mL > 0) {
@@ -980,7 +924,7 @@ struct SuffixSorter {
     template <int kCap>
     int small_chain()
     {
-        const int64_t half = n / 2;
+        const int64_t half = sg_half(), top = sg_top();
         const int64_t m_in = m;
         HIP_TRY(hipMemsetAsync(w.sg_ctr, 0, kSgChain * sizeof(SmallGroupCounters), st));
         int64_t hr = h;
@@ -989,14 +933,14 @@ struct SuffixSorter {
             IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
             const int kbits = std::min(bit_length((uint64_t)(n - 1) + (uint64_t)hr), 64 - rbits);   // (no radix keys are made)
             constexpr int kTile = sg_tile<kCap>();                           // (every group has <= kCap members here)
-            LAUNCH(L, DQ_K_GATHER_KEY2, m_in, 0,
+            LAUNCH(L, DQ_K_SMALL_ROUND, m_in, 0,
                    hipLaunchKernelGGL((small_group_round_kernel<IdxT, kCap>), dim3((unsigned)((m_in + kTile - 1) / kTile)),
                                       dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
-                                      (const IdxT *)w.ISA, m_in, n, hr, kbits, d_sa, B, Bs, B + half, Bs + half, B + n,
-                                      Bs + n, w.sg_ctr + r, r == 0 ? (const SmallGroupCounters *)nullptr : w.sg_ctr + r - 1));
-            LAUNCH(L, DQ_K_SEG_APPLY, m_in, 0,
+                                      (const IdxT *)w.ISA, m_in, n, hr, kbits, d_sa, B, Bs, B + half, Bs + half, B + top,
+                                      Bs + top, w.sg_ctr + r, r == 0 ? (const SmallGroupCounters *)nullptr : w.sg_ctr + r - 1));
+            LAUNCH(L, DQ_K_ISA_UPDATE, m_in, 0,
                    hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(m_in)), dim3(kBlock), 0, st,
-                                      (const uint64_t *)(B + n), (const IdxT *)(Bs + n), (int64_t)0, w.ISA,
+                                      (const uint64_t *)(B + top), (const IdxT *)(Bs + top), (int64_t)0, w.ISA,
                                       (const SmallGroupCounters *)(w.sg_ctr + r)));
             rcur ^= 1;
             hr *= 2;
@@ -1040,8 +984,15 @@ struct SuffixSorter {
             t_info[0] += 1;
             t_info[2] += m;
             const int kbits = bit_length((uint64_t)(n - 1) + (uint64_t)h);
-            if (kbits + rbits > 64) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
-            rc = (uses_small_round(m) && !keys_ready) ? doubling_round_small(kbits) : doubling_round_radix(kbits);
+            // (rank << kbits | key2) must fit 64 bits.  For 2^31 < n <= 2^32 a repeat longer than 2^32 - n bytes
+            // needs 33 + 32: the key then carries rank >> 1 (unique per group: tied groups have >= 2 members)
+            // and the rebucket pass reads the true rank from the ISA.  check_args() keeps n <= 2^32.
+            // (DQ_FORCE_RSHIFT: the tests take this path on small inputs)
+            const int rshift = (kbits + rbits > 64 || (getenv("DQ_FORCE_RSHIFT") && !keys_ready)) ? 1 : 0;
+            if (kbits + rbits - rshift > 64) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
+            if (rshift && keys_ready) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
+            rc = (uses_small_round(m) && !keys_ready && !rshift) ? doubling_round_small(kbits)
+                                                                 : doubling_round_radix(kbits, rshift);
             if (rc != DQ_OK) return rc;
             h *= 2;
         }
@@ -1063,7 +1014,7 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
 int64_t small_limit()
 {
     if (const char *v = getenv("DQ_SMALL_N")) return std::min<int64_t>(std::max(0, atoi(v)), kSmallMaxN);
-    return sort_engine() == 1 ? kSmallMaxN : 0;
+    return kSmallMaxN;
 }
 
 template <typename IdxT>
@@ -1099,6 +1050,9 @@ int check_args(const void *text, int64_t n, const void *sa)
     if (n > 0 && (!text || !sa)) return fail(DQ_ERR_BAD_ARGS, "null buffer");
     if (sizeof(IdxT) == 4 && n > 0x7fffffffLL)
         return fail(DQ_ERR_TOO_LARGE, "n exceeds 2^31-1; use the i64 entry point");
+    // a doubling round sorts (rank, key2) as ONE 64-bit word: 32 + 32 bits at most (see run())
+    if (n > (1ll << 32))
+        return fail(DQ_ERR_TOO_LARGE, "n exceeds 2^32: the 64-bit entry points take texts of up to 4 GiB");
     return DQ_OK;
 }
 
@@ -1128,7 +1082,7 @@ int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device)
         IdxT *io_sa = reinterpret_cast<IdxT *>(c.pinned_io + kSmallTextArea);
         memcpy(c.pinned_io, text, (size_t)n);
         rc = sufsort_small<IdxT>(c, c.stream, c.pinned_io, n, io_sa);
-        if (rc != DQ_OK) { c.pending.clear(); return rc; }
+        if (rc != DQ_OK) { drop_pending(c, c.stream); return rc; }
         memcpy(sa, io_sa, (size_t)n * sizeof(IdxT));
         return DQ_OK;
     }
@@ -1142,7 +1096,7 @@ int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device)
     HIP_TRY(hipMemcpyAsync(w.text, text, (size_t)n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(w.text + n, 0, 64, st));
     rc = sufsort_device<IdxT>(c, st, w, n, w.SAbuf);
-    if (rc != DQ_OK) { (void)hipStreamSynchronize(st); c.pending.clear(); return rc; }
+    if (rc != DQ_OK) { drop_pending(c, st); return rc; }
     HIP_TRY(hipMemcpyAsync(sa, w.SAbuf, (size_t)n * sizeof(IdxT), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return DQ_OK;
@@ -1163,8 +1117,9 @@ int sufsort_dev(const void *d_text, int64_t n, void *d_sa, int32_t device, void 
     rc = init_ctx(c, dev);
     if (rc != DQ_OK) return rc;
     if (n <= small_limit()) {
-        rc = sufsort_small<IdxT>(c, stream ? (hipStream_t)stream : c.stream, (const uint8_t *)d_text, n, (IdxT *)d_sa);
-        if (rc != DQ_OK) c.pending.clear();
+        hipStream_t sst = stream ? (hipStream_t)stream : c.stream;
+        rc = sufsort_small<IdxT>(c, sst, (const uint8_t *)d_text, n, (IdxT *)d_sa);
+        if (rc != DQ_OK) drop_pending(c, sst);
         return rc;
     }
     Workspace<IdxT> w = carve<IdxT>(nullptr, n, false);
@@ -1175,7 +1130,7 @@ int sufsort_dev(const void *d_text, int64_t n, void *d_sa, int32_t device, void 
     HIP_TRY(hipMemcpyAsync(w.text, d_text, (size_t)n, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemsetAsync(w.text + n, 0, 64, st));
     rc = sufsort_device<IdxT>(c, st, w, n, (IdxT *)d_sa);
-    if (rc != DQ_OK) { (void)hipStreamSynchronize(st); c.pending.clear(); return rc; }
+    if (rc != DQ_OK) { drop_pending(c, st); return rc; }
     HIP_TRY(hipStreamSynchronize(st));
     return DQ_OK;
 }
@@ -1188,6 +1143,11 @@ int sufsort_dev(const void *d_text, int64_t n, void *d_sa, int32_t device, void 
 // so the PCIe transfers of neighbouring inputs overlap the sort.  Inputs that need the
 // short-text path or that are larger than the slot size go through the plain host entry point.
 constexpr int kBatchSlots = 3;
+
+struct JoinAll {                        // joins whatever was started, also when leaving by exception
+    std::vector<std::thread> v;
+    ~JoinAll() { for (std::thread &t : v) if (t.joinable()) t.join(); }
+};
 
 int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *const *texts, const int64_t *lens,
                     int32_t *const *sas, std::string *err)
@@ -1207,22 +1167,31 @@ int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *con
         return DQ_OK;
     }
     if (hipSetDevice(device) != hipSuccess) { *err = "hipSetDevice failed"; return DQ_ERR_HIP; }
+    // the three device slots and streams live in the device context: allocated once, grown on demand
+    DeviceCtx &bc = g_ctx[device];
+    std::lock_guard<std::mutex> batch_lock(bc.batch_mu);
     struct Slot { uint8_t *text = nullptr; int32_t *sa = nullptr; int job = -1; };
     Slot slots[kBatchSlots];
-    hipStream_t s_in = nullptr, s_sort = nullptr, s_out = nullptr;
-    auto cleanup = [&]() {
-        for (Slot &sl : slots) { if (sl.text) (void)hipFree(sl.text); if (sl.sa) (void)hipFree(sl.sa); }
-        if (s_in) (void)hipStreamDestroy(s_in);
-        if (s_sort) (void)hipStreamDestroy(s_sort);
-        if (s_out) (void)hipStreamDestroy(s_out);
-    };
-    bool ok = hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&s_sort, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking) == hipSuccess;
-    for (Slot &sl : slots)
-        ok = ok && hipMalloc((void **)&sl.text, (size_t)cap + 64) == hipSuccess &&
-             hipMalloc((void **)&sl.sa, (size_t)cap * sizeof(int32_t)) == hipSuccess;
-    if (!ok) { cleanup(); *err = "batch slot allocation failed"; return DQ_ERR_OOM; }
+    {
+        bool ok = true;
+        for (hipStream_t *st : {&bc.b_in, &bc.b_sort, &bc.b_out})
+            if (!*st) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+        if (ok && bc.bslot_cap < (size_t)cap) {
+            for (int k = 0; k < kBatchSlots; ++k) {
+                if (bc.bslot_text[k]) (void)hipFree(bc.bslot_text[k]);
+                if (bc.bslot_sa[k]) (void)hipFree(bc.bslot_sa[k]);
+                bc.bslot_text[k] = nullptr; bc.bslot_sa[k] = nullptr;
+            }
+            bc.bslot_cap = 0;
+            for (int k = 0; k < kBatchSlots; ++k)
+                ok = ok && hipMalloc((void **)&bc.bslot_text[k], (size_t)cap + 64) == hipSuccess &&
+                     hipMalloc((void **)&bc.bslot_sa[k], (size_t)cap * sizeof(int32_t)) == hipSuccess;
+            if (ok) bc.bslot_cap = (size_t)cap;
+        }
+        if (!ok) { *err = "batch slot allocation failed"; return DQ_ERR_OOM; }
+        for (int k = 0; k < kBatchSlots; ++k) { slots[k].text = bc.bslot_text[k]; slots[k].sa = bc.bslot_sa[k]; }
+    }
+    hipStream_t s_in = bc.b_in, s_sort = bc.b_sort, s_out = bc.b_out;
 
     // slot hand-over: free -> filled (text on the device) -> sorted (SA on the device) -> free
     std::mutex mu;
@@ -1242,13 +1211,16 @@ int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *con
     };
     auto give = [&](std::vector<int> &q, int k) { { std::lock_guard<std::mutex> lk(mu); q.push_back(k); } cv.notify_all(); };
     auto fail_stage = [&](int stage, int rc, const std::string &what) {
-        errs[stage] = what;
-        int expect = DQ_OK;
-        failed.compare_exchange_strong(expect, rc);
+        {   // under the mutex: a waiter between its predicate check and its block must not miss this
+            std::lock_guard<std::mutex> lk(mu);
+            errs[stage] = what;
+            int expect = DQ_OK;
+            failed.compare_exchange_strong(expect, rc);
+        }
         cv.notify_all();
     };
 
-    std::thread t_in([&]() {
+    auto stage_in = [&]() {
         (void)hipSetDevice(device);
         for (int j : jobs) {
             if (lens[j] <= direct) continue;                                // handled after the pipeline
@@ -1262,8 +1234,8 @@ int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *con
         }
         { std::lock_guard<std::mutex> lk(mu); in_done = true; }
         cv.notify_all();
-    });
-    std::thread t_sort([&]() {
+    };
+    auto stage_sort = [&]() {
         (void)hipSetDevice(device);
         for (;;) {
             const int k = take(filled, &in_done);
@@ -1275,8 +1247,8 @@ int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *con
         }
         { std::lock_guard<std::mutex> lk(mu); sort_done = true; }
         cv.notify_all();
-    });
-    std::thread t_out([&]() {
+    };
+    auto stage_out = [&]() {
         (void)hipSetDevice(device);
         for (;;) {
             const int k = take(sorted, &sort_done);
@@ -1287,9 +1259,19 @@ int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *con
             if (e != hipSuccess) { fail_stage(2, DQ_ERR_HIP, std::string("batch copy-out: ") + hipGetErrorString(e)); break; }
             give(freeq, k);
         }
-    });
-    t_in.join(); t_sort.join(); t_out.join();
-    cleanup();
+    };
+    {
+        // a thread that cannot be started (std::system_error) fails the batch instead of terminating:
+        // the stages already running are woken through fail_stage and joined
+        JoinAll stages;
+        try {
+            stages.v.emplace_back(stage_in);
+            stages.v.emplace_back(stage_sort);
+            stages.v.emplace_back(stage_out);
+        } catch (const std::exception &e) {
+            fail_stage(0, DQ_ERR_OOM, std::string("batch: cannot start a pipeline thread: ") + e.what());
+        }
+    }
     if (failed.load() != DQ_OK) {
         for (const std::string &e : errs) if (!e.empty()) { *err = e; break; }
         return failed.load();
@@ -1341,6 +1323,7 @@ int32_t dq_sufsort_hip_batch_i32(int32_t count, const uint8_t *const *texts, con
     if (count < 0 || ndev <= 0 || (count > 0 && (!texts || !lens || !sas)))
         return fail(DQ_ERR_BAD_ARGS, "bad batch arguments");
     if (count == 0) return DQ_OK;
+    try {
     // longest-processing-time-first assignment of inputs to devices
     std::vector<int> order(count);
     for (int i = 0; i < count; ++i) order[i] = i;
@@ -1356,17 +1339,28 @@ int32_t dq_sufsort_hip_batch_i32(int32_t count, const uint8_t *const *texts, con
     }
     std::vector<int> rcs(ndev, DQ_OK);
     std::vector<std::string> errs(ndev);
-    std::vector<std::thread> threads;
-    for (int d = 0; d < ndev; ++d) {
-        threads.emplace_back([&, d]() {
-            const int device = devs ? devs[d] : d;
-            rcs[d] = batch_on_device(device, share[d], texts, lens, sas, &errs[d]);
-        });
+    {
+        JoinAll threads;
+        for (int d = 0; d < ndev; ++d) {
+            threads.v.emplace_back([&, d]() {
+                const int device = devs ? devs[d] : d;
+                try {
+                    rcs[d] = batch_on_device(device, share[d], texts, lens, sas, &errs[d]);
+                } catch (const std::exception &e) {
+                    rcs[d] = DQ_ERR_OOM;
+                    errs[d] = std::string("batch: ") + e.what();
+                }
+            });
+        }
     }
-    for (auto &t : threads) t.join();
     for (int d = 0; d < ndev; ++d)
         if (rcs[d] != DQ_OK) { t_err = errs[d]; return rcs[d]; }
     return DQ_OK;
+    } catch (const std::bad_alloc &) {             // nothing may propagate through the C ABI
+        return fail(DQ_ERR_OOM, "batch: host allocation failed");
+    } catch (const std::exception &e) {            // std::system_error from std::thread, ...
+        return fail(DQ_ERR_HIP, e.what());
+    }
 }
 
 int64_t dq_sufsort_hip_workspace_bytes(int64_t n, int32_t index_bytes)
@@ -1381,11 +1375,21 @@ void dq_sufsort_hip_release(void)
 {
     for (int d = 0; d < kMaxDevices; ++d) {
         DeviceCtx &c = g_ctx[d];
+        std::lock_guard<std::mutex> bl(c.batch_mu);        // lock order everywhere: batch_mu, then mu
         std::lock_guard<std::mutex> lk(c.mu);
         if (c.dev < 0) continue;
         if (hipSetDevice(c.dev) != hipSuccess) continue;
         if (c.ws) (void)hipFree(c.ws);
         c.ws = nullptr; c.ws_bytes = 0;
+        {
+            for (int k = 0; k < 3; ++k) {
+                if (c.bslot_text[k]) (void)hipFree(c.bslot_text[k]);
+                if (c.bslot_sa[k]) (void)hipFree(c.bslot_sa[k]);
+                c.bslot_text[k] = nullptr; c.bslot_sa[k] = nullptr;
+            }
+            c.bslot_cap = 0;
+            for (hipStream_t *st : {&c.b_in, &c.b_sort, &c.b_out}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
+        }
         for (hipEvent_t e : c.pool) (void)hipEventDestroy(e);
         c.pool.clear();
         if (c.pinned) (void)hipHostFree(c.pinned);
@@ -1400,7 +1404,11 @@ void dq_sufsort_hip_release(void)
     }
 }
 
-int32_t dq_profile_enable(int32_t on) { g_prof_on.store(on == 2 ? 2 : (on ? 1 : 0)); return DQ_OK; }
+int32_t dq_profile_enable(int32_t on)
+{
+    g_prof_on.store((on == 2 || (on >= 100 && on < 100 + DQ_K_COUNT)) ? on : (on ? 1 : 0));
+    return DQ_OK;
+}
 
 void dq_profile_reset(void)
 {
@@ -1420,6 +1428,8 @@ int32_t dq_profile_get(int32_t category, int64_t *launches, double *total_ms, in
     if (alg_bytes) *alg_bytes = s.bytes;
     return DQ_OK;
 }
+
+int32_t dq_profile_category_count(void) { return DQ_K_COUNT; }
 
 const char *dq_profile_kernel_name(int32_t category)
 {

@@ -36,7 +36,8 @@ extern "C" {
 #define DQ_ERR_BAD_ARGS   (-1)   /* null pointer with n > 0, negative n, bad device / count        */
 #define DQ_ERR_OOM        (-2)   /* device (or pinned host) allocation failed                       */
 #define DQ_ERR_HIP        (-3)   /* any other HIP runtime error; see dq_last_error()                */
-#define DQ_ERR_TOO_LARGE  (-4)   /* n exceeds the index width (i32: n > 2^31-1, ISuffixSort's limit)*/
+#define DQ_ERR_TOO_LARGE  (-4)   /* n exceeds the index width (i32: n > 2^31-1, ISuffixSort's limit;  */
+                                 /* i64: n > 2^32)                                                  */
 #define DQ_ERR_NO_DEVICE  (-5)   /* no HIP device visible                                           */
 
 int32_t dq_abi_version(void);
@@ -48,7 +49,10 @@ const char *dq_last_error(void);               /* thread-local, never NULL      
  * n == 0 is a no-op; n == 1 -> {0}; n == 2 -> {0,1} iff text[0] < text[1] else {1,0}
  * (DivSufSort.cs:22-38).  device: HIP device ordinal, or -1 for DQ_HIP_DEVICE / device 0. */
 int32_t dq_sufsort_hip_i32(const uint8_t *text, int64_t n, int32_t *sa, int32_t device);
-/* Same contract with 64-bit indices, for inputs beyond ISuffixSort's int limit (n >= 2^31). */
+/* Same contract with 64-bit indices, for inputs beyond ISuffixSort's int limit: 2^31 <= n <= 2^32
+ * bytes (any n is accepted up to that).  n > 2^32 returns DQ_ERR_TOO_LARGE before any device work:
+ * a doubling round sorts (rank, rank of the suffix h bytes on) as one 64-bit word, 32 + 32 bits at
+ * most, and the workspace of ~42 n bytes would not fit 288 GB much beyond that anyway. */
 int32_t dq_sufsort_hip_i64(const uint8_t *text, int64_t n, int64_t *sa, int32_t device);
 
 /* ---- device-resident variant: text and sa are device pointers on `device` ----------------------
@@ -75,24 +79,34 @@ void dq_sufsort_hip_release(void);
 /* ---- measurement hooks (bench.py) -----------------------------------------------------------------
  * With profiling on, every kernel launch is bracketed by hipEvents on the launch stream and the
  * elapsed time is accumulated per kernel category when the sort finishes. */
-#define DQ_K_PACK_KEYS           0
-#define DQ_K_RADIX_UPSWEEP       1
-#define DQ_K_RADIX_SCAN          2
-#define DQ_K_RADIX_RANK_SCATTER  3   /* radix_rank_kernel: the dominant kernel; 2*(8+w) B/element/launch */
-#define DQ_K_SEG_REDUCE          4
-#define DQ_K_SEG_SCAN            5
-#define DQ_K_SEG_APPLY           6
-#define DQ_K_GATHER_KEY2         7
-#define DQ_K_RADIX_HIST          8   /* text / key digit histograms + offset scans */
-#define DQ_K_SMALL_SORT          9   /* small_sufsort_kernel: a whole short text (n <= 8192) in one workgroup */
-#define DQ_K_COUNT               10
+#define DQ_K_TEXT_HIST            0   /* text_hist_kernel (+ text_digit_offsets_kernel): 1 B/text byte            */
+#define DQ_K_RADIX_HIST           1   /* radix_hist_kernel + radix_hist_scan_kernel: 8 B/key                        */
+#define DQ_K_RADIX_RANK           2   /* radix_rank_kernel, one digit pass; B/element by pass kind (w = index      */
+                                      /* bytes): text->words 9, words 16, last words pass 16+w, tie-recording      */
+                                      /* last pass 8+w+1/8 (+16 B per tile and digit), pairs 2*(8+w), text->pairs  */
+                                      /* 9+w                                                                       */
+#define DQ_K_SEG_FUSED            3   /* seg_fused_kernel: rebucket of a sorted list, 8 (+w..3w when writing)       */
+#define DQ_K_TIE_SEAM             4   /* tie_seam_kernel: ties across tile seams, 24 B per (tile, digit)            */
+#define DQ_K_TIE_COLLECT          5   /* tie_collect_kernel: tie bits -> list of tied suffixes, 1/8 B/suffix        */
+#define DQ_K_SMALL_FINISH         6   /* small_group_finish_kernel: groups <= 8 by direct text comparison           */
+#define DQ_K_SMALL_ROUND          7   /* small_group_round_kernel: one doubling round for groups <= 8 (32)          */
+#define DQ_K_ISA_UPDATE           8   /* isa_update_kernel: deferred rank updates of a small-group round            */
+#define DQ_K_ISA_FROM_PAIRS       9   /* isa_from_pairs_kernel: first ISA from suffix-binned words, 8+w             */
+#define DQ_K_KEY2_FROM_PAIRS     10   /* key2_from_pairs_kernel: first key2 gather inside the suffix window         */
+#define DQ_K_GATHER_KEY2         11   /* gather_key2_kernel: (rank, ISA[s+h]) composite keys, 16+2w                 */
+#define DQ_K_GATHER_TEXT_KEY     12   /* gather_text_key_kernel: (rank, next bytes of text) keys                    */
+#define DQ_K_ISA_FROM_SA         13   /* isa_from_sa_kernel + isa_scatter_kernel: ISA for the switch to doubling    */
+#define DQ_K_SMALL_SORT          14   /* small_sufsort_kernel: a whole short text (n <= 8192) in one workgroup      */
+#define DQ_K_COUNT               15
 
-int32_t dq_profile_enable(int32_t on);   /* 0 off, 1 every kernel, 2 only radix_rank_kernel (cheapest) */
+/* 0 off, 1 every kernel, 2 only radix_rank_kernel, 100 + c only category c (cheapest: the timed region) */
+int32_t dq_profile_enable(int32_t on);
 void    dq_profile_reset(void);
 /* launches, summed milliseconds, summed elements processed, summed algorithmic bytes */
 int32_t dq_profile_get(int32_t category, int64_t *launches, double *total_ms, int64_t *elements,
                        int64_t *alg_bytes);
 const char *dq_profile_kernel_name(int32_t category);
+int32_t dq_profile_category_count(void);   /* DQ_K_COUNT of the loaded library */
 
 /* Shape of the last sort on this thread: doubling rounds after the initial 8-byte sort, number
  * of suffixes still in non-singleton groups after the initial sort, and the sum of that count

@@ -64,6 +64,8 @@ def lib() -> ctypes.CDLL:
             getattr(L, f"dq_oracle_verify_sampled_{suf}").argtypes = [u8p, u8p, i64, i64, ctypes.c_uint64]
             getattr(L, f"dq_oracle_sufcheck_{suf}").restype = ctypes.c_int32
             getattr(L, f"dq_oracle_sufcheck_{suf}").argtypes = [u8p, i64, u8p, i64]
+            getattr(L, f"dq_oracle_sufcheck_mt_{suf}").restype = ctypes.c_int32
+            getattr(L, f"dq_oracle_sufcheck_mt_{suf}").argtypes = [u8p, i64, u8p, i64, ctypes.c_int32]
             if hasattr(L, f"dq_oracle_divsufsort_{suf}"):
                 getattr(L, f"dq_oracle_divsufsort_{suf}").restype = ctypes.c_int32
                 getattr(L, f"dq_oracle_divsufsort_{suf}").argtypes = [u8p, u8p, i64]
@@ -143,6 +145,15 @@ def sufcheck(text, sa) -> int:
     T = _text(text)
     sa = np.ascontiguousarray(sa)
     return int(getattr(lib(), f"dq_oracle_sufcheck_{_suf(sa)}")(_ptr(T), T.size, _ptr(sa), sa.size))
+
+
+def sufcheck_mt(text, sa, threads: int = 0) -> int:
+    """LDSSChecker.Check evaluated by several threads (full-size configurations); same codes."""
+    T = _text(text)
+    sa = np.ascontiguousarray(sa)
+    if threads <= 0:
+        threads = min(64, os.cpu_count() or 1)
+    return int(getattr(lib(), f"dq_oracle_sufcheck_mt_{_suf(sa)}")(_ptr(T), T.size, _ptr(sa), sa.size, threads))
 
 
 def verify(text, sa) -> None:

@@ -67,6 +67,11 @@ int64_t dq_oracle_verify_sampled_i64(const uint8_t *T, const int64_t *SA, int64_
 int32_t dq_oracle_sufcheck_i32(const uint8_t *T, int64_t n, const int32_t *SA, int64_t sa_len);
 int32_t dq_oracle_sufcheck_i64(const uint8_t *T, int64_t n, const int64_t *SA, int64_t sa_len);
 
+/* The same check evaluated by `threads` threads (checkers_mt.c), for the full-size configurations:
+ * same phases, same result codes. */
+int32_t dq_oracle_sufcheck_mt_i32(const uint8_t *T, int64_t n, const int32_t *SA, int64_t sa_len, int32_t threads);
+int32_t dq_oracle_sufcheck_mt_i64(const uint8_t *T, int64_t n, const int64_t *SA, int64_t sa_len, int32_t threads);
+
 /* .NET System.Random(int seed) compat generator (Knuth subtractive), used by
  * every reference test/bench buffer: new Random(670761).NextBytes(buf)
  * (LibDivSufSortTests.cs:29, SuffixSortingBenchmarks.cs:15). */

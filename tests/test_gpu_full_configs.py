@@ -1,0 +1,129 @@
+"""Every BASELINE.json configuration at FULL size, through the C ABI, under `pytest -m gpu`.
+
+configs[1]  64 MiB uniform random                      (also in test_gpu_parity.py)
+configs[2]  256 MiB enwik8-style text                  bit-compared with the oracle's LibDivSufSort restatement
+target      256 MiB uniform random (north-star run)    bit-compared with the oracle's LibDivSufSort restatement
+configs[3]  2 GiB uniform random, 64-bit SA            LDSSChecker.Check (threaded evaluation) + 10^6 sampled strict pairs;
+                                                       host entry point against device entry point bit for bit
+configs[4]  128 x 16 MiB through the batch entry point 4 buffers bit-compared, all 128 through LDSSChecker.Check
+plus the int32 interface near its size limit (n >= 2^30: 64-bit status words, 32768-entry ISA windows), once on
+random data and once with a long repeat (dense doubling rounds at that size).
+
+The reference's acceptance test for a provider is LibDivSufSortTests.Verify (cs:43-64): strict suffix order, then
+LDSSChecker.Check == Done.  LDSSChecker.Check alone already accepts exactly one array per text (the suffix array),
+so where the strict loop (O(n * LCP)) or the CPU restatement is too slow, Check + sampled strict pairs decide.
+"""
+import ctypes
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GiB = 1 << 30
+
+
+def host_ram_bytes():
+    try:
+        return os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+    except (ValueError, OSError):
+        return 0
+
+
+def need_ram(gib):
+    have = host_ram_bytes()
+    if have and have < gib * GiB:
+        pytest.skip(f"host has {have / GiB:.0f} GiB of RAM, this case needs {gib} GiB (text + SA + checker)")
+
+
+@pytest.fixture(scope="module")
+def ldss(backend_lib):
+    from deltaq_amd import HipSuffixSort
+    assert backend_lib.dq_device_count() >= 1, "no MI355X visible: the HIP path cannot be tested"
+    yield HipSuffixSort(0)
+    backend_lib.dq_sufsort_hip_release()          # the 2 GiB case leaves ~100 GiB of cached workspace behind
+
+
+def check_by_properties(oracle_mod, T, SA, seed):
+    assert oracle_mod.sufcheck_mt(T, SA) == oracle_mod.CHECK_DONE
+    assert oracle_mod.verify_sampled(T, SA, 1_000_000, seed) == -1
+
+
+def test_config2_enwik_256MiB_bit_exact(ldss, oracle_mod):
+    n = 256 << 20
+    T = oracle_mod.gen_enwik_like(n, 0xD17A0)               # R = 256 KiB, the bench's configs[2] buffer
+    SA = ldss.Sort(T)
+    check_by_properties(oracle_mod, T, SA, 3)
+    assert np.array_equal(SA, oracle_mod.divsufsort(T))
+
+
+def test_target_uniform_256MiB_bit_exact(ldss, oracle_mod):
+    import torch
+    n = 256 << 20
+    T = oracle_mod.gen_uniform(n, 0x5EED0003)
+    SA = ldss.Sort(T)                                       # ISuffixSort.Sort(text): host in, host out
+    dSA = ldss.Sort(torch.from_numpy(T).cuda())             # device-resident entry point (what bench.py times)
+    assert np.array_equal(dSA.cpu().numpy(), SA)
+    del dSA
+    check_by_properties(oracle_mod, T, SA, 4)
+    assert np.array_equal(SA, oracle_mod.divsufsort(T))
+
+
+def test_config3_2GiB_int64(ldss, oracle_mod):
+    import torch
+    need_ram(48)
+    n = 1 << 31                                             # beyond ISuffixSort's int interface: i64 entry points
+    T = oracle_mod.gen_uniform(n, 0x5EED0004)
+    SA = ldss.Sort(T, index_dtype=np.int64)                 # dq_sufsort_hip_i64, > 4 GiB copies
+    assert SA.dtype == np.int64 and SA.size == n
+    check_by_properties(oracle_mod, T, SA, 7)
+    dT = torch.from_numpy(T).cuda()
+    dSA = torch.empty(n, dtype=torch.int64, device="cuda")
+    ldss.Sort(dT, dSA)                                      # dq_sufsort_hip_dev_i64
+    same = True
+    step = 1 << 28
+    for a in range(0, n, step):                             # compare in pieces: no second 16 GiB host copy
+        same = same and np.array_equal(dSA[a:a + step].cpu().numpy(), SA[a:a + step])
+    assert same
+    # the int32 interface must refuse this length, like the reference's int-indexed spans
+    from deltaq_amd import SuffixSortError, _abi
+    with pytest.raises(SuffixSortError) as ei:
+        ldss.Sort(T, np.empty(n, np.int32))
+    assert ei.value.code == _abi.DQ_ERR_TOO_LARGE
+
+
+@pytest.mark.parametrize("shape", ["uniform", "long-repeat"])
+def test_int32_interface_above_2_pow_30(ldss, oracle_mod, shape):
+    """n >= 2^30 with 32-bit indices: radix_rank_kernel and tie_seam_kernel run with 64-bit status words,
+    the packed words carry ib = 31 index bits; with a long repeat the sort also takes the dense path at
+    that size (suffix-binned first ISA with 32768-entry windows, doubling rounds)."""
+    need_ram(24)
+    n = (3 << 29) + 12345                                   # 1.5 GiB and a ragged tail
+    T = oracle_mod.gen_uniform(n, 0x5EED0007)
+    if shape == "long-repeat":
+        T[1000:200_000] = T[5_000_000:5_199_000]            # a 199 000-byte repeat: ~15 doubling rounds
+        T[n - 70_000:] = T[123_456:193_456]                 # and one that runs into the end of the text
+    SA = ldss.Sort(T)
+    assert SA.dtype == np.int32
+    check_by_properties(oracle_mod, T, SA, 9)
+    from deltaq_amd import _abi
+    info = _abi.last_sort_info()
+    assert (info["rounds"] > 8) == (shape == "long-repeat"), info
+
+
+def test_config4_batch_128x16MiB(backend_lib, oracle_mod):
+    need_ram(24)
+    cnt, n = 128, 16 << 20
+    texts = [oracle_mod.gen_uniform(n, 0x5EED0500 + j) for j in range(cnt)]
+    sas = [np.empty(n, np.int32) for _ in range(cnt)]
+    tp = (ctypes.c_void_p * cnt)(*[t.ctypes.data for t in texts])
+    sp = (ctypes.c_void_p * cnt)(*[s.ctypes.data for s in sas])
+    ln = (ctypes.c_int64 * cnt)(*[n] * cnt)
+    rc = backend_lib.dq_sufsort_hip_batch_i32(cnt, tp, ln, sp, 1, None)
+    assert rc == 0, backend_lib.dq_last_error()
+    for j in (0, 1, 63, 127):
+        assert np.array_equal(sas[j], oracle_mod.divsufsort(texts[j])), j
+    for j in range(cnt):
+        assert oracle_mod.sufcheck_mt(texts[j], sas[j]) == oracle_mod.CHECK_DONE, j

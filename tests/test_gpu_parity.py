@@ -125,7 +125,7 @@ def test_single_workgroup_sorter_every_small_size(ldss, oracle_mod, backend_lib)
     backend_lib.dq_profile_reset()
     ldss.Sort(oracle_mod.net_random_bytes(5000))
     launches = ctypes.c_int64()
-    backend_lib.dq_profile_get(9, ctypes.byref(launches), None, None, None)
+    backend_lib.dq_profile_get(14, ctypes.byref(launches), None, None, None)     # DQ_K_SMALL_SORT
     backend_lib.dq_profile_enable(0)
     assert launches.value == 1
 
@@ -187,6 +187,7 @@ FUZZ_ENVS = [
     {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2", "DQ_SMALL_N": "0"},   # tie bits with most suffixes tied
     {"DQ_SPARSE": "1", "DQ_SMALL_N": "0"},                 # finisher + key extension + fallback on dense inputs
     {"DQ_NO_BINNED_ISA": "1", "DQ_NO_CHAIN": "1"},         # first ISA by scatter, one host round trip per small-group round
+    {"DQ_FORCE_RSHIFT": "1", "DQ_SMALL_N": "0"},           # composite keys carry rank >> 1, true rank read from the ISA (n near 2^32)
 ]
 
 
@@ -290,6 +291,8 @@ FORCED_PATHS = [
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "4", "DQ_SPARSE": "0", "DQ_NO_SMALL": "1"},   # doubling without the small-group rounds
     {"DQ_NO_FUSED_TIES": "1"},                                   # packed sort + general rebucket pass instead of tie bits
     {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2"},                     # tie bits with MANY ties (dense doubling after them)
+    {"DQ_FORCE_RSHIFT": "1"},                                    # doubling rounds with rank >> 1 in the composite key
+    {"DQ_FORCE_RSHIFT": "1", "DQ_SPARSE": "1"},
 ]
 
 
@@ -317,24 +320,6 @@ def test_every_code_path_is_bit_exact(ldss, oracle_mod, monkeypatch, env):
         assert np.array_equal(SA, oracle_mod.divsufsort(T)), (env, T.size)
     T = oracle_mod.gen_uniform(1_000_003, 7)
     assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
-
-
-def test_legacy_three_kernel_engine_matches(oracle_mod):
-    """DQ_SORT_ENGINE=sweep3 (upsweep/scan/downsweep) is read once per process: run it in a child."""
-    import os, subprocess, sys, textwrap
-    code = textwrap.dedent("""
-        import sys, numpy as np
-        sys.path.insert(0, %r)
-        import oracle
-        from deltaq_amd import HipSuffixSort
-        s = HipSuffixSort(0)
-        for T in (oracle.gen_uniform(2_000_000, 3), oracle.gen_enwik_like(300_000, 5, 8192)):
-            assert np.array_equal(s.Sort(T), oracle.divsufsort(T))
-        print("ok")
-    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DQ_SORT_ENGINE="sweep3")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_shared_provider_from_many_threads(ldss, oracle_mod):

@@ -111,6 +111,37 @@ def test_checker_result_codes(oracle_mod):
     assert oracle_mod.sufcheck(np.zeros(0, np.uint8), np.zeros(0, np.int32)) == oracle_mod.CHECK_DONE
 
 
+def test_threaded_checker_agrees_with_the_sequential_restatement(oracle_mod):
+    """checkers_mt.c (used on the full-size configurations) returns the code of checkers.c's
+    LDSSChecker.Check restatement on correct arrays and on corrupted ones, for any thread count."""
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 5, 1000, 100_003):
+        T = oracle_mod.gen_uniform(n, 5) & (3 if n % 2 else 255)
+        sa = oracle_mod.divsufsort(T)
+        for dt in (np.int32, np.int64):
+            s = sa.astype(dt)
+            for th in (1, 3, 8, 64):
+                assert oracle_mod.sufcheck_mt(T, s, th) == oracle_mod.CHECK_DONE
+            assert oracle_mod.sufcheck_mt(T, s[:-1], 4) == oracle_mod.CHECK_BAD_ARGUMENTS
+            for trial in range(24 if n >= 5 else 0):
+                b = s.copy()
+                i, j = (int(x) for x in rng.integers(0, n, 2))
+                kind = trial % 4
+                if kind == 0:
+                    b[i], b[j] = b[j], b[i]
+                elif kind == 1:
+                    b[i] = b[j]
+                elif kind == 2:
+                    b[i] = n + 5
+                else:
+                    b[i] = -1
+                want = oracle_mod.sufcheck(T, b)
+                for th in (1, 2, 7, 16):
+                    assert oracle_mod.sufcheck_mt(T, b, th) == want, (n, trial, th)
+    Z = np.zeros(1000, np.uint8)
+    assert oracle_mod.sufcheck_mt(Z, np.arange(1000, dtype=np.int32), 5) == oracle_mod.CHECK_WRONG_POSITION
+
+
 def test_prefix_doubling_model_matches_oracle(oracle_mod):
     """The numpy model of the GPU algorithm (tests/pd_model.py) against the oracle."""
     import pd_model
