@@ -147,8 +147,8 @@ struct OnesweepCtl {
 //   kItems   keys per thread per tile (tile = 256 * kItems)
 //   kMode    kPairs : (key, suffix) pairs are loaded            (every pass but the first)
 //            kText  : FIRST pass of round 0: keys are built on the fly from the text
-//                     (key = first kb bytes at the suffix, big-endian, zero padded past the
-//                     end) and the suffix index is synthesised.  Lanes own 4 consecutive
+//                     (key = first `keybits` bits at the suffix, big-endian, zero padded past
+//                     the end) and the suffix index is synthesised.  Lanes own 4 consecutive
 //                     suffixes (3 dwords of text each); the pass need not be stable with
 //                     respect to the text order because members of a tie group are re-ranked
 //                     by the doubling rounds anyway.
@@ -186,7 +186,7 @@ template <typename IdxT, typename StatusT, int kItems, int kMode, int kMinWaves,
           bool kEarlyVals = false, bool kLdsMatch = true, int kExchRounds = 1>
 __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     const uint64_t *__restrict__ kin, const IdxT *__restrict__ vin,
-    uint64_t *__restrict__ kout, IdxT *__restrict__ vout, int64_t m, int shift, int kb, int ib,
+    uint64_t *__restrict__ kout, IdxT *__restrict__ vout, int64_t m, int shift, int keybits, int ib,
     const int64_t *__restrict__ digit_offset /*[256] for this pass*/,
     StatusT *__restrict__ status /*[ntiles][256]*/, OnesweepCtl *__restrict__ ctl,
     int64_t *__restrict__ sticky_error, uint32_t *__restrict__ ebits = nullptr,
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     uint64_t key[kItems];
     if (kFromText) {
         const uint32_t *t32 = reinterpret_cast<const uint32_t *>(kin);
-        const int kshift = 8 * (8 - kb);
+        const int kshift = 64 - keybits;                      // key = leading `keybits` bits of the suffix
 #pragma unroll
         for (int j = 0; j < kItems / 4; ++j) {
             const int e0 = (j * kThreads + tid) * 4;           // first of this lane's 4 suffixes

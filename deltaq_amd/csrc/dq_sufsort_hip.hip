@@ -38,6 +38,7 @@
 #include "dq_small_groups.h"
 #include "dq_ties.h"
 #include "dq_isa_pairs.h"
+#include "dq_bucket_sort.h"
 
 namespace {
 
@@ -75,7 +76,7 @@ const char *const kKernelNames[DQ_K_COUNT] = {
     "text_hist_kernel", "radix_hist_kernel", "radix_rank_kernel", "seg_fused_kernel",
     "tie_seam_kernel", "tie_collect_kernel", "small_group_finish_kernel", "small_group_round_kernel",
     "isa_update_kernel", "isa_from_pairs_kernel", "key2_from_pairs_kernel", "gather_key2_kernel",
-    "gather_text_key_kernel", "isa_from_sa_kernel", "small_sufsort_kernel"};
+    "gather_text_key_kernel", "isa_from_sa_kernel", "small_sufsort_kernel", "bucket_sort_kernel"};
 
 struct ProfRec { int cat; hipEvent_t a, b; int64_t elems, bytes; };
 
@@ -210,6 +211,7 @@ struct Workspace {
     uint8_t *text;
     uint64_t *K0, *K1;
     IdxT *Va, *Vb, *ISA, *SAbuf;
+    int64_t *bkt_bounds;        // tile bounds of the bucketed round 0 (dq_bucket_sort.h)
     int64_t *totals;            // [0] active count, [1] sticky look-back timeout flag
     SmallGroupCounters *sg_ctr; // one per chained small-group round
     uint32_t *hist_partial;     // [kHistBlocks][8][256]
@@ -238,6 +240,7 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.Vb = (IdxT *)take((un + 2) * sizeof(IdxT));
     w.ISA = (IdxT *)take(un * sizeof(IdxT));
     w.SAbuf = with_sa ? (IdxT *)take(un * sizeof(IdxT)) : nullptr;
+    w.bkt_bounds = (int64_t *)take((un / 4096 + 4) * 8);
     w.totals = (int64_t *)take(64);
     w.sg_ctr = (SmallGroupCounters *)take(kSgChain * sizeof(SmallGroupCounters));
     w.hist_partial = (uint32_t *)take((size_t)kHistBlocks * kMaxPasses * kRadixSize * 4);
@@ -287,7 +290,8 @@ int prepare_status(Launcher &L, Workspace<IdxT> &w, int64_t m, int passes)
 template <typename IdxT, typename StatusT, int kMode>
 int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin,
                      uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb, int ib,
-                     uint32_t *ebits = nullptr, uint64_t *seam_tab = nullptr, int shift_override = -1)
+                     uint32_t *ebits = nullptr, uint64_t *seam_tab = nullptr, int shift_override = -1,
+                     int keybits = 0)
 {
     using Cfg = RankCfg<IdxT, kMode>;
     constexpr int kItems = Cfg::kItems;
@@ -310,7 +314,8 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
            hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, kItems, kMode, Cfg::kMinWaves, kThreads,
                                                  false, Cfg::kLdsMatch, Cfg::kRounds>),
                               dim3((unsigned)ntiles), dim3(kThreads), 0, L.st, kin, vin, kout, vout, m,
-                              shift_override >= 0 ? shift_override : pass * kRadixBits + ib, kb, ib,
+                              shift_override >= 0 ? shift_override : pass * kRadixBits + ib,
+                              keybits > 0 ? keybits : 8 * kb, ib,
                               (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1,
                               ebits, seam_tab));
     return DQ_OK;
@@ -319,13 +324,13 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
 template <typename IdxT, int kMode>
 int rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin, uint64_t *kout,
               IdxT *vout, int64_t m, int pass, int kb, int ib = 0, uint32_t *ebits = nullptr,
-              uint64_t *seam_tab = nullptr, int shift_override = -1)
+              uint64_t *seam_tab = nullptr, int shift_override = -1, int keybits = 0)
 {
     if (m < (1ll << 30))
         return launch_rank_pass<IdxT, uint32_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits, seam_tab,
-                                                       shift_override);
+                                                       shift_override, keybits);
     return launch_rank_pass<IdxT, uint64_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits, seam_tab,
-                                                   shift_override);
+                                                   shift_override, keybits);
 }
 
 template <int kPasses>
@@ -486,7 +491,8 @@ int onesweep_sort_text_passes(Launcher &L, Workspace<IdxT> &w, int64_t n, uint64
 template <typename IdxT>
 int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int kb, int ib, uint32_t *ebits,
                  const uint64_t *seam_tab, const IdxT *d_sa, uint64_t *act_rank, IdxT *act_suf, int64_t *count,
-                 bool *overflow, int64_t fin_cap, uint64_t *fin_rank, IdxT *fin_suf, int64_t *fin_left)
+                 bool *overflow, int64_t fin_cap, uint64_t *fin_rank, IdxT *fin_suf, int64_t *fin_left,
+                 bool seams = true, int64_t h_fin = -1)
 {
     using Cfg = RankCfg<IdxT, kKeysLastTies>;
     const int64_t ntiles = (n + Cfg::kThreads * Cfg::kItems - 1) / (Cfg::kThreads * Cfg::kItems);
@@ -496,9 +502,11 @@ int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int k
     const int64_t nwords = (n + 63) / 64;
     TieCounters *ctr = reinterpret_cast<TieCounters *>(w.totals + 6);
     const int64_t wb = (int64_t)sizeof(IdxT);
-    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(TieCounters), L.st));
+    // (without seams the producer -- bucket_sort_kernel -- has already used ctr->overflow: zeroed by the caller)
+    if (seams) HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(TieCounters), L.st));
     const unsigned sg = (unsigned)((ntiles * kRadixSize + kBlock - 1) / kBlock);
-    if (n < (1ll << 30)) {
+    if (!seams) {
+    } else if (n < (1ll << 30)) {
         LAUNCH(L, DQ_K_TIE_SEAM, ntiles * kRadixSize, ntiles * kRadixSize * (16 + (int64_t)sizeof(uint64_t)),
                hipLaunchKernelGGL(tie_seam_kernel<uint32_t>, dim3(sg), dim3(kBlock), 0, L.st, seam_tab, ntiles, ib, dofs,
                                   reinterpret_cast<const uint32_t *>(area + 256), ebits));
@@ -520,7 +528,7 @@ int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int k
                hipLaunchKernelGGL((small_group_finish_kernel<IdxT, 8, 32>),
                                   dim3((unsigned)std::min<int64_t>((fin_cap + kFinishThreads - 1) / kFinishThreads, 256 * 16)),
                                   dim3(kFinishThreads), 0, L.st, (const uint64_t *)act_rank, (const IdxT *)act_suf, (const uint8_t *)w.text,
-                                  fin_cap, n, (int64_t)kb, const_cast<IdxT *>(d_sa), fin_rank, fin_suf, left_over,
+                                  fin_cap, n, h_fin >= 0 ? h_fin : (int64_t)kb, const_cast<IdxT *>(d_sa), fin_rank, fin_suf, left_over,
                                   (const unsigned long long *)&ctr->count));
     }
     HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 64, hipMemcpyDeviceToHost, L.st));     // [1] sticky flag, [3] leftovers, [6..7] counters
@@ -677,6 +685,93 @@ struct SuffixSorter {
         return DQ_OK;
     }
 
+    // ---- bucketed round 0 (see dq_bucket_sort.h).  *done = false: the path does not apply, or it met a
+    //      bucket / bin it does not take (the state the plain passes expect has then been restored).
+    int round0_bucketed(uint64_t *K[2], int kb, bool *done)
+    {
+        *done = false;
+        const int ib = bit_length((uint64_t)(n - 1));
+        if (getenv("DQ_NO_BUCKET") || getenv("DQ_NO_FUSED_TIES") || getenv("DQ_SPARSE") || getenv("DQ_KEY_BYTES")) return DQ_OK;
+        const bool forced = getenv("DQ_BUCKET") != nullptr;
+        if (ib > 31 || 64 - ib < 18 || n < (1 << 16)) return DQ_OK;          // a suffix must fit 31 bits next to the tie flag
+        // longest 2-byte bucket expected under an order-0 model of the text (c.pinned still holds the histogram)
+        int64_t cmax = 0;
+        for (int b = 0; b < 256; ++b) cmax = std::max(cmax, c.pinned[b]);
+        const double pm = (double)cmax / (double)n;
+        const double est = (double)n * pm * pm;
+        const double need = est + 6.0 * std::sqrt(est) + 64.0;
+        int64_t X;
+        if (need <= 1536) X = 1536;
+        else if (need <= 5120) X = 5120;
+        else if (forced) X = 5120;
+        else return DQ_OK;
+        if (!forced && n < (1 << 22)) return DQ_OK;                            // (launch-bound sizes gain nothing)
+        const int64_t C = kBktCap - X;
+        const int keybits = std::min(64 - ib, 36);
+        const int lowbits = keybits - 16;
+        const int64_t ntiles = (n + C - 1) / C;
+        uint32_t *ebits = reinterpret_cast<uint32_t *>(w.Vb);                  // zeroed by onesweep_sort_text_prepare
+        TieCounters *ctr = reinterpret_cast<TieCounters *>(w.totals + 6);     // zero since run()
+        BucketFlags *flags = reinterpret_cast<BucketFlags *>(&ctr->overflow);
+        const uint64_t *text64 = reinterpret_cast<const uint64_t *>(w.text);
+        // digit p of the 2-byte bucket of suffix i is T[i + 1 - p]
+        hipLaunchKernelGGL(text_digit_offsets_kernel, dim3(2), dim3(kBlock), 0, st,
+                           (const int64_t *)w.bytehist, (const uint8_t *)w.text, n, 2, w.digit_offset);
+        HIP_TRY(hipGetLastError());
+        int rc = rank_pass<IdxT, kTextPacked>(L, w, text64, (const IdxT *)nullptr, K[1], (IdxT *)nullptr, n, 0, kb, ib,
+                                             nullptr, nullptr, ib + lowbits, keybits);
+        if (rc != DQ_OK) return rc;
+        rc = rank_pass<IdxT, kKeys>(L, w, K[1], (const IdxT *)nullptr, K[0], (IdxT *)nullptr, n, 1, kb, ib, nullptr, nullptr,
+                                    ib + lowbits + 8, keybits);
+        if (rc != DQ_OK) return rc;
+        LAUNCH(L, DQ_K_BUCKET_SORT, ntiles, ntiles * 16 * 8,
+               hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)((ntiles + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                                  st, (const uint64_t *)K[0], n, ib + lowbits, C, X, ntiles, w.bkt_bounds, flags));
+        // (geometry experiments: DQ_BKT_GEOM = 0: 1024 x 12, 2 workgroups/CU; 1: 1024 x 12, 1/CU; 2: 512 x 24, 2/CU)
+        const int geom = getenv("DQ_BKT_GEOM") ? atoi(getenv("DQ_BKT_GEOM")) : 1;
+        if (geom == 1) {
+            LAUNCH(L, DQ_K_BUCKET_SORT, n, n * (8 + wb) + n / 8,
+                   hipLaunchKernelGGL((bucket_sort_kernel<IdxT, 1024, 12, 4>), dim3((unsigned)ntiles), dim3(1024), 0, st,
+                                      (const uint64_t *)K[0], ib, lowbits, (const int64_t *)w.bkt_bounds, d_sa, ebits, flags));
+        } else if (geom == 2) {
+            LAUNCH(L, DQ_K_BUCKET_SORT, n, n * (8 + wb) + n / 8,
+                   hipLaunchKernelGGL((bucket_sort_kernel<IdxT, 512, 24, 4>), dim3((unsigned)ntiles), dim3(512), 0, st,
+                                      (const uint64_t *)K[0], ib, lowbits, (const int64_t *)w.bkt_bounds, d_sa, ebits, flags));
+        } else {
+            LAUNCH(L, DQ_K_BUCKET_SORT, n, n * (8 + wb) + n / 8,
+                   hipLaunchKernelGGL((bucket_sort_kernel<IdxT, 1024, 12, 8>), dim3((unsigned)ntiles), dim3(1024), 0, st,
+                                      (const uint64_t *)K[0], ib, lowbits, (const int64_t *)w.bkt_bounds, d_sa, ebits, flags));
+        }
+        bool overflow = false;
+        fin_cap = n / 8;
+        const int64_t hb = keybits / 8;                  // whole bytes the members of a tie group share
+        rc = collect_ties<IdxT>(L, c, w, n, kb, ib, ebits, nullptr, (const IdxT *)d_sa, K[1], w.Va, &m, &overflow,
+                                fin_cap, K[0], w.Vb, &fin_left, /*seams=*/false, hb);
+        if (rc != DQ_OK) return rc;
+        if (overflow) {
+            // a bucket or a bin this path does not take (or a run of equal keys too long for the tie walk):
+            // back to the plain digit passes, with the state they expect
+            if (getenv("DQ_TRACE")) fprintf(stderr, "[dq] bucketed round 0 gave up (n=%lld): plain digit passes\n", (long long)n);
+            rc = prepare_status<IdxT>(L, w, n, kMaxPasses);
+            if (rc != DQ_OK) return rc;
+            HIP_TRY(hipMemsetAsync(w.Vb, 0, (size_t)((n + 63) / 64 + 1) * 8, st));
+            HIP_TRY(hipMemsetAsync(w.totals, 0, 64, st));
+            hipLaunchKernelGGL(text_digit_offsets_kernel, dim3(kb), dim3(kBlock), 0, st,
+                               (const int64_t *)w.bytehist, (const uint8_t *)w.text, n, kb, w.digit_offset);
+            HIP_TRY(hipGetLastError());
+            m = 0; fin_cap = 0; fin_left = 0;
+            return DQ_OK;
+        }
+        fin_done = m <= fin_cap;
+        Kr[0] = K[1]; Kr[1] = K[0];
+        Vr[0] = w.Va; Vr[1] = w.Vb;
+        rcur = 0;
+        h = hb;
+        rbits = ib;
+        *done = true;
+        return DQ_OK;
+    }
+
     // ---- round 0: leading kb bytes of every suffix as a key (or packed word), full radix ranking,
     //      then the first rebucket: X = members of groups of size > 1.  *dense_built tells whether
     //      the rebucket pass already wrote the inverse suffix array.
@@ -692,6 +787,14 @@ struct SuffixSorter {
         if (rc != DQ_OK) return rc;
         V[kb & 1] = d_sa;
         V[(kb & 1) ^ 1] = w.Va;
+        // Random-like input (packed words = few ties expected) of a size whose 2-byte buckets fit a workgroup's
+        // LDS: two digit passes on the top 16 key bits, then every bucket is finished in LDS (dq_bucket_sort.h).
+        if (packed) {
+            bool done = false;
+            rc = round0_bucketed(K, kb, &done);
+            if (rc != DQ_OK) return rc;
+            if (done) { *dense_built = false; return DQ_OK; }
+        }
         // Packed words were chosen because few ties are expected: the last pass then records the tie
         // structure itself (1 bit per suffix + 2 words per tile and digit, in the idle Vb buffer)
         // instead of writing the sorted words for a rebucket pass to read back.

@@ -97,7 +97,8 @@ void dq_sufsort_hip_release(void);
 #define DQ_K_GATHER_TEXT_KEY     12   /* gather_text_key_kernel: (rank, next bytes of text) keys                    */
 #define DQ_K_ISA_FROM_SA         13   /* isa_from_sa_kernel + isa_scatter_kernel: ISA for the switch to doubling    */
 #define DQ_K_SMALL_SORT          14   /* small_sufsort_kernel: a whole short text (n <= 8192) in one workgroup      */
-#define DQ_K_COUNT               15
+#define DQ_K_BUCKET_SORT         15   /* bucket_sort_kernel (+ bucket_bounds_kernel): buckets finished in LDS, 8+w+1/8  */
+#define DQ_K_COUNT               16
 
 /* 0 off, 1 every kernel, 2 only radix_rank_kernel, 100 + c only category c (cheapest: the timed region) */
 int32_t dq_profile_enable(int32_t on);

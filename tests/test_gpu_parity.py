@@ -151,6 +151,45 @@ def test_tie_bits_of_the_last_pass(ldss, oracle_mod, backend_lib):
     assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
 
 
+def test_bucketed_round0(ldss, oracle_mod, backend_lib, monkeypatch):
+    """dq_bucket_sort.h: two digit passes on the top 16 key bits, then every bucket finished in LDS.  Taken by
+    random-like inputs of >= 4 MiB on its own; forced here on small and on unsuitable inputs, where tiles
+    spanning too many buckets, over-long buckets and over-full bins must fall back to the plain passes."""
+    import ctypes
+    rnd = oracle_mod.gen_uniform
+
+    def bucket_launches(T):
+        backend_lib.dq_profile_reset()
+        backend_lib.dq_profile_enable(1)
+        sa = ldss.Sort(T)
+        backend_lib.dq_profile_enable(0)
+        n = ctypes.c_int64()
+        backend_lib.dq_profile_get(15, ctypes.byref(n), None, None, None)        # DQ_K_BUCKET_SORT
+        assert np.array_equal(sa, oracle_mod.divsufsort(T))
+        return n.value
+
+    assert bucket_launches(rnd(5_000_000, 1)) == 2                      # bounds + sort kernel
+    assert bucket_launches(rnd((9 << 20) + 13, 2)) == 2
+    T = rnd(8_000_000, 9)
+    T[::7] = 0                                                          # skewed: the order-0 model says no
+    assert bucket_launches(T) == 0
+    monkeypatch.setenv("DQ_BUCKET", "1")
+    for n in (70_000, 300_001, 1 << 20, 3_000_000):
+        assert bucket_launches(rnd(n, n)) == 2
+    cases = {
+        "6-bit alphabet": rnd(2_000_000, 5) & 0x3F,
+        "run of 60000 x 0x41": np.concatenate([rnd(1_000_000, 24), np.full(60_000, 0x41, np.uint8), rnd(5_000_000, 25)]),
+        "repeat + zero tail": np.concatenate([rnd(3_000_000, 26), rnd(3_000_000, 26)[1000:6000], np.zeros(9, np.uint8)]),
+        "all zeros": np.zeros(200_000, np.uint8),
+        "two symbols": rnd(1_000_000, 3) & 1,
+    }
+    for name, T in cases.items():
+        T = np.ascontiguousarray(T, dtype=np.uint8)
+        assert np.array_equal(ldss.Sort(T), oracle_mod.divsufsort(T)), name
+    T = rnd(4_000_001, 77)
+    assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
+
+
 def structured_text(rng, n):
     """Random text with the structure suffix sorters are sensitive to: a random alphabet size, runs of
     one byte, copies of earlier pieces (long repeats), periodic stretches and zero tails."""
@@ -188,6 +227,7 @@ FUZZ_ENVS = [
     {"DQ_SPARSE": "1", "DQ_SMALL_N": "0"},                 # finisher + key extension + fallback on dense inputs
     {"DQ_NO_BINNED_ISA": "1", "DQ_NO_CHAIN": "1"},         # first ISA by scatter, one host round trip per small-group round
     {"DQ_FORCE_RSHIFT": "1", "DQ_SMALL_N": "0"},           # composite keys carry rank >> 1, true rank read from the ISA (n near 2^32)
+    {"DQ_BUCKET": "1", "DQ_SMALL_N": "0"},                 # bucketed round 0 wherever packed words are chosen (+ its fallbacks)
 ]
 
 
