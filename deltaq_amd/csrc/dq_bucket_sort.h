@@ -62,149 +62,230 @@ __global__ __launch_bounds__(kBlock) void bucket_bounds_kernel(const uint64_t *_
     bounds[t] = lo;
 }
 
-// Geometry: kBktThreads x kBktItems = kBktCap; kMinWaves waves per SIMD are asked for (two workgroups per CU:
-// 73.8 KB of LDS each).
-template <typename IdxT, int kBktThreads, int kBktItems, int kMinWaves>
-__global__ __launch_bounds__(kBktThreads, kMinWaves) void bucket_sort_kernel(
-    const uint64_t *__restrict__ W, int ib, int lowbits, const int64_t *__restrict__ bounds,
+// bucket_sort_kernel: 1024 threads x 12 words; ONE persistent workgroup per CU (key buffer + bin table +
+// suffixes = 144 KB of LDS) that walks over tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The words of the workgroup's
+// NEXT tile are requested as soon as the current tile's words have left the load registers and stay in
+// flight while the current tile is sorted (plain global loads: barriers do not drain them), so a tile does
+// not wait for HBM -- as long as nothing in the loop spills: a scratch reload waits for every older load.
+// Hence one register per element from load to store:  key << 6 | arrival number in the bin  -- unique inside
+// the tile, so the place of an element in its bin is simply the number of smaller members; the suffixes wait
+// in LDS.  What bounds the kernel (tools/kbench/bsort.hip stamps the phases): LDS accesses that hit random
+// banks -- the bin count atomics, the bin starts, the walk over the bin and the two scatters cost ~7 cycles
+// per wave access instead of 2 -- about 30 000 cycles per 12 288-word tile.
+constexpr int kBktThreads = 1024;
+constexpr int kBktItems = kBktCap / kBktThreads;
+constexpr int kBktNB = 24576;                              // bins: load factor <= 1/2
+constexpr int kBktArrBits = 6;                             // arrival numbers < 64 (kBktMaxBin = 48)
+constexpr int kBktWalk = 4;                                // bin members inspected without a branch
+static_assert(kBktMaxBin < (1 << kBktArrBits), "arrival numbers must fit");
+
+// developer instrumentation (tools/kbench/bsort.hip): per-tile phase timestamps from thread 0
+#ifdef DQ_BKT_PHASE_TIMING
+__device__ long long *g_bkt_ts = nullptr;            // [ntiles][16]
+#define DQ_BKT_PHASE(i) do { if (threadIdx.x == 0 && g_bkt_ts) g_bkt_ts[(long long)tile * 16 + (i)] = clock64(); } while (0)
+#else
+#define DQ_BKT_PHASE(i) do { } while (0)
+#endif
+
+template <typename IdxT>
+__global__ __launch_bounds__(kBktThreads, 4) void bucket_sort_kernel(
+    const uint64_t *__restrict__ W, int ib, int lowbits, const int64_t *__restrict__ bounds, int64_t ntiles,
     IdxT *__restrict__ SA, uint32_t *__restrict__ ebits, BucketFlags *__restrict__ flags)
 {
-    static_assert(kBktThreads * kBktItems == kBktCap, "one tile per workgroup");
-    constexpr int kBktBinsPerThread = kBktBins / kBktThreads;
-    __shared__ uint32_t buf[kBktCap];                       // keys in bin order, then suffixes in sorted order
-    __shared__ uint32_t bins[kBktBins / 2];                 // two 16-bit counters per word: counts, then starts
+    constexpr int kBinsPerThread = kBktNB / kBktThreads;   // 24 sixteen-bit counters = 12 LDS words
+    constexpr int kWords = kBinsPerThread / 2;
+    __shared__ uint32_t buf[kBktCap + kBktWalk];            // unique keys in bin order, then suffixes in sorted order
+    __shared__ uint32_t bins[kBktNB / 2 + 2];               // two 16-bit counters per word: counts, then starts
+    __shared__ uint32_t sufs[kBktCap];                      // the tile's suffixes in load order (registers are scarce)
     __shared__ uint32_t wtot[kBktThreads / kWave];
+    __shared__ uint64_t s_edge[2];                          // first and last word of the tile
     __shared__ uint32_t s_overflow;
 
-    const int tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     const int lane = lane_id();
-    const int wv = tid >> 6;
-    const int64_t lo = bounds[blockIdx.x];
-    const int M = (int)(bounds[blockIdx.x + 1] - lo);
-    if (M <= 0) return;
-    if (M > kBktCap) { if (tid == 0) atomicExch(&flags->overflow, 1ull); return; }   // (bounds kernel flagged it too)
-
-    // ---- the tile's key range (uniform over the workgroup) ----
+    const uint32_t wv = tid >> 6;
     const int bshift = ib + lowbits;
-    const uint64_t kfirst = W[lo] >> bshift, klast = W[lo + M - 1] >> bshift;
-    const uint64_t range = (klast - kfirst + 1) << lowbits;                // tile keys are < range
-    // (range > kBktBins keeps the multiplier below 2^32; lowbits >= 14 guarantees it)
-    if (klast - kfirst >= 4096 || range > (1ull << 32) || range <= (uint64_t)kBktBins) {
-        if (tid == 0) atomicExch(&flags->overflow, 1ull);
-        return;
-    }
-    const uint32_t mult = (uint32_t)(((uint64_t)kBktBins << 32) / range);  // bin = key * mult >> 32 < kBktBins
-    const uint64_t kbase = kfirst << lowbits;
     const uint32_t imask = (uint32_t)((1ull << ib) - 1);
+    const uint16_t *start16 = reinterpret_cast<const uint16_t *>(bins);
 
-    for (int i = tid; i < kBktBins / 2; i += kBktThreads) bins[i] = 0;
-    if (tid == 0) s_overflow = 0;
+    int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    // (lo, M) of the tile whose words are being fetched; M > capacity has been flagged by the bounds kernel
+    int64_t lo_n = bounds[tile];
+    uint32_t M_n = (uint32_t)(bounds[tile + 1] - lo_n);
+    if (M_n > (uint32_t)kBktCap) M_n = 0;
+    uint64_t wd[kBktItems];
+    // Clamped, not predicated: the loads stay in flight together.  (And every array element is always assigned
+    // unconditionally: a conditional element write turns the register array into one wide phi that the
+    // allocator spills.)
+#define DQ_BKT_FETCH()                                                            \
+    do {                                                                          \
+        const uint64_t *Wn = W + (M_n ? lo_n : 0);   /* (an empty tile may start at n) */ \
+        const uint32_t last_ = M_n > 0 ? M_n - 1 : 0;                             \
+        _Pragma("unroll") for (int k = 0; k < kBktItems; ++k) {                   \
+            const uint32_t e_ = (uint32_t)(k * kBktThreads) + tid;                \
+            wd[k] = Wn[e_ < last_ ? e_ : last_];                                  \
+        }                                                                         \
+    } while (0)
+    DQ_BKT_FETCH();
 
-    // ---- load; element e = k * kBktThreads + tid of the tile: tile-relative key and suffix, 32 bits each ----
-    uint32_t key[kBktItems], idx[kBktItems];
-#pragma unroll
-    for (int k = 0; k < kBktItems; ++k) {
-        const int e = k * kBktThreads + tid;
-        const uint64_t wd = W[lo + (e < M ? e : M - 1)];          // (clamped, not predicated: the loads stay in flight together)
-        key[k] = (uint32_t)((wd >> ib) - kbase);
-        idx[k] = (uint32_t)wd & imask;
-    }
-    __syncthreads();
-
-    // ---- bin counts; the returned old count is the element's arrival number inside its bin ----
-    uint32_t slot[kBktItems];
-#pragma unroll
-    for (int k = 0; k < kBktItems; ++k) {
-        // (every array element is assigned unconditionally: a conditional element write turns the whole
-        // register array into one wide phi and the allocator spills it)
-        const int e = k * kBktThreads + tid;
-        const uint32_t bin = __umulhi(key[k], mult);
-        const uint32_t sh = (bin & 1u) * 16u;
-        uint32_t old = 0;
-        if (e < M) old = atomicAdd(&bins[bin >> 1], 1u << sh);
-        slot[k] = (old >> sh) & 0xffffu;
-    }
-    __syncthreads();
-
-    // ---- exclusive scan of the bin counts: thread t owns kBktBinsPerThread consecutive bins ----
-    {
-        constexpr int kWords = kBktBinsPerThread / 2;
-        uint32_t sum = 0, mx = 0;
-#pragma unroll
-        for (int i = 0; i < kWords; ++i) {
-            const uint32_t c = bins[tid * kWords + i];
-            const uint32_t a = c & 0xffffu, b = c >> 16;
-            sum += a + b;
-            mx = a > mx ? a : mx;
-            mx = b > mx ? b : mx;
-        }
-        if (mx > (uint32_t)kBktMaxBin) s_overflow = 1;
-        const uint32_t incl = wave_incl_sum(sum);
-        if (lane == kWave - 1) wtot[wv] = incl;
+    for (;;) {
+        const int64_t lo = lo_n;
+        const uint32_t M = M_n;
+        DQ_BKT_PHASE(0);
+        // ---- this tile's words leave the fetch registers: key (relative to the tile's first bucket) and suffix ----
+        if (tid == 0) { s_edge[0] = wd[0]; s_overflow = 0; }
+        if (tid == kBktThreads - 1) s_edge[1] = wd[kBktItems - 1];          // (clamped loads: element M-1)
+        for (uint32_t i = tid; i < (uint32_t)(kBktNB / 2 + 2); i += kBktThreads) bins[i] = 0;
         __syncthreads();
-        uint32_t run = incl - sum;
+        DQ_BKT_PHASE(1);
+        const uint64_t kfirst = s_edge[0] >> bshift, klast = s_edge[1] >> bshift;
+        const uint64_t range = (klast - kfirst + 1) << lowbits;            // tile keys are < range
+        // range << 6 must fit 32 bits; range > bins keeps the multiplier below 2^32 (lowbits >= 15 guarantees it)
+        const bool bad = M != 0 && (range > (1ull << (32 - kBktArrBits)) || range <= (uint64_t)kBktNB);
+        // bin = key * mult >> 32 < bins: mult <= bins * 2^32 / range.  (A float reciprocal is within 2^-22 of the
+        // exact quotient; the factor 1 - 2^-20 keeps the product below it.  Any positive multiplier is monotone.)
+        const uint32_t mult = (bad || M == 0) ? 0u
+            : (uint32_t)((float)kBktNB * 4294967296.0f * __frcp_rn((float)range) * (1.0f - 0x1p-20f));
+        const uint64_t kbase = kfirst << lowbits;
+        uint32_t key[kBktItems];
 #pragma unroll
-        for (int i = 0; i < kBktThreads / kWave; ++i) if (i < wv) run += wtot[i];
-#pragma unroll
-        for (int i = 0; i < kWords; ++i) {
-            const uint32_t c = bins[tid * kWords + i];
-            const uint32_t a = c & 0xffffu, b = c >> 16;
-            bins[tid * kWords + i] = run | ((run + a) << 16);      // starts (<= 12288: 16 bits)
-            run += a + b;
+        for (int k = 0; k < kBktItems; ++k) {
+            key[k] = (uint32_t)((wd[k] >> ib) - kbase);
+            sufs[k * kBktThreads + tid] = (uint32_t)wd[k] & imask;          // read back by this same thread
         }
-    }
-    __syncthreads();
-    if (s_overflow) { if (tid == 0) atomicExch(&flags->overflow, 1ull); return; }
-
-    // ---- scatter the 32-bit keys into bin order ----
-    const uint16_t *start16 = reinterpret_cast<const uint16_t *>(bins);     // start of bin b (b < kBktBins)
+        // ---- request the next tile ----
+        const int64_t tn = tile + gridDim.x;
+        if (tn < ntiles) {
+            lo_n = bounds[tn];
+            M_n = (uint32_t)(bounds[tn + 1] - lo_n);
+            if (M_n > (uint32_t)kBktCap) M_n = 0;
+            DQ_BKT_FETCH();
+        }
+        if (bad) {
+            if (tid == 0) atomicExch(&flags->overflow, 1ull);
+        } else if (M != 0) {
+            // ---- bin counts; the returned old count (arrival number) makes the key unique ----
 #pragma unroll
-    for (int k = 0; k < kBktItems; ++k) {
-        const int e = k * kBktThreads + tid;
-        const uint32_t s = slot[k] + start16[__umulhi(key[k], mult)];
-        slot[k] = s;
-        if (e < M) buf[s] = key[k];
-    }
-    __syncthreads();
-
-    // ---- final place = bin start + members of my bin that precede me (smaller key, or equal key and
-    //      earlier slot); "an equal key precedes me" is the tie bit of my final position ----
-#pragma unroll
-    for (int k = 0; k < kBktItems; ++k) {
-        const int e = k * kBktThreads + tid;
-        uint32_t f = 0xffffffffu;
-        if (e < M) {
-            const uint32_t bin = __umulhi(key[k], mult);
-            const uint32_t s0 = start16[bin];
-            const uint32_t s1 = bin + 1 < (uint32_t)kBktBins ? (uint32_t)start16[bin + 1] : (uint32_t)M;
-            uint32_t r = s0, tie = 0;
-#pragma unroll 1
-            for (uint32_t j = s0; j < s1; ++j) {
-                const uint32_t o = buf[j];
-                const uint32_t eq_before = (o == key[k]) & (j < slot[k]);
-                r += (o < key[k]) | eq_before;
-                tie |= eq_before;
+            for (int k = 0; k < kBktItems; ++k) {
+                const uint32_t e = (uint32_t)(k * kBktThreads) + tid;
+                const uint32_t bin = __umulhi(key[k], mult);
+                const uint32_t sh = (bin & 1u) * 16u;
+                uint32_t old = 0;
+                if (e < M) old = atomicAdd(&bins[bin >> 1], 1u << sh);
+                key[k] = (key[k] << kBktArrBits) | ((old >> sh) & ((1u << kBktArrBits) - 1));
             }
-            f = r | (tie << 31);
-        }
-        slot[k] = f;                                        // final place (| tie flag), or ~0 for "no element"
-    }
-    __syncthreads();                                        // every key has been read: buf now takes the suffixes
+            __syncthreads();
+            DQ_BKT_PHASE(2);
+
+            // ---- exclusive scan of the bin counts: thread t owns kBinsPerThread consecutive bins ----
+            {
+                uint32_t c[kWords];
+                uint32_t sum = 0, mx = 0;
 #pragma unroll
-    for (int k = 0; k < kBktItems; ++k) {
-        if (slot[k] != 0xffffffffu) buf[slot[k] & 0x7fffffffu] = idx[k] | (slot[k] & 0x80000000u);
-    }
-    __syncthreads();
+                for (int i = 0; i < kWords; ++i) {
+                    c[i] = bins[tid * kWords + i];
+                    const uint32_t a = c[i] & 0xffffu, b = c[i] >> 16;
+                    sum += a + b;
+                    mx = a > mx ? a : mx;
+                    mx = b > mx ? b : mx;
+                }
+                if (mx > (uint32_t)kBktMaxBin) s_overflow = 1;
+                const uint32_t incl = wave_incl_sum_dpp(sum);               // (DPP: no lane-index registers kept across the loop)
+                if (lane == kWave - 1) wtot[wv] = incl;
+                __syncthreads();
+                uint32_t run = incl - sum;
 #pragma unroll
-    for (int k = 0; k < kBktItems; ++k) {
-        const int e = k * kBktThreads + tid;
-        if (e < M) {
-            const uint32_t v = buf[e];
-            const int64_t o = lo + e;
-            SA[o] = (IdxT)(v & 0x7fffffffu);                 // (n <= 2^31 on this path: a suffix fits 31 bits)
-            if (v >> 31) atomicOr(&ebits[(uint64_t)o >> 5], 1u << ((uint32_t)o & 31u));
+                for (int i = 0; i < kBktThreads / kWave; ++i) if (i < (int)wv) run += wtot[i];
+#pragma unroll
+                for (int i = 0; i < kWords; ++i) {
+                    const uint32_t a = c[i] & 0xffffu, b = c[i] >> 16;
+                    bins[tid * kWords + i] = run | ((run + a) << 16);      // starts (<= 12288: 16 bits)
+                    run += a + b;
+                }
+                if (tid == kBktThreads - 1) bins[kBktNB / 2] = run;         // start of the bin after the last: M
+            }
+            __syncthreads();
+            DQ_BKT_PHASE(3);
+            if (s_overflow) {                               // (uniform: written before the barrier above)
+                if (tid == 0) atomicExch(&flags->overflow, 1ull);
+            } else {
+                // ---- scatter the unique keys into bin order ----
+#pragma unroll
+                for (int k = 0; k < kBktItems; ++k) {
+                    const uint32_t e = (uint32_t)(k * kBktThreads) + tid;
+                    const uint32_t s = start16[__umulhi(key[k] >> kBktArrBits, mult)] + (key[k] & ((1u << kBktArrBits) - 1));
+                    if (e < M) buf[s] = key[k];
+                }
+                __syncthreads();
+                DQ_BKT_PHASE(4);
+
+                // ---- final place = bin start + smaller members of my bin; a member with my key and a smaller
+                //      arrival number makes the tie bit of my final position.  The first kBktWalk members are
+                //      read without a branch (a bin holds < 1/2 element on average); longer bins take the loop. ----
+                uint32_t fin[kBktItems];
+#pragma unroll
+                for (int k = 0; k < kBktItems; ++k) {
+                    const uint32_t e = (uint32_t)(k * kBktThreads) + tid;
+                    const uint32_t bin = __umulhi(key[k] >> kBktArrBits, mult);
+                    const uint32_t s0 = start16[bin], s1 = start16[bin + 1];
+                    uint32_t r = s0, tie = 0;
+#pragma unroll
+                    for (int q = 0; q < kBktWalk; ++q) {
+                        const uint32_t o = buf[s0 + q];                     // (buf has kBktWalk entries of slack)
+                        const uint32_t less = (s0 + q < s1) & (o < key[k]);
+                        r += less;
+                        tie |= less & ((o >> kBktArrBits) == (key[k] >> kBktArrBits));
+                    }
+                    if (s1 > s0 + kBktWalk) {
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+                        for (uint32_t j = s0 + kBktWalk; j < s1; ++j) {
+                            const uint32_t o = buf[j];
+                            const uint32_t less = o < key[k];
+                            r += less;
+                            tie |= less & ((o >> kBktArrBits) == (key[k] >> kBktArrBits));
+                        }
+                    }
+                    fin[k] = e < M ? (r | (tie << 31)) : 0xffffffffu;      // final place (| tie flag), or "no element"
+                }
+                __syncthreads();                            // every key has been read: buf now takes the suffixes
+                DQ_BKT_PHASE(5);
+#pragma unroll
+                for (int k = 0; k < kBktItems; ++k) {
+                    if (fin[k] != 0xffffffffu)
+                        buf[fin[k] & 0x7fffffffu] = sufs[k * kBktThreads + tid] | (fin[k] & 0x80000000u);
+                }
+                __syncthreads();
+                DQ_BKT_PHASE(6);
+                // ---- sorted suffixes out, coalesced; the few tie bits by atomic OR ----
+                IdxT *out = SA + lo;
+                uint32_t v[kBktItems];
+#pragma unroll
+                for (int k = 0; k < kBktItems; ++k) {
+                    const uint32_t e = (uint32_t)(k * kBktThreads) + tid;
+                    v[k] = buf[e < M ? e : 0];
+                }
+                uint32_t ties = 0;
+#pragma unroll
+                for (int k = 0; k < kBktItems; ++k) {
+                    const uint32_t e = (uint32_t)(k * kBktThreads) + tid;
+                    if (e < M) out[e] = (IdxT)(v[k] & 0x7fffffffu);         // (n <= 2^31 on this path: a suffix fits 31 bits)
+                    ties |= (e < M && (v[k] >> 31)) ? (1u << k) : 0u;
+                }
+                while (ties) {
+                    const int k = __builtin_ctz(ties);
+                    ties &= ties - 1;
+                    const uint64_t o = (uint64_t)(lo + k * kBktThreads + tid);
+                    atomicOr(&ebits[o >> 5], 1u << ((uint32_t)o & 31u));
+                }
+                DQ_BKT_PHASE(7);
+            }
         }
+        if (tn >= ntiles) break;
+        tile = tn;
+        __syncthreads();                                    // buf, bins and s_edge are reused
     }
+#undef DQ_BKT_FETCH
 }
 
 }  // namespace dq

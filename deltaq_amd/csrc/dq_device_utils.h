@@ -48,6 +48,20 @@ __device__ __forceinline__ T wave_incl_sum(T v)
     return v;
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP only (no lane-index registers, no LDS permute):
+// Hillis-Steele inside each row of 16 lanes (row_shr 1, 2, 4, 8, zeros shifted in), then lane 15 of rows
+// 0 / 2 added to rows 1 / 3 (row_bcast:15) and lane 31 to rows 2 and 3 (row_bcast:31).
+__device__ __forceinline__ uint32_t wave_incl_sum_dpp(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_incl_max(T v)
 {

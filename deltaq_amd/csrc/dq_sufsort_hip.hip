@@ -84,6 +84,7 @@ struct ProfRec { int cat; hipEvent_t a, b; int64_t elems, bytes; };
 struct DeviceCtx {
     std::mutex mu;
     int dev = -1;
+    int ncu = 0;                        // compute units of the device (grid of the persistent kernels)
     hipStream_t stream = nullptr;
     char *ws = nullptr;
     size_t ws_bytes = 0;
@@ -693,19 +694,21 @@ struct SuffixSorter {
         const int ib = bit_length((uint64_t)(n - 1));
         if (getenv("DQ_NO_BUCKET") || getenv("DQ_NO_FUSED_TIES") || getenv("DQ_SPARSE") || getenv("DQ_KEY_BYTES")) return DQ_OK;
         const bool forced = getenv("DQ_BUCKET") != nullptr;
-        if (ib > 31 || 64 - ib < 18 || n < (1 << 16)) return DQ_OK;          // a suffix must fit 31 bits next to the tie flag
+        if (ib > 31 || n < (1 << 16)) return DQ_OK;                          // (low bits = 36 - 16 or 33 - 16 >= 15)          // a suffix must fit 31 bits next to the tie flag
         // longest 2-byte bucket expected under an order-0 model of the text (c.pinned still holds the histogram)
         int64_t cmax = 0;
         for (int b = 0; b < 256; ++b) cmax = std::max(cmax, c.pinned[b]);
         const double pm = (double)cmax / (double)n;
         const double est = (double)n * pm * pm;
         const double need = est + 6.0 * std::sqrt(est) + 64.0;
-        int64_t X;
-        if (need <= 1536) X = 1536;
-        else if (need <= 5120) X = 5120;
-        else if (forced) X = 5120;
-        else return DQ_OK;
-        if (!forced && n < (1 << 22)) return DQ_OK;                            // (launch-bound sizes gain nothing)
+        int64_t X = ((int64_t)need + 255) / 256 * 256;                         // longest bucket the tiles are cut for
+        if (X > 5120) {
+            if (!forced) return DQ_OK;
+            X = 5120;
+        }
+        // a tile must not span more than 64 buckets (its keys, relative to its first bucket, take 26 bits + 6
+        // arrival bits): buckets of >= 192 words on average, i.e. texts of >= 12 MiB
+        if (!forced && n < (12 << 20)) return DQ_OK;
         const int64_t C = kBktCap - X;
         const int keybits = std::min(64 - ib, 36);
         const int lowbits = keybits - 16;
@@ -727,21 +730,14 @@ struct SuffixSorter {
         LAUNCH(L, DQ_K_BUCKET_SORT, ntiles, ntiles * 16 * 8,
                hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)((ntiles + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                                   st, (const uint64_t *)K[0], n, ib + lowbits, C, X, ntiles, w.bkt_bounds, flags));
-        // (geometry experiments: DQ_BKT_GEOM = 0: 1024 x 12, 2 workgroups/CU; 1: 1024 x 12, 1/CU; 2: 512 x 24, 2/CU)
-        const int geom = getenv("DQ_BKT_GEOM") ? atoi(getenv("DQ_BKT_GEOM")) : 1;
-        if (geom == 1) {
-            LAUNCH(L, DQ_K_BUCKET_SORT, n, n * (8 + wb) + n / 8,
-                   hipLaunchKernelGGL((bucket_sort_kernel<IdxT, 1024, 12, 4>), dim3((unsigned)ntiles), dim3(1024), 0, st,
-                                      (const uint64_t *)K[0], ib, lowbits, (const int64_t *)w.bkt_bounds, d_sa, ebits, flags));
-        } else if (geom == 2) {
-            LAUNCH(L, DQ_K_BUCKET_SORT, n, n * (8 + wb) + n / 8,
-                   hipLaunchKernelGGL((bucket_sort_kernel<IdxT, 512, 24, 4>), dim3((unsigned)ntiles), dim3(512), 0, st,
-                                      (const uint64_t *)K[0], ib, lowbits, (const int64_t *)w.bkt_bounds, d_sa, ebits, flags));
-        } else {
-            LAUNCH(L, DQ_K_BUCKET_SORT, n, n * (8 + wb) + n / 8,
-                   hipLaunchKernelGGL((bucket_sort_kernel<IdxT, 1024, 12, 8>), dim3((unsigned)ntiles), dim3(1024), 0, st,
-                                      (const uint64_t *)K[0], ib, lowbits, (const int64_t *)w.bkt_bounds, d_sa, ebits, flags));
+        if (c.ncu <= 0) {
+            int v = 0;
+            c.ncu = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c.dev) == hipSuccess && v > 0 ? v : 256;
         }
+        LAUNCH(L, DQ_K_BUCKET_SORT, n, n * (8 + wb) + n / 8,                  // persistent: one workgroup per CU
+               hipLaunchKernelGGL(bucket_sort_kernel<IdxT>, dim3((unsigned)std::min<int64_t>(ntiles, c.ncu)),
+                                  dim3(kBktThreads), 0, st, (const uint64_t *)K[0], ib, lowbits,
+                                  (const int64_t *)w.bkt_bounds, ntiles, d_sa, ebits, flags));
         bool overflow = false;
         fin_cap = n / 8;
         const int64_t hb = keybits / 8;                  // whole bytes the members of a tie group share

@@ -153,7 +153,7 @@ def test_tie_bits_of_the_last_pass(ldss, oracle_mod, backend_lib):
 
 def test_bucketed_round0(ldss, oracle_mod, backend_lib, monkeypatch):
     """dq_bucket_sort.h: two digit passes on the top 16 key bits, then every bucket finished in LDS.  Taken by
-    random-like inputs of >= 4 MiB on its own; forced here on small and on unsuitable inputs, where tiles
+    random-like inputs of >= 12 MiB on its own; forced here on small and on unsuitable inputs, where tiles
     spanning too many buckets, over-long buckets and over-full bins must fall back to the plain passes."""
     import ctypes
     rnd = oracle_mod.gen_uniform
@@ -168,9 +168,10 @@ def test_bucketed_round0(ldss, oracle_mod, backend_lib, monkeypatch):
         assert np.array_equal(sa, oracle_mod.divsufsort(T))
         return n.value
 
-    assert bucket_launches(rnd(5_000_000, 1)) == 2                      # bounds + sort kernel
-    assert bucket_launches(rnd((9 << 20) + 13, 2)) == 2
-    T = rnd(8_000_000, 9)
+    assert bucket_launches(rnd(13_000_000, 1)) == 2                     # bounds + sort kernel
+    assert bucket_launches(rnd((17 << 20) + 13, 2)) == 2
+    assert bucket_launches(rnd(5_000_000, 3)) == 0                      # too small: tiles would span too many buckets
+    T = rnd(16_000_000, 9)
     T[::7] = 0                                                          # skewed: the order-0 model says no
     assert bucket_launches(T) == 0
     monkeypatch.setenv("DQ_BUCKET", "1")
