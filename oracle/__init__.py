@@ -66,6 +66,8 @@ def lib() -> ctypes.CDLL:
             getattr(L, f"dq_oracle_sufcheck_{suf}").argtypes = [u8p, i64, u8p, i64]
             getattr(L, f"dq_oracle_sufcheck_mt_{suf}").restype = ctypes.c_int32
             getattr(L, f"dq_oracle_sufcheck_mt_{suf}").argtypes = [u8p, i64, u8p, i64, ctypes.c_int32]
+            getattr(L, f"dq_oracle_sais_{suf}").restype = ctypes.c_int32
+            getattr(L, f"dq_oracle_sais_{suf}").argtypes = [u8p, u8p, i64]
             if hasattr(L, f"dq_oracle_divsufsort_{suf}"):
                 getattr(L, f"dq_oracle_divsufsort_{suf}").restype = ctypes.c_int32
                 getattr(L, f"dq_oracle_divsufsort_{suf}").argtypes = [u8p, u8p, i64]
@@ -110,6 +112,16 @@ def divsufsort(text, dtype=np.int32) -> np.ndarray:
     rc = fn(_ptr(T), _ptr(sa), T.size)
     if rc != 0:
         raise RuntimeError(f"oracle divsufsort failed: {rc}")
+    return sa
+
+
+def sais(text, dtype=np.int32) -> np.ndarray:
+    """Restatement of SAIS.Sort(text) (SAIS.cs:14-41): the second, linear-time CPU implementation."""
+    T = _text(text)
+    sa = np.empty(T.size, dtype=dtype)
+    rc = getattr(lib(), f"dq_oracle_sais_{_suf(sa)}")(_ptr(T), _ptr(sa), T.size)
+    if rc != 0:
+        raise RuntimeError(f"oracle sais failed: {rc}")
     return sa
 
 

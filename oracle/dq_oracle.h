@@ -36,6 +36,12 @@ extern "C" {
 int32_t dq_oracle_divsufsort_i32(const uint8_t *T, int32_t *SA, int64_t n);
 int32_t dq_oracle_divsufsort_i64(const uint8_t *T, int64_t *SA, int64_t n);
 
+/* Restatement of the reference's second provider, SAIS (src/DeltaQ.SuffixSorting.SAIS/SAIS.cs): induced
+ * sorting, linear time.  Independent of the divsufsort restatement; the two must agree on every input.
+ * Returns 0 on success, -1 on bad arguments, -2 on allocation failure. */
+int32_t dq_oracle_sais_i32(const uint8_t *T, int32_t *SA, int64_t n);
+int32_t dq_oracle_sais_i64(const uint8_t *T, int64_t *SA, int64_t n);
+
 /* Per-phase wall time (seconds) of the last dq_oracle_divsufsort_* call on
  * this thread: [0] classify+bucket, [1] sssort, [2] trsort, [3] place B*,
  * [4] induce (construct_SA). */

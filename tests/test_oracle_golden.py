@@ -58,6 +58,52 @@ def test_divsufsort_restatement_on_reference_random_buffers(oracle_mod, golden, 
     assert np.array_equal(sa64, sa)
 
 
+@pytest.mark.parametrize("name", asset_names())
+def test_sais_restatement_on_reference_fixtures(oracle_mod, golden, name):
+    # SAISTests enumerates every file of test/assets (the two LibDivSufSortTests skips included)
+    T = load_asset(name)
+    sa = oracle_mod.sais(T)
+    oracle_mod.verify(T, sa)
+    assert sha_i32(sa) == golden["assets"][name]["sa_sha256_le_i32"]
+    assert np.array_equal(oracle_mod.sais(T, dtype=np.int64), sa)
+
+
+@pytest.mark.parametrize("size", [0, 1, 2, 4, 8, 16, 32, 51, 0x1000, 0x8000, 0x8000 - 1])
+def test_sais_restatement_on_reference_random_buffers(oracle_mod, golden, size):
+    T = oracle_mod.net_random_bytes(size)
+    sa = oracle_mod.sais(T)
+    assert sha_i32(sa) == golden["net_random_670761"][str(size)]["sa_sha256_le_i32"]
+
+
+def test_two_cpu_restatements_agree(oracle_mod):
+    """SAIS (induced sorting) and LibDivSufSort (B* sorting + induction) restated independently: any
+    translation slip in either shows up as a difference.  Known answers, random structured inputs, long
+    repeats (deep SAIS recursion), medium sizes."""
+    T = np.frombuffer("¯\\_(ツ)_/¯".encode("utf-8"), dtype=np.uint8)
+    assert oracle_mod.sais(T).tolist() == [4, 8, 10, 2, 3, 9, 6, 7, 12, 1, 11, 0, 5]
+    assert oracle_mod.sais(np.array([1, 2, 3, 4], dtype=np.uint8)).tolist() == [0, 1, 2, 3]
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        n = int(rng.integers(1, 3000))
+        sigma = int(rng.choice([1, 2, 3, 4, 16, 256]))
+        T = rng.integers(0, sigma, n, dtype=np.uint8)
+        if trial % 3 == 0:
+            T[-min(n, 9):] = 0
+        a = oracle_mod.sais(T)
+        assert np.array_equal(a, oracle_mod.naive_sa(T)), (trial, n, sigma)
+        assert np.array_equal(a, oracle_mod.divsufsort(T)), (trial, n, sigma)
+    a, b = b"a", b"ab"
+    while len(b) < 200_000:
+        a, b = b, b + a
+    cases = [np.frombuffer(b, dtype=np.uint8), np.zeros(100_000, np.uint8),
+             np.tile(oracle_mod.gen_uniform(1000, 9), 300),
+             oracle_mod.gen_uniform(1 << 21, 0x5EED0002), oracle_mod.gen_enwik_like(1 << 21, 0xD17A0, 64 * 1024)]
+    for T in cases:
+        sa = oracle_mod.sais(T)
+        assert np.array_equal(sa, oracle_mod.divsufsort(T))
+        assert oracle_mod.sufcheck(T, sa) == 0
+
+
 def test_divsufsort_matches_naive_on_pathological_inputs(oracle_mod):
     cases = []
     for n in (3, 7, 8, 9, 63, 64, 65, 1023, 1024, 1025, 5000):
