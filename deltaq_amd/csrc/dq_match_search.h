@@ -1,0 +1,173 @@
+// dq_match_search.h -- Diff.Create's match search on the device-resident suffix array.
+//
+// Reference: src/DeltaQ.BsDiff/Diff.cs:267-298  Search(I, oldData, newData[scan..], 0, oldData.Length, out pos)
+//            (CompareBytes :244-246 = SequenceCompareTo, MatchLength :248-265), called from the scan loop at :106.
+//
+// What Search returns is fixed by the text alone, not by its probe sequence: SequenceCompareTo is a total
+// order, so "suffix I[mid] < query" is monotone over the suffix array and the loop ends with
+//     start = max(g - 1, 0),  end = start + 1,     g = number of suffixes of old smaller than the query,
+// (I[n] is the zeroed sentinel slot of Diff.cs:78, i.e. suffix 0), and the answer is the longer of the two
+// match lengths, ties to `end`.  Any way of finding g is bit-exact; this kernel uses a lower-bound search
+// that skips the prefix both interval ends are known to share with the query (min(llcp, rlcp)), so a query
+// costs O(match length + log n) byte comparisons instead of O(match length * log n).
+//
+//   match_search_kernel   one query per lane.  Comparisons of up to kMsLaneBytes bytes beyond the known
+//                         common prefix are done by the lane itself (in the regions where old and new
+//                         differ -- where the scan loop calls Search at every byte -- nearly all are);
+//                         longer ones are handed to the whole wave, one at a time: 64 lanes x 8 bytes per
+//                         step, first mismatch by ballot.  Random access to the SA (w B per probe) and to
+//                         old (one 64-B sector per probe): latency-bound, ~log2(n) dependent probes.
+//   cap > 0               a query whose comparison runs more than `cap` bytes past the known prefix is given
+//                         up (len = -1): speculative batches inside a long match must not cost O(match
+//                         length) each; the caller repeats that one position with cap = 0.
+#pragma once
+#include "dq_device_utils.h"
+
+namespace dq {
+
+constexpr int kMsThreads = 256;
+constexpr int kMsLaneBytes = 24;
+
+__device__ __forceinline__ uint64_t ms_readlane64(uint64_t v, int lane)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+}
+
+// 8 bytes at p (any alignment) from three aligned dwords; every dword touched holds at least one of the 12
+// bytes p[0..11], which the caller guarantees to be inside the buffer
+__device__ __forceinline__ uint64_t ms_load8(const uint8_t *p)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Length of the common prefix of a[0..la) and b[0..lb), given that the first k bytes are equal.  Called by
+// the WHOLE wave with wave-uniform arguments.
+__device__ __forceinline__ int64_t ms_wave_lcp(const uint8_t *a, int64_t la, const uint8_t *b, int64_t lb, int64_t k)
+{
+    const int lane = lane_id();
+    const int64_t lim = la < lb ? la : lb;
+    // 512 bytes per step while 12 more bytes exist beyond every lane's 8
+    while (k + 64 * 8 + 4 <= lim) {
+        const int64_t j = k + 8 * lane;
+        const uint64_t x = ms_load8(a + j) ^ ms_load8(b + j);
+        const uint64_t bad = __ballot(x != 0);
+        if (bad) {
+            const int f = __builtin_ctzll(bad);
+            const uint64_t xf = ms_readlane64(x, f);
+            return k + 8 * f + (__builtin_ctzll(xf) >> 3);
+        }
+        k += 64 * 8;
+    }
+    // the rest byte by byte, 64 at a time
+    while (k < lim) {
+        const int64_t j = k + lane;
+        const bool diff = j < lim && a[j] != b[j];
+        const uint64_t bad = __ballot(diff);
+        if (bad) return k + __builtin_ctzll(bad);
+        k += 64;
+    }
+    return lim;
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(kMsThreads) void match_search_kernel(
+    const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa, const uint8_t *__restrict__ nw, int64_t m,
+    const int64_t *__restrict__ scans, int64_t scan0, int64_t count, int64_t cap, IdxT *__restrict__ pos_out,
+    IdxT *__restrict__ len_out)
+{
+    const int lane = lane_id();
+    const int64_t qi = (int64_t)blockIdx.x * kMsThreads + threadIdx.x;
+    const bool live = qi < count;
+    const int64_t scan = live ? (scans ? scans[qi] : scan0 + qi) : 0;
+    const uint8_t *q = nw + scan;
+    const int64_t lq = live ? m - scan : 0;
+
+    // lcp(query, suffix at old position p), given k equal leading bytes: per lane up to kMsLaneBytes, then
+    // the wave takes over.  Every lane of the wave calls this the same number of times (the search loops
+    // below are padded with idle rounds), so the hand-over loop always has all 64 lanes.
+    bool gave_up = false;
+    auto lcp_with = [&](int64_t p, int64_t k, bool want) -> int64_t {
+        const uint8_t *a = old + p;
+        const int64_t la = n - p;
+        const int64_t lim = la < lq ? la : lq;
+        int64_t j = k;
+        bool more = false;
+        if (want) {
+            const int64_t stop = j + kMsLaneBytes < lim ? j + kMsLaneBytes : lim;
+            while (j < stop && a[j] == q[j]) ++j;
+            more = j == stop && stop < lim;
+            if (more && cap > 0 && j - k >= cap) { gave_up = true; more = false; }
+        }
+        uint64_t need = __ballot(more);
+        while (need) {
+            const int f = __builtin_ctzll(need);
+            need &= need - 1;
+            const uint8_t *fa = reinterpret_cast<const uint8_t *>(ms_readlane64(reinterpret_cast<uint64_t>(a), f));
+            const uint8_t *fq = reinterpret_cast<const uint8_t *>(ms_readlane64(reinterpret_cast<uint64_t>(q), f));
+            const int64_t fla = (int64_t)ms_readlane64((uint64_t)la, f), flq = (int64_t)ms_readlane64((uint64_t)lq, f);
+            const int64_t fj = (int64_t)ms_readlane64((uint64_t)j, f);
+            int64_t lim2 = fla < flq ? fla : flq;
+            const int64_t fk = (int64_t)ms_readlane64((uint64_t)k, f);
+            bool capped = false;
+            if (cap > 0 && lim2 > fk + cap) { lim2 = fk + cap; capped = true; }       // (wave-uniform: cap is)
+            const int64_t r = ms_wave_lcp(fa, lim2, fq, lim2, fj);
+            if (lane == f) {
+                j = r;
+                if (capped && r == lim2) gave_up = true;
+            }
+        }
+        return j;
+    };
+    // suffix at p < query, from their lcp
+    auto less_than_query = [&](int64_t p, int64_t l) -> bool {
+        const int64_t la = n - p;
+        if (l == la || l == lq) return la < lq;                  // one is a prefix of the other: the shorter first
+        return old[p + l] < q[l];
+    };
+
+    // ---- g = number of suffixes smaller than the query: lower bound over [L, R) ----
+    int64_t L = 0, R = live ? n : 0;
+    int64_t llcp = 0, rlcp = 0;                                   // lcp with SA[L-1] / SA[R] once they have been probed
+    for (;;) {
+        const bool active = L < R && !gave_up;
+        if (!__any(active)) break;
+        int64_t mid = 0, p = 0;
+        if (active) {
+            mid = L + ((R - L) >> 1);
+            p = (int64_t)sa[mid];
+        }
+        const int64_t l = lcp_with(p, llcp < rlcp ? llcp : rlcp, active);
+        if (active && !gave_up) {
+            if (less_than_query(p, l)) { L = mid + 1; llcp = l; }
+            else { R = mid; rlcp = l; }
+        }
+    }
+    const int64_t g = L;
+
+    // ---- the two candidates: I[start], I[end] with start = max(g - 1, 0), end = start + 1, I[n] = 0 ----
+    const int64_t start = g > 0 ? g - 1 : 0, end = start + 1;
+    const bool usable = live && !gave_up && n > 0;
+    const int64_t ps = usable ? (int64_t)sa[start] : 0;
+    const int64_t pe = usable && end < n ? (int64_t)sa[end] : 0;
+    // x: lcp with I[start].  g >= 1: SA[g-1] was the last probe that moved L (llcp); g == 0: SA[0] = SA[R] (rlcp)
+    const int64_t x = g > 0 ? llcp : rlcp;
+    // y: lcp with I[end].  g >= 1 and g < n: SA[g] = SA[R] was probed (rlcp); otherwise it has to be measured
+    const bool y_known = g > 0 && g < n;
+    const int64_t y_meas = lcp_with(pe, 0, usable && !y_known);
+    const int64_t y = y_known ? rlcp : y_meas;
+    if (live) {
+        if (gave_up) { pos_out[qi] = (IdxT)0; len_out[qi] = (IdxT)-1; }
+        else if (n == 0) { pos_out[qi] = (IdxT)0; len_out[qi] = (IdxT)0; }        // I = { 0 }: both candidates are I[0]
+        else if (x > y) { pos_out[qi] = (IdxT)ps; len_out[qi] = (IdxT)x; }
+        else { pos_out[qi] = (IdxT)pe; len_out[qi] = (IdxT)y; }
+    }
+}
+
+}  // namespace dq

@@ -39,6 +39,7 @@
 #include "dq_ties.h"
 #include "dq_isa_pairs.h"
 #include "dq_bucket_sort.h"
+#include "dq_match_search.h"
 
 namespace {
 
@@ -76,7 +77,8 @@ const char *const kKernelNames[DQ_K_COUNT] = {
     "text_hist_kernel", "radix_hist_kernel", "radix_rank_kernel", "seg_fused_kernel",
     "tie_seam_kernel", "tie_collect_kernel", "small_group_finish_kernel", "small_group_round_kernel",
     "isa_update_kernel", "isa_from_pairs_kernel", "key2_from_pairs_kernel", "gather_key2_kernel",
-    "gather_text_key_kernel", "isa_from_sa_kernel", "small_sufsort_kernel", "bucket_sort_kernel"};
+    "gather_text_key_kernel", "isa_from_sa_kernel", "small_sufsort_kernel", "bucket_sort_kernel",
+    "match_search_kernel"};
 
 struct ProfRec { int cat; hipEvent_t a, b; int64_t elems, bytes; };
 
@@ -1234,6 +1236,81 @@ int sufsort_dev(const void *d_text, int64_t n, void *d_sa, int32_t device, void 
     return DQ_OK;
 }
 
+// ------------------------------------------------------------------ match search (Diff.cs:267-298) on the device
+template <typename IdxT>
+int match_search_dev(const void *d_old, int64_t n, const void *d_sa, const void *d_new, int64_t m,
+                     const int64_t *d_scans, int64_t scan0, int64_t count, int64_t cap, void *d_pos, void *d_len,
+                     int32_t device, void *stream)
+{
+    if (n < 0 || m < 0 || count < 0 || cap < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
+    if ((n > 0 && (!d_old || !d_sa)) || (m > 0 && !d_new) || (count > 0 && (!d_pos || !d_len)))
+        return fail(DQ_ERR_BAD_ARGS, "null buffer");
+    if (!d_scans && (scan0 < 0 || scan0 + count > m + 1)) return fail(DQ_ERR_BAD_ARGS, "scan range outside the new data");
+    if (sizeof(IdxT) == 4 && (n > 0x7fffffffLL || m > 0x7fffffffLL))
+        return fail(DQ_ERR_TOO_LARGE, "n or m exceeds 2^31-1; use the i64 entry point");
+    int dev = 0;
+    int rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    if (count == 0) return DQ_OK;
+    DeviceCtx &c = g_ctx[dev];
+    std::lock_guard<std::mutex> lk(c.mu);
+    rc = init_ctx(c, dev);
+    if (rc != DQ_OK) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+    Launcher L{c, st, g_prof_on.load()};
+    // per query: ~log2(n) probes of one SA entry and one 64-byte sector of old, + the match itself
+    const int64_t probes = bit_length((uint64_t)std::max<int64_t>(n, 1));
+    auto launch = [&]() -> int {
+        LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * probes * ((int64_t)sizeof(IdxT) + 64),
+               hipLaunchKernelGGL(match_search_kernel<IdxT>, dim3((unsigned)((count + kMsThreads - 1) / kMsThreads)),
+                                  dim3(kMsThreads), 0, st, (const uint8_t *)d_old, n, (const IdxT *)d_sa,
+                                  (const uint8_t *)d_new, m, d_scans, scan0, count, cap, (IdxT *)d_pos, (IdxT *)d_len));
+        return DQ_OK;
+    };
+    rc = launch();
+    if (rc != DQ_OK) { drop_pending(c, st); return rc; }
+    HIP_TRY(hipStreamSynchronize(st));
+    return flush_profile(c);
+}
+
+// host buffers in / out: what a P/Invoke caller without device memory of its own uses (and the tests)
+template <typename IdxT>
+int match_search_host(const uint8_t *old, int64_t n, const IdxT *sa, const uint8_t *nw, int64_t m, const int64_t *scans,
+                      int64_t scan0, int64_t count, int64_t cap, IdxT *pos, IdxT *len, int32_t device)
+{
+    if (n < 0 || m < 0 || count < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
+    if ((n > 0 && (!old || !sa)) || (m > 0 && !nw) || (count > 0 && (!pos || !len))) return fail(DQ_ERR_BAD_ARGS, "null buffer");
+    int dev = 0;
+    int rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    if (count == 0) return DQ_OK;
+    HIP_TRY(hipSetDevice(dev));
+    char *base = nullptr;
+    const size_t b_old = align_up((size_t)n + 16), b_sa = align_up((size_t)n * sizeof(IdxT) + 16), b_new = align_up((size_t)m + 16);
+    const size_t b_sc = scans ? align_up((size_t)count * 8) : 0, b_out = align_up((size_t)count * sizeof(IdxT));
+    hipError_t e = hipMalloc((void **)&base, b_old + b_sa + b_new + b_sc + 2 * b_out);
+    if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(match search buffers)", e);
+    char *d_old = base, *d_sa = d_old + b_old, *d_new = d_sa + b_sa, *d_sc = d_new + b_new, *d_pos = d_sc + b_sc,
+         *d_len = d_pos + b_out;
+    auto done = [&](int code) { (void)hipFree(base); return code; };
+    if (n > 0) {
+        if (hipMemcpy(d_old, old, (size_t)n, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_sa, sa, (size_t)n * sizeof(IdxT), hipMemcpyHostToDevice) != hipSuccess)
+            return done(fail(DQ_ERR_HIP, "match search: copy-in failed"));
+    }
+    if (m > 0 && hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice) != hipSuccess)
+        return done(fail(DQ_ERR_HIP, "match search: copy-in failed"));
+    if (scans && hipMemcpy(d_sc, scans, (size_t)count * 8, hipMemcpyHostToDevice) != hipSuccess)
+        return done(fail(DQ_ERR_HIP, "match search: copy-in failed"));
+    rc = match_search_dev<IdxT>(d_old, n, d_sa, d_new, m, scans ? (const int64_t *)d_sc : nullptr, scan0, count, cap, d_pos,
+                                d_len, dev, nullptr);
+    if (rc != DQ_OK) return done(rc);
+    if (hipMemcpy(pos, d_pos, (size_t)count * sizeof(IdxT), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(len, d_len, (size_t)count * sizeof(IdxT), hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(DQ_ERR_HIP, "match search: copy-out failed"));
+    return done(DQ_OK);
+}
+
 // ------------------------------------------------------------------ batch: one device's share, pipelined
 // Three stages on three host threads and three streams, kBatchSlots device buffers in flight:
 //   copy-in   text j -> slot          (pageable host memory: the copy blocks its thread, not the others)
@@ -1460,6 +1537,34 @@ int32_t dq_sufsort_hip_batch_i32(int32_t count, const uint8_t *const *texts, con
     } catch (const std::exception &e) {            // std::system_error from std::thread, ...
         return fail(DQ_ERR_HIP, e.what());
     }
+}
+
+int32_t dq_bsdiff_search_dev_i32(const void *d_old, int64_t n, const void *d_sa, const void *d_new, int64_t m,
+                                 const int64_t *d_scans, int64_t scan0, int64_t count, int64_t cap, void *d_pos,
+                                 void *d_len, int32_t device, void *stream)
+{
+    return match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, d_scans, scan0, count, cap, d_pos, d_len, device, stream);
+}
+
+int32_t dq_bsdiff_search_dev_i64(const void *d_old, int64_t n, const void *d_sa, const void *d_new, int64_t m,
+                                 const int64_t *d_scans, int64_t scan0, int64_t count, int64_t cap, void *d_pos,
+                                 void *d_len, int32_t device, void *stream)
+{
+    return match_search_dev<int64_t>(d_old, n, d_sa, d_new, m, d_scans, scan0, count, cap, d_pos, d_len, device, stream);
+}
+
+int32_t dq_bsdiff_search_i32(const uint8_t *old_data, int64_t n, const int32_t *sa, const uint8_t *new_data, int64_t m,
+                             const int64_t *scans, int64_t scan0, int64_t count, int64_t cap, int32_t *pos, int32_t *len,
+                             int32_t device)
+{
+    return match_search_host<int32_t>(old_data, n, sa, new_data, m, scans, scan0, count, cap, pos, len, device);
+}
+
+int32_t dq_bsdiff_search_i64(const uint8_t *old_data, int64_t n, const int64_t *sa, const uint8_t *new_data, int64_t m,
+                             const int64_t *scans, int64_t scan0, int64_t count, int64_t cap, int64_t *pos, int64_t *len,
+                             int32_t device)
+{
+    return match_search_host<int64_t>(old_data, n, sa, new_data, m, scans, scan0, count, cap, pos, len, device);
 }
 
 int64_t dq_sufsort_hip_workspace_bytes(int64_t n, int32_t index_bytes)

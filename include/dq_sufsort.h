@@ -70,6 +70,32 @@ int32_t dq_sufsort_hip_dev_i64(const void *d_text, int64_t n, void *d_sa, int32_
 int32_t dq_sufsort_hip_batch_i32(int32_t count, const uint8_t *const *texts, const int64_t *lens,
                                  int32_t *const *sas, int32_t ndev, const int32_t *devs);
 
+/* ---- Diff.Create's match search on the device-resident suffix array ----------
+ * Replaces, for a batch of scan positions, the reference's
+ *   Search(I, oldData, newData[scan..], 0, oldData.Length, out pos)          src/DeltaQ.BsDiff/Diff.cs:267-298
+ * as called by the scan loop (Diff.cs:106): for every query q the pair (pos[q], len[q]) is exactly what Search
+ * returns -- the suffix-array neighbour of the query with the longer common prefix (MatchLength, Diff.cs:248-265),
+ * ties to the upper neighbour, the zeroed sentinel slot I[n] = 0 of Diff.cs:78 included.  sa is the n-entry
+ * suffix array of old_data (what dq_sufsort_hip_dev_* leaves on the device); the sentinel is implied.
+ * Queries: scan = scans[q] when scans != NULL, else scan0 + q; 0 <= scan <= m.
+ * cap: 0 = exact for every query.  cap > 0 = a query whose comparison would run more than `cap` bytes past what
+ * is already known to match is given up and returns len = -1, pos = 0 (speculative batches inside a long
+ * match must not cost O(match length) each: the caller repeats that one position with cap = 0).
+ * The _dev_ forms take device pointers on `device` (d_scans too) and enqueue on `stream` (NULL = the library's
+ * stream), returning after the stream has drained; the plain forms take host pointers and copy. */
+int32_t dq_bsdiff_search_dev_i32(const void *d_old, int64_t n, const void *d_sa, const void *d_new, int64_t m,
+                                 const int64_t *d_scans, int64_t scan0, int64_t count, int64_t cap, void *d_pos,
+                                 void *d_len, int32_t device, void *stream);
+int32_t dq_bsdiff_search_dev_i64(const void *d_old, int64_t n, const void *d_sa, const void *d_new, int64_t m,
+                                 const int64_t *d_scans, int64_t scan0, int64_t count, int64_t cap, void *d_pos,
+                                 void *d_len, int32_t device, void *stream);
+int32_t dq_bsdiff_search_i32(const uint8_t *old_data, int64_t n, const int32_t *sa, const uint8_t *new_data, int64_t m,
+                             const int64_t *scans, int64_t scan0, int64_t count, int64_t cap, int32_t *pos, int32_t *len,
+                             int32_t device);
+int32_t dq_bsdiff_search_i64(const uint8_t *old_data, int64_t n, const int64_t *sa, const uint8_t *new_data, int64_t m,
+                             const int64_t *scans, int64_t scan0, int64_t count, int64_t cap, int64_t *pos, int64_t *len,
+                             int32_t device);
+
 /* Device workspace (bytes) a sort of n bytes with index_bytes (4 or 8) wide indices needs,
  * excluding the caller's text and sa buffers. */
 int64_t dq_sufsort_hip_workspace_bytes(int64_t n, int32_t index_bytes);
@@ -98,7 +124,8 @@ void dq_sufsort_hip_release(void);
 #define DQ_K_ISA_FROM_SA         13   /* isa_from_sa_kernel + isa_scatter_kernel: ISA for the switch to doubling    */
 #define DQ_K_SMALL_SORT          14   /* small_sufsort_kernel: a whole short text (n <= 8192) in one workgroup      */
 #define DQ_K_BUCKET_SORT         15   /* bucket_sort_kernel (+ bucket_bounds_kernel): buckets finished in LDS, 8+w+1/8  */
-#define DQ_K_COUNT               16
+#define DQ_K_MATCH_SEARCH        16   /* match_search_kernel: Diff.cs Search for a batch of scan positions              */
+#define DQ_K_COUNT               17
 
 /* 0 off, 1 every kernel, 2 only radix_rank_kernel, 100 + c only category c (cheapest: the timed region) */
 int32_t dq_profile_enable(int32_t on);

@@ -71,6 +71,13 @@ def lib() -> ctypes.CDLL:
             if hasattr(L, f"dq_oracle_divsufsort_{suf}"):
                 getattr(L, f"dq_oracle_divsufsort_{suf}").restype = ctypes.c_int32
                 getattr(L, f"dq_oracle_divsufsort_{suf}").argtypes = [u8p, u8p, i64]
+        for suf in ("i32", "i64"):
+            getattr(L, f"dq_oracle_bsdiff_search_{suf}").restype = ctypes.c_int32
+            getattr(L, f"dq_oracle_bsdiff_search_{suf}").argtypes = [u8p, i64, u8p, u8p, i64, u8p, i64, i64, u8p, u8p]
+            getattr(L, f"dq_oracle_bsdiff_scan_{suf}").restype = ctypes.c_int32
+            getattr(L, f"dq_oracle_bsdiff_scan_{suf}").argtypes = [u8p, i64, u8p, u8p, i64] + [u8p] * 7
+        L.dq_oracle_bspatch_apply.restype = ctypes.c_int32
+        L.dq_oracle_bspatch_apply.argtypes = [u8p, i64, u8p, i64, u8p, i64, u8p, i64, i64, u8p]
         L.dq_oracle_naive_sa_i32.restype = ctypes.c_int32
         L.dq_oracle_naive_sa_i32.argtypes = [u8p, u8p, i64]
         L.dq_oracle_netrandom_bytes.restype = None
@@ -178,6 +185,60 @@ def verify(text, sa) -> None:
         raise AssertionError(f"Input was unsorted at i={bad}, j={bad + 1}")
     if rc != CHECK_DONE:
         raise AssertionError(f"sufcheck returned {rc}")
+
+
+# ---- the suffix array's consumer: Diff.Create's search and scan loop -------------------------------
+def bsdiff_search(old, sa, new, scans=None, scan0=0, count=None):
+    """Search(I, old, new[scan..], 0, n, out pos) (Diff.cs:267-298) for a batch of scan positions:
+    returns (pos, len) arrays of sa's dtype."""
+    O, N = _text(old), _text(new)
+    sa = np.ascontiguousarray(sa)
+    if scans is not None:
+        scans = np.ascontiguousarray(scans, dtype=np.int64)
+        count = scans.size
+    elif count is None:
+        count = N.size - scan0
+    pos = np.empty(count, dtype=sa.dtype)
+    ln = np.empty(count, dtype=sa.dtype)
+    fn = getattr(lib(), f"dq_oracle_bsdiff_search_{_suf(sa)}")
+    rc = fn(_ptr(O), O.size, _ptr(sa), _ptr(N), N.size, _ptr(scans) if scans is not None else 0, scan0, count,
+            _ptr(pos), _ptr(ln))
+    if rc != 0:
+        raise RuntimeError(f"oracle bsdiff_search failed: {rc}")
+    return pos, ln
+
+
+def bsdiff_scan(old, sa, new):
+    """The scan loop of Diff.Create (Diff.cs:91-232): returns (ctrl triples [k, 3] int64, diff bytes, extra
+    bytes, number of Search calls)."""
+    O, N = _text(old), _text(new)
+    sa = np.ascontiguousarray(sa)
+    m = N.size
+    ctrl = np.empty(3 * (m + 1), dtype=np.int64)
+    diff = np.empty(max(m, 1), dtype=np.uint8)
+    extra = np.empty(max(m, 1), dtype=np.uint8)
+    cnt = (ctypes.c_int64 * 4)()
+    base = ctypes.addressof(cnt)
+    fn = getattr(lib(), f"dq_oracle_bsdiff_scan_{_suf(sa)}")
+    rc = fn(_ptr(O), O.size, _ptr(sa), _ptr(N), m, _ptr(ctrl), base, _ptr(diff), base + 8, _ptr(extra), base + 16,
+            base + 24)
+    if rc != 0:
+        raise RuntimeError(f"oracle bsdiff_scan failed: {rc}")
+    return ctrl[:3 * cnt[0]].reshape(-1, 3).copy(), diff[:cnt[1]].copy(), extra[:cnt[2]].copy(), int(cnt[3])
+
+
+def bspatch_apply(old, ctrl, diff, extra, newsize) -> np.ndarray:
+    """Patch.ApplyInternal (Patch.cs:95-168) on raw streams."""
+    O = _text(old)
+    ctrl = np.ascontiguousarray(ctrl, dtype=np.int64).reshape(-1)
+    diff = np.ascontiguousarray(diff, dtype=np.uint8)
+    extra = np.ascontiguousarray(extra, dtype=np.uint8)
+    out = np.empty(newsize, dtype=np.uint8)
+    rc = lib().dq_oracle_bspatch_apply(_ptr(O), O.size, _ptr(ctrl), ctrl.size // 3, _ptr(diff), diff.size,
+                                       _ptr(extra), extra.size, newsize, _ptr(out))
+    if rc != 0:
+        raise RuntimeError(f"Corrupt patch ({rc})")
+    return out
 
 
 # ---- input generators ----------------------------------------------------------------

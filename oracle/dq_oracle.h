@@ -78,6 +78,28 @@ int32_t dq_oracle_sufcheck_i64(const uint8_t *T, int64_t n, const int64_t *SA, i
 int32_t dq_oracle_sufcheck_mt_i32(const uint8_t *T, int64_t n, const int32_t *SA, int64_t sa_len, int32_t threads);
 int32_t dq_oracle_sufcheck_mt_i64(const uint8_t *T, int64_t n, const int64_t *SA, int64_t sa_len, int32_t threads);
 
+/* ---- the suffix array's consumer (bsdiff_scan.c): Diff.Create's match search and scan loop, restated ----
+ * Search(I, old, new[scan..], 0, n, out pos) (Diff.cs:267-298) for scan = scans[q] (or scan0 + q when scans
+ * is NULL), q < count.  SA has n entries; the zeroed sentinel I[n] (Diff.cs:78) is supplied internally. */
+int32_t dq_oracle_bsdiff_search_i32(const uint8_t *old, int64_t n, const int32_t *SA, const uint8_t *nw, int64_t m,
+                                    const int64_t *scans, int64_t scan0, int64_t count, int32_t *pos_out,
+                                    int32_t *len_out);
+int32_t dq_oracle_bsdiff_search_i64(const uint8_t *old, int64_t n, const int64_t *SA, const uint8_t *nw, int64_t m,
+                                    const int64_t *scans, int64_t scan0, int64_t count, int64_t *pos_out,
+                                    int64_t *len_out);
+/* The scan loop of Diff.Create (Diff.cs:91-232) on raw streams: ctrl receives *nctrl (add, copy, seek)
+ * triples (capacity 3 * (m + 1) int64), diff / extra the raw bytes (capacity m each). */
+int32_t dq_oracle_bsdiff_scan_i32(const uint8_t *old, int64_t n, const int32_t *SA, const uint8_t *nw, int64_t m,
+                                  int64_t *ctrl, int64_t *nctrl, uint8_t *diff, int64_t *ndiff, uint8_t *extra,
+                                  int64_t *nextra, int64_t *searches);
+int32_t dq_oracle_bsdiff_scan_i64(const uint8_t *old, int64_t n, const int64_t *SA, const uint8_t *nw, int64_t m,
+                                  int64_t *ctrl, int64_t *nctrl, uint8_t *diff, int64_t *ndiff, uint8_t *extra,
+                                  int64_t *nextra, int64_t *searches);
+/* Patch.ApplyInternal (Patch.cs:95-168) on the same raw streams; 0 or -3 ("Corrupt patch"). */
+int32_t dq_oracle_bspatch_apply(const uint8_t *old, int64_t n, const int64_t *ctrl, int64_t nctrl,
+                                const uint8_t *diff, int64_t ndiff, const uint8_t *extra, int64_t nextra,
+                                int64_t newsize, uint8_t *out);
+
 /* .NET System.Random(int seed) compat generator (Knuth subtractive), used by
  * every reference test/bench buffer: new Random(670761).NextBytes(buf)
  * (LibDivSufSortTests.cs:29, SuffixSortingBenchmarks.cs:15). */
