@@ -285,7 +285,66 @@ def other_configs(sorter, dev):
         recs.append({"config": name, "device_resident_ms": round(ms, 3), "device_resident_MBps": round(host.size / 1e3 / ms, 1),
                      "through_abi_ms": abi["ms"], "through_abi_MBps": abi["MBps"], "rounds": rounds})
         del host
+    recs.append(match_search_record(sorter, dev))
+    recs.append(reference_benchmark_shape(sorter))
     return recs
+
+
+def reference_benchmark_shape(sorter):
+    """The reference's own benchmark (bench/DeltaQ.Benchmarks/SuffixSortingBenchmarks.cs:27-65): Sort(asset) on
+    new Random(670761).NextBytes(size) buffers of 0 ... 32 KiB and 64 KiB ... 1 MiB; here a few of those sizes,
+    through the host interface (what BenchmarkDotNet would time), median of 20 calls, beside the oracle's
+    LibDivSufSort restatement on one host core."""
+    import numpy as np
+    import oracle
+    rows = []
+    for size in (4096, 32768, 65536, 262144, 1048576):
+        T = oracle.net_random_bytes(size)
+        sa = np.ones(size, np.int32)
+        sorter.Sort(T, sa)
+        ts = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            sorter.Sort(T, sa)
+            ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        ref = oracle.divsufsort(T)
+        ct = time.perf_counter() - t0
+        rows.append({"bytes": size, "through_abi_us": round(sorted(ts)[len(ts) // 2] * 1e6, 1),
+                     "cpu_oracle_us": round(ct * 1e6, 1), "bit_exact": bool(np.array_equal(ref, sa))})
+    return {"config": "reference benchmark shape: Sort(new Random(670761).NextBytes(size)), host interface", "sizes": rows}
+
+
+def match_search_record(sorter, dev):
+    """SURVEY.md section 8(f) row 1, the sort's consumer: Diff.cs Search for 10^6 consecutive scan positions of a
+    differing region (two independent 16 MiB random buffers), suffix array left on the device by the sorter;
+    the oracle's restatement of Search answers a sample of them on one host core."""
+    import numpy as np
+    import torch
+    import oracle
+    from deltaq_amd import HipMatchSearch, _abi
+    from tools import datagen
+    L = _abi.load()
+    n, count, sample = 16 << 20, 1_000_000, 100_000
+    old, new = datagen.gen_uniform(n, SEED_BATCH), datagen.gen_uniform(n, SEED_BATCH + 1)
+    d_old, d_new = torch.from_numpy(old).to(dev), torch.from_numpy(new).to(dev)
+    d_sa = sorter.Sort(d_old)
+    ms = HipMatchSearch(dev.index)
+    ms.Search(d_sa, d_old, d_new, scan0=0, count=1000)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    pos, ln = ms.Search(d_sa, d_old, d_new, scan0=0, count=count)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    sa = d_sa.cpu().numpy()
+    t0 = time.perf_counter()
+    wpos, wlen = oracle.bsdiff_search(old, sa, new, scan0=0, count=sample)
+    ct = time.perf_counter() - t0
+    ok = bool(np.array_equal(pos[:sample].cpu().numpy(), wpos) and np.array_equal(ln[:sample].cpu().numpy(), wlen))
+    return {"config": "match search (Diff.cs:267-298 Search) on the device-resident SA: 16 MiB old, 10^6 scan positions",
+            "device_resident_ms": round(dt * 1e3, 3), "M_queries_per_s": round(count / dt / 1e6, 1),
+            "cpu_oracle_M_queries_per_s": round(sample / ct / 1e6, 3), "cores": 1,
+            "bit_exact_vs_oracle_sample": ok}
 
 
 def batch_config4(world, rank, local_rank, dev, backend, sorter):

@@ -183,7 +183,7 @@ __device__ long long *g_phase_ts = nullptr;          // [ntiles][8]
 #endif
 
 template <typename IdxT, typename StatusT, int kItems, int kMode, int kMinWaves, int kThreads = kBlock,
-          bool kEarlyVals = false, bool kLdsMatch = true, int kExchRounds = 1>
+          bool kEarlyVals = false, bool kLdsMatch = true, int kExchRounds = 1, bool kAtomicBase = false>
 __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     const uint64_t *__restrict__ kin, const IdxT *__restrict__ vin,
     uint64_t *__restrict__ kout, IdxT *__restrict__ vout, int64_t m, int shift, int keybits, int ib,
@@ -217,7 +217,13 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     const int w = tid >> 6;
     const int lane = lane_id();
 
-    if (tid == 0) {
+    // kAtomicBase (first pass of a sort only: nothing to be stable against): a tile reserves its place in every
+    // digit's output region with ONE returning atomic add per digit on a table of 256 cursors (the first 256
+    // 64-bit words of `status`, zeroed like the status words) instead of the decoupled look-back -- no
+    // dependence on other tiles at all, so no ticket either.  Tiles land in whatever order the adds arrive.
+    if (kAtomicBase) {
+        if (tid == 0) s_tile = blockIdx.x;
+    } else if (tid == 0) {
         // Tiles are handed out by an atomic ticket, so a tile's predecessors are always running.
         // (Experiment kept behind DQ_XCD_REMAP: permuting ticket -> tile inside groups of 64 so that
         // the workgroups of one XCD get 8 consecutive tiles and adjacent digit runs meet in one
@@ -381,6 +387,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     constexpr int kLookWin = DQ_LOOK_WIN;
     uint32_t tot = 0, incl = 0;
     StatusT sw[kLookWin];
+    unsigned long long abase = 0;
     StatusT *mine = status + tile * kRadixSize + (tid & (kRadixSize - 1));
     if (tid < kRadixSize) {
 #pragma unroll
@@ -389,12 +396,17 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
             whist[i][tid] = tot;
             tot += c;
         }
+        if (kAtomicBase) {
+            // (the returned value is not needed before the LDS exchanges are done: the round trip overlaps them)
+            abase = atomicAdd(reinterpret_cast<unsigned long long *>(status) + tid, (unsigned long long)tot);
+        } else {
         if (tile == 0) status_store<StatusT>(mine, SB::kPrefix | (StatusT)tot);
         else status_store<StatusT>(mine, SB::kAgg | (StatusT)tot);
 #pragma unroll
         for (int j = 0; j < kLookWin; ++j)
             sw[j] = (tile - 1 - j >= 0) ? status_load<StatusT>(status + (tile - 1 - j) * kRadixSize + tid)
                                         : SB::kPrefix;
+        }
         incl = wave_incl_sum(tot);                             // tile-local scan over digits
         if (lane == kWave - 1) wtmp[w] = incl;
     }
@@ -463,7 +475,9 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
 #ifdef DQ_EXPERIMENT_SKIP_LOOKBACK
         if (false) {
 #else
-        if (tile > 0) {
+        if (kAtomicBase) {
+            excl = (StatusT)abase;
+        } else if (tile > 0) {
 #endif
             int64_t t = tile - 1;
             uint32_t spins = 0;

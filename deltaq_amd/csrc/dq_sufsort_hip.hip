@@ -275,6 +275,8 @@ template <typename IdxT, int kMode> struct RankCfg {
     // LDS match tables beat 8 ballots on near-uniform digits (words: -6%), but equal digits in a wave are
     // same-address LDS atomics: pair passes run on text-like (skewed) data and keep the ballots
     static constexpr bool kLdsMatch = kWords;
+    // the first pass of a sort has no earlier order to keep: atomic cursors instead of the look-back
+    static constexpr bool kAtomicBase = (kMode == kTextPacked || kMode == kText);
 };
 
 // Zero the look-back state (ticket + status words) of ALL digit passes of one sort with a single
@@ -315,7 +317,7 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
     const int64_t alg_extra = kMode == kKeysLastTies ? m / 8 + ntiles * kRadixSize * 16 : 0;
     LAUNCH(L, DQ_K_RADIX_RANK, m, m * alg + alg_extra,
            hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, kItems, kMode, Cfg::kMinWaves, kThreads,
-                                                 false, Cfg::kLdsMatch, Cfg::kRounds>),
+                                                 false, Cfg::kLdsMatch, Cfg::kRounds, Cfg::kAtomicBase>),
                               dim3((unsigned)ntiles), dim3(kThreads), 0, L.st, kin, vin, kout, vout, m,
                               shift_override >= 0 ? shift_override : pass * kRadixBits + ib,
                               keybits > 0 ? keybits : 8 * kb, ib,

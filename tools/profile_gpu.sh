@@ -15,5 +15,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
       python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-build --no-profile "$@" > "$OUT/pmc_$C.log" 2>&1
 done
 cd "$ROOT"
-python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.txt" 2>&1
+python3 tools/summarize_profile.py "$OUT" "${DQ_PROFILE_WORKLOAD:-uniform-256MiB}" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

@@ -67,6 +67,8 @@ def main():
                 # gfx950: FETCH_SIZE reports 1/2 of the bytes of coalesced streaming reads
                 # (MI355X_MICROARCH.md, HBM section; calibrated here on kernels with known reads)
                 v["hbm_bytes_per_launch"] = (2 * v["FETCH_SIZE_KiB_per_launch"] + v["WRITE_SIZE_KiB_per_launch"]) * 1024
+        if len(sys.argv) > 2:
+            traffic["workload"] = sys.argv[2]            # bench.py reports traffic only for the workload it was measured on
         json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1, sort_keys=True)
 
 
