@@ -193,6 +193,9 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     uint64_t *__restrict__ seam_tab /*[ntiles][256][2]*/ = nullptr)
 {
     constexpr bool kFromText = (kMode == kText || kMode == kTextPacked);
+    // arrival-order ranking (below) only where digits are near-uniform -- packed words are chosen for random-like
+    // text; a skewed digit would put hundreds of same-address LDS atomics of a tile in a row
+    constexpr bool kAtomicRank = kAtomicBase && kMode == kTextPacked;
     constexpr bool kTies = (kMode == kKeysLastTies);
     constexpr bool kHasVals = (kMode == kPairs || kMode == kText);
     static_assert(!kFromText || (kItems % 4) == 0, "text mode packs 4 suffixes per lane");
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
         s_tile = t;
     }
     for (int i = tid; i < kWavesB * kRadixSize; i += kThreads) (&whist[0][0])[i] = 0;
-    if (kLdsMatch) {
+    if (kLdsMatch && !kAtomicRank) {
         // per-wave digit -> lane-mask tables live in the (not yet used) exchange buffer
         static_assert(kExchN >= kWavesB * kRadixSize, "exchange buffer must hold the match tables");
         for (int i = tid; i < kWavesB * kRadixSize; i += kThreads) exch[i] = 0;
@@ -332,7 +335,17 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
         return match_digit8(d);
     };
     (void)lanebit;
-    if (valid == kTileN) {
+    if (kAtomicRank) {
+        // The first pass of a sort keeps no earlier order, so the rank of a key inside (tile, digit) may be its
+        // arrival number: ONE returning LDS add per key on a digit histogram shared by the whole workgroup
+        // (row 0 of whist), all 24 of a lane in flight together -- instead of the match table, its read-back and
+        // the per-wave counter, three dependent LDS round trips per key.
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) {
+            const uint32_t d = digit_of(key[k], shift);
+            pos[k] = atomicAdd(&whist[0][d], elem(k) < valid ? 1u : 0u);
+        }
+    } else if (valid == kTileN) {
 #pragma unroll
         for (int k = 0; k < kItems; ++k) {
             const uint32_t d = digit_of(key[k], shift);
@@ -374,7 +387,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
             }
         }
     }
-    if (kLdsMatch) __syncthreads();          // the match tables alias the exchange buffer
+    if (kLdsMatch && !kAtomicRank) __syncthreads();          // the match tables alias the exchange buffer
     DQ_PHASE(2);
     if (!kEarlyVals) load_vals();
     __syncthreads();
@@ -426,7 +439,8 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const uint32_t d = digit_of(key[k], shift);
-        pos[k] += tile_base[d] + myhist[d];
+        // (kAtomicRank: pos is already the place inside the tile's digit run; the per-wave offsets are not used)
+        pos[k] += kAtomicRank ? tile_base[d] : tile_base[d] + myhist[d];
     }
     if (valid != kTileN) {
 #pragma unroll
