@@ -34,7 +34,9 @@ constexpr int kBktBins = kBktCap;                          // ~1 element per bin
 constexpr int kBktMaxBin = 48;                             // a fuller bin = not the data this path is for
 
 struct BucketFlags {
-    unsigned long long overflow;        // a bucket longer than X, a tile spanning too many buckets, a bin too full
+    // non-zero = the path gave up: 2 a bucket longer than X, 4 a tile spanning too many buckets, 8 a bin too
+    // full (1 is tie_collect_kernel's "run of equal keys too long": the word is TieCounters::overflow)
+    unsigned long long overflow;
 };
 
 // bounds[t] for t = 0..ntiles: first bucket boundary at or after t*C (bounds[ntiles] = n)
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void bucket_bounds_kernel(const uint64_t *_
     const uint64_t b = W[p - 1] >> bshift;
     int64_t lo = p, hi = p + X < n ? p + X : n;             // the boundary lies in [lo, hi] unless the bucket is too long
     if (hi < n && (W[hi] >> bshift) == b) {
-        atomicExch(&flags->overflow, 1ull);
+        atomicOr(&flags->overflow, 2ull);                    // reason bits: see BucketFlags
         bounds[t] = p;
         return;
     }
@@ -141,12 +143,14 @@ __global__ __launch_bounds__(kBktThreads, 4) void bucket_sort_kernel(
         DQ_BKT_PHASE(1);
         const uint64_t kfirst = s_edge[0] >> bshift, klast = s_edge[1] >> bshift;
         const uint64_t range = (klast - kfirst + 1) << lowbits;            // tile keys are < range
-        // range << 6 must fit 32 bits; range > bins keeps the multiplier below 2^32 (lowbits >= 15 guarantees it)
-        const bool bad = M != 0 && (range > (1ull << (32 - kBktArrBits)) || range <= (uint64_t)kBktNB);
+        // range << 6 must fit 32 bits
+        const bool bad = M != 0 && range > (1ull << (32 - kBktArrBits));
         // bin = key * mult >> 32 < bins: mult <= bins * 2^32 / range.  (A float reciprocal is within 2^-22 of the
         // exact quotient; the factor 1 - 2^-20 keeps the product below it.  Any positive multiplier is monotone.)
+        // (a tile of few, short buckets may have range <= bins: the multiplier then saturates just below 2^32
+        // and bin = key - 1 or key, still monotone and < range <= bins)
         const uint32_t mult = (bad || M == 0) ? 0u
-            : (uint32_t)((float)kBktNB * 4294967296.0f * __frcp_rn((float)range) * (1.0f - 0x1p-20f));
+            : (uint32_t)fminf((float)kBktNB * 4294967296.0f * __frcp_rn((float)range) * (1.0f - 0x1p-20f), 4294967040.0f);
         const uint64_t kbase = kfirst << lowbits;
         uint32_t key[kBktItems];
 #pragma unroll
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(kBktThreads, 4) void bucket_sort_kernel(
             DQ_BKT_FETCH();
         }
         if (bad) {
-            if (tid == 0) atomicExch(&flags->overflow, 1ull);
+            if (tid == 0) atomicOr(&flags->overflow, 4ull);
         } else if (M != 0) {
             // ---- bin counts; the returned old count (arrival number) makes the key unique ----
 #pragma unroll
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(kBktThreads, 4) void bucket_sort_kernel(
             __syncthreads();
             DQ_BKT_PHASE(3);
             if (s_overflow) {                               // (uniform: written before the barrier above)
-                if (tid == 0) atomicExch(&flags->overflow, 1ull);
+                if (tid == 0) atomicOr(&flags->overflow, 8ull);
             } else {
                 // ---- scatter the unique keys into bin order ----
 #pragma unroll

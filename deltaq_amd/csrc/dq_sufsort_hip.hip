@@ -541,6 +541,7 @@ int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int k
     if (c.pinned[1] != 0) return fail(DQ_ERR_HIP, "radix look-back timed out (device spin bound hit)");
     *count = c.pinned[6];
     *overflow = c.pinned[7] != 0;
+    if (*overflow && getenv("DQ_TRACE")) fprintf(stderr, "[dq] tie / bucket overflow flags: %lld\n", (long long)c.pinned[7]);
     *fin_left = c.pinned[3];
     (void)wb;
     return DQ_OK;
@@ -599,6 +600,8 @@ struct SuffixSorter {
     // the finisher already ran (speculatively, right after the tie bits were collected)
     bool fin_done = false;
     int64_t fin_cap = 0, fin_left = 0;
+    // round 0 was bucketed: however many suffixes are tied, they are tied shallowly (random-like text)
+    bool shallow_ties = false;
 
     SuffixSorter(DeviceCtx &c_, hipStream_t st_, Workspace<IdxT> &w_, int64_t n_, IdxT *sa_)
         : c(c_), st(st_), w(w_), n(n_), d_sa(sa_), L{c_, st_, g_prof_on.load()} {}
@@ -692,61 +695,85 @@ struct SuffixSorter {
 
     // ---- bucketed round 0 (see dq_bucket_sort.h).  *done = false: the path does not apply, or it met a
     //      bucket / bin it does not take (the state the plain passes expect has then been restored).
-    int round0_bucketed(uint64_t *K[2], int kb, bool *done)
+    int round0_bucketed(uint64_t *K[2], int kb, bool packed, bool *done)
     {
         *done = false;
         const int ib = bit_length((uint64_t)(n - 1));
         if (getenv("DQ_NO_BUCKET") || getenv("DQ_NO_FUSED_TIES") || getenv("DQ_SPARSE") || getenv("DQ_KEY_BYTES")) return DQ_OK;
         const bool forced = getenv("DQ_BUCKET") != nullptr;
-        if (ib > 31 || n < (1 << 16)) return DQ_OK;                          // (low bits = 36 - 16 or 33 - 16 >= 15)          // a suffix must fit 31 bits next to the tie flag
-        // longest 2-byte bucket expected under an order-0 model of the text (c.pinned still holds the histogram)
+        if (ib > 31 || n < (1 << 16)) return DQ_OK;                           // a suffix must fit 31 bits next to the tie flag
+        // order-0 model of the text (c.pinned still holds the byte histogram): entropy, most frequent byte
         int64_t cmax = 0;
-        for (int b = 0; b < 256; ++b) cmax = std::max(cmax, c.pinned[b]);
-        const double pm = (double)cmax / (double)n;
-        const double est = (double)n * pm * pm;
-        const double need = est + 6.0 * std::sqrt(est) + 64.0;
-        int64_t X = ((int64_t)need + 255) / 256 * 256;                         // longest bucket the tiles are cut for
-        if (X > 5120) {
-            if (!forced) return DQ_OK;
-            X = 5120;
+        double h0 = 0;
+        for (int b = 0; b < 256; ++b) {
+            cmax = std::max(cmax, c.pinned[b]);
+            if (c.pinned[b] > 0) { const double p = (double)c.pinned[b] / (double)n; h0 -= p * std::log2(p); }
         }
-        // a tile must not span more than 64 buckets (its keys, relative to its first bucket, take 26 bits + 6
-        // arrival bits): buckets of >= 192 words on average, i.e. texts of >= 12 MiB
-        if (!forced && n < (12 << 20)) return DQ_OK;
-        const int64_t C = kBktCap - X;
         const int keybits = std::min(64 - ib, 36);
-        const int lowbits = keybits - 16;
+        if (!packed) {
+            // Words were not chosen because too many suffixes would stay tied for the tie-bit path of the plain
+            // passes (2 GiB of random bytes: 33 key bits leave 1/4 of them tied).  Those ties are shallow, which the
+            // direct-comparison finisher takes; the key must still separate most suffixes, and the k-gram sample
+            // must not have seen repetition (it then set kb = 8).
+            const double tied = (double)n * std::exp2(-(double)keybits * h0 / 8.0);
+            if (!forced && (kb >= 8 || tied > 0.3)) return DQ_OK;
+        }
+        // longest bucket expected when the words are grouped by their first 2 (3) bytes; tiles are cut for it
+        const double pm = (double)cmax / (double)n;
+        int bbytes = 2;
+        double est = (double)n * pm * pm;
+        double need = est + 6.0 * std::sqrt(est) + 64.0;
+        // a tile must not span more than 64 two-byte buckets (its keys, relative to its first bucket, take 26
+        // bits + 6 arrival bits): buckets of >= 192 words on average, i.e. texts of >= 12 MiB
+        const bool force3 = forced && atoi(getenv("DQ_BUCKET")) == 3;          // (tests: 3-byte buckets on mid-size inputs)
+        if (need > 5120 || (!forced && n < (12 << 20)) || force3) {
+            if (keybits - 24 >= 8 && (forced || n >= (12 << 20))) {
+                bbytes = 3;
+                est *= pm;
+                need = est + 6.0 * std::sqrt(est) + 64.0;
+            }
+            if (need > 5120 || (bbytes == 2 && !forced)) {
+                if (!forced) return DQ_OK;
+                need = 5120;
+            }
+        }
+        const int64_t X = std::min<int64_t>(((int64_t)need + 255) / 256 * 256, 5120);
+        const int64_t C = kBktCap - X;
+        const int lowbits = keybits - 8 * bbytes;
         const int64_t ntiles = (n + C - 1) / C;
         uint32_t *ebits = reinterpret_cast<uint32_t *>(w.Vb);                  // zeroed by onesweep_sort_text_prepare
         TieCounters *ctr = reinterpret_cast<TieCounters *>(w.totals + 6);     // zero since run()
         BucketFlags *flags = reinterpret_cast<BucketFlags *>(&ctr->overflow);
         const uint64_t *text64 = reinterpret_cast<const uint64_t *>(w.text);
-        // digit p of the 2-byte bucket of suffix i is T[i + 1 - p]
-        hipLaunchKernelGGL(text_digit_offsets_kernel, dim3(2), dim3(kBlock), 0, st,
-                           (const int64_t *)w.bytehist, (const uint8_t *)w.text, n, 2, w.digit_offset);
+        // digit p of the bucket of suffix i is T[i + bbytes - 1 - p]
+        hipLaunchKernelGGL(text_digit_offsets_kernel, dim3(bbytes), dim3(kBlock), 0, st,
+                           (const int64_t *)w.bytehist, (const uint8_t *)w.text, n, bbytes, w.digit_offset);
         HIP_TRY(hipGetLastError());
         int rc = rank_pass<IdxT, kTextPacked>(L, w, text64, (const IdxT *)nullptr, K[1], (IdxT *)nullptr, n, 0, kb, ib,
                                              nullptr, nullptr, ib + lowbits, keybits);
         if (rc != DQ_OK) return rc;
-        rc = rank_pass<IdxT, kKeys>(L, w, K[1], (const IdxT *)nullptr, K[0], (IdxT *)nullptr, n, 1, kb, ib, nullptr, nullptr,
-                                    ib + lowbits + 8, keybits);
-        if (rc != DQ_OK) return rc;
+        for (int p = 1; p < bbytes; ++p) {                   // pass p reads buffer p & 1 and writes the other
+            rc = rank_pass<IdxT, kKeys>(L, w, K[p & 1], (const IdxT *)nullptr, K[(p & 1) ^ 1], (IdxT *)nullptr, n, p, kb, ib,
+                                        nullptr, nullptr, ib + lowbits + 8 * p, keybits);
+            if (rc != DQ_OK) return rc;
+        }
+        uint64_t *Ks = K[bbytes & 1], *Kfree = K[(bbytes & 1) ^ 1];           // sorted words / the other buffer
         LAUNCH(L, DQ_K_BUCKET_SORT, ntiles, ntiles * 16 * 8,
                hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)((ntiles + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                                  st, (const uint64_t *)K[0], n, ib + lowbits, C, X, ntiles, w.bkt_bounds, flags));
+                                  st, (const uint64_t *)Ks, n, ib + lowbits, C, X, ntiles, w.bkt_bounds, flags));
         if (c.ncu <= 0) {
             int v = 0;
             c.ncu = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c.dev) == hipSuccess && v > 0 ? v : 256;
         }
         LAUNCH(L, DQ_K_BUCKET_SORT, n, n * (8 + wb) + n / 8,                  // persistent: one workgroup per CU
                hipLaunchKernelGGL(bucket_sort_kernel<IdxT>, dim3((unsigned)std::min<int64_t>(ntiles, c.ncu)),
-                                  dim3(kBktThreads), 0, st, (const uint64_t *)K[0], ib, lowbits,
+                                  dim3(kBktThreads), 0, st, (const uint64_t *)Ks, ib, lowbits,
                                   (const int64_t *)w.bkt_bounds, ntiles, d_sa, ebits, flags));
         bool overflow = false;
         fin_cap = n / 8;
         const int64_t hb = keybits / 8;                  // whole bytes the members of a tie group share
-        rc = collect_ties<IdxT>(L, c, w, n, kb, ib, ebits, nullptr, (const IdxT *)d_sa, K[1], w.Va, &m, &overflow,
-                                fin_cap, K[0], w.Vb, &fin_left, /*seams=*/false, hb);
+        rc = collect_ties<IdxT>(L, c, w, n, kb, ib, ebits, nullptr, (const IdxT *)d_sa, Kfree, w.Va, &m, &overflow,
+                                fin_cap, Ks, w.Vb, &fin_left, /*seams=*/false, hb);
         if (rc != DQ_OK) return rc;
         if (overflow) {
             // a bucket or a bin this path does not take (or a run of equal keys too long for the tie walk):
@@ -763,11 +790,12 @@ struct SuffixSorter {
             return DQ_OK;
         }
         fin_done = m <= fin_cap;
-        Kr[0] = K[1]; Kr[1] = K[0];
+        Kr[0] = Kfree; Kr[1] = Ks;
         Vr[0] = w.Va; Vr[1] = w.Vb;
         rcur = 0;
         h = hb;
         rbits = ib;
+        shallow_ties = true;                             // ties of random-like text: the finisher, not the ISA
         *done = true;
         return DQ_OK;
     }
@@ -789,9 +817,9 @@ struct SuffixSorter {
         V[(kb & 1) ^ 1] = w.Va;
         // Random-like input (packed words = few ties expected) of a size whose 2-byte buckets fit a workgroup's
         // LDS: two digit passes on the top 16 key bits, then every bucket is finished in LDS (dq_bucket_sort.h).
-        if (packed) {
+        {
             bool done = false;
-            rc = round0_bucketed(K, kb, &done);
+            rc = round0_bucketed(K, kb, packed, &done);
             if (rc != DQ_OK) return rc;
             if (done) { *dense_built = false; return DQ_OK; }
         }
@@ -1071,7 +1099,7 @@ struct SuffixSorter {
         t_info[1] = m;
         if (m == 0) return flush_profile(c);
 
-        bool sparse = m * 6 <= n;
+        bool sparse = m * 6 <= n || shallow_ties;
         if (const char *v = getenv("DQ_SPARSE")) sparse = atoi(v) != 0;
         if (keys_ready) sparse = false;      // the ISA exists and the list is already keyed for a doubling round
         if (sparse) rc = finish_sparse();

@@ -19,8 +19,15 @@ if which == "2g":
     out = torch.empty(n, dtype=torch.int64, device="cuda")
     print("workspace GiB", L.dq_sufsort_hip_workspace_bytes(n, 8) / 2**30, flush=True)
     t0 = time.time(); s.Sort(dT, out); torch.cuda.synchronize(); print("sort (first call)", round(time.time() - t0, 3), "s", _abi.last_sort_info(), flush=True)
+    L.dq_profile_enable(1); L.dq_profile_reset()
     t0 = time.time(); s.Sort(dT, out); torch.cuda.synchronize(); dt = time.time() - t0
-    print(f"2 GiB i64 device-resident: {dt*1e3:.1f} ms = {n/1e6/dt:.0f} MB/s", flush=True)
+    L.dq_profile_enable(0)
+    print(f"2 GiB i64 device-resident: {dt*1e3:.1f} ms = {n/1e6/dt:.0f} MB/s  {_abi.last_sort_info()}", flush=True)
+    for k, v in _abi.profile_snapshot().items():
+        if v["launches"]:
+            print(f"   {k:24s} launches={v['launches']:4d} total={v['ms']:9.3f} ms  alg={v['alg_bytes']/max(v['ms'],1e-9)/1e6:8.1f} GB/s", flush=True)
+    if len(sys.argv) > 2 and sys.argv[2] == "nocheck":
+        sys.exit(0)
     SA = out.cpu().numpy()
     t0 = time.time(); rc = oracle.sufcheck(T, SA); print("sufcheck_i64", rc, round(time.time() - t0, 1), "s", flush=True)
     print("sampled strict order (1e6 pairs):", oracle.verify_sampled(T, SA, 1_000_000, 7), flush=True)

@@ -189,6 +189,18 @@ def test_bucketed_round0(ldss, oracle_mod, backend_lib, monkeypatch):
         assert np.array_equal(ldss.Sort(T), oracle_mod.divsufsort(T)), name
     T = rnd(4_000_001, 77)
     assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
+    # three digit passes + 3-byte buckets (what texts beyond ~300 MiB take, e.g. BASELINE configs[3]), forced on 40 MB
+    monkeypatch.setenv("DQ_BUCKET", "3")
+    T = rnd(40_000_003, 78)
+    T[1_000_000:1_003_000] = T[9_000_000:9_003_000]                      # a repeat: leftovers of the finisher
+    backend_lib.dq_profile_reset()
+    backend_lib.dq_profile_enable(1)
+    sa = ldss.Sort(T)
+    backend_lib.dq_profile_enable(0)
+    from deltaq_amd import _abi
+    assert _abi.profile_snapshot()["bucket_sort_kernel"]["launches"] == 2
+    assert _abi.last_sort_info()["initial_active"] < 40_000                # ... and it did not fall back: 36-bit keys leave few ties
+    assert np.array_equal(sa, oracle_mod.divsufsort(T))
 
 
 def structured_text(rng, n):
