@@ -106,24 +106,42 @@ __global__ __launch_bounds__(kTieThreads) void tie_collect_kernel(const uint64_t
     }
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(&ctr->count, (unsigned long long)tot) : 0ull;
     __syncthreads();
-    if (cnt == 0) return;
-    int64_t out = (int64_t)s_base + off;
-    int64_t head = 0;
-    uint64_t rest = own;
-    while (rest) {
-        const int b = __builtin_ctzll(rest);
-        rest &= rest - 1;
-        const int64_t p = i * 64 + b;
-        if (!((E >> b) & 1ull)) head = p;               // first member of a group
-        act_rank[out] = (uint64_t)head;
-        act_suf[out] = SA[p];
-        ++out;
-    }
-    for (uint32_t k = 0; k < tail; ++k) {
-        const int64_t p = (i + 1) * 64 + k;
-        act_rank[out] = (uint64_t)head;
-        act_suf[out] = SA[p];
-        ++out;
+    // ---- emission, the whole wave on one word at a time: lane b takes bit b, so the SA reads and the list
+    //      writes of a word are coalesced (a lane walking its own 64 bits wrote 16 bytes at a time: 16.6 ms for
+    //      the 4.75e8 tied suffixes of a 2 GiB random text, against ~4 ms this way) ----
+    const int64_t out = (int64_t)s_base + off;
+    uint64_t todo = __ballot(cnt != 0);
+    const uint64_t lbit = 1ull << lane;
+    while (todo) {
+        const int j = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint64_t own_j = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(own >> 32), j) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)own, j);
+        const uint64_t E_j = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(E >> 32), j) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)E, j);
+        const int64_t out_j = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)out >> 32), j) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)out, j));
+        const uint32_t tail_j = (uint32_t)__builtin_amdgcn_readlane((int)tail, j);
+        const int64_t p0 = (i - lane + j) * 64;                         // first position of word j of this wave
+        if (own_j & lbit) {
+            const uint64_t below = lbit - 1;
+            const int64_t p = p0 + lane;
+            // head of my group: me, or the nearest position below me that does not tie with its predecessor
+            // (it exists inside the word: positions continuing an earlier word's group are not in own)
+            const int64_t head = (E_j & lbit) ? p0 + (63 - __builtin_clzll(~E_j & below)) : p;
+            const int64_t o = out_j + __popcll(own_j & below);
+            act_rank[o] = (uint64_t)head;
+            act_suf[o] = SA[p];
+        }
+        if (tail_j) {
+            // my last group runs on into the following words: its head is the highest non-tie bit of the word
+            const int64_t head = p0 + (63 - __builtin_clzll(~E_j));
+            const int64_t o0 = out_j + __popcll(own_j);
+            for (uint32_t k = (uint32_t)lane; k < tail_j; k += kWave) {
+                act_rank[o0 + k] = (uint64_t)head;
+                act_suf[o0 + k] = SA[p0 + 64 + k];
+            }
+        }
     }
     (void)n;
 }
