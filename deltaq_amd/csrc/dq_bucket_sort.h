@@ -231,23 +231,27 @@ __global__ __launch_bounds__(kBktThreads, 4) void bucket_sort_kernel(
 #pragma unroll
                 for (int k = 0; k < kBktItems; ++k) {
                     const uint32_t e = (uint32_t)(k * kBktThreads) + tid;
-                    const uint32_t bin = __umulhi(key[k] >> kBktArrBits, mult);
-                    const uint32_t s0 = start16[bin], s1 = start16[bin + 1];
-                    uint32_t r = s0, tie = 0;
+                    uint32_t r = 0, tie = 0;
+                    if (e < M) {                // (item slots beyond the tile's last element do no LDS work: a tile
+                                                // of a 256 MiB text is 5/8 full, and whole items are then skipped)
+                        const uint32_t bin = __umulhi(key[k] >> kBktArrBits, mult);
+                        const uint32_t s0 = start16[bin], s1 = start16[bin + 1];
+                        r = s0;
 #pragma unroll
-                    for (int q = 0; q < kBktWalk; ++q) {
-                        const uint32_t o = buf[s0 + q];                     // (buf has kBktWalk entries of slack)
-                        const uint32_t less = (s0 + q < s1) & (o < key[k]);
-                        r += less;
-                        tie |= less & ((o >> kBktArrBits) == (key[k] >> kBktArrBits));
-                    }
-                    if (s1 > s0 + kBktWalk) {
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-                        for (uint32_t j = s0 + kBktWalk; j < s1; ++j) {
-                            const uint32_t o = buf[j];
-                            const uint32_t less = o < key[k];
+                        for (int q = 0; q < kBktWalk; ++q) {
+                            const uint32_t o = buf[s0 + q];                 // (buf has kBktWalk entries of slack)
+                            const uint32_t less = (s0 + q < s1) & (o < key[k]);
                             r += less;
                             tie |= less & ((o >> kBktArrBits) == (key[k] >> kBktArrBits));
+                        }
+                        if (s1 > s0 + kBktWalk) {
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+                            for (uint32_t j = s0 + kBktWalk; j < s1; ++j) {
+                                const uint32_t o = buf[j];
+                                const uint32_t less = o < key[k];
+                                r += less;
+                                tie |= less & ((o >> kBktArrBits) == (key[k] >> kBktArrBits));
+                            }
                         }
                     }
                     fin[k] = e < M ? (r | (tie << 31)) : 0xffffffffu;      // final place (| tie flag), or "no element"

@@ -106,10 +106,32 @@ __global__ __launch_bounds__(kTieThreads) void tie_collect_kernel(const uint64_t
     }
     if (threadIdx.x == 0) s_base = tot ? atomicAdd(&ctr->count, (unsigned long long)tot) : 0ull;
     __syncthreads();
-    // ---- emission, the whole wave on one word at a time: lane b takes bit b, so the SA reads and the list
-    //      writes of a word are coalesced (a lane walking its own 64 bits wrote 16 bytes at a time: 16.6 ms for
-    //      the 4.75e8 tied suffixes of a 2 GiB random text, against ~4 ms this way) ----
+    // ---- emission.  Many ties: the whole wave on one word at a time, lane b takes bit b, so the SA reads and
+    //      the list writes of a word are coalesced (a lane walking its own 64 bits wrote 16 bytes at a time: 16.6 ms
+    //      for the 4.75e8 tied suffixes of a 2 GiB random text, against 5.0 ms this way) ----
     const int64_t out = (int64_t)s_base + off;
+    // (few ties -- the usual case after a 32...36-bit key: most words have no member at all and a lane walking its
+    // own few bits is cheaper than the wave visiting every non-empty word)
+    const uint32_t wave_members = __shfl(incl, kWave - 1, kWave);
+    if (wave_members < 512u) {
+        int64_t o = out, head = 0;
+        uint64_t rest = own;
+        while (rest) {
+            const int b = __builtin_ctzll(rest);
+            rest &= rest - 1;
+            const int64_t p = i * 64 + b;
+            if (!((E >> b) & 1ull)) head = p;               // first member of a group
+            act_rank[o] = (uint64_t)head;
+            act_suf[o] = SA[p];
+            ++o;
+        }
+        for (uint32_t k = 0; k < tail; ++k) {
+            act_rank[o] = (uint64_t)head;
+            act_suf[o] = SA[(i + 1) * 64 + k];
+            ++o;
+        }
+        return;
+    }
     uint64_t todo = __ballot(cnt != 0);
     const uint64_t lbit = 1ull << lane;
     while (todo) {
