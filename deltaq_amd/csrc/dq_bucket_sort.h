@@ -116,6 +116,10 @@ __global__ __launch_bounds__(kBktThreads, 4) void bucket_sort_kernel(
     int64_t lo_n = bounds[tile];
     uint32_t M_n = (uint32_t)(bounds[tile + 1] - lo_n);
     if (M_n > (uint32_t)kBktCap) M_n = 0;
+    // ... and the bounds of the one after that: a dependent load in front of the fetch, so it is requested a
+    // whole tile ahead of its use
+    int64_t lo_nn = 0, hi_nn = 0;
+    if (tile + gridDim.x < ntiles) { lo_nn = bounds[tile + gridDim.x]; hi_nn = bounds[tile + gridDim.x + 1]; }
     uint64_t wd[kBktItems];
     // Clamped, not predicated: the loads stay in flight together.  (And every array element is always assigned
     // unconditionally: a conditional element write turns the register array into one wide phi that the
@@ -161,10 +165,11 @@ __global__ __launch_bounds__(kBktThreads, 4) void bucket_sort_kernel(
         // ---- request the next tile ----
         const int64_t tn = tile + gridDim.x;
         if (tn < ntiles) {
-            lo_n = bounds[tn];
-            M_n = (uint32_t)(bounds[tn + 1] - lo_n);
+            lo_n = lo_nn;
+            M_n = (uint32_t)(hi_nn - lo_nn);
             if (M_n > (uint32_t)kBktCap) M_n = 0;
             DQ_BKT_FETCH();
+            if (tn + gridDim.x < ntiles) { lo_nn = bounds[tn + gridDim.x]; hi_nn = bounds[tn + gridDim.x + 1]; }
         }
         if (bad) {
             if (tid == 0) atomicOr(&flags->overflow, 4ull);
