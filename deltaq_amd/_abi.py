@@ -27,6 +27,7 @@ EXPORTS = (
     "dq_sufsort_hip_dev_i32", "dq_sufsort_hip_dev_i64",
     "dq_sufsort_hip_batch_i32",
     "dq_bsdiff_search_dev_i32", "dq_bsdiff_search_dev_i64", "dq_bsdiff_search_i32", "dq_bsdiff_search_i64",
+    "dq_bsdiff_create", "dq_bsdiff_patch_bound", "dq_bsdiff_scan_i32", "dq_bspatch_apply",
     "dq_sufsort_hip_workspace_bytes", "dq_sufsort_hip_release",
     "dq_profile_enable", "dq_profile_reset", "dq_profile_get", "dq_profile_kernel_name",
     "dq_profile_category_count",
@@ -99,6 +100,15 @@ def load() -> ctypes.CDLL:
     for name in ("dq_bsdiff_search_i32", "dq_bsdiff_search_i64"):
         getattr(L, name).restype = i32
         getattr(L, name).argtypes = [vp, i64, vp, vp, i64, vp, i64, i64, i64, vp, vp, i32]
+    L.dq_bsdiff_create.restype = i32
+    L.dq_bsdiff_create.argtypes = [vp, i64, vp, i64, vp, i64, ctypes.POINTER(i64), i32]
+    L.dq_bsdiff_patch_bound.restype = i64
+    L.dq_bsdiff_patch_bound.argtypes = [i64, i64]
+    L.dq_bsdiff_scan_i32.restype = i32
+    L.dq_bsdiff_scan_i32.argtypes = [vp, i64, vp, i64, vp, i64, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), vp,
+                                     ctypes.POINTER(i64), vp, i32]
+    L.dq_bspatch_apply.restype = i32
+    L.dq_bspatch_apply.argtypes = [vp, i64, vp, i64, vp, i64, ctypes.POINTER(i64)]
     L.dq_sufsort_hip_workspace_bytes.restype = i64
     L.dq_sufsort_hip_workspace_bytes.argtypes = [i64, i32]
     L.dq_sufsort_hip_release.restype = None

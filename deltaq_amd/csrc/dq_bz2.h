@@ -1,0 +1,545 @@
+// dq_bz2.h -- bzip2 streams for the BSDIFF40 container (host code).
+//
+// The reference frames the three parts of a patch with SharpZipLib's BZip2OutputStream / BZip2InputStream
+// (src/DeltaQ.BsDiff/Diff.cs:15-18, DeltaQ.BsDiff.csproj:42; third-party, not vendored).  What has to match is the
+// FORMAT (bzip2 1.0: any conforming decoder must read what is written here, and what any conforming encoder
+// wrote must be read here), not SharpZipLib's byte stream -- the reference itself pins patches only by round
+// trips (BsDiffTests.cs:30-78).  tests/test_bz2_container.py checks both directions against libbz2 (Python's bz2).
+//
+//   bz2_decompress   the whole decoder (tables, MTF / RUNA-RUNB, inverse BWT, run-length, CRCs): pure host code
+//   bz2_compress     run-length pre-pass, MTF / RUNA-RUNB, up to 6 Huffman tables refined over 50-symbol groups
+//                    (the usual 4 iterations), canonical codes; the Burrows-Wheeler transform of a block is taken
+//                    from a suffix array of block+block supplied by the caller -- in this library the MI355X
+//                    suffix sorter itself (rotations i < j compare like the suffixes of block+block at i, j over
+//                    their first n characters; rotations that are equal as strings carry equal last characters,
+//                    so their mutual order does not matter)
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+namespace dq {
+namespace bz2 {
+
+constexpr int kMaxAlpha = 258;
+constexpr int kMaxCodeLen = 20;           // what a decoder must accept
+constexpr int kEncCodeLen = 17;           // what this encoder produces (as libbz2)
+constexpr int kGroupSize = 50;
+constexpr int kMaxGroups = 6;
+constexpr int kMaxSelectors = 2 + 900000 / kGroupSize;
+constexpr uint64_t kBlockMagic = 0x314159265359ull, kEndMagic = 0x177245385090ull;
+
+inline const uint32_t *crc_table()
+{
+    static uint32_t tab[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i << 24;
+            for (int k = 0; k < 8; ++k) c = (c & 0x80000000u) ? (c << 1) ^ 0x04c11db7u : c << 1;
+            tab[i] = c;
+        }
+        ready = true;
+    }
+    return tab;
+}
+
+inline uint32_t crc_update(uint32_t crc, const uint8_t *p, size_t n)
+{
+    const uint32_t *t = crc_table();
+    for (size_t i = 0; i < n; ++i) crc = (crc << 8) ^ t[(crc >> 24) ^ p[i]];
+    return crc;
+}
+
+// ------------------------------------------------------------------ decoder
+struct BitReader {
+    const uint8_t *p;
+    size_t n, pos = 0;
+    uint64_t buf = 0;
+    int have = 0;
+    bool overrun = false;
+    BitReader(const uint8_t *p_, size_t n_) : p(p_), n(n_) {}
+    uint32_t bits(int k)                 // k <= 32
+    {
+        while (have < k) {
+            if (pos >= n) { overrun = true; buf <<= 8; have += 8; continue; }
+            buf = (buf << 8) | p[pos++];
+            have += 8;
+        }
+        const uint32_t v = (uint32_t)((buf >> (have - k)) & ((k == 32) ? 0xffffffffull : ((1ull << k) - 1)));
+        have -= k;
+        return v;
+    }
+    uint32_t bit() { return bits(1); }
+};
+
+enum { kOk = 0, kCorrupt = -1, kTruncated = -2 };
+
+// Decodes one whole stream (possibly several concatenated streams, as bzip2 allows).
+inline int bz2_decompress(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
+{
+    BitReader br(src, n);
+    std::vector<uint32_t> tt;
+    bool first_stream = true;
+    for (;;) {
+        if (br.pos >= n && br.have < 8) { return first_stream ? kTruncated : kOk; }
+        if (br.bits(8) != 'B' || br.bits(8) != 'Z' || br.bits(8) != 'h') return first_stream ? kCorrupt : kOk;
+        const int level = (int)br.bits(8) - '0';
+        if (level < 1 || level > 9) return kCorrupt;
+        const uint32_t block_max = (uint32_t)level * 100000u;
+        uint32_t combined = 0;
+        for (;;) {
+            const uint64_t magic = ((uint64_t)br.bits(24) << 24) | br.bits(24);
+            if (br.overrun) return kTruncated;
+            if (magic == kEndMagic) {
+                const uint32_t stored = br.bits(32);
+                if (br.overrun) return kTruncated;
+                if (stored != combined) return kCorrupt;
+                br.have -= br.have % 8;                       // streams are byte aligned
+                break;
+            }
+            if (magic != kBlockMagic) return kCorrupt;
+            const uint32_t block_crc = br.bits(32);
+            if (br.bit()) return kCorrupt;                    // randomised blocks: deprecated, never written
+            const uint32_t orig_ptr = br.bits(24);
+            // symbols in use
+            uint8_t seq_to_unseq[256];
+            int n_in_use = 0;
+            {
+                const uint32_t used16 = br.bits(16);
+                for (int i = 0; i < 16; ++i) {
+                    if (used16 & (0x8000u >> i)) {
+                        const uint32_t m16 = br.bits(16);
+                        for (int j = 0; j < 16; ++j)
+                            if (m16 & (0x8000u >> j)) seq_to_unseq[n_in_use++] = (uint8_t)(i * 16 + j);
+                    }
+                }
+            }
+            if (n_in_use == 0) return kCorrupt;
+            const int alpha = n_in_use + 2;
+            const int n_groups = (int)br.bits(3);
+            if (n_groups < 2 || n_groups > kMaxGroups) return kCorrupt;
+            const int n_sel = (int)br.bits(15);
+            if (n_sel < 1) return kCorrupt;
+            std::vector<uint8_t> selector((size_t)n_sel);
+            {
+                uint8_t pos[kMaxGroups];
+                for (int i = 0; i < n_groups; ++i) pos[i] = (uint8_t)i;
+                for (int i = 0; i < n_sel; ++i) {
+                    int j = 0;
+                    while (br.bit()) { if (++j >= n_groups) return kCorrupt; }
+                    const uint8_t v = pos[j];
+                    for (; j > 0; --j) pos[j] = pos[j - 1];
+                    pos[0] = v;
+                    selector[(size_t)i] = v;
+                }
+            }
+            // coding tables
+            uint8_t len[kMaxGroups][kMaxAlpha];
+            for (int t = 0; t < n_groups; ++t) {
+                int curr = (int)br.bits(5);
+                for (int i = 0; i < alpha; ++i) {
+                    for (;;) {
+                        if (curr < 1 || curr > kMaxCodeLen) return kCorrupt;
+                        if (!br.bit()) break;
+                        curr += br.bit() ? -1 : 1;
+                    }
+                    len[t][i] = (uint8_t)curr;
+                }
+            }
+            if (br.overrun) return kTruncated;
+            int32_t limit[kMaxGroups][kMaxCodeLen + 2], base[kMaxGroups][kMaxCodeLen + 2], perm[kMaxGroups][kMaxAlpha];
+            int min_len[kMaxGroups];
+            for (int t = 0; t < n_groups; ++t) {
+                int mn = 32, mx = 0;
+                for (int i = 0; i < alpha; ++i) { mn = std::min<int>(mn, len[t][i]); mx = std::max<int>(mx, len[t][i]); }
+                min_len[t] = mn;
+                int pp = 0;
+                for (int l = mn; l <= mx; ++l)
+                    for (int i = 0; i < alpha; ++i)
+                        if (len[t][i] == l) perm[t][pp++] = i;
+                int cnt[kMaxCodeLen + 2] = {0};
+                for (int i = 0; i < alpha; ++i) cnt[len[t][i]]++;
+                int32_t code = 0, idx = 0;
+                for (int l = 0; l <= kMaxCodeLen + 1; ++l) { limit[t][l] = -1; base[t][l] = 0; }
+                for (int l = mn; l <= mx; ++l) {
+                    base[t][l] = idx - code;                    // perm index = code + base
+                    code += cnt[l];
+                    idx += cnt[l];
+                    limit[t][l] = code - 1;                     // largest code of this length
+                    code <<= 1;
+                }
+                for (int l = mx + 1; l <= kMaxCodeLen + 1; ++l) limit[t][l] = 0x7fffffff;      // forces termination
+            }
+            // MTF / run-length decoding into tt (the last column of the sorted rotations)
+            tt.clear();
+            tt.reserve(block_max);
+            uint32_t unzftab[256] = {0};
+            uint8_t mtf[256];
+            for (int i = 0; i < 256; ++i) mtf[i] = (uint8_t)i;
+            const int eob = n_in_use + 1;
+            int group_no = -1, group_pos = 0, t = 0;
+            int64_t run = 0, run_weight = 1;                   // pending RUNA/RUNB run: its length so far
+            bool in_run = false;
+            auto flush_run = [&]() -> bool {
+                if (!in_run) return true;
+                if (tt.size() + (size_t)run > block_max) return false;
+                const uint8_t ch = seq_to_unseq[mtf[0]];
+                unzftab[ch] += (uint32_t)run;
+                tt.insert(tt.end(), (size_t)run, (uint32_t)ch);
+                run = 0;
+                run_weight = 1;
+                in_run = false;
+                return true;
+            };
+            for (;;) {
+                if (group_pos == 0) {
+                    if (++group_no >= n_sel) return kCorrupt;
+                    group_pos = kGroupSize;
+                    t = selector[(size_t)group_no];
+                }
+                --group_pos;
+                int l = min_len[t];
+                int32_t code = (int32_t)br.bits(l);
+                while (l <= kMaxCodeLen && code > limit[t][l]) { code = (code << 1) | (int32_t)br.bit(); ++l; }
+                if (l > kMaxCodeLen || br.overrun) return br.overrun ? kTruncated : kCorrupt;
+                const int32_t pi = code + base[t][l];
+                if (pi < 0 || pi >= alpha) return kCorrupt;
+                const int sym = perm[t][pi];
+                if (sym == eob) break;
+                if (sym <= 1) {                                // RUNA = 0, RUNB = 1: digits 1 / 2 of a bijective base-2 number
+                    if (run_weight > (1 << 21)) return kCorrupt;
+                    in_run = true;
+                    run += (int64_t)(sym + 1) * run_weight;
+                    run_weight <<= 1;
+                    continue;
+                }
+                if (!flush_run()) return kCorrupt;
+                if (tt.size() >= block_max) return kCorrupt;
+                const int idx = sym - 1;                       // MTF position
+                if (idx >= n_in_use) return kCorrupt;
+                const uint8_t v = mtf[idx];
+                memmove(mtf + 1, mtf, (size_t)idx);
+                mtf[0] = v;
+                const uint8_t ch = seq_to_unseq[v];
+                unzftab[ch]++;
+                tt.push_back((uint32_t)ch);
+            }
+            if (!flush_run()) return kCorrupt;
+            const uint32_t nblock = (uint32_t)tt.size();
+            if (orig_ptr >= nblock) return kCorrupt;
+            // inverse BWT: tt[cftab[ch]++] |= i << 8, then follow the chain from orig_ptr
+            uint32_t cftab[257];
+            cftab[0] = 0;
+            for (int i = 0; i < 256; ++i) cftab[i + 1] = cftab[i] + unzftab[i];
+            for (uint32_t i = 0; i < nblock; ++i) {
+                const uint8_t ch = (uint8_t)(tt[i] & 0xff);
+                tt[cftab[ch]++] |= i << 8;
+            }
+            // un-run-length (4 equal bytes + a count byte) while following the chain; CRC of the output
+            uint32_t crc = 0xffffffffu;
+            const uint32_t *ctab = crc_table();
+            uint32_t tpos = tt[orig_ptr] >> 8;
+            int same = 0, prev = -1;
+            for (uint32_t i = 0; i < nblock; ++i) {
+                const uint32_t e = tt[tpos];
+                const uint8_t ch = (uint8_t)(e & 0xff);
+                tpos = e >> 8;
+                if (same == 4) {                               // ch is a repeat count
+                    for (int k = 0; k < ch; ++k) {
+                        out.push_back((uint8_t)prev);
+                        crc = (crc << 8) ^ ctab[(crc >> 24) ^ (uint8_t)prev];
+                    }
+                    same = 0;
+                    prev = -1;
+                    continue;
+                }
+                out.push_back(ch);
+                crc = (crc << 8) ^ ctab[(crc >> 24) ^ ch];
+                same = (ch == prev) ? same + 1 : 1;
+                prev = ch;
+            }
+            crc = ~crc;
+            if (crc != block_crc) return kCorrupt;
+            combined = ((combined << 1) | (combined >> 31)) ^ crc;
+        }
+        first_stream = false;
+    }
+}
+
+// ------------------------------------------------------------------ encoder
+struct BitWriter {
+    std::vector<uint8_t> &out;
+    uint64_t buf = 0;
+    int have = 0;
+    explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
+    void bits(int k, uint32_t v)         // k <= 32
+    {
+        buf = (buf << k) | (k == 32 ? (uint64_t)v : ((uint64_t)v & ((1ull << k) - 1)));
+        have += k;
+        while (have >= 8) { out.push_back((uint8_t)(buf >> (have - 8))); have -= 8; }
+    }
+    void flush() { if (have > 0) { out.push_back((uint8_t)(buf << (8 - have))); have = 0; } }
+};
+
+// Code lengths (<= max_len) of a Huffman code for freq[0..alpha): package of the classic libbz2 approach --
+// build the tree, and while it is too deep flatten the frequencies and rebuild.
+inline void make_code_lengths(uint8_t *len, const int32_t *freq, int alpha, int max_len)
+{
+    std::vector<int64_t> weight((size_t)alpha * 2 + 2);
+    std::vector<int32_t> parent((size_t)alpha * 2 + 2), heap((size_t)alpha + 2);
+    std::vector<int32_t> f(freq, freq + alpha);
+    for (;;) {
+        // weights carry the depth in their low 8 bits, as in libbz2
+        for (int i = 0; i < alpha; ++i) weight[(size_t)i + 1] = (int64_t)(f[(size_t)i] == 0 ? 1 : f[(size_t)i]) << 8;
+        int n_nodes = alpha, n_heap = 0;
+        heap[0] = 0; weight[0] = 0; parent[0] = -2;
+        auto up = [&](int z) {
+            const int32_t tmp = heap[(size_t)z];
+            while (weight[(size_t)tmp] < weight[(size_t)heap[(size_t)(z >> 1)]]) { heap[(size_t)z] = heap[(size_t)(z >> 1)]; z >>= 1; }
+            heap[(size_t)z] = tmp;
+        };
+        auto down = [&](int z) {
+            const int32_t tmp = heap[(size_t)z];
+            for (;;) {
+                int y = z << 1;
+                if (y > n_heap) break;
+                if (y < n_heap && weight[(size_t)heap[(size_t)y + 1]] < weight[(size_t)heap[(size_t)y]]) ++y;
+                if (weight[(size_t)tmp] < weight[(size_t)heap[(size_t)y]]) break;
+                heap[(size_t)z] = heap[(size_t)y];
+                z = y;
+            }
+            heap[(size_t)z] = tmp;
+        };
+        for (int i = 1; i <= alpha; ++i) { parent[(size_t)i] = -1; heap[(size_t)++n_heap] = i; up(n_heap); }
+        while (n_heap > 1) {
+            const int32_t n1 = heap[1]; heap[1] = heap[(size_t)n_heap--]; down(1);
+            const int32_t n2 = heap[1]; heap[1] = heap[(size_t)n_heap--]; down(1);
+            ++n_nodes;
+            parent[(size_t)n1] = parent[(size_t)n2] = n_nodes;
+            const int64_t w1 = weight[(size_t)n1], w2 = weight[(size_t)n2];
+            weight[(size_t)n_nodes] = ((w1 & ~0xffll) + (w2 & ~0xffll)) | (1 + std::max(w1 & 0xff, w2 & 0xff));
+            parent[(size_t)n_nodes] = -1;
+            heap[(size_t)++n_heap] = n_nodes;
+            up(n_heap);
+        }
+        bool too_long = false;
+        for (int i = 1; i <= alpha; ++i) {
+            int j = 0, k = i;
+            while (parent[(size_t)k] >= 0) { k = parent[(size_t)k]; ++j; }
+            len[i - 1] = (uint8_t)j;
+            if (j > max_len) too_long = true;
+        }
+        if (!too_long) return;
+        for (int i = 0; i < alpha; ++i) f[(size_t)i] = 1 + (f[(size_t)i] == 0 ? 0 : f[(size_t)i]) / 2;
+    }
+}
+
+// sa_of_doubled(text, n2, sa): suffix array (int32, n2 entries) of the n2 = 2 * nblock bytes block+block.
+using DoubledSorter = std::function<int(const uint8_t *text, int64_t n2, int32_t *sa)>;
+
+// One block: `blk` is the run-length coded data (nblock bytes), crc the CRC of the original bytes it stands for.
+inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32_t crc, const DoubledSorter &sorter)
+{
+    const int32_t nblock = (int32_t)blk.size();
+    // ---- Burrows-Wheeler transform through the suffix array of block+block ----
+    std::vector<uint8_t> doubled((size_t)nblock * 2);
+    memcpy(doubled.data(), blk.data(), (size_t)nblock);
+    memcpy(doubled.data() + nblock, blk.data(), (size_t)nblock);
+    std::vector<int32_t> sa((size_t)nblock * 2);
+    const int rc = sorter(doubled.data(), (int64_t)nblock * 2, sa.data());
+    if (rc != 0) return rc;
+    std::vector<uint8_t> last((size_t)nblock);
+    int32_t orig_ptr = -1, row = 0;
+    for (int32_t i = 0; i < 2 * nblock; ++i) {
+        const int32_t s = sa[(size_t)i];
+        if (s >= nblock) continue;
+        if (s == 0) orig_ptr = row;
+        last[(size_t)row++] = blk[(size_t)(s == 0 ? nblock - 1 : s - 1)];
+    }
+    if (row != nblock || orig_ptr < 0) return -3;
+    // ---- symbols in use, MTF, RUNA / RUNB ----
+    bool in_use[256] = {false};
+    for (int32_t i = 0; i < nblock; ++i) in_use[blk[(size_t)i]] = true;
+    uint8_t unseq_to_seq[256];
+    int n_in_use = 0;
+    for (int i = 0; i < 256; ++i) if (in_use[i]) unseq_to_seq[i] = (uint8_t)n_in_use++;
+    const int eob = n_in_use + 1, alpha = n_in_use + 2;
+    std::vector<uint16_t> mtfv;
+    mtfv.reserve((size_t)nblock + 1);
+    int32_t mtf_freq[kMaxAlpha] = {0};
+    {
+        uint8_t yy[256];
+        for (int i = 0; i < n_in_use; ++i) yy[i] = (uint8_t)i;
+        int64_t zrun = 0;
+        auto flush_zeros = [&]() {
+            if (zrun == 0) return;
+            --zrun;
+            for (;;) {                                          // bijective base 2: RUNA = 1, RUNB = 2
+                const uint16_t s = (uint16_t)(zrun & 1);
+                mtfv.push_back(s);
+                mtf_freq[s]++;
+                if (zrun < 2) break;
+                zrun = (zrun - 2) / 2;
+            }
+            zrun = 0;
+        };
+        for (int32_t i = 0; i < nblock; ++i) {
+            const uint8_t c = unseq_to_seq[last[(size_t)i]];
+            if (yy[0] == c) { ++zrun; continue; }
+            flush_zeros();
+            int j = 1;
+            uint8_t prev = yy[0];
+            while (yy[j] != c) { const uint8_t t = yy[j]; yy[j] = prev; prev = t; ++j; }
+            yy[j] = prev;
+            yy[0] = c;
+            mtfv.push_back((uint16_t)(j + 1));
+            mtf_freq[j + 1]++;
+        }
+        flush_zeros();
+        mtfv.push_back((uint16_t)eob);
+        mtf_freq[eob]++;
+    }
+    const int32_t n_mtf = (int32_t)mtfv.size();
+    // ---- coding tables: initial split by frequency, 4 refinement rounds over groups of 50 symbols ----
+    const int n_groups = n_mtf < 200 ? 2 : n_mtf < 600 ? 3 : n_mtf < 1200 ? 4 : n_mtf < 2400 ? 5 : 6;
+    uint8_t len[kMaxGroups][kMaxAlpha];
+    {
+        int32_t rem = n_mtf;
+        int gs = 0;
+        for (int part = n_groups; part > 0; --part) {
+            const int32_t target = rem / part;
+            int ge = gs - 1;
+            int32_t acc = 0;
+            while (acc < target && ge < alpha - 1) { ++ge; acc += mtf_freq[ge]; }
+            if (ge > gs && part != n_groups && part != 1 && ((n_groups - part) % 2 == 1)) { acc -= mtf_freq[ge]; --ge; }
+            for (int v = 0; v < alpha; ++v) len[part - 1][v] = (v >= gs && v <= ge) ? 0 : 15;
+            gs = ge + 1;
+            rem -= acc;
+        }
+    }
+    const int32_t n_sel = (n_mtf + kGroupSize - 1) / kGroupSize;
+    std::vector<uint8_t> selector((size_t)n_sel);
+    std::vector<int32_t> rfreq((size_t)kMaxGroups * kMaxAlpha);
+    for (int iter = 0; iter < 4; ++iter) {
+        std::fill(rfreq.begin(), rfreq.end(), 0);
+        for (int32_t g = 0; g < n_sel; ++g) {
+            const int32_t a = g * kGroupSize, b = std::min<int32_t>(a + kGroupSize, n_mtf);
+            int32_t best_cost = 0x7fffffff;
+            int best = 0;
+            for (int t = 0; t < n_groups; ++t) {
+                int32_t cost = 0;
+                for (int32_t i = a; i < b; ++i) cost += len[t][mtfv[(size_t)i]];
+                if (cost < best_cost) { best_cost = cost; best = t; }
+            }
+            selector[(size_t)g] = (uint8_t)best;
+            for (int32_t i = a; i < b; ++i) rfreq[(size_t)best * kMaxAlpha + mtfv[(size_t)i]]++;
+        }
+        for (int t = 0; t < n_groups; ++t) make_code_lengths(len[t], &rfreq[(size_t)t * kMaxAlpha], alpha, kEncCodeLen);
+    }
+    // canonical codes
+    uint32_t code[kMaxGroups][kMaxAlpha];
+    for (int t = 0; t < n_groups; ++t) {
+        int mn = 32, mx = 0;
+        for (int i = 0; i < alpha; ++i) { mn = std::min<int>(mn, len[t][i]); mx = std::max<int>(mx, len[t][i]); }
+        uint32_t c = 0;
+        for (int l = mn; l <= mx; ++l) {
+            for (int i = 0; i < alpha; ++i) if (len[t][i] == l) code[t][i] = c++;
+            c <<= 1;
+        }
+    }
+    // ---- the block ----
+    bw.bits(24, (uint32_t)(kBlockMagic >> 24));
+    bw.bits(24, (uint32_t)(kBlockMagic & 0xffffff));
+    bw.bits(32, crc);
+    bw.bits(1, 0);
+    bw.bits(24, (uint32_t)orig_ptr);
+    {
+        uint32_t used16 = 0;
+        for (int i = 0; i < 16; ++i)
+            for (int j = 0; j < 16; ++j)
+                if (in_use[i * 16 + j]) used16 |= 0x8000u >> i;
+        bw.bits(16, used16);
+        for (int i = 0; i < 16; ++i) {
+            if (!(used16 & (0x8000u >> i))) continue;
+            uint32_t m16 = 0;
+            for (int j = 0; j < 16; ++j) if (in_use[i * 16 + j]) m16 |= 0x8000u >> j;
+            bw.bits(16, m16);
+        }
+    }
+    bw.bits(3, (uint32_t)n_groups);
+    bw.bits(15, (uint32_t)n_sel);
+    {
+        uint8_t pos[kMaxGroups];
+        for (int i = 0; i < n_groups; ++i) pos[i] = (uint8_t)i;
+        for (int32_t g = 0; g < n_sel; ++g) {
+            const uint8_t v = selector[(size_t)g];
+            int j = 0;
+            while (pos[j] != v) ++j;
+            for (int k = j; k > 0; --k) pos[k] = pos[k - 1];
+            pos[0] = v;
+            for (int k = 0; k < j; ++k) bw.bits(1, 1);
+            bw.bits(1, 0);
+        }
+    }
+    for (int t = 0; t < n_groups; ++t) {
+        int curr = len[t][0];
+        bw.bits(5, (uint32_t)curr);
+        for (int i = 0; i < alpha; ++i) {
+            while (curr < len[t][i]) { bw.bits(2, 2); ++curr; }      // 10: increment
+            while (curr > len[t][i]) { bw.bits(2, 3); --curr; }      // 11: decrement
+            bw.bits(1, 0);
+        }
+    }
+    for (int32_t g = 0; g < n_sel; ++g) {
+        const int t = selector[(size_t)g];
+        const int32_t a = g * kGroupSize, b = std::min<int32_t>(a + kGroupSize, n_mtf);
+        for (int32_t i = a; i < b; ++i) bw.bits(len[t][mtfv[(size_t)i]], code[t][mtfv[(size_t)i]]);
+    }
+    return 0;
+}
+
+// level 1..9: blocks of level * 100000 - 19 run-length coded bytes (libbz2's limit).
+inline int bz2_compress(const uint8_t *src, size_t n, std::vector<uint8_t> &out, const DoubledSorter &sorter, int level = 9)
+{
+    BitWriter bw(out);
+    bw.bits(8, 'B'); bw.bits(8, 'Z'); bw.bits(8, 'h'); bw.bits(8, (uint32_t)('0' + level));
+    const size_t block_max = (size_t)level * 100000 - 19;
+    uint32_t combined = 0;
+    std::vector<uint8_t> blk;
+    blk.reserve(block_max + 8);
+    size_t i = 0;
+    while (i < n) {
+        blk.clear();
+        uint32_t crc = 0xffffffffu;
+        // run-length pre-pass: a run of 4..255 equal bytes becomes 4 bytes + (length - 4)
+        while (i < n && blk.size() + 5 <= block_max) {
+            const uint8_t c = src[i];
+            size_t run = 1;
+            while (run < 255 && i + run < n && src[i + run] == c) ++run;
+            crc = crc_update(crc, src + i, run);
+            if (run >= 4) {
+                blk.insert(blk.end(), 4, c);
+                blk.push_back((uint8_t)(run - 4));
+            } else {
+                blk.insert(blk.end(), run, c);
+            }
+            i += run;
+        }
+        crc = ~crc;
+        const int rc = compress_block(bw, blk, crc, sorter);
+        if (rc != 0) return rc;
+        combined = ((combined << 1) | (combined >> 31)) ^ crc;
+    }
+    bw.bits(24, (uint32_t)(kEndMagic >> 24));
+    bw.bits(24, (uint32_t)(kEndMagic & 0xffffff));
+    bw.bits(32, combined);
+    bw.flush();
+    return 0;
+}
+
+}  // namespace bz2
+}  // namespace dq

@@ -40,6 +40,8 @@
 #include "dq_isa_pairs.h"
 #include "dq_bucket_sort.h"
 #include "dq_match_search.h"
+#include "dq_bz2.h"
+#include "dq_bsdiff.h"
 
 namespace {
 
@@ -1341,6 +1343,148 @@ int match_search_host(const uint8_t *old, int64_t n, const IdxT *sa, const uint8
     return done(DQ_OK);
 }
 
+// ------------------------------------------------------------------ BSDIFF40: Diff.Create / Patch.Apply (dq_bsdiff.h)
+// Answers of the match search for a window of scan positions ahead of the scan loop.  Windows start small after a
+// jump (inside a region of long matches every position of a window costs up to `cap` byte comparisons, and the
+// loop will leave the window with its next jump) and double while the loop consumes them to the end (a region
+// where old and new differ: one Search per byte).
+struct SearchWindows {
+    const void *d_old, *d_sa, *d_new;
+    int64_t n, m;
+    int device;
+    int32_t *d_pos = nullptr, *d_len = nullptr;          // kMaxWindow entries each, on the device
+    std::vector<int32_t> h_pos, h_len;
+    int64_t w0 = -1, wc = 0, next_size = kMinWindow;
+    int64_t windows = 0, exact = 0;
+    static constexpr int64_t kMinWindow = 1024, kMaxWindow = 65536, kCap = 4096;
+
+    int refill(int64_t scan)
+    {
+        // the previous window was used up to its end: the loop is walking byte by byte -> a larger one
+        next_size = (w0 >= 0 && scan == w0 + wc) ? std::min(next_size * 2, kMaxWindow) : kMinWindow;
+        const int64_t count = std::min(next_size, m - scan);
+        int rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, count, kCap, d_pos, d_len, device, nullptr);
+        if (rc != DQ_OK) return rc;
+        HIP_TRY(hipMemcpy(h_pos.data(), d_pos, (size_t)count * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h_len.data(), d_len, (size_t)count * 4, hipMemcpyDeviceToHost));
+        w0 = scan;
+        wc = count;
+        ++windows;
+        return DQ_OK;
+    }
+    int operator()(int64_t scan, int64_t *pos, int64_t *len)
+    {
+        if (scan < w0 || scan >= w0 + wc) {
+            const int rc = refill(scan);
+            if (rc != DQ_OK) return rc;
+        }
+        int64_t p = h_pos[(size_t)(scan - w0)], l = h_len[(size_t)(scan - w0)];
+        if (l < 0) {                                     // undecided within the cap: this one position, exactly
+            int rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, 1, 0, d_pos, d_len, device, nullptr);
+            if (rc != DQ_OK) return rc;
+            int32_t one[2];
+            HIP_TRY(hipMemcpy(&one[0], d_pos, 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&one[1], d_len, 4, hipMemcpyDeviceToHost));
+            p = one[0];
+            l = one[1];
+            h_pos[(size_t)(scan - w0)] = one[0];
+            h_len[(size_t)(scan - w0)] = one[1];
+            ++exact;
+        }
+        *pos = p;
+        *len = l;
+        return DQ_OK;
+    }
+};
+
+// Diff.Create's data path up to the raw streams: sort old on the device, keep the SA there, run the scan loop
+int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, bsdiff::RawStreams &raw)
+{
+    if (n < 0 || m < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
+    if ((n > 0 && !old) || (m > 0 && !nw)) return fail(DQ_ERR_BAD_ARGS, "null buffer");
+    if (n > 0x7fffffffLL || m > 0x7fffffffLL) return fail(DQ_ERR_TOO_LARGE, "the BSDIFF40 path takes files below 2 GiB (int indices, as the reference)");
+    int dev = 0;
+    int rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    if (m == 0) return DQ_OK;
+    HIP_TRY(hipSetDevice(dev));
+    char *base = nullptr;
+    const size_t b_old = align_up((size_t)n + 16), b_sa = align_up((size_t)n * 4 + 16), b_new = align_up((size_t)m + 16);
+    const size_t b_win = align_up((size_t)SearchWindows::kMaxWindow * 4);
+    hipError_t e = hipMalloc((void **)&base, b_old + b_sa + b_new + 2 * b_win);
+    if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(bsdiff buffers)", e);
+    struct Free { char *p; ~Free() { (void)hipFree(p); } } guard{base};
+    char *d_old = base, *d_sa = d_old + b_old, *d_new = d_sa + b_sa;
+    if (n > 0) HIP_TRY(hipMemcpy(d_old, old, (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice));
+    rc = sufsort_dev<int32_t>(d_old, n, d_sa, dev, nullptr);                       // Diff.cs:90; the SA never leaves the device
+    if (rc != DQ_OK) return rc;
+    SearchWindows win{d_old, d_sa, d_new, n, m, dev};
+    win.d_pos = reinterpret_cast<int32_t *>(d_new + b_new);
+    win.d_len = reinterpret_cast<int32_t *>(d_new + b_new + b_win);
+    win.h_pos.resize((size_t)SearchWindows::kMaxWindow);
+    win.h_len.resize((size_t)SearchWindows::kMaxWindow);
+    rc = bsdiff::scan_loop(old, n, nw, m, win, raw);
+    raw.windows = win.windows;
+    raw.exact = win.exact;
+    return rc;
+}
+
+// one bzip2 stream; the Burrows-Wheeler transform of each block through the suffix sorter
+int bz2_stream(const std::vector<uint8_t> &src, std::vector<uint8_t> &out, int dev)
+{
+    int sort_rc = DQ_OK;
+    const int rc = bz2::bz2_compress(src.data(), src.size(), out,
+                                     [&](const uint8_t *t, int64_t n2, int32_t *sa) -> int {
+                                         sort_rc = sufsort_host<int32_t>(t, n2, sa, dev);
+                                         return sort_rc == DQ_OK ? 0 : -2;
+                                     });
+    if (rc == -2) return sort_rc;
+    if (rc != 0) return fail(DQ_ERR_HIP, "bzip2 block transform failed");
+    return DQ_OK;
+}
+
+int bsdiff_create_host(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, std::vector<uint8_t> &patch)
+{
+    bsdiff::RawStreams raw;
+    int rc = bsdiff_raw(old, n, nw, m, device, raw);
+    if (rc != DQ_OK) return rc;
+    int dev = 0;
+    rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    std::vector<uint8_t> zc, zd, ze;
+    if ((rc = bz2_stream(raw.ctrl, zc, dev)) != DQ_OK || (rc = bz2_stream(raw.diff, zd, dev)) != DQ_OK ||
+        (rc = bz2_stream(raw.extra, ze, dev)) != DQ_OK)
+        return rc;
+    patch.assign((size_t)bsdiff::kHeaderSize, 0);                                  // Diff.cs:54-70 / :247-252
+    bsdiff::write_packed_long(&patch[0], bsdiff::kSignature);
+    bsdiff::write_packed_long(&patch[8], (int64_t)zc.size());
+    bsdiff::write_packed_long(&patch[16], (int64_t)zd.size());
+    bsdiff::write_packed_long(&patch[24], m);
+    patch.insert(patch.end(), zc.begin(), zc.end());
+    patch.insert(patch.end(), zd.begin(), zd.end());
+    patch.insert(patch.end(), ze.begin(), ze.end());
+    return DQ_OK;
+}
+
+// Patch.Apply (Patch.cs:52-168): host only
+int bspatch_apply_host(const uint8_t *old, int64_t n, const uint8_t *patch, int64_t plen, uint8_t *out, int64_t cap, int64_t *out_len)
+{
+    if (n < 0 || plen < 0 || cap < 0 || (n > 0 && !old) || !patch) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
+    bsdiff::Header h;
+    if (bsdiff::parse_header(patch, plen, &h) != 0) return fail(DQ_ERR_BAD_ARGS, "Corrupt patch");
+    if (out_len) *out_len = h.new_size;
+    if (!out) return DQ_OK;                                                        // size query
+    if (cap < h.new_size) return fail(DQ_ERR_BAD_ARGS, "output buffer too small");
+    std::vector<uint8_t> ctrl, diff, extra;
+    const uint8_t *pc = patch + bsdiff::kHeaderSize, *pd = pc + h.ctrl_len, *pe = pd + h.diff_len;
+    if (bz2::bz2_decompress(pc, (size_t)h.ctrl_len, ctrl) != 0 || bz2::bz2_decompress(pd, (size_t)h.diff_len, diff) != 0 ||
+        bz2::bz2_decompress(pe, (size_t)(plen - bsdiff::kHeaderSize - h.ctrl_len - h.diff_len), extra) != 0)
+        return fail(DQ_ERR_BAD_ARGS, "Corrupt patch");
+    if (bsdiff::apply_streams(old, n, ctrl, diff, extra, h.new_size, out) != 0) return fail(DQ_ERR_BAD_ARGS, "Corrupt patch");
+    return DQ_OK;
+}
+
 // ------------------------------------------------------------------ batch: one device's share, pipelined
 // Three stages on three host threads and three streams, kBatchSlots device buffers in flight:
 //   copy-in   text j -> slot          (pageable host memory: the copy blocks its thread, not the others)
@@ -1595,6 +1739,62 @@ int32_t dq_bsdiff_search_i64(const uint8_t *old_data, int64_t n, const int64_t *
                              int32_t device)
 {
     return match_search_host<int64_t>(old_data, n, sa, new_data, m, scans, scan0, count, cap, pos, len, device);
+}
+
+int32_t dq_bsdiff_scan_i32(const uint8_t *old_data, int64_t n, const uint8_t *new_data, int64_t m, int64_t *ctrl,
+                           int64_t ctrl_cap, int64_t *nctrl, uint8_t *diff, int64_t *ndiff, uint8_t *extra, int64_t *nextra,
+                           int64_t *stats, int32_t device)
+{
+    try {
+        bsdiff::RawStreams raw;
+        const int rc = bsdiff_raw(old_data, n, new_data, m, device, raw);
+        if (rc != DQ_OK) return rc;
+        const int64_t triples = (int64_t)raw.ctrl.size() / 24;
+        if (triples > ctrl_cap) return fail(DQ_ERR_BAD_ARGS, "control buffer too small");
+        for (int64_t i = 0; i < 3 * triples; ++i) ctrl[i] = bsdiff::read_packed_long(&raw.ctrl[(size_t)i * 8]);
+        if (!raw.diff.empty()) memcpy(diff, raw.diff.data(), raw.diff.size());
+        if (!raw.extra.empty()) memcpy(extra, raw.extra.data(), raw.extra.size());
+        *nctrl = triples; *ndiff = (int64_t)raw.diff.size(); *nextra = (int64_t)raw.extra.size();
+        if (stats) { stats[0] = raw.searches; stats[1] = raw.windows; stats[2] = raw.exact; }
+        return DQ_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(DQ_ERR_OOM, "bsdiff: host allocation failed");
+    }
+}
+
+int32_t dq_bsdiff_create(const uint8_t *old_data, int64_t n, const uint8_t *new_data, int64_t m, uint8_t *patch,
+                         int64_t cap, int64_t *patch_len, int32_t device)
+{
+    try {
+        std::vector<uint8_t> v;
+        const int rc = bsdiff_create_host(old_data, n, new_data, m, device, v);
+        if (rc != DQ_OK) return rc;
+        if (patch_len) *patch_len = (int64_t)v.size();
+        if ((int64_t)v.size() > cap || !patch) return fail(DQ_ERR_BAD_ARGS, "patch buffer too small (see dq_bsdiff_patch_bound)");
+        memcpy(patch, v.data(), v.size());
+        return DQ_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(DQ_ERR_OOM, "bsdiff: host allocation failed");
+    }
+}
+
+int64_t dq_bsdiff_patch_bound(int64_t n, int64_t m)
+{
+    if (n < 0 || m < 0) return -1;
+    // three bzip2 streams: 24 bytes of control per triple (at most m + 1 triples), m diff + extra bytes in total;
+    // bzip2 never grows its input by more than 1 % + 600 bytes per stream
+    const int64_t raw = 24 * (m + 1) + m;
+    return bsdiff::kHeaderSize + raw + raw / 100 + 3 * 600 + 64;
+}
+
+int32_t dq_bspatch_apply(const uint8_t *old_data, int64_t n, const uint8_t *patch, int64_t patch_len, uint8_t *out,
+                         int64_t cap, int64_t *out_len)
+{
+    try {
+        return bspatch_apply_host(old_data, n, patch, patch_len, out, cap, out_len);
+    } catch (const std::bad_alloc &) {
+        return fail(DQ_ERR_OOM, "bspatch: host allocation failed");
+    }
 }
 
 int64_t dq_sufsort_hip_workspace_bytes(int64_t n, int32_t index_bytes)

@@ -96,6 +96,30 @@ int32_t dq_bsdiff_search_i64(const uint8_t *old_data, int64_t n, const int64_t *
                              const int64_t *scans, int64_t scan0, int64_t count, int64_t cap, int64_t *pos, int64_t *len,
                              int32_t device);
 
+/* ---- Diff.Create / Patch.Apply natively: the BSDIFF40 container ----------------
+ * dq_bsdiff_create   = Diff.Create(oldData, newData, output, suffixSort)         src/DeltaQ.BsDiff/Diff.cs:27-253
+ *   old file -> suffix array on the device (stays there) -> match search kernel, asked for windows of scan
+ *   positions by the reference's own scan loop (Diff.cs:100-232, kept statement for statement on the host) ->
+ *   control triples / diff / extra -> three bzip2 streams (each block's Burrows-Wheeler transform is one more run
+ *   of the device sorter) -> "BSDIFF40" header (Constants.cs, SpanExtensions.cs packed longs) + streams.
+ *   The raw streams equal the reference loop's byte for byte; the bzip2 framing is a valid encoding of them (any
+ *   bzip2 decoder reads it; the reference does not pin SharpZipLib's bytes either).  patch: cap bytes
+ *   (dq_bsdiff_patch_bound(n, m) always suffices); *patch_len receives the length.  Files below 2 GiB (int).
+ * dq_bsdiff_scan_i32 = the same up to the raw streams: ctrl receives *nctrl (add, copy, seek) triples (capacity
+ *   ctrl_cap triples; m + 1 always suffices), diff / extra the raw bytes (capacity m each); stats (optional,
+ *   3 entries): Search calls of the loop, windows requested from the device, positions asked again exactly.
+ * dq_bspatch_apply   = Patch.Apply(input, openPatchStream, output)                src/DeltaQ.BsDiff/Patch.cs:52-168
+ *   host code only (no device needed).  out == NULL: only *out_len = size of the new file.  A patch the
+ *   reference would reject with "Corrupt patch" returns DQ_ERR_BAD_ARGS with that message in dq_last_error(). */
+int32_t dq_bsdiff_create(const uint8_t *old_data, int64_t n, const uint8_t *new_data, int64_t m, uint8_t *patch,
+                         int64_t cap, int64_t *patch_len, int32_t device);
+int64_t dq_bsdiff_patch_bound(int64_t n, int64_t m);
+int32_t dq_bsdiff_scan_i32(const uint8_t *old_data, int64_t n, const uint8_t *new_data, int64_t m, int64_t *ctrl,
+                           int64_t ctrl_cap, int64_t *nctrl, uint8_t *diff, int64_t *ndiff, uint8_t *extra, int64_t *nextra,
+                           int64_t *stats, int32_t device);
+int32_t dq_bspatch_apply(const uint8_t *old_data, int64_t n, const uint8_t *patch, int64_t patch_len, uint8_t *out,
+                         int64_t cap, int64_t *out_len);
+
 /* Device workspace (bytes) a sort of n bytes with index_bytes (4 or 8) wide indices needs,
  * excluding the caller's text and sa buffers. */
 int64_t dq_sufsort_hip_workspace_bytes(int64_t n, int32_t index_bytes);

@@ -1,0 +1,45 @@
+// bz2_harness.cpp -- TEST INFRASTRUCTURE: exposes the product's host-side bzip2 codec (deltaq_amd/csrc/dq_bz2.h) to the
+// CPU tests through ctypes.  The encoder's Burrows-Wheeler transform needs a suffix array of block+block; the
+// product takes it from the MI355X sorter, this harness from a naive comparison sort (small inputs only), so that
+// the format logic of the encoder can be checked against libbz2 on a machine without a GPU.
+//   g++ -O2 -std=c++17 -fPIC -shared tests/native/bz2_harness.cpp -o tests/native/libbz2_harness.so
+#include <cstdlib>
+#include <numeric>
+
+#include "../../deltaq_amd/csrc/dq_bz2.h"
+
+static int naive_sorter(const uint8_t *t, int64_t n, int32_t *sa)
+{
+    std::iota(sa, sa + n, 0);
+    std::sort(sa, sa + n, [&](int32_t a, int32_t b) {
+        const int64_t la = n - a, lb = n - b, m = la < lb ? la : lb;
+        const int c = memcmp(t + a, t + b, (size_t)m);
+        return c != 0 ? c < 0 : la < lb;
+    });
+    return 0;
+}
+
+extern "C" {
+
+// returns the compressed length, or a negative code; cap = capacity of out
+int64_t t_bz2_compress(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap, int32_t level)
+{
+    std::vector<uint8_t> v;
+    const int rc = dq::bz2::bz2_compress(src, (size_t)n, v, naive_sorter, level);
+    if (rc != 0) return rc;
+    if ((int64_t)v.size() > cap) return -100;
+    memcpy(out, v.data(), v.size());
+    return (int64_t)v.size();
+}
+
+int64_t t_bz2_decompress(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap)
+{
+    std::vector<uint8_t> v;
+    const int rc = dq::bz2::bz2_decompress(src, (size_t)n, v);
+    if (rc != 0) return rc;
+    if ((int64_t)v.size() > cap) return -100;
+    if (!v.empty()) memcpy(out, v.data(), v.size());
+    return (int64_t)v.size();
+}
+
+}

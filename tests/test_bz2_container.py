@@ -1,0 +1,128 @@
+"""CPU tests of the host-side half of the BSDIFF40 row: the bzip2 codec (deltaq_amd/csrc/dq_bz2.h) against libbz2
+(Python's bz2) in both directions, packed longs / header / Patch.Apply against patches framed by libbz2 from the
+oracle's raw streams.  The encoder's block transform is the GPU sorter's job in the product; here a naive
+sorter stands in (tests/native/bz2_harness.cpp), so that the format logic is checked without a GPU."""
+import bz2
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+NATIVE = os.path.join(ROOT, "tests", "native")
+
+
+@pytest.fixture(scope="module")
+def harness():
+    so = os.path.join(NATIVE, "libbz2_harness.so")
+    src = os.path.join(NATIVE, "bz2_harness.cpp")
+    hdr = os.path.join(ROOT, "deltaq_amd", "csrc", "dq_bz2.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    L.t_bz2_compress.restype = ctypes.c_int64
+    L.t_bz2_compress.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
+    L.t_bz2_decompress.restype = ctypes.c_int64
+    L.t_bz2_decompress.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+
+    class H:
+        @staticmethod
+        def compress(b, level=9):
+            out = np.empty(len(b) * 2 + 1000, np.uint8)
+            r = L.t_bz2_compress(b, len(b), out.ctypes.data, out.size, level)
+            assert r >= 0, r
+            return out[:r].tobytes()
+
+        @staticmethod
+        def decompress(b, cap):
+            out = np.empty(cap + 16, np.uint8)
+            r = L.t_bz2_decompress(b, len(b), out.ctypes.data, out.size)
+            return r, out[:max(r, 0)].tobytes()
+    return H
+
+
+def sample_inputs(oracle_mod):
+    rng = np.random.default_rng(1)
+    cases = [b"", b"a", b"ab", b"aaaa", b"aaaaa", b"a" * 255, b"a" * 256, b"a" * 259, b"a" * 1000, b"abc" * 1000,
+             bytes(range(256)) * 10, b"banana", b"\x00" * 70000]
+    for n in (10, 100, 1000, 5000, 30000):
+        cases.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+        cases.append(rng.integers(0, 3, n, dtype=np.uint8).tobytes())
+        cases.append((rng.integers(0, 256, n, dtype=np.uint8) * (rng.integers(0, 10, n) == 0)).astype(np.uint8).tobytes())
+    cases.append(oracle_mod.gen_enwik_like(120_000, 3, 4096).tobytes())
+    return cases
+
+
+def test_decoder_reads_libbz2_streams(harness, oracle_mod):
+    for i, c in enumerate(sample_inputs(oracle_mod)):
+        for level in (1, 9):
+            r, d = harness.decompress(bz2.compress(c, level), len(c))
+            assert r == len(c) and d == c, (i, level)
+    r, d = harness.decompress(bz2.compress(b"hello ") + bz2.compress(b"world"), 100)       # concatenated streams
+    assert d == b"hello world"
+    multi = oracle_mod.gen_enwik_like(450_000, 3, 4096).tobytes()                          # several 100 kB blocks
+    assert harness.decompress(bz2.compress(multi, 1), len(multi))[1] == multi
+
+
+def test_encoder_output_is_read_by_libbz2(harness, oracle_mod):
+    for i, c in enumerate(sample_inputs(oracle_mod)):
+        z = harness.compress(c)
+        assert bz2.decompress(z) == c, i
+        assert harness.decompress(z, len(c))[1] == c, i
+        if len(c) < 800_000:
+            assert len(z) == len(bz2.compress(c)), i          # same tables as libbz2 on single-block inputs
+    multi = oracle_mod.gen_enwik_like(350_000, 5, 4096).tobytes() + oracle_mod.gen_uniform(150_000, 4).tobytes()
+    assert bz2.decompress(harness.compress(multi, 1)) == multi
+
+
+def test_decoder_rejects_damage(harness, oracle_mod):
+    c = oracle_mod.gen_enwik_like(5000, 1, 512).tobytes()
+    z = bytearray(bz2.compress(c))
+    assert harness.decompress(bytes(z[:-5]), 6000)[0] == -2                  # truncated
+    z[len(z) // 2] ^= 0x10
+    assert harness.decompress(bytes(z), 6000)[0] == -1                       # CRC / structure
+    assert harness.decompress(b"BZh9" + b"\x00" * 20, 100)[0] < 0
+    assert harness.decompress(b"not bzip2", 100)[0] < 0
+
+
+def packed(y):
+    b = bytearray(struct.pack("<Q", abs(y)))
+    if y < 0:
+        b[7] |= 0x80
+    return bytes(b)
+
+
+def reference_style_patch(oracle_mod, old, new):
+    """What Diff.Create writes, built from the oracle's raw streams and libbz2's framing."""
+    sa = oracle_mod.divsufsort(old)
+    ctrl, diff, extra, _ = oracle_mod.bsdiff_scan(old, sa, new)
+    c = b"".join(packed(int(v)) for v in ctrl.reshape(-1))
+    zc, zd, ze = bz2.compress(c), bz2.compress(diff.tobytes()), bz2.compress(extra.tobytes())
+    return b"BSDIFF40" + packed(len(zc)) + packed(len(zd)) + packed(new.size) + zc + zd + ze
+
+
+@pytest.mark.parametrize("size", [0, 1, 512, 999, 1024, 4096])
+def test_patch_apply_roundtrip_like_BsDiffTests(backend_lib, oracle_mod, size):
+    from deltaq_amd import Patch
+    old = oracle_mod.net_random_bytes(size)
+    for new in (old.copy(), oracle_mod.gen_uniform(size, 5), np.concatenate([old[size // 2:], old[:size // 3]])):
+        patch = reference_style_patch(oracle_mod, old, new)
+        assert Patch.Apply(old, patch) == new.tobytes()
+
+
+def test_patch_apply_rejects_corrupt_patches(backend_lib, oracle_mod):
+    from deltaq_amd import Patch
+    old = oracle_mod.gen_enwik_like(20000, 1, 1024)
+    new = np.concatenate([old[:5000], oracle_mod.gen_uniform(300, 2), old[7000:]])
+    patch = reference_style_patch(oracle_mod, old, new)
+    assert Patch.Apply(old, patch) == new.tobytes()
+    for bad in (patch[:31], b"BSDIFF41" + patch[8:], patch[:8] + packed(-5) + patch[16:], patch[:60],
+                patch[:24] + packed(new.size + 10) + patch[32:]):
+        with pytest.raises(ValueError, match="Corrupt patch"):
+            Patch.Apply(old, bad)
+    with pytest.raises(ValueError, match="Corrupt patch"):
+        Patch.Apply(old[:100], patch)                                       # the wrong old file: reads past its end

@@ -1,0 +1,83 @@
+"""GPU tests of Diff.Create natively (dq_bsdiff_create / dq_bsdiff_scan_i32): the raw streams of the scan loop --
+driven by windows of device match-search answers -- against the oracle's restatement of Diff.cs:91-232 bit for
+bit; the container read by a reference-style reader (header + libbz2 + the oracle's ApplyInternal) and by the
+product's own Patch.Apply; patches framed by libbz2 applied by the product."""
+import bz2
+import io
+
+import numpy as np
+import pytest
+
+from test_bz2_container import packed, reference_style_patch
+from test_gpu_match_search import edited
+
+pytestmark = pytest.mark.gpu
+
+
+def unpacked(b):
+    y = int.from_bytes(b[:7] + bytes([b[7] & 0x7F]), "little")
+    return -y if b[7] & 0x80 else y
+
+
+def reference_style_apply(oracle_mod, old, patch):
+    """Patch.Apply as the reference does it: header, three bzip2 streams (libbz2), ApplyInternal (oracle)."""
+    assert patch[:8] == b"BSDIFF40"
+    lc, ld, newsize = unpacked(patch[8:16]), unpacked(patch[16:24]), unpacked(patch[24:32])
+    c = bz2.decompress(patch[32:32 + lc])
+    d = bz2.decompress(patch[32 + lc:32 + lc + ld])
+    e = bz2.decompress(patch[32 + lc + ld:])
+    ctrl = np.array([unpacked(c[i:i + 8]) for i in range(0, len(c), 8)], dtype=np.int64).reshape(-1, 3)
+    return oracle_mod.bspatch_apply(old, ctrl, np.frombuffer(d, np.uint8), np.frombuffer(e, np.uint8), newsize)
+
+
+def pairs(oracle_mod):
+    rng = np.random.default_rng(17)
+    out = []
+    for size in (0, 1, 2, 512, 999, 1024, 4096):                         # BsDiffTests.cs sizes
+        old = oracle_mod.net_random_bytes(size)
+        out.append((old, old.copy()))
+        out.append((old, oracle_mod.gen_uniform(max(size, 3), 9)))
+    old = oracle_mod.gen_enwik_like(300_000, 3, 8192)
+    out.append((old, edited(rng, old, 30)))                               # text with edits: many short and long matches
+    old = oracle_mod.gen_uniform(500_000, 21)
+    out.append((old, edited(rng, old, 12)))                               # random data with edits: long matches, jumps
+    out.append((old, oracle_mod.gen_uniform(200_000, 22)))                # nothing in common: one Search per byte
+    out.append((np.zeros(100_000, np.uint8), np.zeros(90_000, np.uint8)))
+    out.append((oracle_mod.gen_uniform(1000, 1), np.zeros(0, np.uint8)))
+    return out
+
+
+def test_raw_streams_equal_the_reference_loop(backend_lib, oracle_mod):
+    from deltaq_amd import Diff
+    for old, new in pairs(oracle_mod):
+        ctrl, diff, extra, stats = Diff.Scan(old, new)
+        sa = oracle_mod.divsufsort(old)
+        wc, wd, we, searches = oracle_mod.bsdiff_scan(old, sa, new)
+        assert np.array_equal(ctrl, wc) and np.array_equal(diff, wd) and np.array_equal(extra, we), (old.size, new.size)
+        assert stats["searches"] == searches
+
+
+def test_create_apply_roundtrip_and_cross_compatibility(backend_lib, oracle_mod):
+    from deltaq_amd import Diff, Patch, HipSuffixSort
+    for old, new in pairs(oracle_mod):
+        out = io.BytesIO()
+        Diff.Create(old, new, out, HipSuffixSort(0))
+        patch = out.getvalue()
+        assert patch[:8] == b"BSDIFF40" and len(patch) <= backend_lib.dq_bsdiff_patch_bound(old.size, new.size)
+        assert Patch.Apply(old, patch) == new.tobytes()                                   # product reads product
+        assert np.array_equal(reference_style_apply(oracle_mod, old, patch), new)         # a reference-style reader reads product
+        assert Patch.Apply(old, reference_style_patch(oracle_mod, old, new)) == new.tobytes()     # product reads reference-style
+    with pytest.raises(ValueError):
+        Diff.Create(b"a", b"b", None)
+
+
+def test_bzip2_blocks_through_the_device_sorter(backend_lib, oracle_mod):
+    """Streams longer than one 900 kB bzip2 block: every block's Burrows-Wheeler transform is a run of the HIP sorter
+    on block+block (1.8 MB).  Unrelated files of 3 MB make the extra stream 3 MB long."""
+    from deltaq_amd import Diff, Patch
+    old = oracle_mod.gen_uniform(1_000_000, 5)
+    new = oracle_mod.gen_enwik_like(3_000_000, 6, 4096)
+    patch = Diff.CreateBytes(old, new)
+    assert np.array_equal(reference_style_apply(oracle_mod, old, patch), new)
+    assert Patch.Apply(old, patch) == new.tobytes()
+    assert len(patch) < new.size // 2                                     # text compresses: the framing does its job
