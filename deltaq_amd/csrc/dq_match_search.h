@@ -12,10 +12,10 @@
 // costs O(match length + log n) byte comparisons instead of O(match length * log n).
 //
 //   match_search_kernel   one query per lane.  Comparisons of up to kMsLaneBytes bytes beyond the known
-//                         common prefix are done by the lane itself (in the regions where old and new
-//                         differ -- where the scan loop calls Search at every byte -- nearly all are);
-//                         longer ones are handed to the whole wave, one at a time: 64 lanes x 8 bytes per
-//                         step, first mismatch by ballot.  Random access to the SA (w B per probe) and to
+//                         common prefix are done by the lane itself, 8 bytes a step (in the regions where old
+//                         and new differ -- where the scan loop calls Search at every byte -- nearly all are a
+//                         few bytes long); longer ones are handed to the whole wave, one at a time: 64 lanes
+//                         x 8 bytes per step, first mismatch by ballot.  Random access to the SA (w B per probe) and to
 //                         old (one 64-B sector per probe): latency-bound, ~log2(n) dependent probes.
 //   cap > 0               a query whose comparison runs more than `cap` bytes past the known prefix is given
 //                         up (len = -1): speculative batches inside a long match must not cost O(match
@@ -26,7 +26,7 @@
 namespace dq {
 
 constexpr int kMsThreads = 256;
-constexpr int kMsLaneBytes = 24;
+constexpr int kMsLaneBytes = 256;        // a lane compares this far on its own (8 bytes a step) before the wave takes over
 
 __device__ __forceinline__ uint64_t ms_readlane64(uint64_t v, int lane)
 {
@@ -76,16 +76,42 @@ __device__ __forceinline__ int64_t ms_wave_lcp(const uint8_t *a, int64_t la, con
     return lim;
 }
 
+// prefix_bounds_kernel: ptab[v] = number of suffixes of old below the pk-byte string with big-endian value v, for
+// v = 0 .. 256^pk (ptab[256^pk] = n); one thread per v, the same lower bound as below with a pk-byte pattern.
+// A query of >= pk bytes with prefix value v then has its lower bound inside [ptab[v], ptab[v + 1]], and every
+// suffix strictly inside that range shares those pk bytes with it: the search starts ~8 * pk probes further down.
+// Built once per old file by the scan-loop driver (dq_sufsort_hip.hip::SearchWindows), where a Search is one
+// dependent round trip to the device and its ~log2(n) probes of ~1 us each are what the round trip costs.
 template <typename IdxT>
-__global__ __launch_bounds__(kMsThreads) void match_search_kernel(
-    const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa, const uint8_t *__restrict__ nw, int64_t m,
-    const int64_t *__restrict__ scans, int64_t scan0, int64_t count, int64_t cap, IdxT *__restrict__ pos_out,
-    IdxT *__restrict__ len_out)
+__global__ __launch_bounds__(kBlock) void prefix_bounds_kernel(const uint8_t *__restrict__ old, int64_t n,
+                                                               const IdxT *__restrict__ sa, int pk, IdxT *__restrict__ ptab)
+{
+    const int64_t total = 1ll << (8 * pk);
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (v > total) return;
+    if (v == total) { ptab[v] = (IdxT)n; return; }
+    int64_t L = 0, R = n;
+    while (L < R) {
+        const int64_t mid = L + ((R - L) >> 1);
+        const int64_t p = (int64_t)sa[mid], la = n - p;
+        bool less = la < pk;                               // all compared bytes equal: the shorter (a proper prefix) first
+        for (int j = 0; j < pk && j < la; ++j) {
+            const int a = old[p + j], b = (int)((v >> (8 * (pk - 1 - j))) & 0xff);
+            if (a != b) { less = a < b; break; }
+        }
+        if (less) L = mid + 1; else R = mid;
+    }
+    ptab[v] = (IdxT)L;
+}
+
+// One query per lane: Search(I, old, nw[scan..], 0, n).  Called by whole waves (the wave-wide comparison needs
+// every lane); `live` = this lane has a query.  *len_res = -1 when the cap was hit.
+template <typename IdxT>
+__device__ __forceinline__ void ms_search_one(const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa,
+                                              const uint8_t *__restrict__ nw, int64_t m, int64_t scan, bool live, int64_t cap,
+                                              const IdxT *__restrict__ ptab, int pk, int64_t *pos_res, int64_t *len_res)
 {
     const int lane = lane_id();
-    const int64_t qi = (int64_t)blockIdx.x * kMsThreads + threadIdx.x;
-    const bool live = qi < count;
-    const int64_t scan = live ? (scans ? scans[qi] : scan0 + qi) : 0;
     const uint8_t *q = nw + scan;
     const int64_t lq = live ? m - scan : 0;
 
@@ -101,7 +127,14 @@ __global__ __launch_bounds__(kMsThreads) void match_search_kernel(
         bool more = false;
         if (want) {
             const int64_t stop = j + kMsLaneBytes < lim ? j + kMsLaneBytes : lim;
-            while (j < stop && a[j] == q[j]) ++j;
+            // 8 bytes a step while 12 bytes exist in both buffers (ms_load8 touches whole dwords), then byte by byte
+            bool diff = false;
+            while (j + 8 <= stop && j + 12 <= la && j + 12 <= lq) {
+                const uint64_t x = ms_load8(a + j) ^ ms_load8(q + j);
+                if (x) { j += __builtin_ctzll(x) >> 3; diff = true; break; }
+                j += 8;
+            }
+            if (!diff) while (j < stop && a[j] == q[j]) ++j;
             more = j == stop && stop < lim;
             if (more && cap > 0 && j - k >= cap) { gave_up = true; more = false; }
         }
@@ -134,7 +167,17 @@ __global__ __launch_bounds__(kMsThreads) void match_search_kernel(
 
     // ---- g = number of suffixes smaller than the query: lower bound over [L, R) ----
     int64_t L = 0, R = live ? n : 0;
-    int64_t llcp = 0, rlcp = 0;                                   // lcp with SA[L-1] / SA[R] once they have been probed
+    // lcp with SA[L-1] / SA[R] once they have been probed (l_known / r_known); until then a lower bound of the lcp
+    // with everything inside [L, R)
+    int64_t llcp = 0, rlcp = 0;
+    bool l_known = false, r_known = false;
+    if (ptab && live && lq >= pk) {
+        int64_t v = 0;
+        for (int j = 0; j < pk; ++j) v = (v << 8) | q[j];
+        L = (int64_t)ptab[v];
+        R = (int64_t)ptab[v + 1];
+        llcp = rlcp = pk;
+    }
     for (;;) {
         const bool active = L < R && !gave_up;
         if (!__any(active)) break;
@@ -145,8 +188,8 @@ __global__ __launch_bounds__(kMsThreads) void match_search_kernel(
         }
         const int64_t l = lcp_with(p, llcp < rlcp ? llcp : rlcp, active);
         if (active && !gave_up) {
-            if (less_than_query(p, l)) { L = mid + 1; llcp = l; }
-            else { R = mid; rlcp = l; }
+            if (less_than_query(p, l)) { L = mid + 1; llcp = l; l_known = true; }
+            else { R = mid; rlcp = l; r_known = true; }
         }
     }
     const int64_t g = L;
@@ -156,18 +199,52 @@ __global__ __launch_bounds__(kMsThreads) void match_search_kernel(
     const bool usable = live && !gave_up && n > 0;
     const int64_t ps = usable ? (int64_t)sa[start] : 0;
     const int64_t pe = usable && end < n ? (int64_t)sa[end] : 0;
-    // x: lcp with I[start].  g >= 1: SA[g-1] was the last probe that moved L (llcp); g == 0: SA[0] = SA[R] (rlcp)
-    const int64_t x = g > 0 ? llcp : rlcp;
-    // y: lcp with I[end].  g >= 1 and g < n: SA[g] = SA[R] was probed (rlcp); otherwise it has to be measured
-    const bool y_known = g > 0 && g < n;
+    // x: lcp with I[start].  g >= 1: SA[g-1], the last probe that moved L (llcp); g == 0: SA[0] = SA[R] (rlcp) --
+    // if that end of the interval was probed at all (with a prefix table the search may start right on it)
+    const bool x_known = g > 0 ? l_known : r_known;
+    const int64_t x_meas = lcp_with(ps, 0, usable && !x_known);
+    const int64_t x = x_known ? (g > 0 ? llcp : rlcp) : x_meas;
+    // y: lcp with I[end].  g >= 1 and g < n: SA[g] = SA[R] if it was probed (rlcp); otherwise it has to be measured
+    const bool y_known = g > 0 && g < n && r_known;
     const int64_t y_meas = lcp_with(pe, 0, usable && !y_known);
     const int64_t y = y_known ? rlcp : y_meas;
-    if (live) {
-        if (gave_up) { pos_out[qi] = (IdxT)0; len_out[qi] = (IdxT)-1; }
-        else if (n == 0) { pos_out[qi] = (IdxT)0; len_out[qi] = (IdxT)0; }        // I = { 0 }: both candidates are I[0]
-        else if (x > y) { pos_out[qi] = (IdxT)ps; len_out[qi] = (IdxT)x; }
-        else { pos_out[qi] = (IdxT)pe; len_out[qi] = (IdxT)y; }
-    }
+    if (gave_up) { *pos_res = 0; *len_res = -1; }
+    else if (n == 0) { *pos_res = 0; *len_res = 0; }                              // I = { 0 }: both candidates are I[0]
+    else if (x > y) { *pos_res = ps; *len_res = x; }
+    else { *pos_res = pe; *len_res = y; }
 }
+
+// exact_first (with cap > 0; the scan-loop driver's windows): the FIRST position of the window that hit the cap is
+// searched again without a cap inside the same launch -- it is where the scan loop will meet the next long match
+// and ask for the exact answer, and a second launch for one query costs a whole round trip to the device.
+// (Workgroup 0 only: later ones would pay for long comparisons the loop never looks at.)
+template <typename IdxT>
+__global__ __launch_bounds__(kMsThreads) void match_search_kernel(
+    const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa, const uint8_t *__restrict__ nw, int64_t m,
+    const int64_t *__restrict__ scans, int64_t scan0, int64_t count, int64_t cap, IdxT *__restrict__ pos_out,
+    IdxT *__restrict__ len_out, const IdxT *__restrict__ ptab = nullptr, int pk = 0, int exact_first = 0)
+{
+    __shared__ int s_first;
+    const int64_t qi = (int64_t)blockIdx.x * kMsThreads + threadIdx.x;
+    const bool live = qi < count;
+    const int64_t scan = live ? (scans ? scans[qi] : scan0 + qi) : 0;
+    int64_t pos = 0, len = 0;
+    ms_search_one<IdxT>(old, n, sa, nw, m, scan, live, cap, ptab, pk, &pos, &len);
+    if (exact_first && cap > 0 && blockIdx.x == 0) {                                  // (uniform over the workgroup)
+        if (threadIdx.x == 0) s_first = kMsThreads;
+        __syncthreads();
+        if (live && len < 0) atomicMin(&s_first, (int)threadIdx.x);
+        __syncthreads();
+        const int first = s_first;
+        if (first < kMsThreads) {
+            const bool mine = (int)threadIdx.x == first;
+            int64_t p2 = 0, l2 = 0;
+            ms_search_one<IdxT>(old, n, sa, nw, m, scan, live && mine, 0, ptab, pk, &p2, &l2);
+            if (mine) { pos = p2; len = l2; }
+        }
+    }
+    if (live) { pos_out[qi] = (IdxT)pos; len_out[qi] = (IdxT)len; }
+}
+
 
 }  // namespace dq

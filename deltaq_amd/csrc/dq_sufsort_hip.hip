@@ -1272,7 +1272,7 @@ int sufsort_dev(const void *d_text, int64_t n, void *d_sa, int32_t device, void 
 template <typename IdxT>
 int match_search_dev(const void *d_old, int64_t n, const void *d_sa, const void *d_new, int64_t m,
                      const int64_t *d_scans, int64_t scan0, int64_t count, int64_t cap, void *d_pos, void *d_len,
-                     int32_t device, void *stream)
+                     int32_t device, void *stream, const void *d_ptab = nullptr, int pk = 0, int exact_first = 0)
 {
     if (n < 0 || m < 0 || count < 0 || cap < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
     if ((n > 0 && (!d_old || !d_sa)) || (m > 0 && !d_new) || (count > 0 && (!d_pos || !d_len)))
@@ -1296,7 +1296,8 @@ int match_search_dev(const void *d_old, int64_t n, const void *d_sa, const void 
         LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * probes * ((int64_t)sizeof(IdxT) + 64),
                hipLaunchKernelGGL(match_search_kernel<IdxT>, dim3((unsigned)((count + kMsThreads - 1) / kMsThreads)),
                                   dim3(kMsThreads), 0, st, (const uint8_t *)d_old, n, (const IdxT *)d_sa,
-                                  (const uint8_t *)d_new, m, d_scans, scan0, count, cap, (IdxT *)d_pos, (IdxT *)d_len));
+                                  (const uint8_t *)d_new, m, d_scans, scan0, count, cap, (IdxT *)d_pos, (IdxT *)d_len,
+                                  (const IdxT *)d_ptab, pk, exact_first));
         return DQ_OK;
     };
     rc = launch();
@@ -1345,28 +1346,33 @@ int match_search_host(const uint8_t *old, int64_t n, const IdxT *sa, const uint8
 
 // ------------------------------------------------------------------ BSDIFF40: Diff.Create / Patch.Apply (dq_bsdiff.h)
 // Answers of the match search for a window of scan positions ahead of the scan loop.  Windows start small after a
-// jump (inside a region of long matches every position of a window costs up to `cap` byte comparisons, and the
-// loop will leave the window with its next jump) and double while the loop consumes them to the end (a region
-// where old and new differ: one Search per byte).
+// jump and double while the loop consumes them to the end (a region where old and new differ: one Search per
+// byte, the regime the device is for: 4.2 M searches in 31 ms against 5.4 s on one host core).  The cap is low:
+// the positions of a window that lie inside the next long match would each cost `cap` byte comparisons for
+// nothing (the loop leaves the window with its next jump); the one position where the loop meets that match is
+// asked again exactly.  Between nearly identical files the loop is a chain of dependent round trips to the
+// device (~2 per edit) and runs at about the speed of the reference's CPU loop, not faster.
 struct SearchWindows {
     const void *d_old, *d_sa, *d_new;
     int64_t n, m;
     int device;
-    int32_t *d_pos = nullptr, *d_len = nullptr;          // kMaxWindow entries each, on the device
-    std::vector<int32_t> h_pos, h_len;
+    // kMaxWindow + 2 entries each in PINNED HOST memory that the kernel writes directly (no copy back: between
+    // similar files the loop is a chain of dependent round trips, and two small hipMemcpy cost more than the kernel)
+    int32_t *h_pos = nullptr, *h_len = nullptr;
+    const void *d_ptab = nullptr;                        // prefix table (prefix_bounds_kernel), or none
+    int pk = 0;
     int64_t w0 = -1, wc = 0, next_size = kMinWindow;
     int64_t windows = 0, exact = 0;
-    static constexpr int64_t kMinWindow = 1024, kMaxWindow = 65536, kCap = 4096;
+    static constexpr int64_t kMinWindow = 128, kMaxWindow = 65536, kCap = 64;
 
     int refill(int64_t scan)
     {
         // the previous window was used up to its end: the loop is walking byte by byte -> a larger one
         next_size = (w0 >= 0 && scan == w0 + wc) ? std::min(next_size * 2, kMaxWindow) : kMinWindow;
         const int64_t count = std::min(next_size, m - scan);
-        int rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, count, kCap, d_pos, d_len, device, nullptr);
-        if (rc != DQ_OK) return rc;
-        HIP_TRY(hipMemcpy(h_pos.data(), d_pos, (size_t)count * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(h_len.data(), d_len, (size_t)count * 4, hipMemcpyDeviceToHost));
+        int rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, count, kCap, h_pos, h_len, device, nullptr,
+                                           d_ptab, pk, /*exact_first=*/1);
+        if (rc != DQ_OK) return rc;                      // (returns after the stream has drained: the answers are there)
         w0 = scan;
         wc = count;
         ++windows;
@@ -1380,15 +1386,13 @@ struct SearchWindows {
         }
         int64_t p = h_pos[(size_t)(scan - w0)], l = h_len[(size_t)(scan - w0)];
         if (l < 0) {                                     // undecided within the cap: this one position, exactly
-            int rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, 1, 0, d_pos, d_len, device, nullptr);
+            int rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, 1, 0, h_pos + kMaxWindow,
+                                               h_len + kMaxWindow, device, nullptr, d_ptab, pk);
             if (rc != DQ_OK) return rc;
-            int32_t one[2];
-            HIP_TRY(hipMemcpy(&one[0], d_pos, 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(&one[1], d_len, 4, hipMemcpyDeviceToHost));
-            p = one[0];
-            l = one[1];
-            h_pos[(size_t)(scan - w0)] = one[0];
-            h_len[(size_t)(scan - w0)] = one[1];
+            p = h_pos[kMaxWindow];
+            l = h_len[kMaxWindow];
+            h_pos[(size_t)(scan - w0)] = (int32_t)p;
+            h_len[(size_t)(scan - w0)] = (int32_t)l;
             ++exact;
         }
         *pos = p;
@@ -1410,20 +1414,34 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     HIP_TRY(hipSetDevice(dev));
     char *base = nullptr;
     const size_t b_old = align_up((size_t)n + 16), b_sa = align_up((size_t)n * 4 + 16), b_new = align_up((size_t)m + 16);
-    const size_t b_win = align_up((size_t)SearchWindows::kMaxWindow * 4);
-    hipError_t e = hipMalloc((void **)&base, b_old + b_sa + b_new + 2 * b_win);
+    const size_t b_win = align_up((size_t)(SearchWindows::kMaxWindow + 2) * 4);
+    // prefix table of the match search: 3 bytes (64 MiB of entries) for old files from 4 MiB, 2 bytes from 64 KiB
+    const int pk = n >= (4 << 20) ? 3 : n >= (1 << 16) ? 2 : 0;
+    const size_t b_tab = pk ? align_up(((size_t)1 << (8 * pk)) * 4 + 16) : 0;
+    hipError_t e = hipMalloc((void **)&base, b_old + b_sa + b_new + b_tab);
     if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(bsdiff buffers)", e);
     struct Free { char *p; ~Free() { (void)hipFree(p); } } guard{base};
+    char *pinned = nullptr;
+    e = hipHostMalloc((void **)&pinned, 2 * b_win, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipHostMalloc(search windows)", e);
+    struct FreeHost { char *p; ~FreeHost() { (void)hipHostFree(p); } } hguard{pinned};
     char *d_old = base, *d_sa = d_old + b_old, *d_new = d_sa + b_sa;
     if (n > 0) HIP_TRY(hipMemcpy(d_old, old, (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice));
     rc = sufsort_dev<int32_t>(d_old, n, d_sa, dev, nullptr);                       // Diff.cs:90; the SA never leaves the device
     if (rc != DQ_OK) return rc;
     SearchWindows win{d_old, d_sa, d_new, n, m, dev};
-    win.d_pos = reinterpret_cast<int32_t *>(d_new + b_new);
-    win.d_len = reinterpret_cast<int32_t *>(d_new + b_new + b_win);
-    win.h_pos.resize((size_t)SearchWindows::kMaxWindow);
-    win.h_len.resize((size_t)SearchWindows::kMaxWindow);
+    if (pk) {
+        const int64_t total = (1ll << (8 * pk)) + 1;
+        hipLaunchKernelGGL(prefix_bounds_kernel<int32_t>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           nullptr, (const uint8_t *)d_old, n, (const int32_t *)d_sa, pk, (int32_t *)(d_new + b_new));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        win.d_ptab = d_new + b_new;
+        win.pk = pk;
+    }
+    win.h_pos = reinterpret_cast<int32_t *>(pinned);
+    win.h_len = reinterpret_cast<int32_t *>(pinned + b_win);
     rc = bsdiff::scan_loop(old, n, nw, m, win, raw);
     raw.windows = win.windows;
     raw.exact = win.exact;

@@ -43,6 +43,11 @@ def pairs(oracle_mod):
     out.append((old, edited(rng, old, 12)))                               # random data with edits: long matches, jumps
     out.append((old, oracle_mod.gen_uniform(200_000, 22)))                # nothing in common: one Search per byte
     out.append((np.zeros(100_000, np.uint8), np.zeros(90_000, np.uint8)))
+    old = oracle_mod.gen_enwik_like(5_000_000, 4, 16384)                  # >= 4 MiB: the search starts from a 3-byte prefix table
+    out.append((old, edited(rng, old, 300)))
+    new = oracle_mod.gen_uniform(60_000, 23)
+    new[1000:1003] = old[77:80]
+    out.append((old, new))
     out.append((oracle_mod.gen_uniform(1000, 1), np.zeros(0, np.uint8)))
     return out
 
