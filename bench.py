@@ -287,7 +287,50 @@ def other_configs(sorter, dev):
         del host
     recs.append(match_search_record(sorter, dev))
     recs.append(reference_benchmark_shape(sorter))
+    recs.append(bsdiff_create_record(dev))
     return recs
+
+
+def bsdiff_create_record(dev):
+    """Diff.Create natively (dq_bsdiff_create: device suffix array, device match search
+    in windows under the reference's scan loop, bzip2 framing with the block transform on the device sorter) on a
+    16 MiB random file and a copy with 2000 small edits, beside the CPU pipeline it replaces (oracle restatements
+    of LibDivSufSort and of the Search / scan loop on one core, libbz2)."""
+    import bz2
+    import numpy as np
+    import oracle
+    from deltaq_amd import Diff, Patch
+    from tools import datagen
+    rng = np.random.default_rng(3)
+    old = datagen.gen_uniform(16 << 20, 5)
+    new = bytearray(old.tobytes())
+    for _ in range(2000):
+        k, a, ln = int(rng.integers(0, 3)), int(rng.integers(0, len(new))), int(rng.integers(1, 400))
+        if k == 0:
+            new[a:a] = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+        elif k == 1:
+            del new[a:a + ln]
+        else:
+            new[a:a + ln] = rng.integers(0, 256, min(ln, len(new) - a), dtype=np.uint8).tobytes()
+    new = np.frombuffer(bytes(new), dtype=np.uint8)
+    Diff.CreateBytes(old[:4096], new[:4096], dev.index)
+    t0 = time.perf_counter()
+    patch = Diff.CreateBytes(old, new, dev.index)
+    gt = time.perf_counter() - t0
+    ctrl, diff, extra, stats = Diff.Scan(old, new, dev.index)
+    t0 = time.perf_counter()
+    sa = oracle.divsufsort(old)
+    t1 = time.perf_counter()
+    wc, wd, we, _ = oracle.bsdiff_scan(old, sa, new)
+    t2 = time.perf_counter()
+    for x in (wc, wd, we):
+        bz2.compress(x.tobytes())
+    t3 = time.perf_counter()
+    return {"config": "Diff.Create natively (BSDIFF40): 16 MiB random old, new = old with 2000 small edits",
+            "create_ms": round(gt * 1e3, 1), "patch_bytes": len(patch), "scan_loop": stats,
+            "cpu_pipeline_ms": {"sort": round((t1 - t0) * 1e3), "scan": round((t2 - t1) * 1e3), "bzip2": round((t3 - t2) * 1e3)},
+            "raw_streams_equal_oracle": bool(np.array_equal(ctrl, wc) and np.array_equal(diff, wd) and np.array_equal(extra, we)),
+            "patch_applies": bool(Patch.Apply(old, patch) == new.tobytes())}
 
 
 def reference_benchmark_shape(sorter):
