@@ -53,67 +53,84 @@ struct RawStreams {
     int64_t searches = 0, windows = 0, exact = 0;
 };
 
-// Search provider: int operator()(int64_t scan, int64_t *pos, int64_t *len)  -> 0 or an error code.
-// The loop below is Diff.cs:91-232 statement for statement; `I` is never touched by it except through Search.
+// The greedy alignment of bsdiff as the reference runs it (Diff.cs:91-232), in its three steps per control triple:
+//   1. anchor   from the end of the last match, Search every position until it returns a match that is not just
+//               the previous alignment carried on (more than 8 bytes better than what old[. + shift] already
+//               gives), or one that the previous alignment explains completely                    (:104-125)
+//   2. extend   forwards from the previous anchor and backwards from the new one, each to the length with the
+//               best 2 * matches - length; where the two extensions overlap, cut at the best split  (:129-191)
+//   3. emit     the forward extension as diff bytes (new - old), what lies between the extensions as extra
+//               bytes, and the triple (diff length, extra length, seek in old)                        (:196-223)
+// `search(scan, &pos, &len)` stands for Search(I, old, new[scan..], 0, n, out pos): 0 or an error code.  Every
+// decision is the reference's, so the triples and both byte streams are the reference's (the tests compare them
+// with the oracle's restatement of the same lines).
 template <typename SearchFn>
 int scan_loop(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, SearchFn &&search, RawStreams &out)
 {
-    int64_t scan = 0, pos = 0, len = 0, lastscan = 0, lastpos = 0, lastoffset = 0;
-    uint8_t buf[8];
-    while (scan < m) {                                                              // :100
-        int64_t oldscore = 0;
-        int64_t scsc;
-        for (scsc = scan += len; scan < m; scan++) {                                // :104
-            const int rc = search(scan, &pos, &len);                                // :106
+    struct Anchor { int64_t at = 0, in_old = 0; };          // a matched position of new and where it lies in old
+    Anchor prev;                                             // end of the last emitted forward extension
+    int64_t shift = 0;                                       // old - new offset of the previous alignment
+    int64_t cursor = 0, hit_pos = 0, hit_len = 0;            // scan position, last Search answer
+
+    auto agrees = [&](int64_t i) { return i + shift < n && old[i + shift] == nw[i]; };     // previous alignment still right at i?
+    auto emit_packed = [&](int64_t v) {
+        uint8_t b[8];
+        write_packed_long(b, v);
+        out.ctrl.insert(out.ctrl.end(), b, b + 8);
+    };
+
+    while (cursor < m) {
+        // ---- 1. next anchor ----
+        int64_t carried = 0;                                 // bytes of [.., cursor + hit_len) the previous alignment gets right
+        int64_t counted = cursor += hit_len;                 // ... counted up to here
+        for (; cursor < m; ++cursor) {
+            const int rc = search(cursor, &hit_pos, &hit_len);
             if (rc != 0) return rc;
             ++out.searches;
-            for (; scsc < scan + len; scsc++)
-                if ((scsc + lastoffset < n) && (old[scsc + lastoffset] == nw[scsc])) oldscore++;
-            if ((len == oldscore && len != 0) || (len > oldscore + 8)) break;
-            if ((scan + lastoffset < n) && (old[scan + lastoffset] == nw[scan])) oldscore--;
+            for (; counted < cursor + hit_len; ++counted) carried += agrees(counted);
+            if ((hit_len == carried && hit_len != 0) || hit_len > carried + 8) break;
+            carried -= agrees(cursor);
         }
-        if (len != oldscore || scan == m) {                                         // :127
-            int64_t s = 0, sf = 0, lenf = 0;
-            for (int64_t i = 0; (lastscan + i < scan) && (lastpos + i < n);) {
-                if (old[lastpos + i] == nw[lastscan + i]) s++;
-                i++;
-                if (s * 2 - i > sf * 2 - lenf) { sf = s; lenf = i; }
-            }
-            int64_t lenb = 0;
-            if (scan < m) {                                                         // :147
-                s = 0;
-                int64_t sb = 0;
-                for (int64_t i = 1; (scan >= lastscan + i) && (pos >= i); i++) {
-                    if (old[pos - i] == nw[scan - i]) s++;
-                    if (s * 2 - i > sb * 2 - lenb) { sb = s; lenb = i; }
-                }
-            }
-            if (lastscan + lenf > scan - lenb) {                                    // :167
-                const int64_t overlap = (lastscan + lenf) - (scan - lenb);
-                s = 0;
-                int64_t ss = 0, lens = 0;
-                for (int64_t i = 0; i < overlap; i++) {
-                    if (nw[lastscan + lenf - overlap + i] == old[lastpos + lenf - overlap + i]) s++;
-                    if (nw[scan - lenb + i] == old[pos - lenb + i]) s--;
-                    if (s > ss) { ss = s; lens = i + 1; }
-                }
-                lenf += lens - overlap;
-                lenb -= lens;
-            }
-            const size_t d0 = out.diff.size();                                      // :196 diff string
-            out.diff.resize(d0 + (size_t)lenf);
-            for (int64_t i = 0; i < lenf; i++) out.diff[d0 + (size_t)i] = (uint8_t)(nw[lastscan + i] - old[lastpos + i]);
-            const int64_t extra_len = (scan - lenb) - (lastscan + lenf);            // :203 extra string
-            if (extra_len > 0) out.extra.insert(out.extra.end(), nw + lastscan + lenf, nw + lastscan + lenf + extra_len);
-            const int64_t triple[3] = {lenf, extra_len, (pos - lenb) - (lastpos + lenf)};       // :210-217 ctrl block
-            for (int k = 0; k < 3; ++k) {
-                write_packed_long(buf, triple[k]);
-                out.ctrl.insert(out.ctrl.end(), buf, buf + 8);
-            }
-            lastscan = scan - lenb;
-            lastpos = pos - lenb;
-            lastoffset = pos - scan;
+        if (hit_len == carried && cursor != m) continue;     // the old alignment explains it: keep scanning behind it
+
+        // ---- 2. extensions ----
+        int64_t fwd = 0;                                     // forward from prev, under prev's alignment
+        for (int64_t i = 0, good = 0, best = 0; prev.at + i < cursor && prev.in_old + i < n;) {
+            good += old[prev.in_old + i] == nw[prev.at + i];
+            ++i;
+            if (2 * good - i > 2 * best - fwd) { best = good; fwd = i; }
         }
+        int64_t back = 0;                                    // backward from the new anchor, under its alignment
+        if (cursor < m) {
+            for (int64_t i = 1, good = 0, best = 0; cursor >= prev.at + i && hit_pos >= i; ++i) {
+                good += old[hit_pos - i] == nw[cursor - i];
+                if (2 * good - i > 2 * best - back) { best = good; back = i; }
+            }
+        }
+        const int64_t clash = (prev.at + fwd) - (cursor - back);
+        if (clash > 0) {                                     // both claim `clash` bytes: give each side its better part
+            int64_t balance = 0, best = 0, cut = 0;
+            for (int64_t i = 0; i < clash; ++i) {
+                balance += nw[prev.at + fwd - clash + i] == old[prev.in_old + fwd - clash + i];
+                balance -= nw[cursor - back + i] == old[hit_pos - back + i];
+                if (balance > best) { best = balance; cut = i + 1; }
+            }
+            fwd += cut - clash;
+            back -= cut;
+        }
+
+        // ---- 3. one control triple ----
+        const size_t d0 = out.diff.size();
+        out.diff.resize(d0 + (size_t)fwd);
+        for (int64_t i = 0; i < fwd; ++i) out.diff[d0 + (size_t)i] = (uint8_t)(nw[prev.at + i] - old[prev.in_old + i]);
+        const int64_t gap = (cursor - back) - (prev.at + fwd);
+        if (gap > 0) out.extra.insert(out.extra.end(), nw + prev.at + fwd, nw + prev.at + fwd + gap);
+        emit_packed(fwd);
+        emit_packed(gap);
+        emit_packed((hit_pos - back) - (prev.in_old + fwd));
+        prev.at = cursor - back;
+        prev.in_old = hit_pos - back;
+        shift = hit_pos - cursor;
     }
     return 0;
 }

@@ -86,3 +86,81 @@ def test_corrupt_patch_is_rejected(oracle_mod):
     old = oracle_mod.net_random_bytes(100)
     with pytest.raises(RuntimeError, match="Corrupt patch"):
         oracle_mod.bspatch_apply(old, np.array([[200, 0, 0]]), np.zeros(200, np.uint8), np.zeros(0, np.uint8), 100)
+
+
+# ---- the PRODUCT's scan loop (deltaq_amd/csrc/dq_bsdiff.h) on the CPU: Search answers come from a table the oracle
+#      filled, the loop itself is the shipped code (tests/native/scan_harness.cpp) ----
+@pytest.fixture(scope="module")
+def scan_harness():
+    import ctypes
+    import os
+    import subprocess
+    from conftest import ROOT
+    native = os.path.join(ROOT, "tests", "native")
+    so, src = os.path.join(native, "libscan_harness.so"), os.path.join(native, "scan_harness.cpp")
+    hdr = os.path.join(ROOT, "deltaq_amd", "csrc", "dq_bsdiff.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    L.t_scan_loop.restype = ctypes.c_int64
+    L.t_scan_loop.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 8
+    L.t_packed_roundtrip.restype = ctypes.c_int64
+    L.t_packed_roundtrip.argtypes = [ctypes.c_int64]
+
+    def run(old, new, pos, ln):
+        m = new.size
+        ctrl = np.empty(24 * (m + 1), np.uint8)
+        diff = np.empty(max(m, 1), np.uint8)
+        extra = np.empty(max(m, 1), np.uint8)
+        lens = np.zeros(3, np.int64)
+        pos = np.ascontiguousarray(pos, np.int64)
+        ln = np.ascontiguousarray(ln, np.int64)
+        old = np.ascontiguousarray(old)
+        new = np.ascontiguousarray(new)
+        r = L.t_scan_loop(old.ctypes.data, old.size, new.ctypes.data, m, pos.ctypes.data, ln.ctypes.data,
+                          ctrl.ctypes.data, lens.ctypes.data, diff.ctypes.data, lens.ctypes.data + 8,
+                          extra.ctypes.data, lens.ctypes.data + 16)
+        assert r >= 0
+        raw = ctrl[:lens[0]].reshape(-1, 8).astype(np.int64)
+        mag = sum((raw[:, i] & (0x7f if i == 7 else 0xff)) << (8 * i) for i in range(8))
+        trip = np.where(raw[:, 7] & 0x80, -mag, mag).reshape(-1, 3)
+        return trip, diff[:lens[1]].copy(), extra[:lens[2]].copy(), int(r)
+    run.lib = L
+    return run
+
+
+def test_product_scan_loop_makes_the_references_decisions(oracle_mod, scan_harness):
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        n = int(rng.integers(1, 12000))
+        old = oracle_mod.gen_enwik_like(n, 300 + trial, 1024) if trial % 2 else oracle_mod.gen_uniform(n, 300 + trial)
+        if trial % 5 == 0:
+            old = np.tile(old[: max(1, n // 37)], 37)[:n].copy()            # periodic: long carried alignments
+        new = bytearray(old.tobytes())
+        for _ in range(int(rng.integers(0, 10))):
+            a = int(rng.integers(0, max(1, len(new))))
+            ln = int(rng.integers(1, 300))
+            k = int(rng.integers(0, 4))
+            if k == 0:
+                new[a:a] = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+            elif k == 1:
+                del new[a:a + ln]
+            elif k == 2:
+                new[a:a + ln] = rng.integers(0, 256, min(ln, len(new) - a), dtype=np.uint8).tobytes()
+            else:
+                new[int(rng.integers(0, max(1, len(new)))):0] = new[a:a + ln]
+        if trial == 7:
+            new = bytearray()
+        new = np.frombuffer(bytes(new), dtype=np.uint8)
+        sa = oracle_mod.divsufsort(old)
+        pos, ln = oracle_mod.bsdiff_search(old, sa, new) if new.size else (np.zeros(0, np.int32), np.zeros(0, np.int32))
+        want = oracle_mod.bsdiff_scan(old, sa, new)
+        got = scan_harness(old, new, pos, ln)
+        assert np.array_equal(got[0], want[0]), trial
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), trial
+        assert got[3] == want[3], trial
+
+
+def test_product_packed_longs(scan_harness):
+    for v in (0, 1, -1, 127, 128, -128, 255, 256, 2**31 - 1, -2**31, 2**62, -(2**62), 2**63 - 1, -(2**63 - 1)):
+        assert scan_harness.lib.t_packed_roundtrip(v) == v
