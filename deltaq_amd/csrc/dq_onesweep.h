@@ -17,6 +17,7 @@
 // running (no dependence on dispatch order or XCD placement); every spin is bounded and
 // reports through an error word instead of hanging.
 #pragma once
+#include "dq_coded_keys.h"
 #include "dq_radix.h"
 
 namespace dq {
@@ -76,6 +77,43 @@ __global__ __launch_bounds__(kHistThreads) void radix_hist_kernel(const uint64_t
     }
     __syncthreads();
     for (int i = tid; i < kPasses * kRadixSize; i += kHistThreads) {
+        const uint32_t *h4 = &(&hist[0][0])[i * 4];
+        partial[(int64_t)blockIdx.x * (kMaxPasses * kRadixSize) + i] = h4[0] + h4[1] + h4[2] + h4[3];
+    }
+}
+
+// Same 8 histograms for the CODED round-0 keys (dq_coded_keys.h), which exist nowhere in memory yet: every lane
+// builds the keys of 4 consecutive suffixes from 20 text bytes, as the first digit pass will.
+__global__ __launch_bounds__(kHistThreads) void text_coded_hist_kernel(const uint32_t *__restrict__ t32, int64_t n,
+                                                                       const uint16_t *__restrict__ codetab,
+                                                                       uint32_t *__restrict__ partial)
+{
+    __shared__ uint32_t hist[kMaxPasses][kRadixSize * 4];
+    __shared__ uint16_t ctab[256];
+    const int tid = threadIdx.x;
+    const int sub = tid & 3;
+    for (int i = tid; i < kMaxPasses * kRadixSize * 4; i += kHistThreads) (&hist[0][0])[i] = 0;
+    if (tid < 256) ctab[tid] = codetab[tid];
+    __syncthreads();
+    const int64_t quads = (n + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * kHistThreads + tid; q < quads; q += (int64_t)gridDim.x * kHistThreads) {
+        uint32_t tw[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) tw[c] = t32[q + c];
+        uint64_t key[4];
+        coded_keys4(tw, ctab, key);
+        const int cnt = (n - q * 4) < 4 ? (int)(n - q * 4) : 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < cnt) {
+#pragma unroll
+                for (int p = 0; p < kMaxPasses; ++p)
+                    atomicAdd(&hist[p][(digit_of(key[c], p * kRadixBits) << 2) | sub], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < kMaxPasses * kRadixSize; i += kHistThreads) {
         const uint32_t *h4 = &(&hist[0][0])[i * 4];
         partial[(int64_t)blockIdx.x * (kMaxPasses * kRadixSize) + i] = h4[0] + h4[1] + h4[2] + h4[3];
     }
@@ -183,16 +221,19 @@ __device__ long long *g_phase_ts = nullptr;          // [ntiles][8]
 #endif
 
 template <typename IdxT, typename StatusT, int kItems, int kMode, int kMinWaves, int kThreads = kBlock,
-          bool kEarlyVals = false, bool kLdsMatch = true, int kExchRounds = 1, bool kAtomicBase = false>
+          bool kEarlyVals = false, bool kLdsMatch = true, int kExchRounds = 1, bool kAtomicBase = false,
+          bool kCoded = false>
 __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     const uint64_t *__restrict__ kin, const IdxT *__restrict__ vin,
     uint64_t *__restrict__ kout, IdxT *__restrict__ vout, int64_t m, int shift, int keybits, int ib,
     const int64_t *__restrict__ digit_offset /*[256] for this pass*/,
     StatusT *__restrict__ status /*[ntiles][256]*/, OnesweepCtl *__restrict__ ctl,
     int64_t *__restrict__ sticky_error, uint32_t *__restrict__ ebits = nullptr,
-    uint64_t *__restrict__ seam_tab /*[ntiles][256][2]*/ = nullptr)
+    uint64_t *__restrict__ seam_tab /*[ntiles][256][2]*/ = nullptr,
+    const uint16_t *__restrict__ codetab /*[256], kCoded*/ = nullptr)
 {
     constexpr bool kFromText = (kMode == kText || kMode == kTextPacked);
+    static_assert(!kCoded || kMode == kText, "coded keys: first pass of the pair sort only");
     // arrival-order ranking (below) only where digits are near-uniform -- packed words are chosen for random-like
     // text; a skewed digit would put hundreds of same-address LDS atomics of a tile in a row
     constexpr bool kAtomicRank = kAtomicBase && kMode == kTextPacked;
@@ -215,10 +256,12 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     __shared__ IdxT gofs[kRadixSize];
     __shared__ uint32_t wtmp[kRadixSize / kWave];
     __shared__ uint32_t s_tile;
+    __shared__ uint16_t ctab[kCoded ? 256 : 1];          // byte -> codeword << 4 | length (dq_alpha_code.h)
 
     const int tid = threadIdx.x;
     const int w = tid >> 6;
     const int lane = lane_id();
+    if (kCoded && tid < 256) ctab[tid] = codetab[tid];
 
     // kAtomicBase (first pass of a sort only: nothing to be stable against): a tile reserves its place in every
     // digit's output region with ONE returning atomic add per digit on a table of 256 cursors (the first 256
@@ -264,7 +307,20 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
 #pragma unroll
         for (int j = 0; j < kItems / 4; ++j) {
             const int e0 = (j * kThreads + tid) * 4;           // first of this lane's 4 suffixes
-            if (e0 < valid) {
+            if (kCoded) {
+                // keys = the first 64 bits of the codewords of T[i], T[i+1], ... (dq_coded_keys.h); the text is
+                // followed by 64 zero bytes, so the 20 bytes of the last lanes are there
+                if (e0 < valid) {
+                    const int64_t qd = (base + e0) >> 2;
+                    uint32_t tw[5];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) tw[c] = t32[qd + c];
+                    coded_keys4(tw, ctab, &key[4 * j]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) key[4 * j + c] = ~0ull;
+                }
+            } else if (e0 < valid) {
                 const int64_t qd = (base + e0) >> 2;
                 const uint32_t w0 = t32[qd], w1 = t32[qd + 1], w2 = t32[qd + 2];
                 const uint64_t x = __builtin_bswap64((uint64_t)w0 | ((uint64_t)w1 << 32));

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/dq_sufsort.h"
+#include "dq_alpha_code.h"
 #include "dq_onesweep.h"
 #include "dq_radix.h"
 #include "dq_sa_kernels.h"
@@ -92,7 +93,7 @@ struct DeviceCtx {
     hipStream_t stream = nullptr;
     char *ws = nullptr;
     size_t ws_bytes = 0;
-    int64_t *pinned = nullptr;          // 4 KiB pinned readback area
+    int64_t *pinned = nullptr;          // 8 KiB pinned: readback area [0, 4 KiB), upload staging [4 KiB, 8 KiB)
     uint8_t *pinned_io = nullptr;       // short texts: text in / SA out, read and written by the kernel itself
     hipEvent_t readback = nullptr;      // "the pinned readback has landed" (work queued behind it keeps running)
     std::vector<ProfRec> pending;
@@ -116,7 +117,7 @@ int init_ctx(DeviceCtx &c, int dev)
     // c.dev is published only once every resource exists: a failure half way (e.g. pinned memory
     // exhausted) frees what was made and leaves the context unbuilt, so the next call retries
     hipError_t e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c.pinned, 4096, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c.pinned, 8192, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c.pinned_io, kSmallIoBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c.readback, hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -220,6 +221,7 @@ struct Workspace {
     int64_t *totals;            // [0] active count, [1] sticky look-back timeout flag
     SmallGroupCounters *sg_ctr; // one per chained small-group round
     uint32_t *hist_partial;     // [kHistBlocks][8][256]
+    uint16_t *codetab;          // [256] codewords of the coded round 0 (dq_alpha_code.h)
     int64_t *digit_offset;      // [8][256]
     int64_t *bytehist;          // [256]
     char *ctl_status;           // per digit pass: OnesweepCtl (256 B) + the tiles' status words
@@ -250,6 +252,7 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.sg_ctr = (SmallGroupCounters *)take(kSgChain * sizeof(SmallGroupCounters));
     w.hist_partial = (uint32_t *)take((size_t)kHistBlocks * kMaxPasses * kRadixSize * 4);
     w.digit_offset = (int64_t *)take((size_t)kMaxPasses * kRadixSize * 8);
+    w.codetab = (uint16_t *)take(512);
     w.bytehist = (int64_t *)take((size_t)(kRadixSize + 8) * 8);        // + the 8 k-gram sample counters
     // smallest tile is 8192 keys; 8-byte status words once a list reaches 2^30 entries
     w.ctl_status_bytes = (size_t)kMaxPasses * align_up(256 + (un / 8192 + 2) * kRadixSize * (un >= (1ull << 30) ? 8 : 4));
@@ -294,7 +297,7 @@ int prepare_status(Launcher &L, Workspace<IdxT> &w, int64_t m, int passes)
     return DQ_OK;
 }
 
-template <typename IdxT, typename StatusT, int kMode>
+template <typename IdxT, typename StatusT, int kMode, bool kCoded = false>
 int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin,
                      uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb, int ib,
                      uint32_t *ebits = nullptr, uint64_t *seam_tab = nullptr, int shift_override = -1,
@@ -319,25 +322,25 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
     const int64_t alg_extra = kMode == kKeysLastTies ? m / 8 + ntiles * kRadixSize * 16 : 0;
     LAUNCH(L, DQ_K_RADIX_RANK, m, m * alg + alg_extra,
            hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, kItems, kMode, Cfg::kMinWaves, kThreads,
-                                                 false, Cfg::kLdsMatch, Cfg::kRounds, Cfg::kAtomicBase>),
+                                                 false, Cfg::kLdsMatch, Cfg::kRounds, Cfg::kAtomicBase, kCoded>),
                               dim3((unsigned)ntiles), dim3(kThreads), 0, L.st, kin, vin, kout, vout, m,
                               shift_override >= 0 ? shift_override : pass * kRadixBits + ib,
                               keybits > 0 ? keybits : 8 * kb, ib,
                               (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1,
-                              ebits, seam_tab));
+                              ebits, seam_tab, (const uint16_t *)w.codetab));
     return DQ_OK;
 }
 
-template <typename IdxT, int kMode>
+template <typename IdxT, int kMode, bool kCoded = false>
 int rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin, uint64_t *kout,
               IdxT *vout, int64_t m, int pass, int kb, int ib = 0, uint32_t *ebits = nullptr,
               uint64_t *seam_tab = nullptr, int shift_override = -1, int keybits = 0)
 {
     if (m < (1ll << 30))
-        return launch_rank_pass<IdxT, uint32_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits, seam_tab,
-                                                       shift_override, keybits);
-    return launch_rank_pass<IdxT, uint64_t, kMode>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits, seam_tab,
-                                                   shift_override, keybits);
+        return launch_rank_pass<IdxT, uint32_t, kMode, kCoded>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits,
+                                                               seam_tab, shift_override, keybits);
+    return launch_rank_pass<IdxT, uint64_t, kMode, kCoded>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits, seam_tab,
+                                                           shift_override, keybits);
 }
 
 template <int kPasses>
@@ -385,6 +388,10 @@ int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V
 // If (almost) that many key bytes fit into one 64-bit word next to the suffix index
 // (ib = bits of n-1), round 0 sorts PACKED words (key << ib | suffix): 16 B per element per
 // pass instead of 24 and no value array; the few extra ties go to the sparse finishing path.
+// coded round 0 (dq_alpha_code.h): from this size on, and only if a byte costs at most this many bits on average
+constexpr int64_t kCodedMinN = 8ll << 20;
+constexpr double kCodedMaxAvgLen = 6.5;
+
 void choose_key_bytes(const int64_t *bytehist, const int64_t *kgram_coll, int64_t n, int *kb_out, bool *packed_out)
 {
     double h0 = 0;
@@ -421,8 +428,9 @@ void choose_key_bytes(const int64_t *bytehist, const int64_t *kgram_coll, int64_
 // round 0, step 1: byte histogram of the text -> key width kb -> per-digit offsets
 template <typename IdxT>
 int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int *kb_out,
-                               bool *packed_out)
+                               bool *packed_out, bool *coded_out)
 {
+    *coded_out = false;
     const int blocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 4) + kBlock - 1) / kBlock + 1);
     HIP_TRY(hipMemsetAsync(w.bytehist, 0, 256 * 8, L.st));
     // (+1 workgroup: the k-gram sample, whose 8 counters sit right behind the byte histogram: one readback)
@@ -448,6 +456,33 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
     }
     *kb_out = kb;
     *packed_out = packed;
+    // Text-like input on the 8-byte pair path: the 64 key bits hold the codewords of an alphabetic prefix code
+    // instead of 8 raw bytes (dq_alpha_code.h) when that makes the key reach at least ~10 characters on average.
+    // The keys' digits are then no longer text bytes: their histograms take one more read of the text.
+    bool coded = !packed && kb == 8 && n >= kCodedMinN;
+    if (const char *v = getenv("DQ_CODED")) coded = atoi(v) != 0 && !packed && kb == 8 && n >= 64;
+    if (coded) {
+        AlphaCode code;
+        coded = build_alpha_code(c.pinned, &code) && (code.avg_len <= kCodedMaxAvgLen || getenv("DQ_CODED"));
+        if (coded) {
+            uint16_t *stage = reinterpret_cast<uint16_t *>(c.pinned + 512);          // the upload half of the pinned area
+            memcpy(stage, code.tab, sizeof(code.tab));
+            HIP_TRY(hipMemcpyAsync(w.codetab, stage, sizeof(code.tab), hipMemcpyHostToDevice, L.st));
+            const int hblocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 2) + kHistThreads - 1) / kHistThreads + 1);
+            int rc2 = L.begin(DQ_K_RADIX_HIST, n, n);
+            if (rc2 != DQ_OK) return rc2;
+            hipLaunchKernelGGL(text_coded_hist_kernel, dim3(hblocks), dim3(kHistThreads), 0, L.st,
+                               reinterpret_cast<const uint32_t *>(w.text), n, (const uint16_t *)w.codetab, w.hist_partial);
+            hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(kMaxPasses), dim3(kHistScanThreads), 0, L.st,
+                               (const uint32_t *)w.hist_partial, hblocks, w.digit_offset);
+            HIP_TRY(hipGetLastError());
+            rc2 = L.end();
+            if (rc2 != DQ_OK) return rc2;
+            if (getenv("DQ_TRACE")) fprintf(stderr, "[dq] coded round 0: %d symbols, %.2f bits per byte\n", code.sigma, code.avg_len);
+            *coded_out = true;
+            return DQ_OK;
+        }
+    }
     hipLaunchKernelGGL(text_digit_offsets_kernel, dim3(kb), dim3(kBlock), 0, L.st,
                        (const int64_t *)w.bytehist, (const uint8_t *)w.text, n, kb, w.digit_offset);
     HIP_TRY(hipGetLastError());
@@ -459,7 +494,7 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
 template <typename IdxT>
 int onesweep_sort_text_passes(Launcher &L, Workspace<IdxT> &w, int64_t n, uint64_t *K[2], IdxT *V[2],
                               int kb, bool packed, IdxT *d_sa, int &cur, uint32_t *ebits = nullptr,
-                              uint64_t *seam_tab = nullptr)
+                              uint64_t *seam_tab = nullptr, bool coded = false)
 {
     const uint64_t *text64 = reinterpret_cast<const uint64_t *>(w.text);
     int rc = DQ_OK;                 // look-back state zeroed by onesweep_sort_text_prepare()
@@ -481,7 +516,8 @@ int onesweep_sort_text_passes(Launcher &L, Workspace<IdxT> &w, int64_t n, uint64
         }
         return DQ_OK;
     }
-    rc = rank_pass<IdxT, kText>(L, w, text64, (const IdxT *)nullptr, K[1], V[1], n, 0, kb);
+    rc = coded ? rank_pass<IdxT, kText, true>(L, w, text64, (const IdxT *)nullptr, K[1], V[1], n, 0, kb)
+               : rank_pass<IdxT, kText>(L, w, text64, (const IdxT *)nullptr, K[1], V[1], n, 0, kb);
     if (rc != DQ_OK) return rc;
     cur = 1;
     for (int p = 1; p < kb; ++p) {
@@ -810,10 +846,10 @@ struct SuffixSorter {
         uint64_t *K[2] = {w.K0, w.K1};
         IdxT *V[2];
         int cur = 0, kb = 8, rc;
-        bool packed = false;
+        bool packed = false, coded = false;
         // pass p writes buffer (p+1)&1, so the last pass (kb-1) writes buffer kb&1: that one
         // must be the caller's SA, which is why the key width is chosen first
-        rc = onesweep_sort_text_prepare<IdxT>(L, c, w, n, &kb, &packed);
+        rc = onesweep_sort_text_prepare<IdxT>(L, c, w, n, &kb, &packed, &coded);
         if (rc != DQ_OK) return rc;
         V[kb & 1] = d_sa;
         V[(kb & 1) ^ 1] = w.Va;
@@ -862,7 +898,7 @@ struct SuffixSorter {
             rc = rank_pass<IdxT, kKeysLast>(L, w, K[cur ^ 1], (const IdxT *)nullptr, K[cur], d_sa, n, kb - 1, kb, ib);
             if (rc != DQ_OK) return rc;
         } else {
-            rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur);
+            rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur, nullptr, nullptr, coded);
             if (rc != DQ_OK) return rc;
         }
         // sorted keys (or packed words) are in K[cur], suffixes in d_sa

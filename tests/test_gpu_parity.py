@@ -151,6 +151,54 @@ def test_tie_bits_of_the_last_pass(ldss, oracle_mod, backend_lib):
     assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
 
 
+def test_coded_round0(ldss, oracle_mod, backend_lib, monkeypatch):
+    """dq_alpha_code.h / dq_coded_keys.h: text-like inputs of >= 8 MiB sort 64-bit keys made of alphabetic codewords
+    (12...14 characters instead of 8 bytes).  The path is recognisable by its extra histogram launch; it is forced
+    here on small inputs and on alphabets where it does not pay (fixed 8-bit codewords = raw bytes)."""
+    import ctypes
+
+    def hist_launches(T, dtype=np.int32):
+        backend_lib.dq_profile_reset()
+        backend_lib.dq_profile_enable(1)
+        sa = ldss.Sort(T, index_dtype=dtype)
+        backend_lib.dq_profile_enable(0)
+        n = ctypes.c_int64()
+        backend_lib.dq_profile_get(1, ctypes.byref(n), None, None, None)         # DQ_K_RADIX_HIST
+        assert np.array_equal(sa, oracle_mod.divsufsort(T).astype(dtype))
+        return n.value
+
+    text = oracle_mod.gen_enwik_like(9_000_001, 21, 65536)
+    coded = hist_launches(text)
+    monkeypatch.setenv("DQ_CODED", "0")
+    plain = hist_launches(text)
+    monkeypatch.delenv("DQ_CODED")
+    assert coded == plain + 1                                            # the coded keys' own digit histograms
+    dna = (oracle_mod.gen_uniform(10_000_000, 23) & 3) + 65
+    hist_launches(np.ascontiguousarray(dna, dtype=np.uint8))             # 4 symbols: fixed 4-bit codewords, 16 characters per key
+    monkeypatch.setenv("DQ_CODED", "1")
+    monkeypatch.setenv("DQ_PACKED", "0")
+    monkeypatch.setenv("DQ_KEY_BYTES", "8")
+    monkeypatch.setenv("DQ_SMALL_N", "0")
+    rnd = oracle_mod.gen_uniform
+    cases = {
+        "uniform bytes (8-bit codewords)": rnd(300_000, 31),
+        "text": oracle_mod.gen_enwik_like(700_003, 32, 4096),
+        "one dominant byte": np.where(rnd(400_000, 33) < 250, 0x20, rnd(400_000, 34)),
+        "zeros present + zero tail": np.concatenate([rnd(200_000, 35) & 7, np.zeros(50, np.uint8)]),
+        "all zeros": np.zeros(100_000, np.uint8),
+        "all 0xff": np.full(70_001, 0xFF, np.uint8),
+        "two symbols": (rnd(500_000, 36) & 1) * 200,
+        "periodic": np.tile(rnd(997, 37), 300),
+        "129 symbols": rnd(600_000, 38) % 129,
+        "tiny": rnd(67, 39) & 15,
+    }
+    for name, T in cases.items():
+        T = np.ascontiguousarray(T, dtype=np.uint8)
+        assert np.array_equal(ldss.Sort(T), oracle_mod.divsufsort(T)), name
+    T = np.ascontiguousarray(oracle_mod.gen_enwik_like(1_000_001, 40, 8192))
+    assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
+
+
 def test_bucketed_round0(ldss, oracle_mod, backend_lib, monkeypatch):
     """dq_bucket_sort.h: two digit passes on the top 16 key bits, then every bucket finished in LDS.  Taken by
     random-like inputs of >= 12 MiB on its own; forced here on small and on unsuitable inputs, where tiles
@@ -241,6 +289,7 @@ FUZZ_ENVS = [
     {"DQ_NO_BINNED_ISA": "1", "DQ_NO_CHAIN": "1"},         # first ISA by scatter, one host round trip per small-group round
     {"DQ_FORCE_RSHIFT": "1", "DQ_SMALL_N": "0"},           # composite keys carry rank >> 1, true rank read from the ISA (n near 2^32)
     {"DQ_BUCKET": "1", "DQ_SMALL_N": "0"},                 # bucketed round 0 wherever packed words are chosen (+ its fallbacks)
+    {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SMALL_N": "0"},   # round-0 keys from alphabetic codewords
 ]
 
 
@@ -346,6 +395,9 @@ FORCED_PATHS = [
     {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2"},                     # tie bits with MANY ties (dense doubling after them)
     {"DQ_FORCE_RSHIFT": "1"},                                    # doubling rounds with rank >> 1 in the composite key
     {"DQ_FORCE_RSHIFT": "1", "DQ_SPARSE": "1"},
+    {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8"},    # coded round-0 keys (dq_alpha_code.h), dense doubling
+    {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "1"},
+    {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_NO_BINNED_ISA": "1", "DQ_NO_SMALL": "1"},
 ]
 
 
