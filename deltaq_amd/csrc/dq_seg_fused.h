@@ -75,8 +75,10 @@ __device__ __forceinline__ uint64_t seg_lookback(uint64_t *st, int64_t tile, Seg
 //           SA already holds the suffixes; ISA is written for every entry only with kWriteISA
 //           (dense path predicted), otherwise it is built later if the dense path is taken.
 // else:     composite keys (rank << kbits | key2); writes SA (kWriteSA) / ISA (kWriteISA).
-// kEmitPairs (with kInitial): instead of the ISA scatter and the list of tied suffixes, one word per entry
-//           (tied? << 63 | rank << kbits | suffix, kbits = bits of n-1) goes to act_rank in list order.
+// kEmitPairs (with kInitial): instead of the ISA scatter, one word per entry
+//           (tied? << 63 | rank << kbits | suffix, kbits = bits of n-1) goes to act_rank in list order; the tied
+//           suffixes are also appended, members of a group adjacent, to (list_rank, act_suf) with 32-bit ranks
+//           (the 64-bit buffers are all busy until the words have been binned) when list_rank is given.
 // totals[0] receives the number of still-active suffixes.
 // rank_from_isa (doubling rounds only): the rank part of the composite keys is rank >> 1 -- still unique
 // per group and order preserving, because groups in the tied list have >= 2 members -- and the
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
     IdxT *__restrict__ SA, IdxT *__restrict__ ISA, uint64_t *__restrict__ act_rank,
     IdxT *__restrict__ act_suf, uint64_t *__restrict__ status /*[3][ntiles]*/, int64_t ntiles,
     SegCtl *__restrict__ ctl, int64_t *__restrict__ totals, int64_t *__restrict__ sticky_error,
-    int rank_from_isa = 0)
+    int rank_from_isa = 0, uint32_t *__restrict__ list_rank = nullptr)
 {
     __shared__ int64_t w_nh[kSegWaves], w_gh[kSegWaves], w_cnt[kSegWaves];
     __shared__ uint64_t s_prefix[3];
@@ -245,6 +247,11 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
                     // (tied?, rank, suffix) in list order, coalesced: the inverse suffix array is built from
                     // these words after they have been binned by suffix (dq_isa_pairs.h); kbits = bits of n-1
                     act_rank[wb + e] = ((uint64_t)(act ? 1 : 0) << 63) | ((uint64_t)nr << kbits) | (uint64_t)suf[k];
+                    if (list_rank && act) {
+                        const int64_t o = cc + __popcll(Ak & lt);
+                        list_rank[o] = (uint32_t)nr;
+                        act_suf[o] = suf[k];
+                    }
                 } else {
                     // dense doubling (ISA maintained) never reads SA again: a still-tied member's slot is
                     // written once, in the round that resolves it

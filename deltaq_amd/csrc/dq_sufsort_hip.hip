@@ -41,6 +41,7 @@
 #include "dq_isa_pairs.h"
 #include "dq_bucket_sort.h"
 #include "dq_match_search.h"
+#include "dq_pair_chains.h"
 #include "dq_bz2.h"
 #include "dq_bsdiff.h"
 
@@ -81,7 +82,7 @@ const char *const kKernelNames[DQ_K_COUNT] = {
     "tie_seam_kernel", "tie_collect_kernel", "small_group_finish_kernel", "small_group_round_kernel",
     "isa_update_kernel", "isa_from_pairs_kernel", "key2_from_pairs_kernel", "gather_key2_kernel",
     "gather_text_key_kernel", "isa_from_sa_kernel", "small_sufsort_kernel", "bucket_sort_kernel",
-    "match_search_kernel"};
+    "match_search_kernel", "pair_chain_kernels"};
 
 struct ProfRec { int cat; hipEvent_t a, b; int64_t elems, bytes; };
 
@@ -388,6 +389,10 @@ int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V
 // If (almost) that many key bytes fit into one 64-bit word next to the suffix index
 // (ib = bits of n-1), round 0 sorts PACKED words (key << ib | suffix): 16 B per element per
 // pass instead of 24 and no value array; the few extra ties go to the sparse finishing path.
+// pair chains (dq_pair_chains.h): tried when a doubling round left > 60% of its list tied, at most this often per sort
+constexpr int kPairChainTries = 3;
+constexpr int64_t kPairChainMinM = 1 << 16;
+
 // coded round 0 (dq_alpha_code.h): from this size on, and only if a byte costs at most this many bits on average
 constexpr int64_t kCodedMinN = 8ll << 20;
 constexpr double kCodedMaxAvgLen = 6.5;
@@ -680,11 +685,15 @@ struct SuffixSorter {
         const size_t need = 256 + (size_t)3 * ntiles * 8;
         if (need > w.seg_status_bytes) return fail(DQ_ERR_HIP, "seg status buffer too small");
         HIP_TRY(hipMemsetAsync(w.seg_status, 0, need, st));
+        // The tied suffixes are also listed group by group (32-bit ranks in the idle Vb, suffixes in Va): if they
+        // are at most n/2, the first doubling round is a small-group round on that list and only the groups of
+        // more than 8 go through the radix passes.
+        uint32_t *list_rank = (uses_small_round(0) && !getenv("DQ_NO_FIRST_SMALL")) ? reinterpret_cast<uint32_t *>(w.Vb) : nullptr;
         LAUNCH(L, DQ_K_SEG_FUSED, n, n * (8 + wb + 8),
                hipLaunchKernelGGL((seg_fused_kernel<IdxT, true, false, false, true>), dim3((unsigned)ntiles),
                                   dim3(kSegThreads), 0, st, (const uint64_t *)keys, (const IdxT *)d_sa, n, ib, kshift0,
                                   d_sa, w.ISA, P0, w.Va, reinterpret_cast<uint64_t *>(w.seg_status + 256), ntiles,
-                                  reinterpret_cast<SegCtl *>(w.seg_status), w.totals, w.totals + 1));
+                                  reinterpret_cast<SegCtl *>(w.seg_status), w.totals, w.totals + 1, 0, list_rank));
         // digit offsets of the two binning passes in closed form: every suffix 0..n-1 occurs once
         const int sh[2] = {ib - 16, ib - 8};
         HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, st));
@@ -716,8 +725,16 @@ struct SuffixSorter {
                    hipLaunchKernelGGL((isa_from_pairs_kernel<IdxT, 32768>), dim3((unsigned)((n + 32767) / 32768)),
                                       dim3(kPairThreads), 0, st, (const uint64_t *)P0, n, ib, w.ISA));
         }
-        // The list comes out in suffix order, not with the members of a group adjacent, so the first
-        // doubling round always takes the radix path (which sorts it); key2 is gathered here for it.
+        if (list_rank && m == 0) return DQ_OK;
+        if (list_rank && uses_small_round(m)) {
+            // (the sorted keys are gone -- their buffer was the output of the first binning pass and is free now)
+            LAUNCH(L, DQ_K_KEY2_FROM_PAIRS, m, m * 12,
+                   hipLaunchKernelGGL(widen_ranks_kernel, dim3(grid_for(m)), dim3(kBlock), 0, st,
+                                      (const uint32_t *)list_rank, m, keys));
+            return DQ_OK;
+        }
+        // Otherwise the list is taken from the words: it comes out in suffix order, not with the members of a
+        // group adjacent, so the first doubling round takes the radix path (which sorts it); key2 is gathered here.
         const bool with_key2 = true;
         const int kbits = bit_length((uint64_t)(n - 1) + (uint64_t)kb);
         unsigned long long *cnt = reinterpret_cast<unsigned long long *>(w.totals + 3);
@@ -1127,6 +1144,76 @@ struct SuffixSorter {
         return DQ_OK;
     }
 
+    // ---- tied pairs inside long repeats, decided chain by chain (dq_pair_chains.h).  Needs m <= n/2 like the
+    //      small-group rounds (same buffer layout: the next list from 0, the records from n/2) and the ISA.
+    //      h is not advanced: the groups that stay behind (>= 3 members, pairs blocked by them) go on doubling.
+    int pair_chain_phase()
+    {
+        uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
+        IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
+        const int64_t half = sg_half();
+        const int64_t ntiles = (m + kPcTile - 1) / kPcTile;
+        const size_t scratch = (size_t)kHistBlocks * kMaxPasses * kRadixSize * 4;          // w.hist_partial
+        if ((size_t)ntiles * 8 > scratch) return DQ_OK;
+        uint32_t *tile_cnt = w.hist_partial;
+        PairCounters *ctr = reinterpret_cast<PairCounters *>(w.totals + 4);
+        const int64_t m_in = m;
+        int rc = L.begin(DQ_K_PAIR_CHAINS, m, m * 2 * (8 + wb));
+        if (rc != DQ_OK) return rc;
+        hipLaunchKernelGGL((pair_split_kernel<IdxT, false>), dim3((unsigned)ntiles), dim3(kPcThreads), 0, st,
+                           (const uint64_t *)A, (const IdxT *)As, m, tile_cnt, (uint64_t *)nullptr, (IdxT *)nullptr,
+                           (uint64_t *)nullptr, (IdxT *)nullptr);
+        hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(kPcScanThreads), 0, st, tile_cnt, ntiles, ctr);
+        hipLaunchKernelGGL((pair_split_kernel<IdxT, true>), dim3((unsigned)ntiles), dim3(kPcThreads), 0, st,
+                           (const uint64_t *)A, (const IdxT *)As, m, tile_cnt, B + half, Bs + half, B, Bs);
+        HIP_TRY(hipGetLastError());
+        rc = L.end();
+        if (rc != DQ_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c.pinned, ctr, sizeof(PairCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const int64_t cnt = c.pinned[0];
+        t_info[0] += 1;
+        t_info[2] += m_in;
+        rcur ^= 1;
+        m = c.pinned[1];
+        if (cnt == 0) return DQ_OK;
+        uint64_t *Kx[2] = {B + half, A + half};
+        IdxT *Vx[2] = {Bs + half, As + half};
+        int xcur = 0;
+        rc = onesweep_sort_pairs<IdxT>(L, w, Kx, Vx, cnt, bit_length((uint64_t)(n - 1)), xcur);
+        if (rc != DQ_OK) return rc;
+        const int64_t rtiles = (cnt + kPcTile - 1) / kPcTile;
+        // per record: next chain end (4 B) + status (1 B) in the idle key buffer, far links (4 B) in the idle value buffer
+        uint32_t *nt = reinterpret_cast<uint32_t *>(Kx[xcur ^ 1]);
+        uint8_t *tstat = reinterpret_cast<uint8_t *>(nt + cnt);
+        uint32_t *far = reinterpret_cast<uint32_t *>(Vx[xcur ^ 1]);
+        uint32_t *tile_head = w.hist_partial;
+        uint32_t *carry = tile_head + align_up((size_t)rtiles);
+        if (2 * align_up((size_t)rtiles) * 4 > scratch) return fail(DQ_ERR_HIP, "pair chain scratch too small");
+        rc = L.begin(DQ_K_PAIR_CHAINS, cnt, cnt * (2 * (8 + wb) + 4 * wb));
+        if (rc != DQ_OK) return rc;
+        const unsigned rgrid = (unsigned)((cnt + kPcThreads - 1) / kPcThreads);
+        hipLaunchKernelGGL(pair_link_kernel<IdxT>, dim3((unsigned)rtiles), dim3(kPcThreads), 0, st,
+                           (const uint64_t *)Kx[xcur], cnt, (const IdxT *)w.ISA, n, h, nt, tstat, far, tile_head);
+        hipLaunchKernelGGL(pair_carry_kernel, dim3(1), dim3(kPcScanThreads), 0, st, (const uint32_t *)tile_head, rtiles, carry);
+        for (int r = 0; r < kPcResolveRounds; ++r)
+            hipLaunchKernelGGL(pair_resolve_kernel, dim3(rgrid), dim3(kPcThreads), 0, st, (const uint32_t *)nt,
+                               (const uint32_t *)carry, cnt, tstat, far);
+        hipLaunchKernelGGL(pair_emit_kernel<IdxT>, dim3(rgrid), dim3(kPcThreads), 0, st, (const uint64_t *)Kx[xcur],
+                           (const IdxT *)Vx[xcur], cnt, (const uint32_t *)nt, (const uint32_t *)carry, (const uint8_t *)tstat,
+                           d_sa, w.ISA, B, Bs, ctr);
+        HIP_TRY(hipGetLastError());
+        rc = L.end();
+        if (rc != DQ_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c.pinned, ctr, sizeof(PairCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        m = c.pinned[1];
+        if (getenv("DQ_TRACE"))
+            fprintf(stderr, "[dq] pair chains h=%lld m=%lld: %lld pairs, %lld entries left\n", (long long)h, (long long)m_in,
+                    (long long)cnt, (long long)m);
+        return DQ_OK;
+    }
+
     int run()
     {
         t_info[0] = t_info[1] = t_info[2] = 0;
@@ -1144,7 +1231,21 @@ struct SuffixSorter {
         else if (!dense_built) rc = build_isa(Kr[rcur], Vr[rcur], m);
         if (rc != DQ_OK) return rc;
 
+        int64_t m_before = 0;             // list length before the last round (0: no round yet)
+        int pair_tries = 0;
         while (m > 0) {
+            // A round that left most of its list tied: long repeats.  Their pairs are decided chain by chain.
+            const bool stagnant = m_before > 0 && m * 5 > m_before * 3;
+            const char *pc = getenv("DQ_PAIR_CHAINS");
+            if ((pc ? atoi(pc) != 0 && (m_before > 0 || atoi(pc) > 1) : stagnant && m >= kPairChainMinM) && pair_tries < kPairChainTries &&
+                uses_small_round(m) && !keys_ready) {
+                ++pair_tries;
+                m_before = 0;
+                rc = pair_chain_phase();
+                if (rc != DQ_OK) return rc;
+                continue;
+            }
+            m_before = m;
             if (only_small_groups && uses_small_round(m) && !keys_ready && !getenv("DQ_NO_CHAIN")) {
                 rc = doubling_rounds_small_chain();           // several rounds, one host round trip; updates h
                 if (rc != DQ_OK) return rc;

@@ -151,6 +151,50 @@ def test_tie_bits_of_the_last_pass(ldss, oracle_mod, backend_lib):
     assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
 
 
+def test_pair_chains(ldss, oracle_mod, backend_lib, monkeypatch):
+    """dq_pair_chains.h: tied pairs inside long repeats take the answer of the end of their chain.  Taken on its own
+    when a doubling round leaves most of its list tied; forced here before and after every round."""
+    import ctypes
+    rnd = oracle_mod.gen_uniform
+
+    def launches(T, dtype=np.int32):
+        backend_lib.dq_profile_reset()
+        backend_lib.dq_profile_enable(1)
+        sa = ldss.Sort(T, index_dtype=dtype)
+        backend_lib.dq_profile_enable(0)
+        n = ctypes.c_int64()
+        backend_lib.dq_profile_get(17, ctypes.byref(n), None, None, None)        # DQ_K_PAIR_CHAINS
+        assert np.array_equal(sa, oracle_mod.divsufsort(T).astype(dtype))
+        return n.value
+
+    base = rnd(3_000_000, 51)
+    one_copy = np.concatenate([base, base[100_000:160_000], rnd(500_000, 52)])               # pairs only: one chain of 60000
+    assert launches(one_copy) >= 2                                                            # split + link phases ran
+    text = oracle_mod.gen_enwik_like(6_000_000, 53, 65536)                                    # ~90 copies of up to 64 KiB
+    assert launches(text) >= 2
+    assert launches(rnd(2_000_000, 54)) == 0                                                  # nothing stagnates
+    for force in ("1", "2"):
+        monkeypatch.setenv("DQ_PAIR_CHAINS", force)
+        monkeypatch.setenv("DQ_SMALL_N", "0")
+        x = rnd(200_000, 55)
+        cases = {
+            "copy at the very end (b+1 = n)": np.concatenate([rnd(300_000, 56), x, rnd(100_000, 57), x]),
+            "three copies (blocked chains)": np.concatenate([x, rnd(1000, 58), x, rnd(1000, 59), x[:150_000], rnd(5, 60)]),
+            "overlapping copies": np.concatenate([x, x[50_000:], x[100_000:], x[:30_000]]),
+            "periodic": np.tile(rnd(4099, 61), 100),
+            "square of a random word": np.concatenate([x, x]),
+            "two symbols": rnd(700_000, 62) & 1,
+            "all equal": np.full(150_000, 9, np.uint8),
+            "text": oracle_mod.gen_enwik_like(900_000, 63, 8192),
+            "short": rnd(3000, 64) & 3,
+        }
+        for name, T in cases.items():
+            T = np.ascontiguousarray(T, dtype=np.uint8)
+            assert np.array_equal(ldss.Sort(T), oracle_mod.divsufsort(T)), (force, name)
+        T = np.ascontiguousarray(cases["three copies (blocked chains)"])
+        assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
+
+
 def test_coded_round0(ldss, oracle_mod, backend_lib, monkeypatch):
     """dq_alpha_code.h / dq_coded_keys.h: text-like inputs of >= 8 MiB sort 64-bit keys made of alphabetic codewords
     (12...14 characters instead of 8 bytes).  The path is recognisable by its extra histogram launch; it is forced
@@ -290,6 +334,8 @@ FUZZ_ENVS = [
     {"DQ_FORCE_RSHIFT": "1", "DQ_SMALL_N": "0"},           # composite keys carry rank >> 1, true rank read from the ISA (n near 2^32)
     {"DQ_BUCKET": "1", "DQ_SMALL_N": "0"},                 # bucketed round 0 wherever packed words are chosen (+ its fallbacks)
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SMALL_N": "0"},   # round-0 keys from alphabetic codewords
+    {"DQ_PAIR_CHAINS": "2", "DQ_SMALL_N": "0"},            # tied pairs decided chain by chain as early and as often as allowed
+    {"DQ_PAIR_CHAINS": "2", "DQ_NO_BINNED_ISA": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0"},
 ]
 
 
@@ -398,6 +444,9 @@ FORCED_PATHS = [
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8"},    # coded round-0 keys (dq_alpha_code.h), dense doubling
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "1"},
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_NO_BINNED_ISA": "1", "DQ_NO_SMALL": "1"},
+    {"DQ_PAIR_CHAINS": "2"},                                     # pair chains (dq_pair_chains.h) before / after every round
+    {"DQ_PAIR_CHAINS": "2", "DQ_NO_BINNED_ISA": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
+    {"DQ_PAIR_CHAINS": "1", "DQ_PACKED": "1", "DQ_KEY_BYTES": "2"},
 ]
 
 
