@@ -465,6 +465,17 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
     // instead of 8 raw bytes (dq_alpha_code.h) when that makes the key reach at least ~10 characters on average.
     // The keys' digits are then no longer text bytes: their histograms take one more read of the text.
     bool coded = !packed && kb == 8 && n >= kCodedMinN;
+    if (coded) {
+        // the code is built on the host while the device waits (0.2 ms for 73 symbols, 3.5 ms for 256): only where
+        // it can pay -- the expected codeword length is at least the order-0 entropy, and texts with more than
+        // 128 symbols must be large enough to hide the construction
+        int sigma = 0;
+        double h0 = 0;
+        for (int b = 0; b < 256; ++b) {
+            if (c.pinned[b] > 0) { ++sigma; const double p = (double)c.pinned[b] / (double)n; h0 -= p * std::log2(p); }
+        }
+        coded = h0 <= kCodedMaxAvgLen - 0.25 && (sigma <= 128 || n >= 4 * kCodedMinN);
+    }
     if (const char *v = getenv("DQ_CODED")) coded = atoi(v) != 0 && !packed && kb == 8 && n >= 64;
     if (coded) {
         AlphaCode code;
@@ -1052,8 +1063,8 @@ struct SuffixSorter {
         const int64_t half = sg_half(), top = sg_top();
         SmallGroupCounters *ctr = reinterpret_cast<SmallGroupCounters *>(w.totals + 4);
         HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(SmallGroupCounters), st));
-        const int64_t m_before = m;
-        if (m < kSgShortList) {
+        const bool cap32 = m < kSgShortList;           // (cap 32 on long lists measured: radix -2.4 ms, this kernel +2.8 ms)
+        if (cap32) {
             constexpr int kTile = sg_tile<kSgMaxGShort>();
             LAUNCH(L, DQ_K_SMALL_ROUND, m, m * (8 + wb + wb + wb + 8 + wb),
                    hipLaunchKernelGGL((small_group_round_kernel<IdxT, kSgMaxGShort>), dim3((unsigned)((m + kTile - 1) / kTile)),
@@ -1094,7 +1105,7 @@ struct SuffixSorter {
         rcur ^= 1;
         m = m1 + mLs;
         // groups only ever split: once nothing went to the radix list, every group fits this round's cap
-        if (mL == 0) small_cap = m_before < kSgShortList ? kSgMaxGShort : kSgMaxG;
+        if (mL == 0) small_cap = cap32 ? kSgMaxGShort : kSgMaxG;
         only_small_groups = mL == 0;
         return DQ_OK;
     }
@@ -1147,8 +1158,9 @@ struct SuffixSorter {
     // ---- tied pairs inside long repeats, decided chain by chain (dq_pair_chains.h).  Needs m <= n/2 like the
     //      small-group rounds (same buffer layout: the next list from 0, the records from n/2) and the ISA.
     //      h is not advanced: the groups that stay behind (>= 3 members, pairs blocked by them) go on doubling.
-    int pair_chain_phase()
+    int pair_chain_phase(bool *paid)
     {
+        *paid = false;
         uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
         IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
         const int64_t half = sg_half();
@@ -1208,6 +1220,7 @@ struct SuffixSorter {
         HIP_TRY(hipMemcpyAsync(c.pinned, ctr, sizeof(PairCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         m = c.pinned[1];
+        *paid = (m_in - m) >= cnt;                       // at least half of the pairs (2 entries each) left the list
         if (getenv("DQ_TRACE"))
             fprintf(stderr, "[dq] pair chains h=%lld m=%lld: %lld pairs, %lld entries left\n", (long long)h, (long long)m_in,
                     (long long)cnt, (long long)m);
@@ -1233,15 +1246,19 @@ struct SuffixSorter {
 
         int64_t m_before = 0;             // list length before the last round (0: no round yet)
         int pair_tries = 0;
+        bool pair_paid = true;            // the last pair-chain phase decided most of its pairs
         while (m > 0) {
-            // A round that left most of its list tied: long repeats.  Their pairs are decided chain by chain.
+            // Tied pairs inside long repeats are decided chain by chain (dq_pair_chains.h): tried once after the
+            // first doubling round, and again after a round that left most of its list tied as long as the phase
+            // before paid off (enwik-like 256 MiB: one phase 34.8 ms, a second one at h = 32 as well 35.9 ms).
             const bool stagnant = m_before > 0 && m * 5 > m_before * 3;
             const char *pc = getenv("DQ_PAIR_CHAINS");
-            if ((pc ? atoi(pc) != 0 && (m_before > 0 || atoi(pc) > 1) : stagnant && m >= kPairChainMinM) && pair_tries < kPairChainTries &&
-                uses_small_round(m) && !keys_ready) {
+            const bool want = pc ? atoi(pc) != 0 && (m_before > 0 || atoi(pc) > 1)
+                                 : m_before > 0 && m >= kPairChainMinM && pair_paid && (pair_tries == 0 || stagnant);
+            if (want && pair_tries < kPairChainTries && uses_small_round(m) && !keys_ready) {
                 ++pair_tries;
                 m_before = 0;
-                rc = pair_chain_phase();
+                rc = pair_chain_phase(&pair_paid);
                 if (rc != DQ_OK) return rc;
                 continue;
             }
