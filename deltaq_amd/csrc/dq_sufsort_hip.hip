@@ -223,6 +223,7 @@ struct Workspace {
     SmallGroupCounters *sg_ctr; // one per chained small-group round
     uint32_t *hist_partial;     // [kHistBlocks][8][256]
     uint16_t *codetab;          // [256] codewords of the coded round 0 (dq_alpha_code.h)
+    uint32_t *pc_tiles;         // per-tile counts / prefix sums of the pair-chain phase (dq_pair_chains.h), m <= n/3
     int64_t *digit_offset;      // [8][256]
     int64_t *bytehist;          // [256]
     char *ctl_status;           // per digit pass: OnesweepCtl (256 B) + the tiles' status words
@@ -254,6 +255,7 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.hist_partial = (uint32_t *)take((size_t)kHistBlocks * kMaxPasses * kRadixSize * 4);
     w.digit_offset = (int64_t *)take((size_t)kMaxPasses * kRadixSize * 8);
     w.codetab = (uint16_t *)take(512);
+    w.pc_tiles = (uint32_t *)take((un / 3 / 2048 + 4) * 8);
     w.bytehist = (int64_t *)take((size_t)(kRadixSize + 8) * 8);        // + the 8 k-gram sample counters
     // smallest tile is 8192 keys; 8-byte status words once a list reaches 2^30 entries
     w.ctl_status_bytes = (size_t)kMaxPasses * align_up(256 + (un / 8192 + 2) * kRadixSize * (un >= (1ull << 30) ? 8 : 4));
@@ -391,7 +393,7 @@ int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V
 // pass instead of 24 and no value array; the few extra ties go to the sparse finishing path.
 // pair chains (dq_pair_chains.h): tried when a doubling round left > 60% of its list tied, at most this often per sort
 constexpr int kPairChainTries = 3;
-constexpr int64_t kPairChainMinM = 1 << 16;
+constexpr int64_t kPairChainMinM = 1 << 11;
 
 // coded round 0 (dq_alpha_code.h): from this size on, and only if a byte costs at most this many bits on average
 constexpr int64_t kCodedMinN = 8ll << 20;
@@ -1164,20 +1166,27 @@ struct SuffixSorter {
         uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
         IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
         const int64_t half = sg_half();
+        const int ib = bit_length((uint64_t)(n - 1));
         const int64_t ntiles = (m + kPcTile - 1) / kPcTile;
         const size_t scratch = (size_t)kHistBlocks * kMaxPasses * kRadixSize * 4;          // w.hist_partial
-        if ((size_t)ntiles * 8 > scratch) return DQ_OK;
-        uint32_t *tile_cnt = w.hist_partial;
+        // (the caller checked 3 m <= n: at most 1.5 records per entry -- a group of 4 has 6 pairs -- fit behind `half`)
+        // Long lists: pairs only (records sorted by x alone, 4 digit passes; groups of 3 and 4 keep doubling, which
+        // is cheap per round there).  Short lists are launch-bound: every round saved counts, so groups up to 4.
+        const int maxg = getenv("DQ_PAIR_MAXG") ? std::min(kPcMaxG, std::max(2, atoi(getenv("DQ_PAIR_MAXG"))))
+                                                : (m < kSgShortList ? kPcMaxG : 2);
+        // record = d << xbits | x.  Pairs only: x padded to whole digits, so that the digit passes over x see nothing of d
+        const int xbits = maxg == 2 ? (ib + 7) / 8 * 8 : ib;
+        uint32_t *tile_cnt = w.pc_tiles;
         PairCounters *ctr = reinterpret_cast<PairCounters *>(w.totals + 4);
         const int64_t m_in = m;
         int rc = L.begin(DQ_K_PAIR_CHAINS, m, m * 2 * (8 + wb));
         if (rc != DQ_OK) return rc;
         hipLaunchKernelGGL((pair_split_kernel<IdxT, false>), dim3((unsigned)ntiles), dim3(kPcThreads), 0, st,
-                           (const uint64_t *)A, (const IdxT *)As, m, tile_cnt, (uint64_t *)nullptr, (IdxT *)nullptr,
+                           (const uint64_t *)A, (const IdxT *)As, m, xbits, maxg, tile_cnt, (uint64_t *)nullptr, (IdxT *)nullptr,
                            (uint64_t *)nullptr, (IdxT *)nullptr);
         hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(kPcScanThreads), 0, st, tile_cnt, ntiles, ctr);
         hipLaunchKernelGGL((pair_split_kernel<IdxT, true>), dim3((unsigned)ntiles), dim3(kPcThreads), 0, st,
-                           (const uint64_t *)A, (const IdxT *)As, m, tile_cnt, B + half, Bs + half, B, Bs);
+                           (const uint64_t *)A, (const IdxT *)As, m, xbits, maxg, tile_cnt, B + half, Bs + half, B, Bs);
         HIP_TRY(hipGetLastError());
         rc = L.end();
         if (rc != DQ_OK) return rc;
@@ -1186,18 +1195,23 @@ struct SuffixSorter {
         const int64_t cnt = c.pinned[0];
         t_info[0] += 1;
         t_info[2] += m_in;
-        rcur ^= 1;
-        m = c.pinned[1];
-        if (cnt == 0) return DQ_OK;
+        if (cnt == 0) {                                   // no small group at all: the copy is the list
+            rcur ^= 1;
+            m = c.pinned[1];
+            return DQ_OK;
+        }
         uint64_t *Kx[2] = {B + half, A + half};
         IdxT *Vx[2] = {Bs + half, As + half};
         int xcur = 0;
-        rc = onesweep_sort_pairs<IdxT>(L, w, Kx, Vx, cnt, bit_length((uint64_t)(n - 1)), xcur);
+        rc = onesweep_sort_pairs<IdxT>(L, w, Kx, Vx, cnt, maxg == 2 ? xbits : 2 * ib, xcur);
+        const uint64_t sort_mask = maxg == 2 ? (1ull << xbits) - 1 : ~0ull;
         if (rc != DQ_OK) return rc;
         const int64_t rtiles = (cnt + kPcTile - 1) / kPcTile;
-        // per record: next chain end (4 B) + status (1 B) in the idle key buffer, far links (4 B) in the idle value buffer
+        // per record: next chain end (4 B) + status (1 B) + answer by ordinal (1 B) in the idle key buffer, far links
+        // (4 B) in the idle value buffer
         uint32_t *nt = reinterpret_cast<uint32_t *>(Kx[xcur ^ 1]);
         uint8_t *tstat = reinterpret_cast<uint8_t *>(nt + cnt);
+        uint8_t *answer = tstat + cnt;
         uint32_t *far = reinterpret_cast<uint32_t *>(Vx[xcur ^ 1]);
         uint32_t *tile_head = w.hist_partial;
         uint32_t *carry = tile_head + align_up((size_t)rtiles);
@@ -1206,24 +1220,33 @@ struct SuffixSorter {
         if (rc != DQ_OK) return rc;
         const unsigned rgrid = (unsigned)((cnt + kPcThreads - 1) / kPcThreads);
         hipLaunchKernelGGL(pair_link_kernel<IdxT>, dim3((unsigned)rtiles), dim3(kPcThreads), 0, st,
-                           (const uint64_t *)Kx[xcur], cnt, (const IdxT *)w.ISA, n, h, nt, tstat, far, tile_head);
+                           (const uint64_t *)Kx[xcur], cnt, xbits, sort_mask, (const IdxT *)w.ISA, n, h, nt, tstat, far, tile_head);
         hipLaunchKernelGGL(pair_carry_kernel, dim3(1), dim3(kPcScanThreads), 0, st, (const uint32_t *)tile_head, rtiles, carry);
         for (int r = 0; r < kPcResolveRounds; ++r)
             hipLaunchKernelGGL(pair_resolve_kernel, dim3(rgrid), dim3(kPcThreads), 0, st, (const uint32_t *)nt,
                                (const uint32_t *)carry, cnt, tstat, far);
-        hipLaunchKernelGGL(pair_emit_kernel<IdxT>, dim3(rgrid), dim3(kPcThreads), 0, st, (const uint64_t *)Kx[xcur],
-                           (const IdxT *)Vx[xcur], cnt, (const uint32_t *)nt, (const uint32_t *)carry, (const uint8_t *)tstat,
-                           d_sa, w.ISA, B, Bs, ctr);
+        if (maxg == 2) {
+            hipLaunchKernelGGL(pair_emit_kernel<IdxT>, dim3(rgrid), dim3(kPcThreads), 0, st, (const uint64_t *)Kx[xcur],
+                               (const IdxT *)Vx[xcur], cnt, xbits, (const uint32_t *)nt, (const uint32_t *)carry,
+                               (const uint8_t *)tstat, d_sa, w.ISA, B, Bs, ctr);
+        } else {
+            hipLaunchKernelGGL(pair_answer_kernel<IdxT>, dim3(rgrid), dim3(kPcThreads), 0, st, (const IdxT *)Vx[xcur], cnt,
+                               (const uint32_t *)nt, (const uint32_t *)carry, (const uint8_t *)tstat, answer);
+            hipLaunchKernelGGL(pair_finish_kernel<IdxT>, dim3((unsigned)ntiles), dim3(kPcThreads), 0, st, (const uint64_t *)A,
+                               (const IdxT *)As, m_in, maxg, (const uint32_t *)tile_cnt, (const uint8_t *)answer, d_sa, w.ISA,
+                               B, Bs, ctr);
+        }
         HIP_TRY(hipGetLastError());
         rc = L.end();
         if (rc != DQ_OK) return rc;
         HIP_TRY(hipMemcpyAsync(c.pinned, ctr, sizeof(PairCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        rcur ^= 1;
         m = c.pinned[1];
-        *paid = (m_in - m) >= cnt;                       // at least half of the pairs (2 entries each) left the list
+        *paid = (m_in - m) * 2 >= m_in;                   // at least half of the list was finished
         if (getenv("DQ_TRACE"))
-            fprintf(stderr, "[dq] pair chains h=%lld m=%lld: %lld pairs, %lld entries left\n", (long long)h, (long long)m_in,
-                    (long long)cnt, (long long)m);
+            fprintf(stderr, "[dq] pair chains h=%lld m=%lld: %lld pair records, %lld entries left\n", (long long)h,
+                    (long long)m_in, (long long)cnt, (long long)m);
         return DQ_OK;
     }
 
@@ -1255,7 +1278,7 @@ struct SuffixSorter {
             const char *pc = getenv("DQ_PAIR_CHAINS");
             const bool want = pc ? atoi(pc) != 0 && (m_before > 0 || atoi(pc) > 1)
                                  : m_before > 0 && m >= kPairChainMinM && pair_paid && (pair_tries == 0 || stagnant);
-            if (want && pair_tries < kPairChainTries && uses_small_round(m) && !keys_ready) {
+            if (want && pair_tries < kPairChainTries && uses_small_round(m) && m * 3 <= n && !keys_ready) {
                 ++pair_tries;
                 m_before = 0;
                 rc = pair_chain_phase(&pair_paid);

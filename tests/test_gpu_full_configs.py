@@ -104,14 +104,15 @@ def test_int32_interface_above_2_pow_30(ldss, oracle_mod, shape):
     n = (3 << 29) + 12345                                   # 1.5 GiB and a ragged tail
     T = oracle_mod.gen_uniform(n, 0x5EED0007)
     if shape == "long-repeat":
-        T[1000:200_000] = T[5_000_000:5_199_000]            # a 199 000-byte repeat: ~15 doubling rounds
+        T[1000:200_000] = T[5_000_000:5_199_000]            # a 199 000-byte repeat: ~15 doubling rounds, or the pair chains
         T[n - 70_000:] = T[123_456:193_456]                 # and one that runs into the end of the text
     SA = ldss.Sort(T)
     assert SA.dtype == np.int32
     check_by_properties(oracle_mod, T, SA, 9)
     from deltaq_amd import _abi
     info = _abi.last_sort_info()
-    assert (info["rounds"] > 8) == (shape == "long-repeat"), info
+    # (the repeats are decided by the doubling rounds -- 15 of them -- or, since dq_pair_chains.h, in a few phases)
+    assert (info["rounds"] >= 3) == (shape == "long-repeat"), info
 
 
 def test_config4_batch_128x16MiB(backend_lib, oracle_mod):
