@@ -1200,13 +1200,15 @@ struct SuffixSorter {
             m = c.pinned[1];
             return DQ_OK;
         }
+        const int64_t rtiles = (cnt + kPcTile - 1) / kPcTile;
+        // (n close to 2^32 with ~2^31 records: the per-tile scratch would not fit -- leave the list as it is)
+        if (2 * align_up((size_t)rtiles) * 4 > scratch) return DQ_OK;
         uint64_t *Kx[2] = {B + half, A + half};
         IdxT *Vx[2] = {Bs + half, As + half};
         int xcur = 0;
         rc = onesweep_sort_pairs<IdxT>(L, w, Kx, Vx, cnt, maxg == 2 ? xbits : 2 * ib, xcur);
         const uint64_t sort_mask = maxg == 2 ? (1ull << xbits) - 1 : ~0ull;
         if (rc != DQ_OK) return rc;
-        const int64_t rtiles = (cnt + kPcTile - 1) / kPcTile;
         // per record: next chain end (4 B) + status (1 B) + answer by ordinal (1 B) in the idle key buffer, far links
         // (4 B) in the idle value buffer
         uint32_t *nt = reinterpret_cast<uint32_t *>(Kx[xcur ^ 1]);
@@ -1215,7 +1217,6 @@ struct SuffixSorter {
         uint32_t *far = reinterpret_cast<uint32_t *>(Vx[xcur ^ 1]);
         uint32_t *tile_head = w.hist_partial;
         uint32_t *carry = tile_head + align_up((size_t)rtiles);
-        if (2 * align_up((size_t)rtiles) * 4 > scratch) return fail(DQ_ERR_HIP, "pair chain scratch too small");
         rc = L.begin(DQ_K_PAIR_CHAINS, cnt, cnt * (2 * (8 + wb) + 4 * wb));
         if (rc != DQ_OK) return rc;
         const unsigned rgrid = (unsigned)((cnt + kPcThreads - 1) / kPcThreads);

@@ -217,6 +217,15 @@ def test_coded_round0(ldss, oracle_mod, backend_lib, monkeypatch):
     plain = hist_launches(text)
     monkeypatch.delenv("DQ_CODED")
     assert coded == plain + 1                                            # the coded keys' own digit histograms
+    # real text: this repository's own documents, repeated with scattered edits up to the size where the path engages
+    import glob, os
+    from conftest import ROOT
+    docs = b"".join(open(f, "rb").read() for f in sorted(glob.glob(os.path.join(ROOT, "*.md"))))
+    rng = np.random.default_rng(5)
+    real = np.frombuffer(docs * (9_000_000 // max(len(docs), 1) + 1), dtype=np.uint8)[:9_500_000].copy()
+    edits = rng.integers(0, real.size, 20_000)
+    real[edits] = rng.integers(32, 127, edits.size).astype(np.uint8)
+    assert hist_launches(real) >= 1
     dna = (oracle_mod.gen_uniform(10_000_000, 23) & 3) + 65
     hist_launches(np.ascontiguousarray(dna, dtype=np.uint8))             # 4 symbols: fixed 4-bit codewords, 16 characters per key
     monkeypatch.setenv("DQ_CODED", "1")

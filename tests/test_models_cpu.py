@@ -124,3 +124,82 @@ def test_place_by_counting_is_a_stable_sort_and_finds_the_ties():
         new_rank = less                                             # rank offset of the subgroup
         for i in range(g):
             assert tied[i] == ((new_rank == new_rank[i]).sum() > 1)
+
+
+def pair_chain_model(T, sa, h, maxg=4, jumps=4):
+    """dq_pair_chains.h in plain Python: groups = suffixes agreeing on h characters (ranks = group starts, as the
+    doubling rounds have them); every group of <= maxg members becomes its pairs (d, x); records sorted; a record
+    links to the next one if that is (d, x+1); a chain end decides by the ranks of x+1 / y+1, by a far link, by
+    stepping h characters, or stays blocked.  Returns {(x, y): 1 (x first) | 2 (y first) | 3 (blocked)}."""
+    n = T.size
+    b = T.tobytes()
+    rank = np.zeros(n, np.int64)                      # group rank of every suffix at depth h (padding: shorter first)
+    start = 0
+    for p in range(1, n + 1):
+        if p == n or b[sa[p]:sa[p] + h] != b[sa[start]:sa[start] + h]:
+            rank[sa[start:p]] = start
+            start = p
+    groups = {}
+    for s in range(n):
+        groups.setdefault(int(rank[s]), []).append(s)
+    recs = []
+    for g in groups.values():
+        if 2 <= len(g) <= maxg:
+            g = sorted(g)
+            recs += [(y - x, x) for i, x in enumerate(g) for y in g[i + 1:]]
+    recs.sort()
+    index = {r: i for i, r in enumerate(recs)}
+    status, far = [0] * len(recs), [0] * len(recs)
+    for i, (d, x) in enumerate(recs):
+        if i + 1 < len(recs) and recs[i + 1] == (d, x + 1):
+            continue                                   # link
+        xx, st = x + 1, 3
+        for _ in range(jumps + 1):
+            yy = xx + d
+            if yy >= n:
+                st = 2
+                break
+            if rank[xx] != rank[yy]:
+                st = 1 if rank[xx] < rank[yy] else 2
+                break
+            if (d, xx) in index:
+                st, far[i] = 4, index[(d, xx)]
+                break
+            xx += h
+        status[i] = st
+    end = [0] * len(recs)                              # first chain end at or after i
+    for i in range(len(recs) - 1, -1, -1):
+        end[i] = i if status[i] else end[i + 1]
+    def resolve(i, depth=0):
+        e = end[i]
+        if status[e] != 4:
+            return status[e]
+        return resolve(far[e], depth + 1) if depth < 64 else 3
+    return {(x, x + d): resolve(i) for i, (d, x) in enumerate(recs)}
+
+
+def test_pair_chains_decide_like_the_suffix_array(oracle_mod):
+    rng = np.random.default_rng(31)
+    x = oracle_mod.gen_uniform(3000, 1) & 7
+    texts = [
+        np.concatenate([x, rng.integers(0, 8, 50, dtype=np.uint8), x[500:2500], rng.integers(0, 8, 70, dtype=np.uint8)]),   # one copy
+        np.concatenate([x, x[100:2000], x[300:1500], np.zeros(3, np.uint8)]),                                              # three copies, zero tail
+        np.concatenate([x[:1500], x[:1500]]),                                                                              # a square: the copy ends at n
+        oracle_mod.gen_enwik_like(6000, 3, 1024),
+        np.tile(oracle_mod.gen_uniform(97, 5) & 3, 30),                                                                    # periodic: every group is large
+    ]
+    decided = total = 0
+    for T in texts:
+        T = np.ascontiguousarray(T, dtype=np.uint8)
+        sa = oracle_mod.divsufsort(T).astype(np.int64)
+        isa = np.empty(T.size, np.int64)
+        isa[sa] = np.arange(T.size)
+        for h in (4, 16):
+            for maxg in (2, 4):
+                ans = pair_chain_model(T, sa, h, maxg)
+                for (a, b), st in ans.items():
+                    total += 1
+                    if st != 3:
+                        decided += 1
+                        assert (st == 1) == (isa[a] < isa[b]), (h, maxg, a, b, st)
+    assert decided > total // 2                        # (and it is worth it: most pairs of these inputs are decided)
