@@ -22,7 +22,7 @@
 //                       characters at a time; failing that the chain is BLOCKED.  Every record learns the index
 //                       of the first chain end at or after it (segmented scan from the right, tile-local here)
 //   pair_carry_kernel   ... and across tiles
-//   pair_resolve_kernel x6: pointer jumping over the far links (they only lead to the right)
+//   pair_resolve_kernel x8: pointer jumping over the far links (they only lead to the right)
 //   pair_answer_kernel  answers back into list order (by ordinal)
 //   pair_finish_kernel  over X again: a small group whose pairs are all decided writes its members to the SA (place
 //                       = number of members that precede it) and the ISA entries that moved; any other small
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(kPcScanThreads) void pair_scan_kernel(uint32_t *__r
 // status of a chain end: 1 x first, 2 y first, 3 blocked, 4 far (takes the answer of record far[i], further right)
 constexpr uint8_t kPcXFirst = 1, kPcYFirst = 2, kPcBlocked = 3, kPcFar = 4;
 constexpr uint32_t kPcNone = 0xffffffffu;
-constexpr int kPcJumps = 4;               // h-steps a chain end tries through larger tie groups
-constexpr int kPcResolveRounds = 6;       // pointer-jumping launches: far links nested up to 2^6 deep
+constexpr int kPcJumps = 64;              // h-steps a chain end tries through larger tie groups (only chain ends pay for them)
+constexpr int kPcResolveRounds = 8;       // pointer-jumping launches: far links nested up to 2^8 deep
 
 // In a wave: the first value != kPcNone among the lanes ABOVE the calling lane (kPcNone if there is none).
 __device__ __forceinline__ uint32_t first_valid_above(uint32_t v)

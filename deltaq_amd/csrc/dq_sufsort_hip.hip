@@ -223,7 +223,7 @@ struct Workspace {
     SmallGroupCounters *sg_ctr; // one per chained small-group round
     uint32_t *hist_partial;     // [kHistBlocks][8][256]
     uint16_t *codetab;          // [256] codewords of the coded round 0 (dq_alpha_code.h)
-    uint32_t *pc_tiles;         // per-tile counts / prefix sums of the pair-chain phase (dq_pair_chains.h), m <= n/3
+    uint32_t *pc_tiles;         // per-tile counts / prefix sums of the pair-chain phase (dq_pair_chains.h), m <= n/2
     int64_t *digit_offset;      // [8][256]
     int64_t *bytehist;          // [256]
     char *ctl_status;           // per digit pass: OnesweepCtl (256 B) + the tiles' status words
@@ -255,7 +255,7 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.hist_partial = (uint32_t *)take((size_t)kHistBlocks * kMaxPasses * kRadixSize * 4);
     w.digit_offset = (int64_t *)take((size_t)kMaxPasses * kRadixSize * 8);
     w.codetab = (uint16_t *)take(512);
-    w.pc_tiles = (uint32_t *)take((un / 3 / 2048 + 4) * 8);
+    w.pc_tiles = (uint32_t *)take((un / 2 / 2048 + 4) * 8);
     w.bytehist = (int64_t *)take((size_t)(kRadixSize + 8) * 8);        // + the 8 k-gram sample counters
     // smallest tile is 8192 keys; 8-byte status words once a list reaches 2^30 entries
     w.ctl_status_bytes = (size_t)kMaxPasses * align_up(256 + (un / 8192 + 2) * kRadixSize * (un >= (1ull << 30) ? 8 : 4));
@@ -1160,20 +1160,23 @@ struct SuffixSorter {
     // ---- tied pairs inside long repeats, decided chain by chain (dq_pair_chains.h).  Needs m <= n/2 like the
     //      small-group rounds (same buffer layout: the next list from 0, the records from n/2) and the ISA.
     //      h is not advanced: the groups that stay behind (>= 3 members, pairs blocked by them) go on doubling.
-    int pair_chain_phase(bool *paid)
+    // *outcome: 0 = given up after the count (most of the list sits in larger groups: their chains would end
+    // blocked), 1 = ran, 2 = ran and finished at least half of the list.
+    int pair_chain_phase(int *outcome, bool forced)
     {
-        *paid = false;
+        *outcome = 1;
         uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
         IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
         const int64_t half = sg_half();
         const int ib = bit_length((uint64_t)(n - 1));
         const int64_t ntiles = (m + kPcTile - 1) / kPcTile;
         const size_t scratch = (size_t)kHistBlocks * kMaxPasses * kRadixSize * 4;          // w.hist_partial
-        // (the caller checked 3 m <= n: at most 1.5 records per entry -- a group of 4 has 6 pairs -- fit behind `half`)
         // Long lists: pairs only (records sorted by x alone, 4 digit passes; groups of 3 and 4 keep doubling, which
-        // is cheap per round there).  Short lists are launch-bound: every round saved counts, so groups up to 4.
-        const int maxg = getenv("DQ_PAIR_MAXG") ? std::min(kPcMaxG, std::max(2, atoi(getenv("DQ_PAIR_MAXG"))))
-                                                : (m < kSgShortList ? kPcMaxG : 2);
+        // is cheap per round there).  Short lists are launch-bound: every round saved counts, so groups up to 4 -- or
+        // up to 3 when the list is longer than n/3: the records (1.5 per entry for groups of 4, at most 1 for
+        // pairs and triples) must fit behind `half`.
+        int maxg = m >= kSgShortList ? 2 : (m * 3 <= n ? kPcMaxG : 3);
+        if (const char *v = getenv("DQ_PAIR_MAXG")) maxg = std::min(m * 3 <= n ? kPcMaxG : 3, std::max(2, atoi(v)));
         // record = d << xbits | x.  Pairs only: x padded to whole digits, so that the digit passes over x see nothing of d
         const int xbits = maxg == 2 ? (ib + 7) / 8 * 8 : ib;
         uint32_t *tile_cnt = w.pc_tiles;
@@ -1185,24 +1188,21 @@ struct SuffixSorter {
                            (const uint64_t *)A, (const IdxT *)As, m, xbits, maxg, tile_cnt, (uint64_t *)nullptr, (IdxT *)nullptr,
                            (uint64_t *)nullptr, (IdxT *)nullptr);
         hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(kPcScanThreads), 0, st, tile_cnt, ntiles, ctr);
-        hipLaunchKernelGGL((pair_split_kernel<IdxT, true>), dim3((unsigned)ntiles), dim3(kPcThreads), 0, st,
-                           (const uint64_t *)A, (const IdxT *)As, m, xbits, maxg, tile_cnt, B + half, Bs + half, B, Bs);
         HIP_TRY(hipGetLastError());
         rc = L.end();
         if (rc != DQ_OK) return rc;
         HIP_TRY(hipMemcpyAsync(c.pinned, ctr, sizeof(PairCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        const int64_t cnt = c.pinned[0];
+        const int64_t cnt = c.pinned[0], copied = c.pinned[1];
+        if (cnt == 0 || (!forced && copied * 5 > m * 2)) { *outcome = 0; return DQ_OK; }
         t_info[0] += 1;
         t_info[2] += m_in;
-        if (cnt == 0) {                                   // no small group at all: the copy is the list
-            rcur ^= 1;
-            m = c.pinned[1];
-            return DQ_OK;
-        }
+        LAUNCH(L, DQ_K_PAIR_CHAINS, m, m * (8 + wb) + cnt * (8 + wb) + copied * (8 + wb),
+               hipLaunchKernelGGL((pair_split_kernel<IdxT, true>), dim3((unsigned)ntiles), dim3(kPcThreads), 0, st,
+                                  (const uint64_t *)A, (const IdxT *)As, m, xbits, maxg, tile_cnt, B + half, Bs + half, B, Bs));
         const int64_t rtiles = (cnt + kPcTile - 1) / kPcTile;
         // (n close to 2^32 with ~2^31 records: the per-tile scratch would not fit -- leave the list as it is)
-        if (2 * align_up((size_t)rtiles) * 4 > scratch) return DQ_OK;
+        if (2 * align_up((size_t)rtiles) * 4 > scratch) { *outcome = 0; return DQ_OK; }
         uint64_t *Kx[2] = {B + half, A + half};
         IdxT *Vx[2] = {Bs + half, As + half};
         int xcur = 0;
@@ -1244,10 +1244,10 @@ struct SuffixSorter {
         HIP_TRY(hipStreamSynchronize(st));
         rcur ^= 1;
         m = c.pinned[1];
-        *paid = (m_in - m) * 2 >= m_in;                   // at least half of the list was finished
+        if ((m_in - m) * 2 >= m_in) *outcome = 2;         // at least half of the list was finished
         if (getenv("DQ_TRACE"))
-            fprintf(stderr, "[dq] pair chains h=%lld m=%lld: %lld pair records, %lld entries left\n", (long long)h,
-                    (long long)m_in, (long long)cnt, (long long)m);
+            fprintf(stderr, "[dq] pair chains h=%lld m=%lld (groups <= %d): %lld pair records, %lld entries in larger groups, %lld entries left\n",
+                    (long long)h, (long long)m_in, maxg, (long long)cnt, (long long)copied, (long long)m);
         return DQ_OK;
     }
 
@@ -1269,21 +1269,27 @@ struct SuffixSorter {
         if (rc != DQ_OK) return rc;
 
         int64_t m_before = 0;             // list length before the last round (0: no round yet)
-        int pair_tries = 0;
-        bool pair_paid = true;            // the last pair-chain phase decided most of its pairs
+        int pair_tries = 0, pair_aborts = 0;
+        bool pair_paid = true;            // the last pair-chain phase finished at least half of its list
+        int64_t pair_h = 0;               // h of the last phase
         while (m > 0) {
-            // Tied pairs inside long repeats are decided chain by chain (dq_pair_chains.h): tried once after the
-            // first doubling round, and again after a round that left most of its list tied as long as the phase
-            // before paid off (enwik-like 256 MiB: one phase 34.8 ms, a second one at h = 32 as well 35.9 ms).
+            // Small tie groups inside long repeats are decided chain by chain (dq_pair_chains.h): tried once after the
+            // first doubling round; again after a round that left most of its list tied if the phase before paid
+            // off, or -- if it did not -- once h has grown 16-fold (chain ends step over larger groups h characters
+            // at a time).  A phase gives up after its count pass when most of the list sits in larger groups.
             const bool stagnant = m_before > 0 && m * 5 > m_before * 3;
             const char *pc = getenv("DQ_PAIR_CHAINS");
             const bool want = pc ? atoi(pc) != 0 && (m_before > 0 || atoi(pc) > 1)
-                                 : m_before > 0 && m >= kPairChainMinM && pair_paid && (pair_tries == 0 || stagnant);
-            if (want && pair_tries < kPairChainTries && uses_small_round(m) && m * 3 <= n && !keys_ready) {
-                ++pair_tries;
+                                 : m_before > 0 && m >= kPairChainMinM &&
+                                   (pair_tries == 0 || (pair_paid ? stagnant : h >= 16 * pair_h));
+            const int max_tries = getenv("DQ_PAIR_TRIES") ? atoi(getenv("DQ_PAIR_TRIES")) : kPairChainTries;
+            if (want && pair_tries < max_tries && pair_aborts < kPairChainTries && uses_small_round(m) && !keys_ready) {
+                int outcome = 0;
                 m_before = 0;
-                rc = pair_chain_phase(&pair_paid);
+                rc = pair_chain_phase(&outcome, pc != nullptr);
                 if (rc != DQ_OK) return rc;
+                if (outcome == 0) ++pair_aborts;
+                else { ++pair_tries; pair_paid = outcome == 2; pair_h = h; }
                 continue;
             }
             m_before = m;
