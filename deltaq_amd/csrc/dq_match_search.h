@@ -53,7 +53,27 @@ __device__ __forceinline__ int64_t ms_wave_lcp(const uint8_t *a, int64_t la, con
 {
     const int lane = lane_id();
     const int64_t lim = la < lb ? la : lb;
-    // 512 bytes per step while 12 more bytes exist beyond every lane's 8
+    // 2 KiB per step (four independent 512-byte slices in flight: a long match is a chain of dependent steps, and the
+    // scan-loop driver waits for it) while 12 more bytes exist beyond every lane's 8
+    while (k + 4 * 64 * 8 + 4 <= lim) {
+        uint64_t x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = k + u * 512 + 8 * lane;
+            x[u] = ms_load8(a + j) ^ ms_load8(b + j);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t bad = __ballot(x[u] != 0);
+            if (bad) {
+                const int f = __builtin_ctzll(bad);
+                const uint64_t xf = ms_readlane64(x[u], f);
+                return k + u * 512 + 8 * f + (__builtin_ctzll(xf) >> 3);
+            }
+        }
+        k += 4 * 64 * 8;
+    }
+    // 512 bytes per step
     while (k + 64 * 8 + 4 <= lim) {
         const int64_t j = k + 8 * lane;
         const uint64_t x = ms_load8(a + j) ^ ms_load8(b + j);
@@ -212,6 +232,158 @@ __device__ __forceinline__ void ms_search_one(const uint8_t *__restrict__ old, i
     else if (n == 0) { *pos_res = 0; *len_res = 0; }                              // I = { 0 }: both candidates are I[0]
     else if (x > y) { *pos_res = ps; *len_res = x; }
     else { *pos_res = pe; *len_res = y; }
+}
+
+// One query per WAVE (the scan-loop driver's windows: a few hundred queries, and the launch is one dependent
+// round trip of the host loop, so what counts is the depth of the probe chain, not the work).  A 65-ary lower
+// bound: the 64 lanes probe 64 split points of [L, R) at once (every entry once the interval has <= 64), each
+// lane comparing its suffix with the query from the prefix the interval is known to share; "suffix < query" is
+// monotone over the lanes, so the number of lanes that say yes is the new interval.  ~log65(R - L) levels instead of
+// log2: 3 for a range of 1e5 suffixes.  cap as in ms_search_one; the answers are the same by construction (g is g).
+template <typename IdxT>
+__device__ __forceinline__ void ms_search_wave(const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa,
+                                               const uint8_t *__restrict__ nw, int64_t m, int64_t scan, int64_t cap,
+                                               const IdxT *__restrict__ ptab, int pk, int64_t *pos_res, int64_t *len_res,
+                                               int64_t *over_at = nullptr)
+{
+    const int lane = lane_id();
+    const uint8_t *q = nw + scan;
+    const int64_t lq = m - scan;
+    bool gave_up = false;                                       // wave-uniform
+    int64_t gave_up_at = -1;                                    // old position whose comparison went over the cap
+    // lcp(query, suffix at p) from k equal bytes, every lane its own p: up to kMsLaneBytes alone, then one lane at a
+    // time with the whole wave; *over = the cap was exceeded
+    auto lcp_lanes = [&](int64_t p, int64_t k, bool want, bool *over) -> int64_t {
+        const uint8_t *a = old + p;
+        const int64_t la = n - p;
+        const int64_t lim = la < lq ? la : lq;
+        int64_t j = k;
+        bool more = false;
+        *over = false;
+        if (want) {
+            const int64_t stop = j + kMsLaneBytes < lim ? j + kMsLaneBytes : lim;
+            bool diff = false;
+            while (j + 8 <= stop && j + 12 <= la && j + 12 <= lq) {
+                const uint64_t x = ms_load8(a + j) ^ ms_load8(q + j);
+                if (x) { j += __builtin_ctzll(x) >> 3; diff = true; break; }
+                j += 8;
+            }
+            if (!diff) while (j < stop && a[j] == q[j]) ++j;
+            more = j == stop && stop < lim;
+            if (more && cap > 0 && j - k >= cap) { *over = true; more = false; }
+        }
+        uint64_t need = __ballot(more);
+        while (need) {
+            const int f = __builtin_ctzll(need);
+            need &= need - 1;
+            const uint8_t *fa = reinterpret_cast<const uint8_t *>(ms_readlane64(reinterpret_cast<uint64_t>(a), f));
+            const int64_t fla = (int64_t)ms_readlane64((uint64_t)la, f);
+            const int64_t fj = (int64_t)ms_readlane64((uint64_t)j, f);
+            int64_t lim2 = fla < lq ? fla : lq;
+            bool capped = false;
+            if (cap > 0 && lim2 > k + cap) { lim2 = k + cap; capped = true; }
+            const int64_t r = ms_wave_lcp(fa, lim2, q, lim2, fj);
+            if (lane == f) {
+                j = r;
+                if (capped && r == lim2) *over = true;
+            }
+        }
+        return j;
+    };
+    auto less_than_query = [&](int64_t p, int64_t l) -> bool {
+        const int64_t la = n - p;
+        if (l == la || l == lq) return la < lq;
+        return old[p + l] < q[l];
+    };
+
+    int64_t L = 0, R = n, llcp = 0, rlcp = 0;
+    bool l_known = false, r_known = false;
+    if (ptab && lq >= pk) {
+        int64_t v = 0;
+        for (int j = 0; j < pk; ++j) v = (v << 8) | q[j];
+        L = (int64_t)ptab[v];
+        R = (int64_t)ptab[v + 1];
+        llcp = rlcp = pk;
+    }
+    while (L < R && !gave_up) {
+        const int64_t span = R - L;
+        const int cnt = span <= kWave ? (int)span : kWave;
+        // split points: every entry, or 64 distinct interior points (span >= 65: consecutive ones differ by >= 1)
+        const int64_t mid = span <= kWave ? L + lane : L + (int64_t)(((unsigned __int128)(uint64_t)span * (uint64_t)(lane + 1)) / 65u);
+        const bool act = lane < cnt;
+        const int64_t p = act ? (int64_t)sa[mid] : 0;
+        bool over;
+        const int64_t l = lcp_lanes(p, llcp < rlcp ? llcp : rlcp, act, &over);
+        const uint64_t ov = __ballot(over);
+        if (ov) { gave_up = true; gave_up_at = (int64_t)ms_readlane64((uint64_t)p, __builtin_ctzll(ov)); break; }
+        const uint64_t yes = __ballot(act && less_than_query(p, l));      // a prefix of the active lanes
+        const int f = __popcll(yes);
+        if (f > 0) {
+            L = (int64_t)ms_readlane64((uint64_t)mid, f - 1) + 1;
+            llcp = (int64_t)ms_readlane64((uint64_t)l, f - 1);
+            l_known = true;
+        }
+        if (f < cnt) {
+            R = (int64_t)ms_readlane64((uint64_t)mid, f);
+            rlcp = (int64_t)ms_readlane64((uint64_t)l, f);
+            r_known = true;
+        }
+    }
+    const int64_t g = L;
+    const int64_t start = g > 0 ? g - 1 : 0, end = start + 1;
+    const bool usable = !gave_up && n > 0;
+    const int64_t ps = usable ? (int64_t)sa[start] : 0;
+    const int64_t pe = usable && end < n ? (int64_t)sa[end] : 0;
+    // the two candidates' match lengths: known from the search where that end of the interval was probed, else measured
+    auto measure = [&](int64_t p) -> int64_t {
+        int64_t lim = (n - p) < lq ? (n - p) : lq;
+        bool capped = false;
+        if (cap > 0 && lim > cap) { lim = cap; capped = true; }
+        const int64_t r = ms_wave_lcp(old + p, lim, q, lim, 0);
+        if (capped && r == lim) { gave_up = true; gave_up_at = p; }
+        return r;
+    };
+    const bool x_known = g > 0 ? l_known : r_known;
+    int64_t x = x_known ? (g > 0 ? llcp : rlcp) : 0;
+    if (usable && !x_known) x = measure(ps);
+    const bool y_known = g > 0 && g < n && r_known;
+    int64_t y = y_known ? rlcp : 0;
+    if (usable && !y_known && !gave_up) y = measure(pe);
+    if (over_at) *over_at = gave_up_at;
+    if (gave_up) { *pos_res = 0; *len_res = -1; }
+    else if (n == 0) { *pos_res = 0; *len_res = 0; }
+    else if (x > y) { *pos_res = ps; *len_res = x; }
+    else { *pos_res = pe; *len_res = y; }
+}
+
+// Window kernel of the scan-loop driver: one wave per position scan0 + i; position 0 -- the one the loop is standing
+// on -- exactly, the speculative ones behind it with the cap.  A capped position is where a long match lies; the
+// loop will ask for the exact answer at the FIRST such position of the window (there it jumps).  A wave cannot see
+// the other positions' results, but it can tell whether it is probably that first one: if the long match it ran into
+// also covers the byte before (old[p-1] == new[scan-1]), the position before is inside the same match and capped
+// too.  If not, the wave searches again without the cap.  (A wrong guess costs time only: a position still capped
+// when the loop reaches it opens a new window there.)
+template <typename IdxT>
+__global__ __launch_bounds__(kMsThreads) void match_search_wave_kernel(
+    const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa, const uint8_t *__restrict__ nw, int64_t m,
+    int64_t scan0, int64_t count, int64_t cap, IdxT *__restrict__ pos_out, IdxT *__restrict__ len_out,
+    const IdxT *__restrict__ ptab, int pk, int poll)
+{
+    const int64_t qi = (int64_t)blockIdx.x * (kMsThreads / kWave) + (threadIdx.x >> 6);
+    if (qi >= count) return;                                     // (whole waves)
+    int64_t pos = 0, len = 0, at = -1;
+    const int64_t scan = scan0 + qi;
+    ms_search_wave<IdxT>(old, n, sa, nw, m, scan, qi == 0 ? 0 : cap, ptab, pk, &pos, &len, &at);
+    if (len < 0 && !(at > 0 && scan > 0 && old[at - 1] == nw[scan - 1]))
+        ms_search_wave<IdxT>(old, n, sa, nw, m, scan, 0, ptab, pk, &pos, &len);
+    if (lane_id() == 0) {
+        // the answers live in pinned host memory and the host loop polls the lengths (pre-set to a "pending" value)
+        // instead of waiting for the stream -- a round trip of the scan loop is worth ~10 us of completion-signal
+        // latency: the position must be there before the length is
+        pos_out[qi] = (IdxT)pos;
+        if (poll) __threadfence_system();
+        len_out[qi] = (IdxT)len;
+    }
 }
 
 // exact_first (with cap > 0; the scan-loop driver's windows): the FIRST position of the window that hit the cap is

@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1543,19 +1544,61 @@ struct SearchWindows {
     // kMaxWindow + 2 entries each in PINNED HOST memory that the kernel writes directly (no copy back: between
     // similar files the loop is a chain of dependent round trips, and two small hipMemcpy cost more than the kernel)
     int32_t *h_pos = nullptr, *h_len = nullptr;
+    bool poll = false;                                   // wave windows: wait by polling the lengths in pinned memory
     const void *d_ptab = nullptr;                        // prefix table (prefix_bounds_kernel), or none
     int pk = 0;
     int64_t w0 = -1, wc = 0, next_size = kMinWindow;
     int64_t windows = 0, exact = 0;
-    static constexpr int64_t kMinWindow = 128, kMaxWindow = 65536, kCap = 64;
+    static constexpr int64_t kMinWindow = 128, kMaxWindow = 65536, kCap = 64, kWaveWindow = 2048;
+    static constexpr int32_t kPending = INT32_MIN;
 
     int refill(int64_t scan)
     {
         // the previous window was used up to its end: the loop is walking byte by byte -> a larger one
         next_size = (w0 >= 0 && scan == w0 + wc) ? std::min(next_size * 2, kMaxWindow) : kMinWindow;
         const int64_t count = std::min(next_size, m - scan);
-        int rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, count, kCap, h_pos, h_len, device, nullptr,
+        int rc;
+        if (count <= kWaveWindow) {
+            // short windows (the loop is hopping from match to match: every launch is a dependent round trip): one WAVE
+            // per position, 65-ary search; the position the loop stands on exactly, the ones behind it with the cap
+            int dev = 0;
+            rc = resolve_device(device, &dev);
+            if (rc != DQ_OK) return rc;
+            DeviceCtx &c = g_ctx[dev];
+            std::lock_guard<std::mutex> lk(c.mu);
+            rc = init_ctx(c, dev);
+            if (rc != DQ_OK) return rc;
+            Launcher L{c, c.stream, g_prof_on.load()};
+            constexpr int kPer = kMsThreads / kWave;
+            const bool poll_now = poll && !L.prof;
+            auto launch = [&]() -> int {
+                LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * 4 * (4 + 64) * 64,
+                       hipLaunchKernelGGL(match_search_wave_kernel<int32_t>, dim3((unsigned)((count + kPer - 1) / kPer)),
+                                          dim3(kMsThreads), 0, c.stream, (const uint8_t *)d_old, n, (const int32_t *)d_sa,
+                                          (const uint8_t *)d_new, m, scan, count, kCap, h_pos, h_len, (const int32_t *)d_ptab, pk,
+                                          poll_now ? 1 : 0));
+                return DQ_OK;
+            };
+            if (poll_now) for (int64_t i = 0; i < count; ++i) h_len[i] = kPending;
+            rc = launch();
+            if (rc != DQ_OK) { drop_pending(c, c.stream); return rc; }
+            // poll the kernel's own completion count (bounded: then the ordinary wait)
+            bool seen = false;
+            if (poll_now) {
+                const auto t0 = std::chrono::steady_clock::now();
+                int64_t next = 0;                        // first position not yet seen answered
+                for (uint32_t spins = 0; !seen; ++spins) {
+                    while (next < count && __atomic_load_n(&h_len[next], __ATOMIC_ACQUIRE) != kPending) ++next;
+                    seen = next == count;
+                    if (!seen && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+                }
+            }
+            if (!seen) HIP_TRY(hipStreamSynchronize(c.stream));
+            rc = flush_profile(c);
+        } else {
+            rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, count, kCap, h_pos, h_len, device, nullptr,
                                            d_ptab, pk, /*exact_first=*/1);
+        }
         if (rc != DQ_OK) return rc;                      // (returns after the stream has drained: the answers are there)
         w0 = scan;
         wc = count;
@@ -1569,15 +1612,24 @@ struct SearchWindows {
             if (rc != DQ_OK) return rc;
         }
         int64_t p = h_pos[(size_t)(scan - w0)], l = h_len[(size_t)(scan - w0)];
-        if (l < 0) {                                     // undecided within the cap: this one position, exactly
-            int rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, 1, 0, h_pos + kMaxWindow,
-                                               h_len + kMaxWindow, device, nullptr, d_ptab, pk);
+        if (l < 0) {
+            // undecided within the cap (the loop has reached the next long match): a new window from here, whose first
+            // position is answered exactly -- and whose other positions are there if the match turns out not to be taken
+            w0 = -1;
+            int rc = refill(scan);
             if (rc != DQ_OK) return rc;
-            p = h_pos[kMaxWindow];
-            l = h_len[kMaxWindow];
-            h_pos[(size_t)(scan - w0)] = (int32_t)p;
-            h_len[(size_t)(scan - w0)] = (int32_t)l;
+            p = h_pos[0];
+            l = h_len[0];
             ++exact;
+            if (l < 0) {                                 // (a long window: its exact position may not be this one)
+                rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, 1, 0, h_pos + kMaxWindow,
+                                               h_len + kMaxWindow, device, nullptr, d_ptab, pk);
+                if (rc != DQ_OK) return rc;
+                p = h_pos[kMaxWindow];
+                l = h_len[kMaxWindow];
+                h_pos[0] = (int32_t)p;
+                h_len[0] = (int32_t)l;
+            }
         }
         *pos = p;
         *len = l;
@@ -1606,7 +1658,7 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(bsdiff buffers)", e);
     struct Free { char *p; ~Free() { (void)hipFree(p); } } guard{base};
     char *pinned = nullptr;
-    e = hipHostMalloc((void **)&pinned, 2 * b_win, hipHostMallocDefault);
+    e = hipHostMalloc((void **)&pinned, 2 * b_win + 256, hipHostMallocCoherent);      // (+ the completion count the loop polls)
     if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipHostMalloc(search windows)", e);
     struct FreeHost { char *p; ~FreeHost() { (void)hipHostFree(p); } } hguard{pinned};
     char *d_old = base, *d_sa = d_old + b_old, *d_new = d_sa + b_sa;
@@ -1626,9 +1678,13 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     }
     win.h_pos = reinterpret_cast<int32_t *>(pinned);
     win.h_len = reinterpret_cast<int32_t *>(pinned + b_win);
+    win.poll = !getenv("DQ_NO_POLL");
     rc = bsdiff::scan_loop(old, n, nw, m, win, raw);
     raw.windows = win.windows;
     raw.exact = win.exact;
+    // (the loop polled the kernels' own completion counts: drain the stream before the buffers go away)
+    const hipError_t drained = hipStreamSynchronize(g_ctx[dev].stream);
+    if (rc == DQ_OK && drained != hipSuccess) return fail(DQ_ERR_HIP, "scan loop: stream did not drain", drained);
     return rc;
 }
 
