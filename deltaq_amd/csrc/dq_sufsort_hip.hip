@@ -1477,7 +1477,19 @@ int match_search_dev(const void *d_old, int64_t n, const void *d_sa, const void 
     Launcher L{c, st, g_prof_on.load()};
     // per query: ~log2(n) probes of one SA entry and one 64-byte sector of old, + the match itself
     const int64_t probes = bit_length((uint64_t)std::max<int64_t>(n, 1));
+    // (DQ_SEARCH_WAVE=1: consecutive positions through the one-wave-per-position kernel of the scan-loop driver, so
+    // that the tests can compare its answers one by one; position 0 is answered exactly whatever the cap)
+    const bool wave = getenv("DQ_SEARCH_WAVE") && !d_scans && count <= 4096;
     auto launch = [&]() -> int {
+        if (wave) {
+            constexpr int kPer = kMsThreads / kWave;
+            LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * 4 * ((int64_t)sizeof(IdxT) + 64) * 64,
+                   hipLaunchKernelGGL(match_search_wave_kernel<IdxT>, dim3((unsigned)((count + kPer - 1) / kPer)),
+                                      dim3(kMsThreads), 0, st, (const uint8_t *)d_old, n, (const IdxT *)d_sa,
+                                      (const uint8_t *)d_new, m, scan0, count, cap, (IdxT *)d_pos, (IdxT *)d_len,
+                                      (const IdxT *)d_ptab, pk, 0));
+            return DQ_OK;
+        }
         LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * probes * ((int64_t)sizeof(IdxT) + 64),
                hipLaunchKernelGGL(match_search_kernel<IdxT>, dim3((unsigned)((count + kMsThreads - 1) / kMsThreads)),
                                   dim3(kMsThreads), 0, st, (const uint8_t *)d_old, n, (const IdxT *)d_sa,

@@ -134,3 +134,31 @@ def test_argument_checks(backend_lib):
     assert f(a.ctypes.data, 8, sa.ctypes.data, a.ctypes.data, 8, None, 6, 4, 0, out.ctypes.data, out.ctypes.data, 0) == _abi.DQ_ERR_BAD_ARGS
     assert f(None, 8, sa.ctypes.data, a.ctypes.data, 8, None, 0, 4, 0, out.ctypes.data, out.ctypes.data, 0) == _abi.DQ_ERR_BAD_ARGS
     assert f(a.ctypes.data, 8, sa.ctypes.data, a.ctypes.data, 8, None, 0, 0, 0, None, None, 0) == _abi.DQ_OK
+
+
+def test_wave_per_position_kernel(ms, oracle_mod, monkeypatch):
+    """match_search_wave_kernel (the scan-loop driver's short windows: one wave per position, 65-ary lower bound),
+    reached here through DQ_SEARCH_WAVE=1: windows of consecutive positions, every answer against the oracle."""
+    monkeypatch.setenv("DQ_SEARCH_WAVE", "1")
+    rng = np.random.default_rng(23)
+    cases = []
+    for size in (1, 2, 3, 64, 65, 66, 999, 4096, 4226, 20000):           # interval sizes around the 64 / 65 split points
+        old = oracle_mod.net_random_bytes(size)
+        cases.append((old, edited(rng, old, 5)))
+        cases.append((rng.integers(0, 2, size, dtype=np.uint8), rng.integers(0, 2, size + 7, dtype=np.uint8)))
+    text = oracle_mod.gen_enwik_like(1_500_000, 9, 64 * 1024)
+    cases.append((text, edited(rng, text, 30)))
+    cases.append((np.zeros(100_000, np.uint8), np.zeros(70_000, np.uint8)))
+    for old, new in cases:
+        sa = oracle_mod.divsufsort(old)
+        starts = [0] + [int(x) for x in rng.integers(0, new.size + 1, 6)] + [max(0, new.size - 50)]
+        for s0 in starts:
+            cnt = min(new.size + 1 - s0, int(rng.integers(1, 700)))
+            want = oracle_mod.bsdiff_search(old, sa, new, scan0=s0, count=cnt)
+            got = ms.Search(sa, old, new, scan0=s0, count=cnt)
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), (old.size, new.size, s0, cnt)
+    old, new = cases[-2]
+    sa64 = oracle_mod.divsufsort(old).astype(np.int64)
+    want = oracle_mod.bsdiff_search(old, sa64, new, scan0=1000, count=500)
+    got = ms.Search(sa64, old, new, scan0=1000, count=500)
+    assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
