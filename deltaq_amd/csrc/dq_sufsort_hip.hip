@@ -224,7 +224,7 @@ struct Workspace {
     SmallGroupCounters *sg_ctr; // one per chained small-group round
     uint32_t *hist_partial;     // [kHistBlocks][8][256]
     uint16_t *codetab;          // [256] codewords of the coded round 0 (dq_alpha_code.h)
-    uint32_t *pc_tiles;         // per-tile counts / prefix sums of the pair-chain phase (dq_pair_chains.h), m <= n/2
+    uint32_t *pc_tiles;         // per-tile counts / prefix sums of the pair-chain phase (dq_pair_chains.h)
     int64_t *digit_offset;      // [8][256]
     int64_t *bytehist;          // [256]
     char *ctl_status;           // per digit pass: OnesweepCtl (256 B) + the tiles' status words
@@ -256,7 +256,7 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.hist_partial = (uint32_t *)take((size_t)kHistBlocks * kMaxPasses * kRadixSize * 4);
     w.digit_offset = (int64_t *)take((size_t)kMaxPasses * kRadixSize * 8);
     w.codetab = (uint16_t *)take(512);
-    w.pc_tiles = (uint32_t *)take((un / 2 / 2048 + 4) * 8);
+    w.pc_tiles = (uint32_t *)take((un / 2048 + 4) * 8);
     w.bytehist = (int64_t *)take((size_t)(kRadixSize + 8) * 8);        // + the 8 k-gram sample counters
     // smallest tile is 8192 keys; 8-byte status words once a list reaches 2^30 entries
     w.ctl_status_bytes = (size_t)kMaxPasses * align_up(256 + (un / 8192 + 2) * kRadixSize * (un >= (1ull << 30) ? 8 : 4));
@@ -398,7 +398,7 @@ constexpr int64_t kPairChainMinM = 1 << 11;
 
 // coded round 0 (dq_alpha_code.h): from this size on, and only if a byte costs at most this many bits on average
 constexpr int64_t kCodedMinN = 8ll << 20;
-constexpr double kCodedMaxAvgLen = 6.5;
+constexpr double kCodedMaxAvgLen = 5.8;       // >= 11 characters per key (a 205-symbol Python source tree: 6.17, no gain)
 
 void choose_key_bytes(const int64_t *bytehist, const int64_t *kgram_coll, int64_t n, int *kb_out, bool *packed_out)
 {
@@ -469,7 +469,7 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
     // The keys' digits are then no longer text bytes: their histograms take one more read of the text.
     bool coded = !packed && kb == 8 && n >= kCodedMinN;
     if (coded) {
-        // the code is built on the host while the device waits (0.2 ms for 73 symbols, 3.5 ms for 256): only where
+        // the code is built on the host while the device waits (0.2 ms for 73 symbols, 1-2 ms for 200+): only where
         // it can pay -- the expected codeword length is at least the order-0 entropy, and texts with more than
         // 128 symbols must be large enough to hide the construction
         int sigma = 0;
@@ -477,7 +477,7 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
         for (int b = 0; b < 256; ++b) {
             if (c.pinned[b] > 0) { ++sigma; const double p = (double)c.pinned[b] / (double)n; h0 -= p * std::log2(p); }
         }
-        coded = h0 <= kCodedMaxAvgLen - 0.25 && (sigma <= 128 || n >= 4 * kCodedMinN);
+        coded = h0 <= kCodedMaxAvgLen - 0.25 && (sigma <= 128 || n >= 2 * kCodedMinN);
     }
     if (const char *v = getenv("DQ_CODED")) coded = atoi(v) != 0 && !packed && kb == 8 && n >= 64;
     if (coded) {
@@ -1158,8 +1158,8 @@ struct SuffixSorter {
         return DQ_OK;
     }
 
-    // ---- tied pairs inside long repeats, decided chain by chain (dq_pair_chains.h).  Needs m <= n/2 like the
-    //      small-group rounds (same buffer layout: the next list from 0, the records from n/2) and the ISA.
+    // ---- small tie groups inside long repeats, decided chain by chain (dq_pair_chains.h).  Needs the ISA and room for
+    //      the records behind the list (always there for m <= n/2; for longer lists if the count pass says so).
     //      h is not advanced: the groups that stay behind (>= 3 members, pairs blocked by them) go on doubling.
     // *outcome: 0 = given up after the count (most of the list sits in larger groups: their chains would end
     // blocked), 1 = ran, 2 = ran and finished at least half of the list.
@@ -1168,7 +1168,6 @@ struct SuffixSorter {
         *outcome = 1;
         uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
         IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
-        const int64_t half = sg_half();
         const int ib = bit_length((uint64_t)(n - 1));
         const int64_t ntiles = (m + kPcTile - 1) / kPcTile;
         const size_t scratch = (size_t)kHistBlocks * kMaxPasses * kRadixSize * 4;          // w.hist_partial
@@ -1176,8 +1175,8 @@ struct SuffixSorter {
         // is cheap per round there).  Short lists are launch-bound: every round saved counts, so groups up to 4 -- or
         // up to 3 when the list is longer than n/3: the records (1.5 per entry for groups of 4, at most 1 for
         // pairs and triples) must fit behind `half`.
-        int maxg = m >= kSgShortList ? 2 : (m * 3 <= n ? kPcMaxG : 3);
-        if (const char *v = getenv("DQ_PAIR_MAXG")) maxg = std::min(m * 3 <= n ? kPcMaxG : 3, std::max(2, atoi(v)));
+        int maxg = m >= kSgShortList ? 2 : (m * 3 <= n ? kPcMaxG : (m * 2 <= n ? 3 : 2));
+        if (const char *v = getenv("DQ_PAIR_MAXG")) maxg = std::min(maxg >= 3 ? maxg : 2, std::max(2, atoi(v)));
         // record = d << xbits | x.  Pairs only: x padded to whole digits, so that the digit passes over x see nothing of d
         const int xbits = maxg == 2 ? (ib + 7) / 8 * 8 : ib;
         uint32_t *tile_cnt = w.pc_tiles;
@@ -1195,7 +1194,16 @@ struct SuffixSorter {
         HIP_TRY(hipMemcpyAsync(c.pinned, ctr, sizeof(PairCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const int64_t cnt = c.pinned[0], copied = c.pinned[1];
-        if (cnt == 0 || (!forced && copied * 5 > m * 2)) { *outcome = 0; return DQ_OK; }
+        // the records (and the ping-pong partner of their sort) go behind the list in both buffer pairs: from n/2 as in
+        // a small-group round, or from the end of a longer list if they still fit
+        const int64_t half = std::max(sg_half(), (m + 1) & ~(int64_t)1);
+        if (cnt == 0 || half + cnt > n || (!forced && copied * 5 > m * 3)) {
+            if (getenv("DQ_TRACE"))
+                fprintf(stderr, "[dq] pair chains h=%lld m=%lld: given up, %lld entries in groups > %d\n", (long long)h, (long long)m,
+                        (long long)copied, maxg);
+            *outcome = 0;
+            return DQ_OK;
+        }
         t_info[0] += 1;
         t_info[2] += m_in;
         LAUNCH(L, DQ_K_PAIR_CHAINS, m, m * (8 + wb) + cnt * (8 + wb) + copied * (8 + wb),
@@ -1273,24 +1281,29 @@ struct SuffixSorter {
         int pair_tries = 0, pair_aborts = 0;
         bool pair_paid = true;            // the last pair-chain phase finished at least half of its list
         int64_t pair_h = 0;               // h of the last phase
+        int64_t abort_h = 0, abort_m = 0; // h and list length when a phase last gave up after its count
         while (m > 0) {
             // Small tie groups inside long repeats are decided chain by chain (dq_pair_chains.h): tried once after the
             // first doubling round; again after a round that left most of its list tied if the phase before paid
             // off, or -- if it did not -- once h has grown 16-fold (chain ends step over larger groups h characters
-            // at a time).  A phase gives up after its count pass when most of the list sits in larger groups.
+            // at a time).  A phase gives up after its count pass when most of the list sits in larger groups, and
+            // is tried again once the list has halved or h has grown 16-fold.
             const bool stagnant = m_before > 0 && m * 5 > m_before * 3;
             const char *pc = getenv("DQ_PAIR_CHAINS");
+            const bool after_abort = abort_h == 0 || m * 2 <= abort_m || h >= 16 * abort_h;
             const bool want = pc ? atoi(pc) != 0 && (m_before > 0 || atoi(pc) > 1)
-                                 : m_before > 0 && m >= kPairChainMinM &&
+                                 : m_before > 0 && m >= kPairChainMinM && after_abort &&
                                    (pair_tries == 0 || (pair_paid ? stagnant : h >= 16 * pair_h));
             const int max_tries = getenv("DQ_PAIR_TRIES") ? atoi(getenv("DQ_PAIR_TRIES")) : kPairChainTries;
-            if (want && pair_tries < max_tries && pair_aborts < kPairChainTries && uses_small_round(m) && !keys_ready) {
+            if (want && pair_tries < max_tries && pair_aborts < 2 * kPairChainTries && !getenv("DQ_NO_SMALL") && n < (1ll << 32) &&
+                m < n && !keys_ready) {
                 int outcome = 0;
                 m_before = 0;
+                const int64_t m_try = m;
                 rc = pair_chain_phase(&outcome, pc != nullptr);
                 if (rc != DQ_OK) return rc;
-                if (outcome == 0) ++pair_aborts;
-                else { ++pair_tries; pair_paid = outcome == 2; pair_h = h; }
+                if (outcome == 0) { ++pair_aborts; abort_h = h; abort_m = m_try; }
+                else { ++pair_tries; pair_paid = outcome == 2; pair_h = h; abort_h = 0; }
                 continue;
             }
             m_before = m;

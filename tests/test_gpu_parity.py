@@ -173,6 +173,9 @@ def test_pair_chains(ldss, oracle_mod, backend_lib, monkeypatch):
     text = oracle_mod.gen_enwik_like(6_000_000, 53, 65536)                                    # ~90 copies of up to 64 KiB
     assert launches(text) >= 2
     assert launches(rnd(2_000_000, 54)) == 0                                                  # nothing stagnates
+    doubled = oracle_mod.gen_enwik_like(2_500_000, 55, 1 << 20)
+    doubled = np.concatenate([doubled, rnd(100_000, 56), doubled, rnd(50_000, 57)])          # a whole file twice: more than n/2
+    assert launches(doubled) >= 2                                                             # suffixes tied, the records still fit
     for force in ("1", "2"):
         monkeypatch.setenv("DQ_PAIR_CHAINS", force)
         monkeypatch.setenv("DQ_SMALL_N", "0")
@@ -197,26 +200,23 @@ def test_pair_chains(ldss, oracle_mod, backend_lib, monkeypatch):
 
 def test_coded_round0(ldss, oracle_mod, backend_lib, monkeypatch):
     """dq_alpha_code.h / dq_coded_keys.h: text-like inputs of >= 8 MiB sort 64-bit keys made of alphabetic codewords
-    (12...14 characters instead of 8 bytes).  The path is recognisable by its extra histogram launch; it is forced
-    here on small inputs and on alphabets where it does not pay (fixed 8-bit codewords = raw bytes)."""
-    import ctypes
+    (12...14 characters instead of 8 bytes).  The path is recognisable by the ties it leaves; it is forced here on
+    small inputs and on alphabets where it does not pay (fixed 8-bit codewords = raw bytes)."""
 
-    def hist_launches(T, dtype=np.int32):
-        backend_lib.dq_profile_reset()
-        backend_lib.dq_profile_enable(1)
+    from deltaq_amd import _abi
+
+    def tied_after_round0(T, dtype=np.int32):
         sa = ldss.Sort(T, index_dtype=dtype)
-        backend_lib.dq_profile_enable(0)
-        n = ctypes.c_int64()
-        backend_lib.dq_profile_get(1, ctypes.byref(n), None, None, None)         # DQ_K_RADIX_HIST
+        info = _abi.last_sort_info()
         assert np.array_equal(sa, oracle_mod.divsufsort(T).astype(dtype))
-        return n.value
+        return info["initial_active"]
 
     text = oracle_mod.gen_enwik_like(9_000_001, 21, 65536)
-    coded = hist_launches(text)
+    coded = tied_after_round0(text)
     monkeypatch.setenv("DQ_CODED", "0")
-    plain = hist_launches(text)
+    plain = tied_after_round0(text)
     monkeypatch.delenv("DQ_CODED")
-    assert coded == plain + 1                                            # the coded keys' own digit histograms
+    assert coded * 4 < plain * 3, (coded, plain)                         # 12-14 characters per key instead of 8: far fewer ties
     # real text: this repository's own documents, repeated with scattered edits up to the size where the path engages
     import glob, os
     from conftest import ROOT
@@ -225,9 +225,9 @@ def test_coded_round0(ldss, oracle_mod, backend_lib, monkeypatch):
     real = np.frombuffer(docs * (9_000_000 // max(len(docs), 1) + 1), dtype=np.uint8)[:9_500_000].copy()
     edits = rng.integers(0, real.size, 20_000)
     real[edits] = rng.integers(32, 127, edits.size).astype(np.uint8)
-    assert hist_launches(real) >= 1
+    tied_after_round0(real)
     dna = (oracle_mod.gen_uniform(10_000_000, 23) & 3) + 65
-    hist_launches(np.ascontiguousarray(dna, dtype=np.uint8))             # 4 symbols: fixed 4-bit codewords, 16 characters per key
+    tied_after_round0(np.ascontiguousarray(dna, dtype=np.uint8))         # 4 symbols: fixed 4-bit codewords, 16 characters per key
     monkeypatch.setenv("DQ_CODED", "1")
     monkeypatch.setenv("DQ_PACKED", "0")
     monkeypatch.setenv("DQ_KEY_BYTES", "8")
