@@ -257,7 +257,7 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.digit_offset = (int64_t *)take((size_t)kMaxPasses * kRadixSize * 8);
     w.codetab = (uint16_t *)take(512);
     w.pc_tiles = (uint32_t *)take((un / 2048 + 4) * 8);
-    w.bytehist = (int64_t *)take((size_t)(kRadixSize + 8) * 8);        // + the 8 k-gram sample counters
+    w.bytehist = (int64_t *)take((size_t)(kRadixSize + 16) * 8);       // + the 8 k-gram sample counters + the long-run flag
     // smallest tile is 8192 keys; 8-byte status words once a list reaches 2^30 entries
     w.ctl_status_bytes = (size_t)kMaxPasses * align_up(256 + (un / 8192 + 2) * kRadixSize * (un >= (1ull << 30) ? 8 : 4));
     w.ctl_status = take(w.ctl_status_bytes);
@@ -440,7 +440,7 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
 {
     *coded_out = false;
     const int blocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 4) + kBlock - 1) / kBlock + 1);
-    HIP_TRY(hipMemsetAsync(w.bytehist, 0, 256 * 8, L.st));
+    HIP_TRY(hipMemsetAsync(w.bytehist, 0, (256 + 9) * 8, L.st));
     // (+1 workgroup: the k-gram sample, whose 8 counters sit right behind the byte histogram: one readback)
     LAUNCH(L, DQ_K_TEXT_HIST, n, n,
            hipLaunchKernelGGL(text_hist_kernel, dim3(blocks + 1), dim3(kBlock), 0, L.st,
@@ -448,7 +448,7 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
                               reinterpret_cast<unsigned long long *>(w.bytehist + 256)));
     int kb = 8;
     bool packed = false;
-    HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, (256 + 8) * 8, hipMemcpyDeviceToHost, L.st));
+    HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, (256 + 9) * 8, hipMemcpyDeviceToHost, L.st));
     HIP_TRY(hipEventRecord(c.readback, L.st));
     // While the host waits for the histogram and picks the key width, the device zeroes what the passes
     // need whatever that choice is: the look-back state of all 8 possible passes and the tie bits.
@@ -771,6 +771,9 @@ struct SuffixSorter {
         if (getenv("DQ_NO_BUCKET") || getenv("DQ_NO_FUSED_TIES") || getenv("DQ_SPARSE") || getenv("DQ_KEY_BYTES")) return DQ_OK;
         const bool forced = getenv("DQ_BUCKET") != nullptr;
         if (ib > 31 || n < (1 << 16)) return DQ_OK;                           // a suffix must fit 31 bits next to the tie flag
+        // a run of >= 64 equal bytes somewhere (zero padding of real binaries; text_hist_kernel saw it): more equal
+        // keys than a bin takes -- the pass would only raise its flag and be repeated by the plain passes
+        if (!forced && c.pinned[256 + 8] != 0) return DQ_OK;
         // order-0 model of the text (c.pinned still holds the byte histogram): entropy, most frequent byte
         int64_t cmax = 0;
         double h0 = 0;

@@ -275,6 +275,9 @@ def test_bucketed_round0(ldss, oracle_mod, backend_lib, monkeypatch):
     T = rnd(16_000_000, 9)
     T[::7] = 0                                                          # skewed: the order-0 model says no
     assert bucket_launches(T) == 0
+    T = rnd(14_000_000, 10)
+    T[5_000_003:5_000_203] = 0                                          # zero padding, 200 bytes: seen by the histogram pass
+    assert bucket_launches(T) == 0
     monkeypatch.setenv("DQ_BUCKET", "1")
     for n in (70_000, 300_001, 1 << 20, 3_000_000):
         assert bucket_launches(rnd(n, n)) == 2
