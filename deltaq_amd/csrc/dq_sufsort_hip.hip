@@ -291,13 +291,13 @@ template <typename IdxT, int kMode> struct RankCfg {
 // Zero the look-back state (ticket + status words) of ALL digit passes of one sort with a single
 // memset, so the passes run back to back.
 template <typename IdxT>
-int prepare_status(Launcher &L, Workspace<IdxT> &w, int64_t m, int passes)
+int prepare_status(Launcher &L, Workspace<IdxT> &w, int64_t m, int passes, int from = 0)
 {
     const size_t word = m < (1ll << 30) ? 4 : 8;
     const size_t stride = align_up(256 + ((size_t)m / 8192 + 2) * kRadixSize * word);
     if ((size_t)passes * stride > w.ctl_status_bytes) return fail(DQ_ERR_HIP, "status buffer too small");
     w.ctl_status_stride = stride;
-    HIP_TRY(hipMemsetAsync(w.ctl_status, 0, (size_t)passes * stride, L.st));
+    if (passes > from) HIP_TRY(hipMemsetAsync(w.ctl_status + (size_t)from * stride, 0, (size_t)(passes - from) * stride, L.st));
     return DQ_OK;
 }
 
@@ -451,8 +451,10 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
     HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, (256 + 9) * 8, hipMemcpyDeviceToHost, L.st));
     HIP_TRY(hipEventRecord(c.readback, L.st));
     // While the host waits for the histogram and picks the key width, the device zeroes what the passes
-    // need whatever that choice is: the look-back state of all 8 possible passes and the tie bits.
-    int rc = prepare_status<IdxT>(L, w, n, kMaxPasses);
+    // need whatever that choice is: the look-back state of the first 3 passes (all the bucketed round 0 runs;
+    // 33 MB per pass at 256 MiB) and the tie bits; the other passes' state once kb is known.
+    constexpr int kEarlyPasses = 3;
+    int rc = prepare_status<IdxT>(L, w, n, kEarlyPasses);
     if (rc != DQ_OK) return rc;
     if (n >= (1 << 16)) HIP_TRY(hipMemsetAsync(w.Vb, 0, (size_t)((n + 63) / 64 + 1) * 8, L.st));
     HIP_TRY(hipEventSynchronize(c.readback));
@@ -464,6 +466,8 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
     }
     *kb_out = kb;
     *packed_out = packed;
+    rc = prepare_status<IdxT>(L, w, n, kb, kEarlyPasses);
+    if (rc != DQ_OK) return rc;
     // Text-like input on the 8-byte pair path: the 64 key bits hold the codewords of an alphabetic prefix code
     // instead of 8 raw bytes (dq_alpha_code.h) when that makes the key reach at least ~10 characters on average.
     // The keys' digits are then no longer text bytes: their histograms take one more read of the text.
