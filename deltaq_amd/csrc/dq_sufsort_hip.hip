@@ -768,9 +768,10 @@ struct SuffixSorter {
 
     // ---- bucketed round 0 (see dq_bucket_sort.h).  *done = false: the path does not apply, or it met a
     //      bucket / bin it does not take (the state the plain passes expect has then been restored).
-    int round0_bucketed(uint64_t *K[2], int kb, bool packed, bool *done)
+    int round0_bucketed(uint64_t *K[2], int kb, bool packed, bool coded, bool *done)
     {
         *done = false;
+        if (coded) return DQ_OK;                          // (the digit offsets on the device are those of the coded keys)
         const int ib = bit_length((uint64_t)(n - 1));
         if (getenv("DQ_NO_BUCKET") || getenv("DQ_NO_FUSED_TIES") || getenv("DQ_SPARSE") || getenv("DQ_KEY_BYTES")) return DQ_OK;
         const bool forced = getenv("DQ_BUCKET") != nullptr;
@@ -895,7 +896,7 @@ struct SuffixSorter {
         // LDS: two digit passes on the top 16 key bits, then every bucket is finished in LDS (dq_bucket_sort.h).
         {
             bool done = false;
-            rc = round0_bucketed(K, kb, packed, &done);
+            rc = round0_bucketed(K, kb, packed, coded, &done);
             if (rc != DQ_OK) return rc;
             if (done) { *dense_built = false; return DQ_OK; }
         }

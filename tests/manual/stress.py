@@ -19,7 +19,11 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 ENVS = [{}, {}, {}, {"DQ_SMALL_N": "0"}, {"DQ_NO_FUSED_TIES": "1"}, {"DQ_NO_SMALL": "1"}, {"DQ_NO_BINNED_ISA": "1"},
         {"DQ_NO_CHAIN": "1"}, {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2"}, {"DQ_PACKED": "1", "DQ_KEY_BYTES": "3"},
-        {"DQ_PACKED": "0", "DQ_KEY_BYTES": "4"}, {"DQ_SPARSE": "1"}, {"DQ_SPARSE": "0"}]
+        {"DQ_PACKED": "0", "DQ_KEY_BYTES": "4"}, {"DQ_SPARSE": "1"}, {"DQ_SPARSE": "0"},
+        {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8"}, {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SMALL_N": "0"},
+        {"DQ_PAIR_CHAINS": "1"}, {"DQ_PAIR_CHAINS": "2", "DQ_SMALL_N": "0"}, {"DQ_PAIR_CHAINS": "2", "DQ_PAIR_MAXG": "4"},
+        {"DQ_PAIR_CHAINS": "1", "DQ_PAIR_MAXG": "3", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2"},
+        {"DQ_PAIR_CHAINS": "2", "DQ_PAIR_MAXG": "2", "DQ_NO_BINNED_ISA": "1"}, {"DQ_BUCKET": "1"}, {"DQ_NO_FIRST_SMALL": "1"}]
 KEYS = sorted({k for e in ENVS for k in e})
 s = HipSuffixSort(0)
 t_end = time.time() + budget
@@ -34,6 +38,10 @@ while time.time() < t_end:
     os.environ.update(env)
     ref = oracle.divsufsort(T)
     mode = int(rng.integers(0, 4))
+    if os.environ.get("STRESS_LOG"):
+        with open(os.environ["STRESS_LOG"], "w") as f:
+            f.write(repr(dict(count=count, n=n, env=env, mode=mode)) + "\n")
+        np.save(os.environ["STRESS_LOG"] + ".npy", T)
     if mode == 0:   got = s.Sort(T)
     elif mode == 1: got = s.Sort(T, index_dtype=np.int64)
     elif mode == 2: got = s.Sort(torch.from_numpy(T).cuda()).cpu().numpy()
