@@ -251,6 +251,8 @@ __device__ __forceinline__ void ms_search_wave(const uint8_t *__restrict__ old, 
     const int64_t lq = m - scan;
     bool gave_up = false;                                       // wave-uniform
     int64_t gave_up_at = -1;                                    // old position whose comparison went over the cap
+    int handed = 0;                                             // lanes of the last level whose comparison the wave had to finish
+    bool narrow = false;                                        // repetitive text: one probe per level from here on
     // lcp(query, suffix at p) from k equal bytes, every lane its own p: up to kMsLaneBytes alone, then one lane at a
     // time with the whole wave; *over = the cap was exceeded
     auto lcp_lanes = [&](int64_t p, int64_t k, bool want, bool *over) -> int64_t {
@@ -273,6 +275,7 @@ __device__ __forceinline__ void ms_search_wave(const uint8_t *__restrict__ old, 
             if (more && cap > 0 && j - k >= cap) { *over = true; more = false; }
         }
         uint64_t need = __ballot(more);
+        handed = __popcll(need);
         while (need) {
             const int f = __builtin_ctzll(need);
             need &= need - 1;
@@ -307,13 +310,18 @@ __device__ __forceinline__ void ms_search_wave(const uint8_t *__restrict__ old, 
     }
     while (L < R && !gave_up) {
         const int64_t span = R - L;
-        const int cnt = span <= kWave ? (int)span : kWave;
+        // Many long comparisons in one level (every suffix around the query shares kilobytes with it: runs, periodic
+        // data) would each be finished by the whole wave, one after the other: from then on a plain binary search,
+        // whose single probe per level starts from the prefix both ends already share.
+        const int cnt = narrow ? 1 : (span <= kWave ? (int)span : kWave);
         // split points: every entry, or 64 distinct interior points (span >= 65: consecutive ones differ by >= 1)
-        const int64_t mid = span <= kWave ? L + lane : L + (int64_t)(((unsigned __int128)(uint64_t)span * (uint64_t)(lane + 1)) / 65u);
+        const int64_t mid = narrow ? L + (span >> 1)
+                                   : (span <= kWave ? L + lane : L + (int64_t)(((unsigned __int128)(uint64_t)span * (uint64_t)(lane + 1)) / 65u));
         const bool act = lane < cnt;
         const int64_t p = act ? (int64_t)sa[mid] : 0;
         bool over;
         const int64_t l = lcp_lanes(p, llcp < rlcp ? llcp : rlcp, act, &over);
+        if (handed > 4) narrow = true;
         const uint64_t ov = __ballot(over);
         if (ov) { gave_up = true; gave_up_at = (int64_t)ms_readlane64((uint64_t)p, __builtin_ctzll(ov)); break; }
         const uint64_t yes = __ballot(act && less_than_query(p, l));      // a prefix of the active lanes
@@ -367,7 +375,7 @@ template <typename IdxT>
 __global__ __launch_bounds__(kMsThreads) void match_search_wave_kernel(
     const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa, const uint8_t *__restrict__ nw, int64_t m,
     int64_t scan0, int64_t count, int64_t cap, IdxT *__restrict__ pos_out, IdxT *__restrict__ len_out,
-    const IdxT *__restrict__ ptab, int pk, int poll)
+    const IdxT *__restrict__ ptab, int pk, uint64_t *__restrict__ packed_out /* (len << 32 | pos) per position, or null */)
 {
     const int64_t qi = (int64_t)blockIdx.x * (kMsThreads / kWave) + (threadIdx.x >> 6);
     if (qi >= count) return;                                     // (whole waves)
@@ -377,12 +385,17 @@ __global__ __launch_bounds__(kMsThreads) void match_search_wave_kernel(
     if (len < 0 && !(at > 0 && scan > 0 && old[at - 1] == nw[scan - 1]))
         ms_search_wave<IdxT>(old, n, sa, nw, m, scan, 0, ptab, pk, &pos, &len);
     if (lane_id() == 0) {
-        // the answers live in pinned host memory and the host loop polls the lengths (pre-set to a "pending" value)
-        // instead of waiting for the stream -- a round trip of the scan loop is worth ~10 us of completion-signal
-        // latency: the position must be there before the length is
-        pos_out[qi] = (IdxT)pos;
-        if (poll) __threadfence_system();
-        len_out[qi] = (IdxT)len;
+        if (packed_out) {
+            // polled by the host loop in pinned memory (a round trip of the scan loop is worth the ~10 us of
+            // completion-signal latency): position and length travel in ONE 64-bit store, so that no ordering between
+            // two stores is needed (two 32-bit stores with a system fence in between were seen out of order by the
+            // host about once in 50 000 windows)
+            __hip_atomic_store(&packed_out[qi], ((uint64_t)(uint32_t)(int32_t)len << 32) | (uint32_t)(int32_t)pos,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            pos_out[qi] = (IdxT)pos;
+            len_out[qi] = (IdxT)len;
+        }
     }
 }
 

@@ -1577,13 +1577,13 @@ struct SearchWindows {
     // kMaxWindow + 2 entries each in PINNED HOST memory that the kernel writes directly (no copy back: between
     // similar files the loop is a chain of dependent round trips, and two small hipMemcpy cost more than the kernel)
     int32_t *h_pos = nullptr, *h_len = nullptr;
-    bool poll = false;                                   // wave windows: wait by polling the lengths in pinned memory
+    uint64_t *h_packed = nullptr;                        // pinned: (len << 32 | pos) of the wave windows, polled by the loop
     const void *d_ptab = nullptr;                        // prefix table (prefix_bounds_kernel), or none
     int pk = 0;
     int64_t w0 = -1, wc = 0, next_size = kMinWindow;
     int64_t windows = 0, exact = 0;
     static constexpr int64_t kMinWindow = 128, kMaxWindow = 65536, kCap = 64, kWaveWindow = 2048;
-    static constexpr int32_t kPending = INT32_MIN;
+    static constexpr uint64_t kPending = 0x8000000080000000ull;   // (no answer looks like this: len >= -1)
 
     int refill(int64_t scan)
     {
@@ -1591,7 +1591,7 @@ struct SearchWindows {
         next_size = (w0 >= 0 && scan == w0 + wc) ? std::min(next_size * 2, kMaxWindow) : kMinWindow;
         const int64_t count = std::min(next_size, m - scan);
         int rc;
-        if (count <= kWaveWindow) {
+        if (count <= kWaveWindow && !getenv("DQ_NO_WAVE_WINDOWS")) {
             // short windows (the loop is hopping from match to match: every launch is a dependent round trip): one WAVE
             // per position, 65-ary search; the position the loop stands on exactly, the ones behind it with the cap
             int dev = 0;
@@ -1603,16 +1603,16 @@ struct SearchWindows {
             if (rc != DQ_OK) return rc;
             Launcher L{c, c.stream, g_prof_on.load()};
             constexpr int kPer = kMsThreads / kWave;
-            const bool poll_now = poll && !L.prof;
+            const bool poll_now = h_packed != nullptr && !L.prof;
             auto launch = [&]() -> int {
                 LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * 4 * (4 + 64) * 64,
                        hipLaunchKernelGGL(match_search_wave_kernel<int32_t>, dim3((unsigned)((count + kPer - 1) / kPer)),
                                           dim3(kMsThreads), 0, c.stream, (const uint8_t *)d_old, n, (const int32_t *)d_sa,
                                           (const uint8_t *)d_new, m, scan, count, kCap, h_pos, h_len, (const int32_t *)d_ptab, pk,
-                                          poll_now ? 1 : 0));
+                                          poll_now ? h_packed : (uint64_t *)nullptr));
                 return DQ_OK;
             };
-            if (poll_now) for (int64_t i = 0; i < count; ++i) h_len[i] = kPending;
+            if (poll_now) for (int64_t i = 0; i < count; ++i) h_packed[i] = kPending;
             rc = launch();
             if (rc != DQ_OK) { drop_pending(c, c.stream); return rc; }
             // poll the kernel's own completion count (bounded: then the ordinary wait)
@@ -1621,12 +1621,27 @@ struct SearchWindows {
                 const auto t0 = std::chrono::steady_clock::now();
                 int64_t next = 0;                        // first position not yet seen answered
                 for (uint32_t spins = 0; !seen; ++spins) {
-                    while (next < count && __atomic_load_n(&h_len[next], __ATOMIC_ACQUIRE) != kPending) ++next;
+                    for (; next < count; ++next) {
+                        const uint64_t v = __atomic_load_n(&h_packed[next], __ATOMIC_ACQUIRE);
+                        if (v == kPending) break;
+                        h_pos[next] = (int32_t)(uint32_t)v;
+                        h_len[next] = (int32_t)(uint32_t)(v >> 32);
+                    }
                     seen = next == count;
                     if (!seen && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
                 }
             }
-            if (!seen) HIP_TRY(hipStreamSynchronize(c.stream));
+            if (!seen) {
+                HIP_TRY(hipStreamSynchronize(c.stream));
+                if (poll_now) {                          // a long kernel (megabytes of equal text): the answers are all there now
+                    for (int64_t i = 0; i < count; ++i) {
+                        const uint64_t v = __atomic_load_n(&h_packed[i], __ATOMIC_ACQUIRE);
+                        if (v == kPending) return fail(DQ_ERR_HIP, "match search: a window position was left unanswered");
+                        h_pos[i] = (int32_t)(uint32_t)v;
+                        h_len[i] = (int32_t)(uint32_t)(v >> 32);
+                    }
+                }
+            }
             rc = flush_profile(c);
         } else {
             rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, count, kCap, h_pos, h_len, device, nullptr,
@@ -1691,7 +1706,7 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(bsdiff buffers)", e);
     struct Free { char *p; ~Free() { (void)hipFree(p); } } guard{base};
     char *pinned = nullptr;
-    e = hipHostMalloc((void **)&pinned, 2 * b_win + 256, hipHostMallocCoherent);      // (+ the completion count the loop polls)
+    e = hipHostMalloc((void **)&pinned, 2 * b_win + (size_t)SearchWindows::kWaveWindow * 8 + 256, hipHostMallocCoherent);   // (+ the packed answers the loop polls)
     if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipHostMalloc(search windows)", e);
     struct FreeHost { char *p; ~FreeHost() { (void)hipHostFree(p); } } hguard{pinned};
     char *d_old = base, *d_sa = d_old + b_old, *d_new = d_sa + b_sa;
@@ -1711,7 +1726,7 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     }
     win.h_pos = reinterpret_cast<int32_t *>(pinned);
     win.h_len = reinterpret_cast<int32_t *>(pinned + b_win);
-    win.poll = !getenv("DQ_NO_POLL");
+    win.h_packed = getenv("DQ_NO_POLL") ? nullptr : reinterpret_cast<uint64_t *>(pinned + 2 * b_win);
     rc = bsdiff::scan_loop(old, n, nw, m, win, raw);
     raw.windows = win.windows;
     raw.exact = win.exact;

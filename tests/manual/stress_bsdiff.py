@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the native Diff.Create / Patch.Apply on a GPU box (not collected by pytest):
+    python tests/manual/stress_bsdiff.py [seconds] [seed]
+Random old files of 0 .. 3 MB (uniform, few symbols, text-like, periodic), new = old with random edits / an unrelated
+file / a prefix; raw streams compared with the oracle's scan loop, patches applied back."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle
+from deltaq_amd import Diff, Patch
+from tools import datagen
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+
+def make_old(n):
+    k = int(rng.integers(0, 5))
+    if k == 0: return datagen.gen_uniform(n, int(rng.integers(1, 1 << 30)))
+    if k == 1: return datagen.gen_uniform(n, int(rng.integers(1, 1 << 30))) & int(rng.integers(1, 16))
+    if k == 2: return datagen.gen_enwik_like(n, int(rng.integers(1, 1 << 30)), int(rng.integers(256, 1 << 16)))
+    if k == 3: return np.tile(datagen.gen_uniform(int(rng.integers(1, 5000)), 7), n // 1 + 1)[:n].copy()
+    return np.zeros(n, np.uint8)
+
+def edited(old):
+    new = bytearray(old.tobytes())
+    for _ in range(int(rng.integers(0, 40))):
+        k = int(rng.integers(0, 4)); a = int(rng.integers(0, max(1, len(new)))); ln = int(rng.integers(1, 3000))
+        if k == 0: new[a:a] = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+        elif k == 1: del new[a:a + ln]
+        elif k == 2: new[a:a + ln] = rng.integers(0, 256, min(ln, len(new) - a), dtype=np.uint8).tobytes()
+        else: new[a:a] = new[max(0, a - 3 * ln):max(0, a - 2 * ln)]
+    return np.frombuffer(bytes(new), dtype=np.uint8)
+
+t_end = time.time() + budget
+count = 0
+while time.time() < t_end:
+    u = rng.random()
+    n = int(rng.integers(0, 300)) if u < 0.15 else int(rng.integers(300, 100_000)) if u < 0.7 else int(rng.integers(100_000, 3_000_000))
+    old = np.ascontiguousarray(make_old(n), dtype=np.uint8)
+    v = rng.random()
+    new = edited(old) if v < 0.7 else (make_old(int(rng.integers(0, 200_000))) if v < 0.85 else old[: int(rng.integers(0, n + 1))].copy())
+    new = np.ascontiguousarray(new, dtype=np.uint8)
+    ctrl, diff, extra, st = Diff.Scan(old, new)
+    sa = oracle.divsufsort(old)
+    wc, wd, we, ns = oracle.bsdiff_scan(old, sa, new)
+    ok = np.array_equal(ctrl, wc) and np.array_equal(diff, wd) and np.array_equal(extra, we)
+    what = "raw streams"
+    if ok and count % 4 == 0:
+        patch = Diff.CreateBytes(old, new)
+        ok = Patch.Apply(old, patch) == new.tobytes()
+        what = "round trip"
+    if not ok:
+        print("failed:", what, "stats", st, flush=True)
+        for rep in range(3):                              # the same pair again, in this process
+            c2, d2, e2, st2 = Diff.Scan(old, new)
+            p2 = Diff.CreateBytes(old, new)
+            print("  again: raw streams", np.array_equal(c2, wc) and np.array_equal(d2, wd) and np.array_equal(e2, we),
+                  "round trip", Patch.Apply(old, p2) == new.tobytes(), "same patch bytes", p2 == (patch if what == "round trip" else p2), flush=True)
+        np.save(os.path.join(ROOT, "gpurun_out", f"bsdiff_fail_old_{seed}_{count}.npy"), old)
+        np.save(os.path.join(ROOT, "gpurun_out", f"bsdiff_fail_new_{seed}_{count}.npy"), new)
+        print("MISMATCH", dict(count=count, n=n, m=new.size), flush=True)
+        sys.exit(1)
+    count += 1
+print(f"bsdiff stress OK: {count} file pairs, seed {seed}", flush=True)

@@ -43,6 +43,10 @@ def pairs(oracle_mod):
     out.append((old, edited(rng, old, 12)))                               # random data with edits: long matches, jumps
     out.append((old, oracle_mod.gen_uniform(200_000, 22)))                # nothing in common: one Search per byte
     out.append((np.zeros(100_000, np.uint8), np.zeros(90_000, np.uint8)))
+    z = np.zeros(2_600_000, np.uint8)                                     # megabytes of equal text: every probe of the exact
+    out.append((z, z.copy()))                                             # search is a long comparison (binary probing, slow path)
+    per = np.tile(oracle_mod.gen_uniform(1000, 8), 1500)
+    out.append((per, np.concatenate([per[:700_000], per[3:]])))           # periodic text with one deletion
     old = oracle_mod.gen_enwik_like(5_000_000, 4, 16384)                  # >= 4 MiB: the search starts from a 3-byte prefix table
     out.append((old, edited(rng, old, 300)))
     new = oracle_mod.gen_uniform(60_000, 23)
