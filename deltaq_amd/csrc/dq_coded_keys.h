@@ -22,7 +22,9 @@ namespace dq {
 // tab[b] = codeword << 4 | length (dq_alpha_code.h); w[0..4] = the 5 little-endian dwords at T[i0]
 DQ_HD inline void coded_keys4(const uint32_t w[5], const uint16_t *tab, uint64_t key[4])
 {
-    unsigned __int128 acc = 0;
+    // 128-bit accumulator as two words; shifts by 0...8 (12) and 0...47 bits written so that a count of 0 is fine:
+    // x >> (64 - s) == (x >> 1) >> (63 - s) for s >= 1, and 0 for s = 0
+    uint64_t hi = 0, lo = 0;
     uint32_t bits = 0, need = 0xffffffffu, off[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 19; ++i) {
@@ -33,11 +35,15 @@ DQ_HD inline void coded_keys4(const uint32_t w[5], const uint16_t *tab, uint64_t
         const bool take = bits < need;
         const uint32_t len = take ? (e & 15u) : 0u;
         const uint32_t code = take ? (e >> 4) : 0u;
-        acc = (acc << len) | code;
+        hi = (hi << len) | ((lo >> 1) >> (63u - len));
+        lo = (lo << len) | code;
         bits += len;
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) key[c] = (uint64_t)(acc >> (bits - off[c] - 64));
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t s = bits - off[c] - 64;          // 0 ... 47: the window's distance from the accumulator's low end
+        key[c] = ((hi << 1) << (63u - s)) | (lo >> s);
+    }
 }
 
 }  // namespace dq
