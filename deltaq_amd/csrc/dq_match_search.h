@@ -371,30 +371,76 @@ __device__ __forceinline__ void ms_search_wave(const uint8_t *__restrict__ old, 
 // also covers the byte before (old[p-1] == new[scan-1]), the position before is inside the same match and capped
 // too.  If not, the wave searches again without the cap.  (A wrong guess costs time only: a position still capped
 // when the loop reaches it opens a new window there.)
+// SECOND STAGE (count2 > 0, polled windows only): where the loop breaks it jumps by the length of the match it
+// broke on, and its next window starts there -- one more dependent round trip.  The waves that answered exactly
+// (position 0, or a re-searched first position of a long match) publish (position, length) in a device mailbox, the
+// smallest position winning; count2 more waves wait for all count (<= 256) first-stage waves, take the winner (t, len) and answer
+// the window at scan0 + t + len in the same launch.  The host uses those answers only if its loop really jumps
+// there (they are tagged with their start), so a wrong guess costs time, never correctness; the wait is bounded.
+constexpr uint64_t kMsSkipped = 0x8000000080000001ull;           // second-stage slot: not computed
+constexpr int kMsLongMatch = 32;                                 // a match the loop will break on (len > oldscore + 8)
+
 template <typename IdxT>
 __global__ __launch_bounds__(kMsThreads) void match_search_wave_kernel(
     const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa, const uint8_t *__restrict__ nw, int64_t m,
     int64_t scan0, int64_t count, int64_t cap, IdxT *__restrict__ pos_out, IdxT *__restrict__ len_out,
-    const IdxT *__restrict__ ptab, int pk, uint64_t *__restrict__ packed_out /* (len << 32 | pos) per position, or null */)
+    const IdxT *__restrict__ ptab, int pk, uint64_t *__restrict__ packed_out /* (len << 32 | pos) per position, or null */,
+    int64_t count2 = 0, uint64_t *__restrict__ packed2 = nullptr /* second stage: [0] its start, [1 + i] its answers */,
+    unsigned long long *__restrict__ mail = nullptr /* [0] winner, [1] finished first-stage waves (cumulative) */,
+    unsigned long long ticket = 0 /* of this launch, < 2^24, growing */, unsigned long long done_target = 0 /* mail[1] when stage 1 is through */)
 {
     const int64_t qi = (int64_t)blockIdx.x * (kMsThreads / kWave) + (threadIdx.x >> 6);
-    if (qi >= count) return;                                     // (whole waves)
+    if (qi >= count + count2) return;                            // (whole waves)
+    int64_t base = scan0, idx = qi;                               // this wave answers position base + idx
+    if (qi >= count) {
+        // ---- second stage: wait for the first one, then take the winner ----
+        idx = qi - count;
+        unsigned long long v = 0;
+        bool ready = false;
+        for (int spins = 0; spins < (1 << 16); ++spins) {
+            if (__hip_atomic_load(&mail[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= done_target) { ready = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (ready) v = __hip_atomic_load(&mail[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // winner word: ticket << 40 | (255 - position) << 32 | length, kept by atomic max: a newer launch beats an older
+        // one, inside a launch the smallest position wins (no reset between launches)
+        const bool go = ready && (v >> 40) == ticket;
+        if (go) base = scan0 + (int64_t)(255 - ((v >> 32) & 0xff)) + (int64_t)(uint32_t)v;
+        if (!go || base + idx >= m) {
+            if (lane_id() == 0) {
+                if (idx == 0) __hip_atomic_store(&packed2[0], kMsSkipped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&packed2[1 + idx], kMsSkipped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        if (idx == 0 && lane_id() == 0)
+            __hip_atomic_store(&packed2[0], (uint64_t)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     int64_t pos = 0, len = 0, at = -1;
-    const int64_t scan = scan0 + qi;
-    ms_search_wave<IdxT>(old, n, sa, nw, m, scan, qi == 0 ? 0 : cap, ptab, pk, &pos, &len, &at);
-    if (len < 0 && !(at > 0 && scan > 0 && old[at - 1] == nw[scan - 1]))
+    const int64_t scan = base + idx;
+    bool exact = idx == 0;
+    ms_search_wave<IdxT>(old, n, sa, nw, m, scan, exact ? 0 : cap, ptab, pk, &pos, &len, &at);
+    if (len < 0 && !(at > 0 && scan > 0 && old[at - 1] == nw[scan - 1])) {
         ms_search_wave<IdxT>(old, n, sa, nw, m, scan, 0, ptab, pk, &pos, &len);
+        exact = true;
+    }
     if (lane_id() == 0) {
         if (packed_out) {
             // polled by the host loop in pinned memory (a round trip of the scan loop is worth the ~10 us of
             // completion-signal latency): position and length travel in ONE 64-bit store, so that no ordering between
             // two stores is needed (two 32-bit stores with a system fence in between were seen out of order by the
             // host about once in 50 000 windows)
-            __hip_atomic_store(&packed_out[qi], ((uint64_t)(uint32_t)(int32_t)len << 32) | (uint32_t)(int32_t)pos,
+            __hip_atomic_store(qi < count ? &packed_out[qi] : &packed2[1 + idx], ((uint64_t)(uint32_t)(int32_t)len << 32) | (uint32_t)(int32_t)pos,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
             pos_out[qi] = (IdxT)pos;
             len_out[qi] = (IdxT)len;
+        }
+        if (mail && qi < count) {
+            if (exact && len >= kMsLongMatch)
+                __hip_atomic_fetch_max(&mail[0], (ticket << 40) | ((unsigned long long)(255 - qi) << 32) | (unsigned long long)(uint32_t)len,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&mail[1], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

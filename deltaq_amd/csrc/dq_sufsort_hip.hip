@@ -1578,6 +1578,11 @@ struct SearchWindows {
     // similar files the loop is a chain of dependent round trips, and two small hipMemcpy cost more than the kernel)
     int32_t *h_pos = nullptr, *h_len = nullptr;
     uint64_t *h_packed = nullptr;                        // pinned: (len << 32 | pos) of the wave windows, polled by the loop
+    void *d_mail = nullptr;                              // device: mailbox of the window kernel's second stage
+    static constexpr int64_t kSecond = 128;              // positions of the predicted next window
+    int64_t sec_region = 0, predicted = 0;               // slot region (offset into h_packed) of the pending second stage
+    bool sec_pending = false, no_second = false;
+    unsigned long long ticket = 0, done_total = 0;       // of the launches with a second stage (the mailbox is never reset)
     const void *d_ptab = nullptr;                        // prefix table (prefix_bounds_kernel), or none
     int pk = 0;
     int64_t w0 = -1, wc = 0, next_size = kMinWindow;
@@ -1585,69 +1590,109 @@ struct SearchWindows {
     static constexpr int64_t kMinWindow = 128, kMaxWindow = 65536, kCap = 64, kWaveWindow = 2048;
     static constexpr uint64_t kPending = 0x8000000080000000ull;   // (no answer looks like this: len >= -1)
 
+    // wait for one pinned slot to leave the "pending" state (bounded polling, then the ordinary stream wait)
+    int await_slot(const uint64_t *slot, hipStream_t st, uint64_t *value)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0;; ++spins) {
+            const uint64_t v = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
+            if (v != kPending) { *value = v; return DQ_OK; }
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+        HIP_TRY(hipStreamSynchronize(st));               // (a slow window -- megabytes of equal text)
+        *value = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
+        if (*value == kPending) return fail(DQ_ERR_HIP, "match search: a window position was left unanswered");
+        return DQ_OK;
+    }
+
     int refill(int64_t scan)
     {
+        int dev = 0;
+        int rc = resolve_device(device, &dev);
+        if (rc != DQ_OK) return rc;
+        DeviceCtx &c = g_ctx[dev];
+        // the window the device was asked to answer ahead (second stage of the previous launch): is it this one?
+        if (sec_pending) {
+            sec_pending = false;
+            const uint64_t *reg = h_packed + sec_region;
+            uint64_t hdr = 0;
+            rc = await_slot(&reg[0], c.stream, &hdr);
+            if (rc != DQ_OK) return rc;
+            if (hdr != kMsSkipped && (int64_t)hdr == scan) {
+                int64_t got = 0;
+                for (; got < kSecond; ++got) {
+                    uint64_t v = 0;
+                    rc = await_slot(&reg[1 + got], c.stream, &v);
+                    if (rc != DQ_OK) return rc;
+                    if (v == kMsSkipped) break;
+                    h_pos[got] = (int32_t)(uint32_t)v;
+                    h_len[got] = (int32_t)(uint32_t)(v >> 32);
+                }
+                if (got > 0) {
+                    w0 = scan;
+                    wc = got;
+                    next_size = kMinWindow;
+                    ++windows;
+                    ++predicted;
+                    return DQ_OK;
+                }
+            }
+        }
         // the previous window was used up to its end: the loop is walking byte by byte -> a larger one
         next_size = (w0 >= 0 && scan == w0 + wc) ? std::min(next_size * 2, kMaxWindow) : kMinWindow;
         const int64_t count = std::min(next_size, m - scan);
-        int rc;
         if (count <= kWaveWindow && !getenv("DQ_NO_WAVE_WINDOWS")) {
             // short windows (the loop is hopping from match to match: every launch is a dependent round trip): one WAVE
             // per position, 65-ary search; the position the loop stands on exactly, the ones behind it with the cap
-            int dev = 0;
-            rc = resolve_device(device, &dev);
-            if (rc != DQ_OK) return rc;
-            DeviceCtx &c = g_ctx[dev];
             std::lock_guard<std::mutex> lk(c.mu);
             rc = init_ctx(c, dev);
             if (rc != DQ_OK) return rc;
             Launcher L{c, c.stream, g_prof_on.load()};
             constexpr int kPer = kMsThreads / kWave;
             const bool poll_now = h_packed != nullptr && !L.prof;
+            // second stage: the window the loop will want after its next jump (dq_match_search.h), minimal windows only.
+            // Its answers are looked at when the loop gets there, not now; two slot regions take turns, so that a
+            // region is written by one launch at a time (the launch in between has answered: the older one is over).
+            const int64_t count2 = (poll_now && d_mail && count == kMinWindow && !no_second && ticket < (1ull << 24) - 2) ? kSecond : 0;
+            uint64_t *reg2 = nullptr;
+            if (count2) {
+                ++ticket;
+                done_total += (unsigned long long)count;
+                sec_region = kWaveWindow + (int64_t)(ticket & 1) * (kSecond + 1);
+                reg2 = h_packed + sec_region;
+                for (int64_t i = 0; i < kSecond + 1; ++i) reg2[i] = kPending;
+            }
             auto launch = [&]() -> int {
                 LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * 4 * (4 + 64) * 64,
-                       hipLaunchKernelGGL(match_search_wave_kernel<int32_t>, dim3((unsigned)((count + kPer - 1) / kPer)),
+                       hipLaunchKernelGGL(match_search_wave_kernel<int32_t>, dim3((unsigned)((count + count2 + kPer - 1) / kPer)),
                                           dim3(kMsThreads), 0, c.stream, (const uint8_t *)d_old, n, (const int32_t *)d_sa,
                                           (const uint8_t *)d_new, m, scan, count, kCap, h_pos, h_len, (const int32_t *)d_ptab, pk,
-                                          poll_now ? h_packed : (uint64_t *)nullptr));
+                                          poll_now ? h_packed : (uint64_t *)nullptr, count2, reg2,
+                                          count2 ? reinterpret_cast<unsigned long long *>(d_mail) : (unsigned long long *)nullptr,
+                                          ticket, done_total));
                 return DQ_OK;
             };
             if (poll_now) for (int64_t i = 0; i < count; ++i) h_packed[i] = kPending;
             rc = launch();
             if (rc != DQ_OK) { drop_pending(c, c.stream); return rc; }
-            // poll the kernel's own completion count (bounded: then the ordinary wait)
-            bool seen = false;
             if (poll_now) {
-                const auto t0 = std::chrono::steady_clock::now();
-                int64_t next = 0;                        // first position not yet seen answered
-                for (uint32_t spins = 0; !seen; ++spins) {
-                    for (; next < count; ++next) {
-                        const uint64_t v = __atomic_load_n(&h_packed[next], __ATOMIC_ACQUIRE);
-                        if (v == kPending) break;
-                        h_pos[next] = (int32_t)(uint32_t)v;
-                        h_len[next] = (int32_t)(uint32_t)(v >> 32);
-                    }
-                    seen = next == count;
-                    if (!seen && (spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+                for (int64_t i = 0; i < count; ++i) {
+                    uint64_t v = 0;
+                    rc = await_slot(&h_packed[i], c.stream, &v);
+                    if (rc != DQ_OK) return rc;
+                    h_pos[i] = (int32_t)(uint32_t)v;
+                    h_len[i] = (int32_t)(uint32_t)(v >> 32);
                 }
-            }
-            if (!seen) {
+                sec_pending = count2 > 0;
+            } else {
                 HIP_TRY(hipStreamSynchronize(c.stream));
-                if (poll_now) {                          // a long kernel (megabytes of equal text): the answers are all there now
-                    for (int64_t i = 0; i < count; ++i) {
-                        const uint64_t v = __atomic_load_n(&h_packed[i], __ATOMIC_ACQUIRE);
-                        if (v == kPending) return fail(DQ_ERR_HIP, "match search: a window position was left unanswered");
-                        h_pos[i] = (int32_t)(uint32_t)v;
-                        h_len[i] = (int32_t)(uint32_t)(v >> 32);
-                    }
-                }
             }
             rc = flush_profile(c);
         } else {
             rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, count, kCap, h_pos, h_len, device, nullptr,
                                            d_ptab, pk, /*exact_first=*/1);
         }
-        if (rc != DQ_OK) return rc;                      // (returns after the stream has drained: the answers are there)
+        if (rc != DQ_OK) return rc;                      // (the answers are there)
         w0 = scan;
         wc = count;
         ++windows;
@@ -1702,11 +1747,11 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     // prefix table of the match search: 3 bytes (64 MiB of entries) for old files from 4 MiB, 2 bytes from 64 KiB
     const int pk = n >= (4 << 20) ? 3 : n >= (1 << 16) ? 2 : 0;
     const size_t b_tab = pk ? align_up(((size_t)1 << (8 * pk)) * 4 + 16) : 0;
-    hipError_t e = hipMalloc((void **)&base, b_old + b_sa + b_new + b_tab);
+    hipError_t e = hipMalloc((void **)&base, b_old + b_sa + b_new + b_tab + 256);      // (+ the mailbox of the window kernel)
     if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(bsdiff buffers)", e);
     struct Free { char *p; ~Free() { (void)hipFree(p); } } guard{base};
     char *pinned = nullptr;
-    e = hipHostMalloc((void **)&pinned, 2 * b_win + (size_t)SearchWindows::kWaveWindow * 8 + 256, hipHostMallocCoherent);   // (+ the packed answers the loop polls)
+    e = hipHostMalloc((void **)&pinned, 2 * b_win + (size_t)(SearchWindows::kWaveWindow + 2 * (SearchWindows::kSecond + 1)) * 8 + 256, hipHostMallocCoherent);   // (+ the packed answers the loop polls)
     if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipHostMalloc(search windows)", e);
     struct FreeHost { char *p; ~FreeHost() { (void)hipHostFree(p); } } hguard{pinned};
     char *d_old = base, *d_sa = d_old + b_old, *d_new = d_sa + b_sa;
@@ -1727,9 +1772,15 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     win.h_pos = reinterpret_cast<int32_t *>(pinned);
     win.h_len = reinterpret_cast<int32_t *>(pinned + b_win);
     win.h_packed = getenv("DQ_NO_POLL") ? nullptr : reinterpret_cast<uint64_t *>(pinned + 2 * b_win);
+    win.d_mail = base + b_old + b_sa + b_new + b_tab;
+    HIP_TRY(hipMemset(win.d_mail, 0, 16));
+    win.no_second = getenv("DQ_NO_SECOND_STAGE") != nullptr;
     rc = bsdiff::scan_loop(old, n, nw, m, win, raw);
     raw.windows = win.windows;
     raw.exact = win.exact;
+    if (getenv("DQ_TRACE"))
+        fprintf(stderr, "[dq] scan loop: %lld searches, %lld windows (%lld of them answered ahead by the second stage), %lld exact repeats\n",
+                (long long)raw.searches, (long long)win.windows, (long long)win.predicted, (long long)win.exact);
     // (the loop polled the kernels' own completion counts: drain the stream before the buffers go away)
     const hipError_t drained = hipStreamSynchronize(g_ctx[dev].stream);
     if (rc == DQ_OK && drained != hipSuccess) return fail(DQ_ERR_HIP, "scan loop: stream did not drain", drained);
