@@ -48,6 +48,47 @@ inline int64_t read_packed_long(const uint8_t *p)
     return (p[7] & 0x80) ? -y : y;
 }
 
+// ---- byte-run helpers of the scan loop (8 bytes a step; the loop walks every byte of both files several times) ----
+inline uint64_t load_u64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+// number of i < len with a[i] == b[i]
+inline int64_t count_equal(const uint8_t *a, const uint8_t *b, int64_t len)
+{
+    int64_t i = 0, c = 0;
+    constexpr uint64_t k7f = 0x7f7f7f7f7f7f7f7full;
+    for (; i + 8 <= len; i += 8) {
+        const uint64_t x = load_u64(a + i) ^ load_u64(b + i);
+        const uint64_t t = ~(((x & k7f) + k7f) | x | k7f);        // 0x80 in every byte of x that is zero
+        c += __builtin_popcountll(t);
+    }
+    for (; i < len; ++i) c += a[i] == b[i];
+    return c;
+}
+
+// length of the common prefix of a[0..len) and b[0..len)
+inline int64_t common_prefix(const uint8_t *a, const uint8_t *b, int64_t len)
+{
+    int64_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+        const uint64_t x = load_u64(a + i) ^ load_u64(b + i);
+        if (x) return i + (__builtin_ctzll(x) >> 3);              // (little endian: the first differing byte is the lowest)
+    }
+    for (; i < len && a[i] == b[i]; ++i) {}
+    return i;
+}
+
+// number of k in 1..len with a[-k] == b[-k] for all 1..k (common suffix of the bytes before a and b)
+inline int64_t common_suffix(const uint8_t *a, const uint8_t *b, int64_t len)
+{
+    int64_t k = 0;
+    for (; k + 8 <= len; k += 8) {
+        const uint64_t x = load_u64(a - k - 8) ^ load_u64(b - k - 8);
+        if (x) return k + (__builtin_clzll(x) >> 3);              // the last byte of the word is the nearest one
+    }
+    for (; k < len && a[-k - 1] == b[-k - 1]; ++k) {}
+    return k;
+}
+
 struct RawStreams {
     std::vector<uint8_t> ctrl, diff, extra;                       // ctrl: 24 bytes (three packed longs) per triple
     int64_t searches = 0, windows = 0, exact = 0;
@@ -87,7 +128,11 @@ int scan_loop(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, Searc
             const int rc = search(cursor, &hit_pos, &hit_len);
             if (rc != 0) return rc;
             ++out.searches;
-            for (; counted < cursor + hit_len; ++counted) carried += agrees(counted);
+            if (counted < cursor + hit_len) {                // bytes of the new match the previous alignment also gets right
+                const int64_t end = cursor + hit_len, upto = end < n - shift ? end : n - shift;
+                if (upto > counted) carried += count_equal(old + counted + shift, nw + counted, upto - counted);
+                counted = end;
+            }
             if ((hit_len == carried && hit_len != 0) || hit_len > carried + 8) break;
             carried -= agrees(cursor);
         }
@@ -96,6 +141,17 @@ int scan_loop(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, Searc
         // ---- 2. extensions ----
         int64_t fwd = 0;                                     // forward from prev, under prev's alignment
         for (int64_t i = 0, good = 0, best = 0; prev.at + i < cursor && prev.in_old + i < n;) {
+            if (good == best && i == fwd) {
+                // standing on the best prefix so far: every further equal byte makes a better one, so a run of them
+                // is taken in one step (the files are mostly such runs)
+                const int64_t room = (cursor - prev.at - i) < (n - prev.in_old - i) ? (cursor - prev.at - i) : (n - prev.in_old - i);
+                const int64_t run = common_prefix(old + prev.in_old + i, nw + prev.at + i, room);
+                good += run;
+                i += run;
+                best = good;
+                fwd = i;
+                if (run == room) break;
+            }
             good += old[prev.in_old + i] == nw[prev.at + i];
             ++i;
             if (2 * good - i > 2 * best - fwd) { best = good; fwd = i; }
@@ -103,6 +159,15 @@ int scan_loop(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, Searc
         int64_t back = 0;                                    // backward from the new anchor, under its alignment
         if (cursor < m) {
             for (int64_t i = 1, good = 0, best = 0; cursor >= prev.at + i && hit_pos >= i; ++i) {
+                if (good == best && back == i - 1) {           // as above, towards the front
+                    const int64_t room = ((cursor - prev.at) < hit_pos ? (cursor - prev.at) : hit_pos) - (i - 1);
+                    const int64_t run = common_suffix(old + hit_pos - (i - 1), nw + cursor - (i - 1), room);
+                    good += run;
+                    i += run;
+                    best = good;
+                    back = i - 1;
+                    if (run == room) break;
+                }
                 good += old[hit_pos - i] == nw[cursor - i];
                 if (2 * good - i > 2 * best - back) { best = good; back = i; }
             }

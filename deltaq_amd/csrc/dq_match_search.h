@@ -374,7 +374,7 @@ __device__ __forceinline__ void ms_search_wave(const uint8_t *__restrict__ old, 
 // SECOND STAGE (count2 > 0, polled windows only): where the loop breaks it jumps by the length of the match it
 // broke on, and its next window starts there -- one more dependent round trip.  The waves that answered exactly
 // (position 0, or a re-searched first position of a long match) publish (position, length) in a device mailbox, the
-// smallest position winning; count2 more waves wait for all count (<= 256) first-stage waves, take the winner (t, len) and answer
+// smallest position winning; count2 more waves wait for all count (<= 4096) first-stage waves, take the winner (t, len) and answer
 // the window at scan0 + t + len in the same launch.  The host uses those answers only if its loop really jumps
 // there (they are tagged with their start), so a wrong guess costs time, never correctness; the wait is bounded.
 constexpr uint64_t kMsSkipped = 0x8000000080000001ull;           // second-stage slot: not computed
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kMsThreads) void match_search_wave_kernel(
     const IdxT *__restrict__ ptab, int pk, uint64_t *__restrict__ packed_out /* (len << 32 | pos) per position, or null */,
     int64_t count2 = 0, uint64_t *__restrict__ packed2 = nullptr /* second stage: [0] its start, [1 + i] its answers */,
     unsigned long long *__restrict__ mail = nullptr /* [0] winner, [1] finished first-stage waves (cumulative) */,
-    unsigned long long ticket = 0 /* of this launch, < 2^24, growing */, unsigned long long done_target = 0 /* mail[1] when stage 1 is through */)
+    unsigned long long ticket = 0 /* of this launch, < 2^20, growing */, unsigned long long done_target = 0 /* mail[1] when stage 1 is through */)
 {
     const int64_t qi = (int64_t)blockIdx.x * (kMsThreads / kWave) + (threadIdx.x >> 6);
     if (qi >= count + count2) return;                            // (whole waves)
@@ -402,10 +402,10 @@ __global__ __launch_bounds__(kMsThreads) void match_search_wave_kernel(
             __builtin_amdgcn_s_sleep(8);
         }
         if (ready) v = __hip_atomic_load(&mail[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // winner word: ticket << 40 | (255 - position) << 32 | length, kept by atomic max: a newer launch beats an older
+        // winner word: ticket << 44 | (4095 - position) << 32 | length, kept by atomic max: a newer launch beats an older
         // one, inside a launch the smallest position wins (no reset between launches)
-        const bool go = ready && (v >> 40) == ticket;
-        if (go) base = scan0 + (int64_t)(255 - ((v >> 32) & 0xff)) + (int64_t)(uint32_t)v;
+        const bool go = ready && (v >> 44) == ticket;
+        if (go) base = scan0 + (int64_t)(4095 - ((v >> 32) & 0xfff)) + (int64_t)(uint32_t)v;
         if (!go || base + idx >= m) {
             if (lane_id() == 0) {
                 if (idx == 0) __hip_atomic_store(&packed2[0], kMsSkipped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kMsThreads) void match_search_wave_kernel(
         }
         if (mail && qi < count) {
             if (exact && len >= kMsLongMatch)
-                __hip_atomic_fetch_max(&mail[0], (ticket << 40) | ((unsigned long long)(255 - qi) << 32) | (unsigned long long)(uint32_t)len,
+                __hip_atomic_fetch_max(&mail[0], (ticket << 44) | ((unsigned long long)(4095 - qi) << 32) | (unsigned long long)(uint32_t)len,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(&mail[1], 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }

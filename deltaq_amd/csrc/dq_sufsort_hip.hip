@@ -1580,6 +1580,7 @@ struct SearchWindows {
     uint64_t *h_packed = nullptr;                        // pinned: (len << 32 | pos) of the wave windows, polled by the loop
     void *d_mail = nullptr;                              // device: mailbox of the window kernel's second stage
     static constexpr int64_t kSecond = 128;              // positions of the predicted next window
+    static constexpr int64_t kSecondMaxFirst = 1024;     // ... behind first stages of up to this many positions
     int64_t sec_region = 0, predicted = 0;               // slot region (offset into h_packed) of the pending second stage
     bool sec_pending = false, no_second = false;
     unsigned long long ticket = 0, done_total = 0;       // of the launches with a second stage (the mailbox is never reset)
@@ -1650,10 +1651,10 @@ struct SearchWindows {
             Launcher L{c, c.stream, g_prof_on.load()};
             constexpr int kPer = kMsThreads / kWave;
             const bool poll_now = h_packed != nullptr && !L.prof;
-            // second stage: the window the loop will want after its next jump (dq_match_search.h), minimal windows only.
+            // second stage: the window the loop will want after its next jump (dq_match_search.h), windows of up to 1024 positions.
             // Its answers are looked at when the loop gets there, not now; two slot regions take turns, so that a
             // region is written by one launch at a time (the launch in between has answered: the older one is over).
-            const int64_t count2 = (poll_now && d_mail && count == kMinWindow && !no_second && ticket < (1ull << 24) - 2) ? kSecond : 0;
+            const int64_t count2 = (poll_now && d_mail && count <= kSecondMaxFirst && !no_second && ticket < (1ull << 20) - 2) ? kSecond : 0;
             uint64_t *reg2 = nullptr;
             if (count2) {
                 ++ticket;
