@@ -1742,6 +1742,12 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     if (rc != DQ_OK) return rc;
     if (m == 0) return DQ_OK;
     HIP_TRY(hipSetDevice(dev));
+    const bool trace = getenv("DQ_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) {
+        if (trace) fprintf(stderr, "[dq] bsdiff %-14s at %8.3f ms\n", what,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     char *base = nullptr;
     const size_t b_old = align_up((size_t)n + 16), b_sa = align_up((size_t)n * 4 + 16), b_new = align_up((size_t)m + 16);
     const size_t b_win = align_up((size_t)(SearchWindows::kMaxWindow + 2) * 4);
@@ -1756,10 +1762,13 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipHostMalloc(search windows)", e);
     struct FreeHost { char *p; ~FreeHost() { (void)hipHostFree(p); } } hguard{pinned};
     char *d_old = base, *d_sa = d_old + b_old, *d_new = d_sa + b_sa;
+    stamp("buffers");
     if (n > 0) HIP_TRY(hipMemcpy(d_old, old, (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice));
+    stamp("files on device");
     rc = sufsort_dev<int32_t>(d_old, n, d_sa, dev, nullptr);                       // Diff.cs:90; the SA never leaves the device
     if (rc != DQ_OK) return rc;
+    stamp("suffix array");
     SearchWindows win{d_old, d_sa, d_new, n, m, dev};
     if (pk) {
         const int64_t total = (1ll << (8 * pk)) + 1;
@@ -1770,6 +1779,7 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
         win.d_ptab = d_new + b_new;
         win.pk = pk;
     }
+    stamp("prefix table");
     win.h_pos = reinterpret_cast<int32_t *>(pinned);
     win.h_len = reinterpret_cast<int32_t *>(pinned + b_win);
     win.h_packed = getenv("DQ_NO_POLL") ? nullptr : reinterpret_cast<uint64_t *>(pinned + 2 * b_win);
@@ -1779,6 +1789,7 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     rc = bsdiff::scan_loop(old, n, nw, m, win, raw);
     raw.windows = win.windows;
     raw.exact = win.exact;
+    stamp("scan loop");
     if (getenv("DQ_TRACE"))
         fprintf(stderr, "[dq] scan loop: %lld searches, %lld windows (%lld of them answered ahead by the second stage), %lld exact repeats\n",
                 (long long)raw.searches, (long long)win.windows, (long long)win.predicted, (long long)win.exact);
