@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised differential run of the native Diff.Create / Patch.Apply on a GPU box (not collected by pytest):
+"""Randomised differential run of the native Diff.Create / Patch.Apply on a GPU box (not collected by pytest;
+STRESS_LOG=<file> keeps the pair being worked on, for the post-mortem of a crash or a hang):
     python tests/manual/stress_bsdiff.py [seconds] [seed]
 Random old files of 0 .. 3 MB (uniform, few symbols, text-like, periodic), new = old with random edits / an unrelated
 file / a prefix; raw streams compared with the oracle's scan loop, patches applied back."""
@@ -20,8 +21,10 @@ def make_old(n):
     if k == 0: return datagen.gen_uniform(n, int(rng.integers(1, 1 << 30)))
     if k == 1: return datagen.gen_uniform(n, int(rng.integers(1, 1 << 30))) & int(rng.integers(1, 16))
     if k == 2: return datagen.gen_enwik_like(n, int(rng.integers(1, 1 << 30)), int(rng.integers(256, 1 << 16)))
-    if k == 3: return np.tile(datagen.gen_uniform(int(rng.integers(1, 5000)), 7), n // 1 + 1)[:n].copy()
-    return np.zeros(n, np.uint8)
+    if k == 3: return np.tile(datagen.gen_uniform(int(rng.integers(64, 5000)), 7), n // 64 + 1)[:n].copy()
+    # one symbol: the reference's own loop is quadratic between such files (a 1.3 MB pair with one 6-byte insertion
+    # takes its restatement 10 minutes: 930 000 searches of ~1 MB each), so they stay short here
+    return np.zeros(min(n, 30_000), np.uint8)
 
 def edited(old):
     new = bytearray(old.tobytes())
@@ -42,9 +45,15 @@ while time.time() < t_end:
     v = rng.random()
     new = edited(old) if v < 0.7 else (make_old(int(rng.integers(0, 200_000))) if v < 0.85 else old[: int(rng.integers(0, n + 1))].copy())
     new = np.ascontiguousarray(new, dtype=np.uint8)
-    ctrl, diff, extra, st = Diff.Scan(old, new)
+    if os.environ.get("STRESS_LOG"):
+        with open(os.environ["STRESS_LOG"], "w") as f:
+            f.write(repr(dict(count=count, n=n, m=int(new.size), t=round(time.time() - (t_end - budget), 1))) + "\n")
+        np.save(os.environ["STRESS_LOG"] + ".old.npy", old); np.save(os.environ["STRESS_LOG"] + ".new.npy", new)
+    t0 = time.time(); ctrl, diff, extra, st = Diff.Scan(old, new); t1 = time.time()
     sa = oracle.divsufsort(old)
-    wc, wd, we, ns = oracle.bsdiff_scan(old, sa, new)
+    wc, wd, we, ns = oracle.bsdiff_scan(old, sa, new); t2 = time.time()
+    if t2 - t0 > 5.0:
+        print(f"slow pair {count}: n={n} m={new.size} device {t1-t0:.1f} s, oracle {t2-t1:.1f} s, {st}, old[:8]={old[:8].tolist()}", flush=True)
     ok = np.array_equal(ctrl, wc) and np.array_equal(diff, wd) and np.array_equal(extra, we)
     what = "raw streams"
     if ok and count % 4 == 0:
