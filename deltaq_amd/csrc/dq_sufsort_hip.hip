@@ -1583,6 +1583,8 @@ struct SearchWindows {
     static constexpr int64_t kSecondMaxFirst = 1024;     // ... behind first stages of up to this many positions
     int64_t sec_region = 0, predicted = 0;               // slot region (offset into h_packed) of the pending second stage
     bool sec_pending = false, no_second = false;
+    int64_t last_capped = -2, capped_streak = 0;         // consecutive positions that came back capped
+    bool from_capped = false;
     unsigned long long ticket = 0, done_total = 0;       // of the launches with a second stage (the mailbox is never reset)
     const void *d_ptab = nullptr;                        // prefix table (prefix_bounds_kernel), or none
     int pk = 0;
@@ -1639,6 +1641,9 @@ struct SearchWindows {
                 }
             }
         }
+        // (the loop jumped: whatever made positions come back capped in a row is behind it)
+        if (!from_capped && !(w0 >= 0 && scan == w0 + wc)) capped_streak = 0;
+        from_capped = false;
         // the previous window was used up to its end: the loop is walking byte by byte -> a larger one
         next_size = (w0 >= 0 && scan == w0 + wc) ? std::min(next_size * 2, kMaxWindow) : kMinWindow;
         const int64_t count = std::min(next_size, m - scan);
@@ -1667,7 +1672,8 @@ struct SearchWindows {
                 LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * 4 * (4 + 64) * 64,
                        hipLaunchKernelGGL(match_search_wave_kernel<int32_t>, dim3((unsigned)((count + count2 + kPer - 1) / kPer)),
                                           dim3(kMsThreads), 0, c.stream, (const uint8_t *)d_old, n, (const int32_t *)d_sa,
-                                          (const uint8_t *)d_new, m, scan, count, kCap, h_pos, h_len, (const int32_t *)d_ptab, pk,
+                                          (const uint8_t *)d_new, m, scan, count, capped_streak >= 2 ? (int64_t)0 : kCap, h_pos, h_len,
+                                          (const int32_t *)d_ptab, pk,
                                           poll_now ? h_packed : (uint64_t *)nullptr, count2, reg2,
                                           count2 ? reinterpret_cast<unsigned long long *>(d_mail) : (unsigned long long *)nullptr,
                                           ticket, done_total));
@@ -1708,8 +1714,14 @@ struct SearchWindows {
         int64_t p = h_pos[(size_t)(scan - w0)], l = h_len[(size_t)(scan - w0)];
         if (l < 0) {
             // undecided within the cap (the loop has reached the next long match): a new window from here, whose first
-            // position is answered exactly -- and whose other positions are there if the match turns out not to be taken
+            // position is answered exactly -- and whose other positions are there if the match turns out not to be taken.
+            // When that happens at one position after the other (the loop is walking through text that matches far
+            // everywhere -- periodic data, runs -- without jumping), the windows are answered exactly throughout:
+            // one launch per 128 positions instead of one per position.
+            capped_streak = (scan == last_capped + 1) ? capped_streak + 1 : 1;
+            last_capped = scan;
             w0 = -1;
+            from_capped = true;
             int rc = refill(scan);
             if (rc != DQ_OK) return rc;
             p = h_pos[0];
