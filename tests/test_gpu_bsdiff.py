@@ -45,6 +45,8 @@ def pairs(oracle_mod):
     out.append((np.zeros(100_000, np.uint8), np.zeros(90_000, np.uint8)))
     z = np.zeros(2_600_000, np.uint8)                                     # megabytes of equal text: every probe of the exact
     out.append((z, z.copy()))                                             # search is a long comparison (binary probing, slow path)
+    z = np.zeros(60_000, np.uint8)                                        # a run with an edit inside: the loop walks on, every
+    out.append((z, np.concatenate([z[:20_000], np.arange(1, 7, dtype=np.uint8), z[20_000:]])))   # position far-matching (exact windows)
     per = np.tile(oracle_mod.gen_uniform(1000, 8), 1500)
     out.append((per, np.concatenate([per[:700_000], per[3:]])))           # periodic text with one deletion
     old = oracle_mod.gen_enwik_like(5_000_000, 4, 16384)                  # >= 4 MiB: the search starts from a 3-byte prefix table
