@@ -10,11 +10,13 @@
 //   --> three bzip2 streams (dq_bz2.h; the Burrows-Wheeler transform of every block is one more run of the HIP
 //   sorter) --> header + streams.
 //
-// The scan loop consumes Search only through (pos, len) (Diff.cs:106), so it is kept exactly as the reference
-// has it and reads from a window of answers the device filled speculatively for the positions ahead of `scan`:
+// The scan loop consumes Search only through (pos, len) (Diff.cs:106), so every decision of it is kept as the
+// reference has it (scan_loop() below) and it reads from a window of answers the device filled speculatively for
+// the positions ahead of `scan`:
 // in a region where old and new differ the loop advances byte by byte and uses every answer; after a match it
 // jumps by `len`, and a jump out of the window simply starts the next window at the new position.  A position
-// whose comparison ran into the cap (inside a long match) comes back undecided and is asked again alone, exactly.
+// whose comparison ran into the cap (inside a long match) comes back undecided and is asked again, exactly, as
+// the first position of a new window.
 // The patch is therefore the one the reference's loop produces, byte for byte in its raw streams
 // (tests/test_gpu_bsdiff.py compares them with the oracle's restatement); the bzip2 framing is a valid encoding of
 // them, not necessarily SharpZipLib's bytes (which the reference does not pin either).

@@ -1565,11 +1565,14 @@ int match_search_host(const uint8_t *old, int64_t n, const IdxT *sa, const uint8
 // ------------------------------------------------------------------ BSDIFF40: Diff.Create / Patch.Apply (dq_bsdiff.h)
 // Answers of the match search for a window of scan positions ahead of the scan loop.  Windows start small after a
 // jump and double while the loop consumes them to the end (a region where old and new differ: one Search per
-// byte, the regime the device is for: 4.2 M searches in 31 ms against 5.4 s on one host core).  The cap is low:
-// the positions of a window that lie inside the next long match would each cost `cap` byte comparisons for
-// nothing (the loop leaves the window with its next jump); the one position where the loop meets that match is
-// asked again exactly.  Between nearly identical files the loop is a chain of dependent round trips to the
-// device (~2 per edit) and runs at about the speed of the reference's CPU loop, not faster.
+// byte, the regime the device is for: 4.2 M searches in 31 ms against 5.4 s on one host core; the one-query-per-lane
+// kernel).  The cap is low: the positions of a window that lie inside the next long match would each cost `cap` byte
+// comparisons for nothing (the loop leaves the window with its next jump).  Between nearly identical files the
+// loop hops from match to match and every launch is a dependent round trip (~1 per edit): windows of up to 2048
+// positions go to the one-wave-per-position kernel (65-ary search; the position the loop stands on and the probable
+// start of the next long match answered exactly), whose answers are polled in pinned memory, whose second stage
+// answers the window behind the predicted jump, and which answers exactly throughout while positions keep coming
+// back capped (dq_match_search.h; DESIGN.md section 2c has the measurements).
 struct SearchWindows {
     const void *d_old, *d_sa, *d_new;
     int64_t n, m;
