@@ -43,12 +43,15 @@ def _rebucket(s, r, ck, SA, ISA, write_isa):
 
 
 def suffix_array(T: np.ndarray, trace: list | None = None, kbytes: int = 8,
-                 sparse: bool | None = None, ebytes: int = 4, sparse_rounds: int = 3) -> np.ndarray:
+                 sparse: bool | None = None, ebytes: int = 4, sparse_rounds: int = 3,
+                 keys: np.ndarray | None = None) -> np.ndarray:
+    """keys: round-0 keys from elsewhere (the coded keys of dq_coded_keys.h) -- any keys that are monotone in the
+    suffix order and whose equality implies `kbytes` equal leading characters."""
     T = np.ascontiguousarray(T, dtype=np.uint8)
     n = T.size
     if n == 0:
         return np.zeros(0, dtype=np.int64)
-    key = initial_keys(T, kbytes)
+    key = initial_keys(T, kbytes) if keys is None else np.ascontiguousarray(keys, dtype=np.uint64)
     order = np.argsort(key, kind="stable")[::1]
     # round 0 need not be stable with respect to the text order: shuffle inside equal keys
     ck = key[order]

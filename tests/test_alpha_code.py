@@ -149,3 +149,22 @@ def test_keys_match_the_specification_and_order_like_the_suffix_array(alpha, ora
         for p in tied[:: max(1, tied.size // 300)]:                              # equal keys: >= 8 equal characters (or the end)
             a, c = int(sa[p]), int(sa[p + 1])
             assert b[a:a + 8] == b[c:c + 8][: len(b[a:a + 8])] or b[c:c + 8] == b[a:a + 8][: len(b[c:c + 8])]
+
+
+def test_doubling_from_coded_keys_gives_the_suffix_array(alpha, oracle_mod):
+    """The whole pipeline in the numpy model (tests/pd_model.py) with the coded keys as round 0 and h = 8 from there
+    on, dense and sparse finishing: the suffix array of the oracle."""
+    import pd_model
+    rng = np.random.default_rng(3)
+    texts = [oracle_mod.gen_enwik_like(20_000, 7, 2048), rng.integers(0, 3, 5000, dtype=np.uint8),
+             np.concatenate([rng.integers(0, 200, 3000, dtype=np.uint8), np.zeros(40, np.uint8)]),
+             np.frombuffer(b"mississippi" * 300, dtype=np.uint8), np.zeros(3000, np.uint8),
+             np.tile(rng.integers(0, 9, 37, dtype=np.uint8), 120)]
+    for t in texts:
+        t = np.ascontiguousarray(t)
+        _, tab, _ = alpha.code(np.bincount(t, minlength=256))
+        keys = alpha.keys(t, tab)
+        want = oracle_mod.divsufsort(t).astype(np.int64)
+        for sparse in (False, True):
+            got = pd_model.suffix_array(t, kbytes=8, sparse=sparse, keys=keys)
+            assert np.array_equal(got, want), (t.size, sparse)
