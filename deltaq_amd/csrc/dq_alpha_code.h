@@ -21,6 +21,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <memory>
 #include <vector>
 
 namespace dq {
@@ -52,15 +53,16 @@ inline bool build_alpha_code(const int64_t hist[256], AlphaCode *out)
     constexpr int kDim = 257;
     // cost[i][j]: cheapest subtree over symbols [i, j) whose root has r levels left (depth R - r); a leaf above
     // depth kCodeMinLen is padded to it.  Two levels at a time (this one and the one below, the latter also
-    // transposed: both operands of the split loop are then contiguous), splits for every level.  The tables are
-    // kept between calls (one sort per call on this thread); only the cells a level can use are touched:
-    // intervals of at most 2^r symbols.
+    // transposed: both operands of the split loop are then contiguous), splits for every level.  Only the cells a
+    // level can use are touched: intervals of at most 2^r symbols.
     struct Tables {
         int64_t cur[kDim][kDim], prev[kDim][kDim], prev_t[kDim][kDim];
         uint8_t split[R + 1][kDim][kDim];                         // split point - i  (1 .. 255)
     };
-    static thread_local std::vector<Tables> store(1);
-    Tables &t = store[0];
+    // (2.2 MB, allocated per call and left uninitialised: only the cells a level writes are ever read, so only those
+    // pages are touched; nothing stays behind on the calling thread)
+    std::unique_ptr<Tables> store(new Tables);
+    Tables &t = *store;
     for (int r = 0; r <= R; ++r) {
         const int depth = R - r;
         const int pad = depth < kCodeMinLen ? kCodeMinLen - depth : 0;

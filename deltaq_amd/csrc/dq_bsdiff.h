@@ -203,24 +203,28 @@ int scan_loop(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, Searc
 }
 
 // Patch.cs:95-168 on the three decoded streams.  Returns 0, or -1 for what the reference reports as "Corrupt patch".
+// Every bound is checked in a form that cannot overflow: the three numbers of a triple are attacker-controlled
+// 63-bit values (CVE-2014-9862 is this bug class in the original bspatch).
 inline int apply_streams(const uint8_t *old, int64_t n, const std::vector<uint8_t> &ctrl, const std::vector<uint8_t> &diff,
                          const std::vector<uint8_t> &extra, int64_t newsize, uint8_t *out)
 {
     int64_t outpos = 0, oldpos = 0;
     size_t cpos = 0, dpos = 0, epos = 0;
     while (outpos < newsize) {
-        if (cpos + 24 > ctrl.size()) return -1;
+        if (ctrl.size() - cpos < 24) return -1;
         const int64_t add = read_packed_long(&ctrl[cpos]), copy = read_packed_long(&ctrl[cpos + 8]),
                       seek = read_packed_long(&ctrl[cpos + 16]);
         cpos += 24;
-        if (add < 0 || copy < 0 || outpos + add > newsize) return -1;                // :131 sanity-check
-        if (dpos + (size_t)add > diff.size() || oldpos < 0 || oldpos + add > n) return -1;       // short reads
+        if (add < 0 || copy < 0 || add > newsize - outpos) return -1;                // :131 sanity-check
+        // short reads (:139-140).  With add == 0 nothing is read, wherever the old-file position stands.
+        if ((uint64_t)add > diff.size() - dpos || (add > 0 && (oldpos > n || add > n - oldpos))) return -1;
         for (int64_t i = 0; i < add; i++) out[outpos + i] = (uint8_t)(diff[dpos + (size_t)i] + old[oldpos + i]);
         outpos += add; dpos += (size_t)add; oldpos += add;
-        if (outpos + copy > newsize || epos + (size_t)copy > extra.size()) return -1;           // :153
+        if (copy > newsize - outpos || (uint64_t)copy > extra.size() - epos) return -1;          // :153
         if (copy > 0) memcpy(out + outpos, &extra[epos], (size_t)copy);
         outpos += copy; epos += (size_t)copy;
-        oldpos += seek;                                                              // :165
+        // :165 -- Stream.Seek to a negative position throws in the reference; a wrapped sum is never a valid position
+        if (__builtin_add_overflow(oldpos, seek, &oldpos) || oldpos < 0) return -1;
     }
     return 0;
 }
@@ -238,7 +242,8 @@ inline int parse_header(const uint8_t *patch, int64_t plen, Header *h)
     h->diff_len = read_packed_long(patch + 16);
     h->new_size = read_packed_long(patch + 24);
     if (h->ctrl_len < 0 || h->diff_len < 0 || h->new_size < 0) return -1;
-    if (kHeaderSize + h->ctrl_len + h->diff_len > plen) return -1;
+    // (no sums of the two lengths: each is a 63-bit value taken from the file)
+    if (h->ctrl_len > plen - kHeaderSize || h->diff_len > plen - kHeaderSize - h->ctrl_len) return -1;
     return 0;
 }
 

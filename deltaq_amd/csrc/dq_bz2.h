@@ -32,20 +32,20 @@ constexpr int kMaxGroups = 6;
 constexpr int kMaxSelectors = 2 + 900000 / kGroupSize;
 constexpr uint64_t kBlockMagic = 0x314159265359ull, kEndMagic = 0x177245385090ull;
 
-inline const uint32_t *crc_table()
-{
-    static uint32_t tab[256];
-    static bool ready = false;
-    if (!ready) {
+struct CrcTable {
+    uint32_t v[256];
+    constexpr CrcTable() : v{}
+    {
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i << 24;
             for (int k = 0; k < 8; ++k) c = (c & 0x80000000u) ? (c << 1) ^ 0x04c11db7u : c << 1;
-            tab[i] = c;
+            v[i] = c;
         }
-        ready = true;
     }
-    return tab;
-}
+};
+// built at compile time: nothing to race on when several threads frame their first patch at once
+inline constexpr CrcTable kCrcTable{};
+inline const uint32_t *crc_table() { return kCrcTable.v; }
 
 inline uint32_t crc_update(uint32_t crc, const uint8_t *p, size_t n)
 {
@@ -76,10 +76,12 @@ struct BitReader {
     uint32_t bit() { return bits(1); }
 };
 
-enum { kOk = 0, kCorrupt = -1, kTruncated = -2 };
+enum { kOk = 0, kCorrupt = -1, kTruncated = -2, kTooLong = -3 };
 
-// Decodes one whole stream (possibly several concatenated streams, as bzip2 allows).
-inline int bz2_decompress(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
+// Decodes one whole stream (possibly several concatenated streams, as bzip2 allows).  max_out bounds the decoded
+// size: a block expands up to ~50x per run-length level and streams concatenate, so a patch of a few KB could
+// otherwise ask for gigabytes; the caller knows how much it can use (Patch.Apply stops reading at newSize).
+inline int bz2_decompress(const uint8_t *src, size_t n, std::vector<uint8_t> &out, size_t max_out = (size_t)-1)
 {
     BitReader br(src, n);
     std::vector<uint32_t> tt;
@@ -250,6 +252,7 @@ inline int bz2_decompress(const uint8_t *src, size_t n, std::vector<uint8_t> &ou
                 tpos = e >> 8;
                 if (same == 4) {                               // ch is a repeat count
                     for (int k = 0; k < ch; ++k) {
+                        if (out.size() >= max_out) return kTooLong;
                         out.push_back((uint8_t)prev);
                         crc = (crc << 8) ^ ctab[(crc >> 24) ^ (uint8_t)prev];
                     }
@@ -257,6 +260,7 @@ inline int bz2_decompress(const uint8_t *src, size_t n, std::vector<uint8_t> &ou
                     prev = -1;
                     continue;
                 }
+                if (out.size() >= max_out) return kTooLong;
                 out.push_back(ch);
                 crc = (crc << 8) ^ ctab[(crc >> 24) ^ ch];
                 same = (ch == prev) ? same + 1 : 1;

@@ -36,6 +36,14 @@ __global__ __launch_bounds__(kBlock) void gather_key2_kernel(uint64_t *__restric
     }
 }
 
+// A list that came keyed for a round (rank << kbits | key2) back to plain group ranks: the round was found to
+// need the shifted-rank form of its keys (64-bit composite near n = 2^32, or DQ_FORCE_RSHIFT in the tests).
+__global__ __launch_bounds__(kBlock) void keys_to_ranks_kernel(uint64_t *__restrict__ comp, int64_t m, int kbits)
+{
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < m; j += (int64_t)gridDim.x * kBlock)
+        comp[j] >>= kbits;
+}
+
 // ---------------------------------------------------------------------------------
 // Sparse finishing (few suffixes still tied, e.g. random-like inputs): instead of building
 // the full inverse suffix array, extend the tied suffixes' keys with the next `ebytes` bytes

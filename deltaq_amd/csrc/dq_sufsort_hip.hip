@@ -45,6 +45,7 @@
 #include "dq_pair_chains.h"
 #include "dq_bz2.h"
 #include "dq_bsdiff.h"
+#include "dq_bspatch.h"
 
 namespace {
 
@@ -1327,9 +1328,15 @@ struct SuffixSorter {
             // needs 33 + 32: the key then carries rank >> 1 (unique per group: tied groups have >= 2 members)
             // and the rebucket pass reads the true rank from the ISA.  check_args() keeps n <= 2^32.
             // (DQ_FORCE_RSHIFT: the tests take this path on small inputs)
-            const int rshift = (kbits + rbits > 64 || (getenv("DQ_FORCE_RSHIFT") && !keys_ready)) ? 1 : 0;
+            const int rshift = (kbits + rbits > 64 || getenv("DQ_FORCE_RSHIFT")) ? 1 : 0;
             if (kbits + rbits - rshift > 64) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
-            if (rshift && keys_ready) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
+            if (rshift && keys_ready) {
+                // the list came keyed from build_isa_binned() (rank << kbits | key2, unshifted): take the group
+                // ranks back out of the keys and let the round gather its own, shifted ones
+                LAUNCH(L, DQ_K_GATHER_KEY2, m, m * 16,
+                       hipLaunchKernelGGL(keys_to_ranks_kernel, dim3(grid_for(m)), dim3(kBlock), 0, st, Kr[rcur], m, kbits));
+                keys_ready = false;
+            }
             rc = (uses_small_round(m) && !keys_ready && !rshift) ? doubling_round_small(kbits)
                                                                  : doubling_round_radix(kbits, rshift);
             if (rc != DQ_OK) return rc;
@@ -1531,6 +1538,11 @@ int match_search_host(const uint8_t *old, int64_t n, const IdxT *sa, const uint8
 {
     if (n < 0 || m < 0 || count < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
     if ((n > 0 && (!old || !sa)) || (m > 0 && !nw) || (count > 0 && (!pos || !len))) return fail(DQ_ERR_BAD_ARGS, "null buffer");
+    // host-resident scan positions are checked here (a position outside [0, m] would be a device read out of bounds);
+    // the device forms take them as they are (include/dq_sufsort.h says so)
+    if (scans)
+        for (int64_t q = 0; q < count; ++q)
+            if (scans[q] < 0 || scans[q] > m) return fail(DQ_ERR_BAD_ARGS, "scan position outside the new data");
     int dev = 0;
     int rc = resolve_device(device, &dev);
     if (rc != DQ_OK) return rc;
@@ -1851,21 +1863,13 @@ int bsdiff_create_host(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t
     return DQ_OK;
 }
 
-// Patch.Apply (Patch.cs:52-168): host only
+// Patch.Apply (Patch.cs:52-168): host only (dq_bspatch.h)
 int bspatch_apply_host(const uint8_t *old, int64_t n, const uint8_t *patch, int64_t plen, uint8_t *out, int64_t cap, int64_t *out_len)
 {
     if (n < 0 || plen < 0 || cap < 0 || (n > 0 && !old) || !patch) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
-    bsdiff::Header h;
-    if (bsdiff::parse_header(patch, plen, &h) != 0) return fail(DQ_ERR_BAD_ARGS, "Corrupt patch");
-    if (out_len) *out_len = h.new_size;
-    if (!out) return DQ_OK;                                                        // size query
-    if (cap < h.new_size) return fail(DQ_ERR_BAD_ARGS, "output buffer too small");
-    std::vector<uint8_t> ctrl, diff, extra;
-    const uint8_t *pc = patch + bsdiff::kHeaderSize, *pd = pc + h.ctrl_len, *pe = pd + h.diff_len;
-    if (bz2::bz2_decompress(pc, (size_t)h.ctrl_len, ctrl) != 0 || bz2::bz2_decompress(pd, (size_t)h.diff_len, diff) != 0 ||
-        bz2::bz2_decompress(pe, (size_t)(plen - bsdiff::kHeaderSize - h.ctrl_len - h.diff_len), extra) != 0)
-        return fail(DQ_ERR_BAD_ARGS, "Corrupt patch");
-    if (bsdiff::apply_streams(old, n, ctrl, diff, extra, h.new_size, out) != 0) return fail(DQ_ERR_BAD_ARGS, "Corrupt patch");
+    const int rc = bsdiff::apply_patch(old, n, patch, plen, out, cap, out_len);
+    if (rc == bsdiff::kPatchSmallBuffer) return fail(DQ_ERR_BAD_ARGS, "output buffer too small");
+    if (rc != bsdiff::kPatchOk) return fail(DQ_ERR_BAD_ARGS, "Corrupt patch");
     return DQ_OK;
 }
 
@@ -2143,6 +2147,8 @@ int32_t dq_bsdiff_scan_i32(const uint8_t *old_data, int64_t n, const uint8_t *ne
         return DQ_OK;
     } catch (const std::bad_alloc &) {
         return fail(DQ_ERR_OOM, "bsdiff: host allocation failed");
+    } catch (const std::exception &e) {            // nothing may propagate through the C ABI
+        return fail(DQ_ERR_HIP, e.what());
     }
 }
 
@@ -2159,6 +2165,8 @@ int32_t dq_bsdiff_create(const uint8_t *old_data, int64_t n, const uint8_t *new_
         return DQ_OK;
     } catch (const std::bad_alloc &) {
         return fail(DQ_ERR_OOM, "bsdiff: host allocation failed");
+    } catch (const std::exception &e) {            // nothing may propagate through the C ABI
+        return fail(DQ_ERR_HIP, e.what());
     }
 }
 
@@ -2178,6 +2186,8 @@ int32_t dq_bspatch_apply(const uint8_t *old_data, int64_t n, const uint8_t *patc
         return bspatch_apply_host(old_data, n, patch, patch_len, out, cap, out_len);
     } catch (const std::bad_alloc &) {
         return fail(DQ_ERR_OOM, "bspatch: host allocation failed");
+    } catch (const std::exception &e) {
+        return fail(DQ_ERR_HIP, e.what());
     }
 }
 

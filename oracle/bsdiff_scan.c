@@ -159,14 +159,17 @@ int32_t dq_oracle_bspatch_apply(const uint8_t *old, int64_t n, const int64_t *ct
     for (int64_t t = 0; outpos < newsize; ++t) {
         if (t >= nctrl) return -3;
         const int64_t add = ctrl[3 * t], copy = ctrl[3 * t + 1], seek = ctrl[3 * t + 2];
-        if (add < 0 || copy < 0 || outpos + add > newsize) return -3;
-        if (dpos + add > ndiff || oldpos < 0 || oldpos + add > n) return -3;      /* short reads: "Corrupt patch" */
+        /* (comparisons in a form that cannot overflow: the triples of a crafted patch are 63-bit values) */
+        if (add < 0 || copy < 0 || add > newsize - outpos) return -3;
+        /* short reads (:139-140): "Corrupt patch"; with add == 0 nothing is read wherever the position stands */
+        if (add > ndiff - dpos || (add > 0 && (oldpos > n || add > n - oldpos))) return -3;
         for (int64_t i = 0; i < add; i++) out[outpos + i] = (uint8_t)(diff[dpos + i] + old[oldpos + i]);
         outpos += add; dpos += add; oldpos += add;
-        if (outpos + copy > newsize || epos + copy > nextra) return -3;
+        if (copy > newsize - outpos || copy > nextra - epos) return -3;
         memcpy(out + outpos, extra + epos, (size_t)copy);
         outpos += copy; epos += copy;
-        oldpos += seek;
+        /* :165 Stream.Seek throws on a negative position */
+        if (__builtin_add_overflow(oldpos, seek, &oldpos) || oldpos < 0) return -3;
     }
     return 0;
 }

@@ -7,6 +7,7 @@
 #include <numeric>
 
 #include "../../deltaq_amd/csrc/dq_bz2.h"
+#include "../../deltaq_amd/csrc/dq_bspatch.h"
 
 static int naive_sorter(const uint8_t *t, int64_t n, int32_t *sa)
 {
@@ -30,6 +31,23 @@ int64_t t_bz2_compress(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap,
     if ((int64_t)v.size() > cap) return -100;
     memcpy(out, v.data(), v.size());
     return (int64_t)v.size();
+}
+
+// limit < 0: no bound on the decoded size
+int64_t t_bz2_decompress_limit(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap, int64_t limit, int32_t *code)
+{
+    std::vector<uint8_t> v;
+    *code = dq::bz2::bz2_decompress(src, (size_t)n, v, limit < 0 ? (size_t)-1 : (size_t)limit);
+    if ((int64_t)v.size() > cap) return -100;
+    if (!v.empty()) memcpy(out, v.data(), v.size());
+    return (int64_t)v.size();
+}
+
+// Patch.Apply as the product runs it (dq_bspatch.h): 0, -1 "Corrupt patch", -2 output buffer too small
+int32_t t_bspatch_apply(const uint8_t *old_data, int64_t n, const uint8_t *patch, int64_t plen, uint8_t *out, int64_t cap,
+                        int64_t *out_len)
+{
+    return dq::bsdiff::apply_patch(old_data, n, patch, plen, out, cap, out_len);
 }
 
 int64_t t_bz2_decompress(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap)
