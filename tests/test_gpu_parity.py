@@ -441,6 +441,32 @@ def test_batch_entry_point(backend_lib, oracle_mod):
         assert np.array_equal(s, oracle_mod.divsufsort(t))
 
 
+def test_batch_entry_point_two_device_slots(backend_lib, oracle_mod):
+    """ndev > 1: the LPT split and the thread-per-device fan-out of dq_sufsort_hip_batch_i32.  A 1-GPU box runs it
+    with devs = {0, 0}: two shares, two host threads, each with its own three-stage pipeline, taking turns on the
+    one device (batch_mu); with more GPUs the same call also runs over all of them."""
+    import ctypes
+    sizes = [3_000_000, 40_000, 1_200_000, 9, 700_000, 2_500_000, 0, 300_000, 5000, 1_900_000, 650_000, 2, 810_000]
+    texts = [oracle_mod.gen_uniform(s, 0x5EED0900 + j) if j % 3 else oracle_mod.gen_enwik_like(s, 77 + j, 8192)
+             for j, s in enumerate(sizes)]
+    cnt = len(texts)
+    ln = (ctypes.c_int64 * cnt)(*[t.size for t in texts])
+    tp = (ctypes.c_void_p * cnt)(*[t.ctypes.data if t.size else None for t in texts])
+    expect = [oracle_mod.divsufsort(t) for t in texts]
+    ndevs = [(2, [0, 0]), (3, [0, 0, 0])]
+    have = backend_lib.dq_device_count()
+    if have > 1:
+        ndevs.append((have, list(range(have))))
+    for ndev, devs in ndevs:
+        sas = [np.full(t.size, -7, np.int32) for t in texts]
+        sp = (ctypes.c_void_p * cnt)(*[s.ctypes.data if s.size else None for s in sas])
+        dv = (ctypes.c_int32 * ndev)(*devs)
+        rc = backend_lib.dq_sufsort_hip_batch_i32(cnt, tp, ln, sp, ndev, dv)
+        assert rc == 0, backend_lib.dq_last_error()
+        for j, (s, e) in enumerate(zip(sas, expect)):
+            assert np.array_equal(s, e), (ndev, j)
+
+
 FORCED_PATHS = [
     {},                                                       # defaults (adaptive)
     {"DQ_PACKED": "1", "DQ_KEY_BYTES": "3", "DQ_SPARSE": "1"},   # packed words, finisher, sparse rounds
@@ -453,6 +479,7 @@ FORCED_PATHS = [
     {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2"},                     # tie bits with MANY ties (dense doubling after them)
     {"DQ_FORCE_RSHIFT": "1"},                                    # doubling rounds with rank >> 1 in the composite key
     {"DQ_FORCE_RSHIFT": "1", "DQ_SPARSE": "1"},
+    {"DQ_FORCE_RSHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "0", "DQ_NO_FIRST_SMALL": "1", "DQ_NO_SMALL": "1"},   # ... on a list that came keyed from the binned first ISA
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8"},    # coded round-0 keys (dq_alpha_code.h), dense doubling
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "1"},
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_NO_BINNED_ISA": "1", "DQ_NO_SMALL": "1"},
