@@ -38,6 +38,7 @@
 #include "dq_seg_fused.h"
 #include "dq_small.h"
 #include "dq_small_groups.h"
+#include "dq_mid_groups.h"
 #include "dq_ties.h"
 #include "dq_isa_pairs.h"
 #include "dq_bucket_sort.h"
@@ -84,7 +85,7 @@ const char *const kKernelNames[DQ_K_COUNT] = {
     "tie_seam_kernel", "tie_collect_kernel", "small_group_finish_kernel", "small_group_round_kernel",
     "isa_update_kernel", "isa_from_pairs_kernel", "key2_from_pairs_kernel", "gather_key2_kernel",
     "gather_text_key_kernel", "isa_from_sa_kernel", "small_sufsort_kernel", "bucket_sort_kernel",
-    "match_search_kernel", "pair_chain_kernels"};
+    "match_search_kernel", "pair_chain_kernels", "mid_group_round_kernel"};
 
 struct ProfRec { int cat; hipEvent_t a, b; int64_t elems, bytes; };
 
@@ -664,6 +665,17 @@ struct SuffixSorter {
     int64_t fin_cap = 0, fin_left = 0;
     // round 0 was bucketed: however many suffixes are tied, they are tied shallowly (random-like text)
     bool shallow_ties = false;
+    // the next long-list round takes mid_group_round_kernel (see doubling_round_small)
+    bool mid_wanted = true;
+    // largest group the LDS class finishes: 0 = off; DQ_MID_GROUPS = 0 | 256 | 512 | 1024 forces it (and keeps it on)
+    static int mid_group_cap()
+    {
+        if (const char *v = getenv("DQ_MID_GROUPS")) {
+            const int g = atoi(v);
+            return g >= 1024 ? 1024 : g >= 512 ? 512 : g >= 256 ? 256 : 0;
+        }
+        return 512;         // (256 MiB of enwik-style text: 31.95 / 31.86 / 32.30 ms with 256 / 512 / 1024, 34.65 without)
+    }
 
     SuffixSorter(DeviceCtx &c_, hipStream_t st_, Workspace<IdxT> &w_, int64_t n_, IdxT *sa_)
         : c(c_), st(st_), w(w_), n(n_), d_sa(sa_), L{c_, st_, g_prof_on.load()} {}
@@ -1076,7 +1088,27 @@ struct SuffixSorter {
         SmallGroupCounters *ctr = reinterpret_cast<SmallGroupCounters *>(w.totals + 4);
         HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(SmallGroupCounters), st));
         const bool cap32 = m < kSgShortList;           // (cap 32 on long lists measured: radix -2.4 ms, this kernel +2.8 ms)
-        if (cap32) {
+        // Long lists whose groups still reach beyond 8 members (the first rounds of a text-like input): the groups of
+        // up to kG members are finished inside LDS by mid_group_round_kernel (dq_mid_groups.h), only longer ones
+        // take the radix passes.  Chosen while the previous round still sent a good part of its list to the radix
+        // path (unknown before the first round: tried there).
+        const int mid_g = mid_group_cap();
+        // (forced by DQ_MID_GROUPS: on lists of any length, so that the tests reach it with small inputs)
+        const bool use_mid = mid_g > 0 && mid_wanted && (!cap32 || getenv("DQ_MID_GROUPS"));
+        if (use_mid) {
+            const int64_t tile = mid_g == 256 ? mg_tile<256>() : mid_g == 512 ? mg_tile<512>() : mg_tile<1024>();
+            const dim3 grid((unsigned)((m + tile - 1) / tile));
+            auto go = [&](auto kern) -> int {
+                LAUNCH(L, DQ_K_MID_ROUND, m, m * (8 + wb + wb + wb + 8 + wb),
+                       hipLaunchKernelGGL(kern, grid, dim3(kMgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
+                                          (const IdxT *)w.ISA, m, n, h, kbits, d_sa, B, Bs, B + half, Bs + half, B + top,
+                                          Bs + top, ctr));
+                return DQ_OK;
+            };
+            const int rc = mid_g == 256 ? go(mid_group_round_kernel<IdxT, 256>)
+                         : mid_g == 512 ? go(mid_group_round_kernel<IdxT, 512>) : go(mid_group_round_kernel<IdxT, 1024>);
+            if (rc != DQ_OK) return rc;
+        } else if (cap32) {
             constexpr int kTile = sg_tile<kSgMaxGShort>();
             LAUNCH(L, DQ_K_SMALL_ROUND, m, m * (8 + wb + wb + wb + 8 + wb),
                    hipLaunchKernelGGL((small_group_round_kernel<IdxT, kSgMaxGShort>), dim3((unsigned)((m + kTile - 1) / kTile)),
@@ -1095,8 +1127,12 @@ struct SuffixSorter {
         HIP_TRY(hipStreamSynchronize(st));
         const int64_t m1 = c.pinned[0] & 0xffffffffll, mU = (int64_t)((uint64_t)c.pinned[0] >> 32), mL = c.pinned[1];
         if (getenv("DQ_TRACE"))
-            fprintf(stderr, "[dq] small round h=%lld m=%lld -> tied %lld, to radix %lld, moved %lld\n", (long long)h,
+            fprintf(stderr, "[dq] %s round h=%lld m=%lld -> tied %lld, to radix %lld, moved %lld\n",
+                    use_mid ? "mid-group" : "small", (long long)h,
                     (long long)m, (long long)m1, (long long)mL, (long long)mU);
+        // the LDS class pays while a round has many groups beyond 8; once one sends less than 1/16 of its list to the
+        // radix path the small-group kernel (lighter per entry) takes over again
+        if (use_mid && !getenv("DQ_MID_GROUPS")) mid_wanted = mL * 16 >= m;
         if (mU > 0) {
             LAUNCH(L, DQ_K_ISA_UPDATE, mU, mU * (8 + wb + wb),
                    hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(mU)), dim3(kBlock), 0, st,
@@ -1117,8 +1153,9 @@ struct SuffixSorter {
         rcur ^= 1;
         m = m1 + mLs;
         // groups only ever split: once nothing went to the radix list, every group fits this round's cap
-        if (mL == 0) small_cap = cap32 ? kSgMaxGShort : kSgMaxG;
-        only_small_groups = mL == 0;
+        // (a mid-group round that sent nothing there says only that every group has <= kG members)
+        if (mL == 0 && !use_mid) small_cap = cap32 ? kSgMaxGShort : kSgMaxG;
+        only_small_groups = mL == 0 && !use_mid;
         return DQ_OK;
     }
 
