@@ -35,16 +35,39 @@ public sealed class HipSuffixSort : ISuffixSort
     private static extern IntPtr dq_last_error();
 
     private readonly int _device;
+    private readonly ISuffixSort? _fallback;
 
     /// <param name="device">HIP device ordinal; -1 = DQ_HIP_DEVICE or device 0.</param>
-    public HipSuffixSort(int device = -1)
+    /// <param name="fallback">
+    /// Provider that takes over when the native call fails (no device, out of device memory, text beyond the
+    /// native limits).  Default: none -- a failure throws <see cref="InvalidOperationException"/> -- unless the
+    /// environment variable DQ_HIP_FALLBACK is set to "divsufsort", which installs the managed
+    /// <c>LibDivSufSort</c> (SURVEY section 8(b), "Preconditions").  The native library itself never falls back.
+    /// </param>
+    public HipSuffixSort(int device = -1, ISuffixSort? fallback = null)
     {
-        if (dq_abi_version() != 1)
-        {
-            throw new InvalidOperationException("libdq_sufsort_hip ABI version mismatch");
-        }
         _device = device;
+        _fallback = fallback;
+        if (_fallback is null
+            && string.Equals(Environment.GetEnvironmentVariable("DQ_HIP_FALLBACK"), "divsufsort", StringComparison.OrdinalIgnoreCase))
+        {
+            _fallback = new DeltaQ.SuffixSorting.LibDivSufSort.LibDivSufSort();
+        }
+
+        try
+        {
+            if (dq_abi_version() != 1)
+            {
+                throw new InvalidOperationException("libdq_sufsort_hip ABI version mismatch");
+            }
+        }
+        catch (DllNotFoundException) when (_fallback is not null)
+        {
+            _nativeMissing = true;            // every call goes to the fallback
+        }
     }
+
+    private readonly bool _nativeMissing;
 
     public static int DeviceCount => dq_device_count();
 
@@ -80,16 +103,34 @@ public sealed class HipSuffixSort : ISuffixSort
         // n = 0 hands the native side null pointers, which it accepts (no-op), like
         // DivSufSort.cs:24.  Exactly text.Length ints are written: Diff.Create's I[n]
         // (Diff.cs:78,89-90) is never touched.
+        if (_nativeMissing)
+        {
+            _fallback!.Sort(text, sa);
+            return;
+        }
+
+        int rc;
         fixed (byte* pText = text)
         fixed (int* pSa = sa)
         {
-            int rc = dq_sufsort_hip_i32(pText, text.Length, pSa, _device);
-            if (rc != 0)
-            {
-                string msg = Marshal.PtrToStringAnsi(dq_last_error()) ?? string.Empty;
-                throw new InvalidOperationException($"dq_sufsort_hip_i32 failed ({rc}): {msg}");
-            }
+            rc = dq_sufsort_hip_i32(pText, text.Length, pSa, _device);
         }
+
+        if (rc == 0)
+        {
+            return;
+        }
+
+        // -1 bad arguments is a caller bug and never retried; -2 OOM, -3 HIP error, -4 too large, -5 no device are
+        // what a fallback is for (include/dq_sufsort.h).  The native side has written nothing it did not finish.
+        if (_fallback is not null && rc != -1)
+        {
+            _fallback.Sort(text, sa);
+            return;
+        }
+
+        string msg = Marshal.PtrToStringAnsi(dq_last_error()) ?? string.Empty;
+        throw new InvalidOperationException($"dq_sufsort_hip_i32 failed ({rc}): {msg}");
     }
 
     private static void ThrowHelper() => throw new ArgumentException("Text and suffix buffers should have the same length");

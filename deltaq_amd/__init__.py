@@ -10,7 +10,7 @@ provider does, and raises if it has not been built.  There is no CPU fallback.
 from ._abi import BackendMissingError, SuffixSortError  # noqa: F401
 from .suffix_sort import HipSuffixSort, device_count, LENGTH_MISMATCH_MESSAGE  # noqa: F401
 from .match_search import HipMatchSearch  # noqa: F401
-from .bsdiff import Diff, Patch  # noqa: F401
+from .bsdiff import Diff, DiffIndex, Patch  # noqa: F401
 
-__all__ = ["HipSuffixSort", "HipMatchSearch", "Diff", "Patch", "device_count", "BackendMissingError", "SuffixSortError",
+__all__ = ["HipSuffixSort", "HipMatchSearch", "Diff", "DiffIndex", "Patch", "device_count", "BackendMissingError", "SuffixSortError",
            "LENGTH_MISMATCH_MESSAGE"]

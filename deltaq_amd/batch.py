@@ -4,7 +4,7 @@ The path shards by INPUT (the many-files bsdiff case: one old file per diff): th
 data-path collective, because one suffix array never spans devices (every doubling round
 would need an all-to-all of ranks over per-link-bound xGMI).
 
-Two layers:
+Three layers:
 
 * ``plan_shards``            longest-processing-time-first assignment of inputs to ranks
                              (the same rule as dq_sufsort_hip_batch_i32 uses for devices).
@@ -14,6 +14,11 @@ Two layers:
                              tests).  The sorter is injected, so the CPU tests exercise the
                              sharding / gather plumbing without a GPU; on a GPU box it
                              defaults to ``HipSuffixSort``.
+* ``diff_many_distributed``  the one exchange step the path has: ONE old file, many new files.  Rank 0 sorts the
+                             old file once, text and suffix array are BROADCAST (``ncclBroadcast`` over xGMI under
+                             ``nccl``), every rank builds a ``DiffIndex`` on the received buffers and diffs its LPT
+                             share of the new files, the patches are gathered to rank 0.  ``Diff.cs:89-90`` is paid
+                             once per old file instead of once per (old, new) pair.
 """
 from __future__ import annotations
 
@@ -129,3 +134,101 @@ def sort_batch_distributed(texts: Optional[Sequence], *, sorter_factory: Optiona
         if lengths[j] > 0:
             dist.send(as_tensor(results[j]), dst=0, group=group)
     return None
+
+
+def diff_many_distributed(old, news: Optional[Sequence], *, sorter_factory: Optional[Callable] = None,
+                          index_factory: Optional[Callable] = None, group=None) -> Optional[List[bytes]]:
+    """BSDIFF40 patches of many new files against ONE old file across the ranks of a process group.
+
+    ``old`` and ``news`` must be given on rank 0 (other ranks pass ``None``).  Returns, on rank 0, the patches in
+    input order (``patch[j]`` turns ``old`` into ``news[j]``; other ranks return ``None``).
+
+    ``sorter_factory()`` -> object with ``Sort(text)`` (default ``HipSuffixSort``);
+    ``index_factory(old_bytes, text_tensor, sa_tensor)`` -> object with ``Create(new) -> bytes`` (default
+    ``DiffIndex`` on the tensors as they arrived: device tensors under ``nccl``, uploaded once under ``gloo``).
+    The CPU tests inject both.
+    """
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    on_gpu = backend == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+
+    def as_u8(x) -> np.ndarray:
+        return x if isinstance(x, np.ndarray) else np.frombuffer(memoryview(x).cast("B"), dtype=np.uint8)
+
+    # ---- plan: new files to ranks by length (the scan loop's cost grows with the new file) ----
+    if rank == 0:
+        old_np = np.ascontiguousarray(as_u8(old), dtype=np.uint8)
+        new_np = [np.ascontiguousarray(as_u8(x), dtype=np.uint8) for x in news]
+        lengths = [int(a.size) for a in new_np]
+        meta = [int(old_np.size), lengths, plan_shards(lengths, world)]
+    else:
+        old_np, new_np, meta = None, None, None
+    box = [meta]
+    dist.broadcast_object_list(box, src=0, group=group)
+    n, lengths, plan = box[0]
+
+    # ---- rank 0 sorts the old file; text + suffix array go to every rank in two broadcasts ----
+    if rank == 0:
+        if sorter_factory is None:
+            from .suffix_sort import HipSuffixSort
+            sorter = HipSuffixSort(dev.index if on_gpu else -1)
+        else:
+            sorter = sorter_factory()
+        text_t = torch.from_numpy(old_np).to(dev)
+        sa = sorter.Sort(text_t if (on_gpu and sorter_factory is None) else old_np)
+        sa_t = sa.to(dev) if isinstance(sa, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(sa, dtype=np.int32)).to(dev)
+    else:
+        text_t = torch.empty(n, dtype=torch.uint8, device=dev)
+        sa_t = torch.empty(n, dtype=torch.int32, device=dev)
+    if n > 0:
+        dist.broadcast(text_t, src=0, group=group)
+        dist.broadcast(sa_t, src=0, group=group)
+    if rank != 0:
+        old_np = text_t.cpu().numpy()                  # the scan loop walks the old file on the host
+
+    # ---- new files to their owners (point-to-point; rank 0 keeps its own share) ----
+    mine = {}
+    if rank == 0:
+        reqs = []
+        for r in range(world):
+            for j in plan[r]:
+                if r == 0:
+                    mine[j] = new_np[j]
+                elif lengths[j] > 0:
+                    reqs.append(dist.isend(torch.from_numpy(new_np[j]).to(dev), dst=r, group=group))
+        for q in reqs:
+            q.wait()
+    else:
+        for j in plan[rank]:
+            buf = torch.empty(lengths[j], dtype=torch.uint8, device=dev)
+            if lengths[j] > 0:
+                dist.recv(buf, src=0, group=group)
+            mine[j] = buf.cpu().numpy()
+
+    # ---- every rank: one index on the broadcast buffers, then its share of the diffs ----
+    if index_factory is None:
+        from .bsdiff import DiffIndex
+        if not text_t.is_cuda:                         # gloo on a GPU box: upload once
+            text_t, sa_t = text_t.cuda(), sa_t.cuda()
+        index = DiffIndex(old_np, device_text=text_t, device_sa=sa_t)
+    else:
+        index = index_factory(old_np, text_t, sa_t)
+    patches = {j: index.Create(mine[j]) for j in plan[rank]}
+    if hasattr(index, "close"):
+        index.close()
+
+    # ---- patches (small: three bzip2 streams) to rank 0 ----
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(patches, gathered, dst=0, group=group)
+    if rank != 0:
+        return None
+    out: List[Optional[bytes]] = [None] * len(lengths)
+    for part in gathered:
+        for j, p in part.items():
+            out[j] = p
+    return out

@@ -70,6 +70,63 @@ class Diff:
                 {"searches": stats[0], "windows": stats[1], "exact": stats[2]})
 
 
+class DiffIndex:
+    """One old file on one device, ready to be diffed against many new files: what ``Diff.Create`` computes from
+    ``oldData`` alone (the suffix array, Diff.cs:89-90) is computed once.  ``Create`` returns the patch
+    ``Diff.CreateBytes(oldData, newData)`` returns.
+
+    ``device_text`` / ``device_sa``: CUDA tensors (uint8 / int32) that already hold the text and its suffix array
+    on this device -- a rank that received them by broadcast -- instead of sorting here."""
+
+    def __init__(self, oldData, device: int = -1, device_text=None, device_sa=None):
+        L = _abi.load()
+        self._lib = L
+        self._old = np.ascontiguousarray(_as_text(oldData))          # the scan loop reads it: kept alive with the index
+        self._keep = (device_text, device_sa)
+        h = ctypes.c_void_p()
+        d_old = d_sa = None
+        if device_text is not None:
+            if device_sa is None or int(device_text.numel()) != self._old.size or int(device_sa.numel()) != self._old.size:
+                raise ValueError("device_text and device_sa must both be given, with one entry per byte of oldData")
+            d_old, d_sa = device_text.data_ptr(), device_sa.data_ptr()
+            device = device_text.device.index if device < 0 and device_text.device.index is not None else device
+        p = self._old.ctypes.data if self._old.size else None
+        _abi.check(L.dq_bsdiff_index_create(p, self._old.size, d_old, d_sa, device, ctypes.byref(h)))
+        self._h = h
+
+    def buffers(self):
+        """(device pointer of the text, device pointer of the suffix array, n)"""
+        a, b, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()
+        _abi.check(self._lib.dq_bsdiff_index_buffers(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
+        return a.value, b.value, n.value
+
+    def Create(self, newData) -> bytes:
+        N = _as_text(newData)
+        cap = self._lib.dq_bsdiff_patch_bound(self._old.size, N.size)
+        buf = np.empty(cap, dtype=np.uint8)
+        ln = ctypes.c_int64()
+        _abi.check(self._lib.dq_bsdiff_index_diff(self._h, N.ctypes.data if N.size else None, N.size, buf.ctypes.data, cap,
+                                                  ctypes.byref(ln)))
+        return buf[:ln.value].tobytes()
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.dq_bsdiff_index_free(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Patch:
     @staticmethod
     def Apply(input, diff, output=None):

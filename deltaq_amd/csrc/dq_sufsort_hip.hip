@@ -74,6 +74,36 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
             return fail(e_ == hipErrorOutOfMemory ? DQ_ERR_OOM : DQ_ERR_HIP, #expr, e_); \
     } while (0)
 
+// ------------------------------------------------------------------ DQ_* flags
+// Every entry point reads the DQ_* environment flags through env(): the first lookup of a name inside a call asks
+// the process environment, later ones get the same answer -- a call sees ONE consistent set of flags, each variable
+// is read once per call and thread, and nothing on the per-kernel path touches the environment.  (The tests flip
+// flags between calls, so the answers are not kept beyond the outermost call on this thread.)
+struct EnvCache {
+    struct Entry { const char *name; bool set; std::string val; };
+    static constexpr int kMax = 64;
+    Entry e[kMax];
+    int count = 0, depth = 0;
+};
+thread_local EnvCache t_env;
+
+const char *env(const char *name)
+{
+    EnvCache &c = t_env;
+    for (int i = 0; i < c.count; ++i)
+        if (c.e[i].name == name || strcmp(c.e[i].name, name) == 0) return c.e[i].set ? c.e[i].val.c_str() : nullptr;
+    const char *v = getenv(name);
+    if (c.depth == 0 || c.count == EnvCache::kMax) return v;          // outside an entry point: nothing is kept
+    EnvCache::Entry &x = c.e[c.count++];
+    x.name = name; x.set = v != nullptr; x.val = v ? v : "";
+    return x.set ? x.val.c_str() : nullptr;
+}
+
+struct EnvScope {
+    EnvScope() { if (t_env.depth++ == 0) t_env.count = 0; }
+    ~EnvScope() { --t_env.depth; }
+};
+
 // ------------------------------------------------------------------ profiling
 struct KernelStat { int64_t launches = 0; double ms = 0; int64_t elems = 0; int64_t bytes = 0; };
 std::mutex g_prof_mu;
@@ -108,11 +138,51 @@ struct DeviceCtx {
     int32_t *bslot_sa[3] = {nullptr, nullptr, nullptr};
     size_t bslot_cap = 0;               // bytes of text each slot holds
     hipStream_t b_in = nullptr, b_sort = nullptr, b_out = nullptr;
+    // Diff.Create (dq_bsdiff_create / dq_bsdiff_index_diff): one diff at a time per device; its device scratch
+    // (new file + mailbox; for the one-shot form also old file, suffix array and prefix table) and the pinned
+    // answer windows are kept between calls -- hipMalloc / hipHostMalloc / hipFree are synchronous driver calls
+    std::mutex diff_mu;
+    char *diff_dev = nullptr;           // per-diff scratch
+    size_t diff_dev_bytes = 0;
+    char *diff_idx = nullptr;           // index buffers of the one-shot form
+    size_t diff_idx_bytes = 0;
+    char *diff_pinned = nullptr;        // fixed size (SearchWindows)
 };
 constexpr int kMaxDevices = 64;
+// A device has several contexts ("slots": stream + workspace + pinned areas each).  Texts of up to kSlotSmallN bytes
+// take whichever slot is free, so that the threads of a host sharing one provider (the reference's benchmark keeps
+// static singletons, SuffixSortingBenchmarks.cs:59-61) overlap their sorts instead of queueing behind one mutex;
+// anything larger, the match search, the batch pipeline and the diffs use slot 0 (a large sort fills the device anyway).
+constexpr int kCtxSlots = 4;
+constexpr int64_t kSlotSmallN = 4ll << 20;
 constexpr size_t kSmallTextArea = kSmallMaxN + 64;
 constexpr size_t kSmallIoBytes = kSmallTextArea + (size_t)kSmallMaxN * 8;
-DeviceCtx g_ctx[kMaxDevices];
+struct DeviceState {
+    DeviceCtx slot[kCtxSlots];
+    std::atomic<unsigned> next{0};
+};
+DeviceState g_dev[kMaxDevices];
+inline DeviceCtx &ctx0(int dev) { return g_dev[dev].slot[0]; }
+
+// holds one slot of a device for the duration of a sort
+struct SlotLease {
+    DeviceCtx *c = nullptr;
+    SlotLease(int dev, int64_t n)
+    {
+        DeviceState &d = g_dev[dev];
+        if (n > kSlotSmallN) { c = &d.slot[0]; c->mu.lock(); return; }
+        for (int k = 1; k < kCtxSlots && !c; ++k)
+            if (d.slot[k].mu.try_lock()) c = &d.slot[k];
+        if (!c && d.slot[0].mu.try_lock()) c = &d.slot[0];
+        if (!c) {
+            c = &d.slot[1 + d.next.fetch_add(1u, std::memory_order_relaxed) % (unsigned)(kCtxSlots - 1)];
+            c->mu.lock();
+        }
+    }
+    ~SlotLease() { c->mu.unlock(); }
+    SlotLease(const SlotLease &) = delete;
+    SlotLease &operator=(const SlotLease &) = delete;
+};
 
 int init_ctx(DeviceCtx &c, int dev)
 {
@@ -429,7 +499,7 @@ void choose_key_bytes(const int64_t *bytehist, const int64_t *kgram_coll, int64_
         const double twins = (double)n * 2.0 * (double)C / ((double)kKgramSamples * (double)kKgramSamples);
         if (C >= kKgramSamples / 16 && twins > 0.25) { packed = false; kb = 8; }
     }
-    if (const char *v = getenv("DQ_PACKED")) packed = atoi(v) != 0 && fit >= 2;
+    if (const char *v = env("DQ_PACKED")) packed = atoi(v) != 0 && fit >= 2;
     if (packed) kb = std::min(kb, fit);
     *kb_out = kb;
     *packed_out = packed;
@@ -461,7 +531,7 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
     if (n >= (1 << 16)) HIP_TRY(hipMemsetAsync(w.Vb, 0, (size_t)((n + 63) / 64 + 1) * 8, L.st));
     HIP_TRY(hipEventSynchronize(c.readback));
     choose_key_bytes(c.pinned, n >= kKgramSamples * 8 ? c.pinned + 256 : nullptr, n, &kb, &packed);
-    if (const char *force = getenv("DQ_KEY_BYTES")) {
+    if (const char *force = env("DQ_KEY_BYTES")) {
         kb = std::min(8, std::max(1, atoi(force)));
         const int fit = (64 - bit_length((uint64_t)(n - 1))) / 8;
         if (kb > fit || kb < 2) packed = false;
@@ -485,10 +555,10 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
         }
         coded = h0 <= kCodedMaxAvgLen - 0.25 && (sigma <= 128 || n >= 2 * kCodedMinN);
     }
-    if (const char *v = getenv("DQ_CODED")) coded = atoi(v) != 0 && !packed && kb == 8 && n >= 64;
+    if (const char *v = env("DQ_CODED")) coded = atoi(v) != 0 && !packed && kb == 8 && n >= 64;
     if (coded) {
         AlphaCode code;
-        coded = build_alpha_code(c.pinned, &code) && (code.avg_len <= kCodedMaxAvgLen || getenv("DQ_CODED"));
+        coded = build_alpha_code(c.pinned, &code) && (code.avg_len <= kCodedMaxAvgLen || env("DQ_CODED"));
         if (coded) {
             uint16_t *stage = reinterpret_cast<uint16_t *>(c.pinned + 512);          // the upload half of the pinned area
             memcpy(stage, code.tab, sizeof(code.tab));
@@ -503,7 +573,7 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
             HIP_TRY(hipGetLastError());
             rc2 = L.end();
             if (rc2 != DQ_OK) return rc2;
-            if (getenv("DQ_TRACE")) fprintf(stderr, "[dq] coded round 0: %d symbols, %.2f bits per byte\n", code.sigma, code.avg_len);
+            if (env("DQ_TRACE")) fprintf(stderr, "[dq] coded round 0: %d symbols, %.2f bits per byte\n", code.sigma, code.avg_len);
             *coded_out = true;
             return DQ_OK;
         }
@@ -604,7 +674,7 @@ int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int k
     if (c.pinned[1] != 0) return fail(DQ_ERR_HIP, "radix look-back timed out (device spin bound hit)");
     *count = c.pinned[6];
     *overflow = c.pinned[7] != 0;
-    if (*overflow && getenv("DQ_TRACE")) fprintf(stderr, "[dq] tie / bucket overflow flags: %lld\n", (long long)c.pinned[7]);
+    if (*overflow && env("DQ_TRACE")) fprintf(stderr, "[dq] tie / bucket overflow flags: %lld\n", (long long)c.pinned[7]);
     *fin_left = c.pinned[3];
     (void)wb;
     return DQ_OK;
@@ -670,7 +740,7 @@ struct SuffixSorter {
     // largest group the LDS class finishes: 0 = off; DQ_MID_GROUPS = 0 | 256 | 512 | 1024 forces it (and keeps it on)
     static int mid_group_cap()
     {
-        if (const char *v = getenv("DQ_MID_GROUPS")) {
+        if (const char *v = env("DQ_MID_GROUPS")) {
             const int g = atoi(v);
             return g >= 1024 ? 1024 : g >= 512 ? 512 : g >= 256 ? 256 : 0;
         }
@@ -706,7 +776,7 @@ struct SuffixSorter {
     //      tied list is (P1, Va) and m its length.
     bool uses_small_round(int64_t mm) const
     {
-        return !getenv("DQ_NO_SMALL") && mm * 2 <= n && n < (1ll << 32);
+        return !env("DQ_NO_SMALL") && mm * 2 <= n && n < (1ll << 32);
     }
 
     int build_isa_binned(uint64_t *keys, uint64_t *P0, int kb, int kshift0)
@@ -719,7 +789,7 @@ struct SuffixSorter {
         // The tied suffixes are also listed group by group (32-bit ranks in the idle Vb, suffixes in Va): if they
         // are at most n/2, the first doubling round is a small-group round on that list and only the groups of
         // more than 8 go through the radix passes.
-        uint32_t *list_rank = (uses_small_round(0) && !getenv("DQ_NO_FIRST_SMALL")) ? reinterpret_cast<uint32_t *>(w.Vb) : nullptr;
+        uint32_t *list_rank = (uses_small_round(0) && !env("DQ_NO_FIRST_SMALL")) ? reinterpret_cast<uint32_t *>(w.Vb) : nullptr;
         LAUNCH(L, DQ_K_SEG_FUSED, n, n * (8 + wb + 8),
                hipLaunchKernelGGL((seg_fused_kernel<IdxT, true, false, false, true>), dim3((unsigned)ntiles),
                                   dim3(kSegThreads), 0, st, (const uint64_t *)keys, (const IdxT *)d_sa, n, ib, kshift0,
@@ -786,8 +856,8 @@ struct SuffixSorter {
         *done = false;
         if (coded) return DQ_OK;                          // (the digit offsets on the device are those of the coded keys)
         const int ib = bit_length((uint64_t)(n - 1));
-        if (getenv("DQ_NO_BUCKET") || getenv("DQ_NO_FUSED_TIES") || getenv("DQ_SPARSE") || getenv("DQ_KEY_BYTES")) return DQ_OK;
-        const bool forced = getenv("DQ_BUCKET") != nullptr;
+        if (env("DQ_NO_BUCKET") || env("DQ_NO_FUSED_TIES") || env("DQ_SPARSE") || env("DQ_KEY_BYTES")) return DQ_OK;
+        const bool forced = env("DQ_BUCKET") != nullptr;
         if (ib > 31 || n < (1 << 16)) return DQ_OK;                           // a suffix must fit 31 bits next to the tie flag
         // a run of >= 64 equal bytes somewhere (zero padding of real binaries; text_hist_kernel saw it): more equal
         // keys than a bin takes -- the pass would only raise its flag and be repeated by the plain passes
@@ -815,7 +885,7 @@ struct SuffixSorter {
         double need = est + 6.0 * std::sqrt(est) + 64.0;
         // a tile must not span more than 64 two-byte buckets (its keys, relative to its first bucket, take 26
         // bits + 6 arrival bits): buckets of >= 192 words on average, i.e. texts of >= 12 MiB
-        const bool force3 = forced && atoi(getenv("DQ_BUCKET")) == 3;          // (tests: 3-byte buckets on mid-size inputs)
+        const bool force3 = forced && atoi(env("DQ_BUCKET")) == 3;          // (tests: 3-byte buckets on mid-size inputs)
         if (need > 5120 || (!forced && n < (12 << 20)) || force3) {
             if (keybits - 24 >= 8 && (forced || n >= (12 << 20))) {
                 bbytes = 3;
@@ -868,7 +938,7 @@ struct SuffixSorter {
         if (overflow) {
             // a bucket or a bin this path does not take (or a run of equal keys too long for the tie walk):
             // back to the plain digit passes, with the state they expect
-            if (getenv("DQ_TRACE")) fprintf(stderr, "[dq] bucketed round 0 gave up (n=%lld): plain digit passes\n", (long long)n);
+            if (env("DQ_TRACE")) fprintf(stderr, "[dq] bucketed round 0 gave up (n=%lld): plain digit passes\n", (long long)n);
             rc = prepare_status<IdxT>(L, w, n, kMaxPasses);
             if (rc != DQ_OK) return rc;
             HIP_TRY(hipMemsetAsync(w.Vb, 0, (size_t)((n + 63) / 64 + 1) * 8, st));
@@ -916,8 +986,8 @@ struct SuffixSorter {
         // Packed words were chosen because few ties are expected: the last pass then records the tie
         // structure itself (1 bit per suffix + 2 words per tile and digit, in the idle Vb buffer)
         // instead of writing the sorted words for a rebucket pass to read back.
-        const bool fused_ties = packed && kb >= 2 && n >= (1 << 16) && !getenv("DQ_NO_FUSED_TIES") &&
-                                !getenv("DQ_SPARSE");
+        const bool fused_ties = packed && kb >= 2 && n >= (1 << 16) && !env("DQ_NO_FUSED_TIES") &&
+                                !env("DQ_SPARSE");
         if (fused_ties) {
             const int ib = bit_length((uint64_t)(n - 1));
             const int64_t nwords = (n + 63) / 64;
@@ -974,9 +1044,9 @@ struct SuffixSorter {
             // a pair ties with probability ~ (tied fraction) * (1 - 1/group size); 1/12 ~ tied fraction 1/6
             predict_dense = c.pinned[0] * 12 > kSamples;
         }
-        if (const char *v = getenv("DQ_SPARSE")) predict_dense = atoi(v) == 0;
+        if (const char *v = env("DQ_SPARSE")) predict_dense = atoi(v) == 0;
         const bool binned = predict_dense && n >= (1 << 16) &&
-                            2 * bit_length((uint64_t)(n - 1)) <= 63 && !getenv("DQ_NO_BINNED_ISA");
+                            2 * bit_length((uint64_t)(n - 1)) <= 63 && !env("DQ_NO_BINNED_ISA");
         if (binned) {
             rc = build_isa_binned(K[cur], K[cur ^ 1], kb, kshift0);
             if (rc != DQ_OK) return rc;
@@ -1094,7 +1164,7 @@ struct SuffixSorter {
         // path (unknown before the first round: tried there).
         const int mid_g = mid_group_cap();
         // (forced by DQ_MID_GROUPS: on lists of any length, so that the tests reach it with small inputs)
-        const bool use_mid = mid_g > 0 && mid_wanted && (!cap32 || getenv("DQ_MID_GROUPS"));
+        const bool use_mid = mid_g > 0 && mid_wanted && (!cap32 || env("DQ_MID_GROUPS") || env("DQ_MID_SHORT"));
         if (use_mid) {
             const int64_t tile = mid_g == 256 ? mg_tile<256>() : mid_g == 512 ? mg_tile<512>() : mg_tile<1024>();
             const dim3 grid((unsigned)((m + tile - 1) / tile));
@@ -1126,13 +1196,13 @@ struct SuffixSorter {
         HIP_TRY(hipMemcpyAsync(c.pinned, ctr, sizeof(SmallGroupCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const int64_t m1 = c.pinned[0] & 0xffffffffll, mU = (int64_t)((uint64_t)c.pinned[0] >> 32), mL = c.pinned[1];
-        if (getenv("DQ_TRACE"))
+        if (env("DQ_TRACE"))
             fprintf(stderr, "[dq] %s round h=%lld m=%lld -> tied %lld, to radix %lld, moved %lld\n",
                     use_mid ? "mid-group" : "small", (long long)h,
                     (long long)m, (long long)m1, (long long)mL, (long long)mU);
         // the LDS class pays while a round has many groups beyond 8; once one sends less than 1/16 of its list to the
         // radix path the small-group kernel (lighter per entry) takes over again
-        if (use_mid && !getenv("DQ_MID_GROUPS")) mid_wanted = mL * 16 >= m;
+        if (use_mid && !env("DQ_MID_GROUPS")) mid_wanted = mL * 16 >= m;
         if (mU > 0) {
             LAUNCH(L, DQ_K_ISA_UPDATE, mU, mU * (8 + wb + wb),
                    hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(mU)), dim3(kBlock), 0, st,
@@ -1222,7 +1292,7 @@ struct SuffixSorter {
         // up to 3 when the list is longer than n/3: the records (1.5 per entry for groups of 4, at most 1 for
         // pairs and triples) must fit behind `half`.
         int maxg = m >= kSgShortList ? 2 : (m * 3 <= n ? kPcMaxG : (m * 2 <= n ? 3 : 2));
-        if (const char *v = getenv("DQ_PAIR_MAXG")) maxg = std::min(maxg >= 3 ? maxg : 2, std::max(2, atoi(v)));
+        if (const char *v = env("DQ_PAIR_MAXG")) maxg = std::min(maxg >= 3 ? maxg : 2, std::max(2, atoi(v)));
         // record = d << xbits | x.  Pairs only: x padded to whole digits, so that the digit passes over x see nothing of d
         const int xbits = maxg == 2 ? (ib + 7) / 8 * 8 : ib;
         uint32_t *tile_cnt = w.pc_tiles;
@@ -1244,7 +1314,7 @@ struct SuffixSorter {
         // a small-group round, or from the end of a longer list if they still fit
         const int64_t half = std::max(sg_half(), (m + 1) & ~(int64_t)1);
         if (cnt == 0 || half + cnt > n || (!forced && copied * 5 > m * 3)) {
-            if (getenv("DQ_TRACE"))
+            if (env("DQ_TRACE"))
                 fprintf(stderr, "[dq] pair chains h=%lld m=%lld: given up, %lld entries in groups > %d\n", (long long)h, (long long)m,
                         (long long)copied, maxg);
             *outcome = 0;
@@ -1300,7 +1370,7 @@ struct SuffixSorter {
         rcur ^= 1;
         m = c.pinned[1];
         if ((m_in - m) * 2 >= m_in) *outcome = 2;         // at least half of the list was finished
-        if (getenv("DQ_TRACE"))
+        if (env("DQ_TRACE"))
             fprintf(stderr, "[dq] pair chains h=%lld m=%lld (groups <= %d): %lld pair records, %lld entries in larger groups, %lld entries left\n",
                     (long long)h, (long long)m_in, maxg, (long long)cnt, (long long)copied, (long long)m);
         return DQ_OK;
@@ -1317,7 +1387,7 @@ struct SuffixSorter {
         if (m == 0) return flush_profile(c);
 
         bool sparse = m * 6 <= n || shallow_ties;
-        if (const char *v = getenv("DQ_SPARSE")) sparse = atoi(v) != 0;
+        if (const char *v = env("DQ_SPARSE")) sparse = atoi(v) != 0;
         if (keys_ready) sparse = false;      // the ISA exists and the list is already keyed for a doubling round
         if (sparse) rc = finish_sparse();
         else if (!dense_built) rc = build_isa(Kr[rcur], Vr[rcur], m);
@@ -1335,13 +1405,13 @@ struct SuffixSorter {
             // at a time).  A phase gives up after its count pass when most of the list sits in larger groups, and
             // is tried again once the list has halved or h has grown 16-fold.
             const bool stagnant = m_before > 0 && m * 5 > m_before * 3;
-            const char *pc = getenv("DQ_PAIR_CHAINS");
+            const char *pc = env("DQ_PAIR_CHAINS");
             const bool after_abort = abort_h == 0 || m * 2 <= abort_m || h >= 16 * abort_h;
             const bool want = pc ? atoi(pc) != 0 && (m_before > 0 || atoi(pc) > 1)
                                  : m_before > 0 && m >= kPairChainMinM && after_abort &&
                                    (pair_tries == 0 || (pair_paid ? stagnant : h >= 16 * pair_h));
-            const int max_tries = getenv("DQ_PAIR_TRIES") ? atoi(getenv("DQ_PAIR_TRIES")) : kPairChainTries;
-            if (want && pair_tries < max_tries && pair_aborts < 2 * kPairChainTries && !getenv("DQ_NO_SMALL") && n < (1ll << 32) &&
+            const int max_tries = env("DQ_PAIR_TRIES") ? atoi(env("DQ_PAIR_TRIES")) : kPairChainTries;
+            if (want && pair_tries < max_tries && pair_aborts < 2 * kPairChainTries && !env("DQ_NO_SMALL") && n < (1ll << 32) &&
                 m < n && !keys_ready) {
                 int outcome = 0;
                 m_before = 0;
@@ -1353,7 +1423,7 @@ struct SuffixSorter {
                 continue;
             }
             m_before = m;
-            if (only_small_groups && uses_small_round(m) && !keys_ready && !getenv("DQ_NO_CHAIN")) {
+            if (only_small_groups && uses_small_round(m) && !keys_ready && !env("DQ_NO_CHAIN")) {
                 rc = doubling_rounds_small_chain();           // several rounds, one host round trip; updates h
                 if (rc != DQ_OK) return rc;
                 continue;
@@ -1365,7 +1435,7 @@ struct SuffixSorter {
             // needs 33 + 32: the key then carries rank >> 1 (unique per group: tied groups have >= 2 members)
             // and the rebucket pass reads the true rank from the ISA.  check_args() keeps n <= 2^32.
             // (DQ_FORCE_RSHIFT: the tests take this path on small inputs)
-            const int rshift = (kbits + rbits > 64 || getenv("DQ_FORCE_RSHIFT")) ? 1 : 0;
+            const int rshift = (kbits + rbits > 64 || env("DQ_FORCE_RSHIFT")) ? 1 : 0;
             if (kbits + rbits - rshift > 64) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
             if (rshift && keys_ready) {
                 // the list came keyed from build_isa_binned() (rank << kbits | key2, unshifted): take the group
@@ -1396,7 +1466,7 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
 // device-wide pipeline; the tests use that to keep the pipeline covered on the fixtures).
 int64_t small_limit()
 {
-    if (const char *v = getenv("DQ_SMALL_N")) return std::min<int64_t>(std::max(0, atoi(v)), kSmallMaxN);
+    if (const char *v = env("DQ_SMALL_N")) return std::min<int64_t>(std::max(0, atoi(v)), kSmallMaxN);
     return kSmallMaxN;
 }
 
@@ -1417,8 +1487,8 @@ int resolve_device(int32_t device, int *out)
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) return fail(DQ_ERR_NO_DEVICE, "no HIP device available", e);
     if (device < 0) {
-        const char *env = getenv("DQ_HIP_DEVICE");
-        device = env ? atoi(env) : 0;
+        const char *v = env("DQ_HIP_DEVICE");
+        device = v ? atoi(v) : 0;
     }
     if (device < 0 || device >= count || device >= kMaxDevices)
         return fail(DQ_ERR_BAD_ARGS, "device ordinal out of range");
@@ -1456,8 +1526,8 @@ int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device)
         sa[0] = lt ? 0 : 1; sa[1] = lt ? 1 : 0;
         return DQ_OK;
     }
-    DeviceCtx &c = g_ctx[dev];
-    std::lock_guard<std::mutex> lk(c.mu);
+    SlotLease lease(dev, n);
+    DeviceCtx &c = *lease.c;
     rc = init_ctx(c, dev);
     if (rc != DQ_OK) return rc;
     if (n <= small_limit()) {
@@ -1495,8 +1565,8 @@ int sufsort_dev(const void *d_text, int64_t n, void *d_sa, int32_t device, void 
     rc = resolve_device(device, &dev);
     if (rc != DQ_OK) return rc;
     if (n == 0) return DQ_OK;
-    DeviceCtx &c = g_ctx[dev];
-    std::lock_guard<std::mutex> lk(c.mu);
+    SlotLease lease(dev, n);
+    DeviceCtx &c = *lease.c;
     rc = init_ctx(c, dev);
     if (rc != DQ_OK) return rc;
     if (n <= small_limit()) {
@@ -1534,7 +1604,7 @@ int match_search_dev(const void *d_old, int64_t n, const void *d_sa, const void 
     int rc = resolve_device(device, &dev);
     if (rc != DQ_OK) return rc;
     if (count == 0) return DQ_OK;
-    DeviceCtx &c = g_ctx[dev];
+    DeviceCtx &c = ctx0(dev);
     std::lock_guard<std::mutex> lk(c.mu);
     rc = init_ctx(c, dev);
     if (rc != DQ_OK) return rc;
@@ -1544,7 +1614,7 @@ int match_search_dev(const void *d_old, int64_t n, const void *d_sa, const void 
     const int64_t probes = bit_length((uint64_t)std::max<int64_t>(n, 1));
     // (DQ_SEARCH_WAVE=1: consecutive positions through the one-wave-per-position kernel of the scan-loop driver, so
     // that the tests can compare its answers one by one; position 0 is answered exactly whatever the cap)
-    const bool wave = getenv("DQ_SEARCH_WAVE") && !d_scans && count <= 4096;
+    const bool wave = env("DQ_SEARCH_WAVE") && !d_scans && count <= 4096;
     auto launch = [&]() -> int {
         if (wave) {
             constexpr int kPer = kMsThreads / kWave;
@@ -1665,7 +1735,7 @@ struct SearchWindows {
         int dev = 0;
         int rc = resolve_device(device, &dev);
         if (rc != DQ_OK) return rc;
-        DeviceCtx &c = g_ctx[dev];
+        DeviceCtx &c = ctx0(dev);
         // the window the device was asked to answer ahead (second stage of the previous launch): is it this one?
         if (sec_pending) {
             sec_pending = false;
@@ -1699,7 +1769,7 @@ struct SearchWindows {
         // the previous window was used up to its end: the loop is walking byte by byte -> a larger one
         next_size = (w0 >= 0 && scan == w0 + wc) ? std::min(next_size * 2, kMaxWindow) : kMinWindow;
         const int64_t count = std::min(next_size, m - scan);
-        if (count <= kWaveWindow && !getenv("DQ_NO_WAVE_WINDOWS")) {
+        if (count <= kWaveWindow && !env("DQ_NO_WAVE_WINDOWS")) {
             // short windows (the loop is hopping from match to match: every launch is a dependent round trip): one WAVE
             // per position, 65-ary search; the position the loop stands on exactly, the ones behind it with the cap
             std::lock_guard<std::mutex> lk(c.mu);
@@ -1795,6 +1865,157 @@ struct SearchWindows {
     }
 };
 
+struct JoinAll {                        // joins whatever was started, also when leaving by exception
+    std::vector<std::thread> v;
+    ~JoinAll() { for (std::thread &t : v) if (t.joinable()) t.join(); }
+};
+
+// ---- "one old file, many new files": the suffix array of old (Diff.cs:89-90) is what a diff costs before its scan loop,
+// and it depends on old alone.  A DiffIndex holds (old, suffix array, prefix table of the match search) on the
+// device; any number of new files are diffed against it (dq_bsdiff_index_*; the reference pays the sort once per
+// Diff.Create call).  The buffers are either the index's own (built here) or the caller's (a rank that received
+// text + suffix array by RCCL broadcast, deltaq_amd/batch.py: diff_many_distributed).
+struct DiffIndex {
+    int dev = 0;
+    int64_t n = 0;
+    const uint8_t *old = nullptr;       // host copy the scan loop walks: the caller's, valid while the index lives
+    char *own = nullptr;                // device allocation of this index (old + SA if built here, prefix table)
+    bool own_cached = false;            // ... which is the device context's cached one-shot buffer (not freed)
+    const char *d_old = nullptr, *d_sa = nullptr;
+    const char *d_tab = nullptr;
+    int pk = 0;
+};
+
+constexpr size_t kDiffPinnedBytes = 2 * ((size_t)(65536 + 2) * 4 + 256) + (size_t)(2048 + 2 * (128 + 1)) * 8 + 256;
+
+size_t diff_tab_bytes(int64_t n, int *pk_out)
+{
+    // prefix table of the match search: 3 bytes (64 MiB of entries) for old files from 4 MiB, 2 bytes from 64 KiB
+    const int pk = n >= (4 << 20) ? 3 : n >= (1 << 16) ? 2 : 0;
+    *pk_out = pk;
+    return pk ? align_up(((size_t)1 << (8 * pk)) * 4 + 16) : 0;
+}
+
+int grow_cached(char **buf, size_t *have, size_t want, const char *what)
+{
+    if (*have >= want) return DQ_OK;
+    if (*buf) { (void)hipFree(*buf); *buf = nullptr; *have = 0; }
+    hipError_t e = hipMalloc((void **)buf, want);
+    if (e != hipSuccess) return fail(DQ_ERR_OOM, what, e);
+    *have = want;
+    return DQ_OK;
+}
+
+// d_old_in / d_sa_in: device-resident text and suffix array of the caller (both or neither).  cached: build into the
+// device context's reusable buffer (the one-shot dq_bsdiff_create; the caller holds diff_mu).
+int diff_index_build(const uint8_t *old, int64_t n, int32_t device, const void *d_old_in, const void *d_sa_in, bool cached,
+                     DiffIndex *ix)
+{
+    if (n < 0 || (n > 0 && !old)) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
+    if ((d_old_in == nullptr) != (d_sa_in == nullptr)) return fail(DQ_ERR_BAD_ARGS, "device text and suffix array go together");
+    if (n > 0x7fffffffLL) return fail(DQ_ERR_TOO_LARGE, "the BSDIFF40 path takes files below 2 GiB (int indices, as the reference)");
+    int dev = 0;
+    int rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    HIP_TRY(hipSetDevice(dev));
+    ix->dev = dev; ix->n = n; ix->old = old;
+    int pk = 0;
+    const size_t b_tab = diff_tab_bytes(n, &pk);
+    const size_t b_old = d_old_in ? 0 : align_up((size_t)n + 16), b_sa = d_old_in ? 0 : align_up((size_t)n * 4 + 16);
+    const size_t total = b_old + b_sa + b_tab;
+    if (total > 0) {
+        if (cached) {
+            DeviceCtx &c = ctx0(dev);
+            rc = grow_cached(&c.diff_idx, &c.diff_idx_bytes, total, "hipMalloc(bsdiff index)");
+            if (rc != DQ_OK) return rc;
+            ix->own = c.diff_idx;
+            ix->own_cached = true;
+        } else {
+            hipError_t e = hipMalloc((void **)&ix->own, total);
+            if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(bsdiff index)", e);
+        }
+    }
+    if (d_old_in) {
+        ix->d_old = (const char *)d_old_in;
+        ix->d_sa = (const char *)d_sa_in;
+    } else {
+        ix->d_old = ix->own;
+        ix->d_sa = ix->own + b_old;
+        if (n > 0) HIP_TRY(hipMemcpy(ix->own, old, (size_t)n, hipMemcpyHostToDevice));
+        rc = sufsort_dev<int32_t>(ix->d_old, n, const_cast<char *>(ix->d_sa), dev, nullptr);     // Diff.cs:90; the SA never leaves the device
+        if (rc != DQ_OK) return rc;
+    }
+    ix->pk = pk;
+    if (pk) {
+        char *tab = ix->own + b_old + b_sa;
+        const int64_t total_e = (1ll << (8 * pk)) + 1;
+        hipLaunchKernelGGL(prefix_bounds_kernel<int32_t>, dim3((unsigned)((total_e + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           nullptr, (const uint8_t *)ix->d_old, n, (const int32_t *)ix->d_sa, pk, (int32_t *)tab);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        ix->d_tab = tab;
+    }
+    return DQ_OK;
+}
+
+void diff_index_drop(DiffIndex *ix)
+{
+    if (ix->own && !ix->own_cached) { (void)hipSetDevice(ix->dev); (void)hipFree(ix->own); }
+    ix->own = nullptr;
+}
+
+// Diff.Create's data path up to the raw streams for one new file: upload it, run the scan loop over windows of answers
+int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::RawStreams &raw)
+{
+    if (m < 0 || (m > 0 && !nw)) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
+    if (m > 0x7fffffffLL) return fail(DQ_ERR_TOO_LARGE, "the BSDIFF40 path takes files below 2 GiB (int indices, as the reference)");
+    if (m == 0) return DQ_OK;
+    const int dev = ix.dev;
+    HIP_TRY(hipSetDevice(dev));
+    DeviceCtx &c = ctx0(dev);
+    const bool trace = env("DQ_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) {
+        if (trace) fprintf(stderr, "[dq] bsdiff %-14s at %8.3f ms\n", what,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    const size_t b_new = align_up((size_t)m + 16);
+    int rc = grow_cached(&c.diff_dev, &c.diff_dev_bytes, b_new + 256, "hipMalloc(bsdiff buffers)");      // (+ the mailbox of the window kernel)
+    if (rc != DQ_OK) return rc;
+    if (!c.diff_pinned) {
+        hipError_t e = hipHostMalloc((void **)&c.diff_pinned, kDiffPinnedBytes, hipHostMallocCoherent);   // (windows + the packed answers the loop polls)
+        if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipHostMalloc(search windows)", e);
+    }
+    char *pinned = c.diff_pinned;
+    const size_t b_win = align_up((size_t)(SearchWindows::kMaxWindow + 2) * 4);
+    static_assert(kDiffPinnedBytes >= 2 * ((size_t)(SearchWindows::kMaxWindow + 2) * 4 + 256) +
+                  (size_t)(SearchWindows::kWaveWindow + 2 * (SearchWindows::kSecond + 1)) * 8 + 256, "pinned window area");
+    char *d_new = c.diff_dev;
+    stamp("buffers");
+    HIP_TRY(hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice));
+    stamp("new on device");
+    SearchWindows win{ix.d_old, ix.d_sa, d_new, ix.n, m, dev};
+    win.d_ptab = ix.d_tab;
+    win.pk = ix.pk;
+    win.h_pos = reinterpret_cast<int32_t *>(pinned);
+    win.h_len = reinterpret_cast<int32_t *>(pinned + b_win);
+    win.h_packed = env("DQ_NO_POLL") ? nullptr : reinterpret_cast<uint64_t *>(pinned + 2 * b_win);
+    win.d_mail = d_new + b_new;
+    HIP_TRY(hipMemset(win.d_mail, 0, 16));
+    win.no_second = env("DQ_NO_SECOND_STAGE") != nullptr;
+    rc = bsdiff::scan_loop(ix.old, ix.n, nw, m, win, raw);
+    raw.windows = win.windows;
+    raw.exact = win.exact;
+    stamp("scan loop");
+    if (trace)
+        fprintf(stderr, "[dq] scan loop: %lld searches, %lld windows (%lld of them answered ahead by the second stage), %lld exact repeats\n",
+                (long long)raw.searches, (long long)win.windows, (long long)win.predicted, (long long)win.exact);
+    // (the loop polled the kernels' own completion counts: drain the stream before the buffers are reused)
+    const hipError_t drained = hipStreamSynchronize(c.stream);
+    if (rc == DQ_OK && drained != hipSuccess) return fail(DQ_ERR_HIP, "scan loop: stream did not drain", drained);
+    return rc;
+}
+
 // Diff.Create's data path up to the raw streams: sort old on the device, keep the SA there, run the scan loop
 int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, bsdiff::RawStreams &raw)
 {
@@ -1805,62 +2026,11 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     int rc = resolve_device(device, &dev);
     if (rc != DQ_OK) return rc;
     if (m == 0) return DQ_OK;
-    HIP_TRY(hipSetDevice(dev));
-    const bool trace = getenv("DQ_TRACE") != nullptr;
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto stamp = [&](const char *what) {
-        if (trace) fprintf(stderr, "[dq] bsdiff %-14s at %8.3f ms\n", what,
-                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
-    };
-    char *base = nullptr;
-    const size_t b_old = align_up((size_t)n + 16), b_sa = align_up((size_t)n * 4 + 16), b_new = align_up((size_t)m + 16);
-    const size_t b_win = align_up((size_t)(SearchWindows::kMaxWindow + 2) * 4);
-    // prefix table of the match search: 3 bytes (64 MiB of entries) for old files from 4 MiB, 2 bytes from 64 KiB
-    const int pk = n >= (4 << 20) ? 3 : n >= (1 << 16) ? 2 : 0;
-    const size_t b_tab = pk ? align_up(((size_t)1 << (8 * pk)) * 4 + 16) : 0;
-    hipError_t e = hipMalloc((void **)&base, b_old + b_sa + b_new + b_tab + 256);      // (+ the mailbox of the window kernel)
-    if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(bsdiff buffers)", e);
-    struct Free { char *p; ~Free() { (void)hipFree(p); } } guard{base};
-    char *pinned = nullptr;
-    e = hipHostMalloc((void **)&pinned, 2 * b_win + (size_t)(SearchWindows::kWaveWindow + 2 * (SearchWindows::kSecond + 1)) * 8 + 256, hipHostMallocCoherent);   // (+ the packed answers the loop polls)
-    if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipHostMalloc(search windows)", e);
-    struct FreeHost { char *p; ~FreeHost() { (void)hipHostFree(p); } } hguard{pinned};
-    char *d_old = base, *d_sa = d_old + b_old, *d_new = d_sa + b_sa;
-    stamp("buffers");
-    if (n > 0) HIP_TRY(hipMemcpy(d_old, old, (size_t)n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice));
-    stamp("files on device");
-    rc = sufsort_dev<int32_t>(d_old, n, d_sa, dev, nullptr);                       // Diff.cs:90; the SA never leaves the device
+    std::lock_guard<std::mutex> one_diff(ctx0(dev).diff_mu);
+    DiffIndex ix;
+    rc = diff_index_build(old, n, dev, nullptr, nullptr, /*cached=*/true, &ix);
     if (rc != DQ_OK) return rc;
-    stamp("suffix array");
-    SearchWindows win{d_old, d_sa, d_new, n, m, dev};
-    if (pk) {
-        const int64_t total = (1ll << (8 * pk)) + 1;
-        hipLaunchKernelGGL(prefix_bounds_kernel<int32_t>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                           nullptr, (const uint8_t *)d_old, n, (const int32_t *)d_sa, pk, (int32_t *)(d_new + b_new));
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
-        win.d_ptab = d_new + b_new;
-        win.pk = pk;
-    }
-    stamp("prefix table");
-    win.h_pos = reinterpret_cast<int32_t *>(pinned);
-    win.h_len = reinterpret_cast<int32_t *>(pinned + b_win);
-    win.h_packed = getenv("DQ_NO_POLL") ? nullptr : reinterpret_cast<uint64_t *>(pinned + 2 * b_win);
-    win.d_mail = base + b_old + b_sa + b_new + b_tab;
-    HIP_TRY(hipMemset(win.d_mail, 0, 16));
-    win.no_second = getenv("DQ_NO_SECOND_STAGE") != nullptr;
-    rc = bsdiff::scan_loop(old, n, nw, m, win, raw);
-    raw.windows = win.windows;
-    raw.exact = win.exact;
-    stamp("scan loop");
-    if (getenv("DQ_TRACE"))
-        fprintf(stderr, "[dq] scan loop: %lld searches, %lld windows (%lld of them answered ahead by the second stage), %lld exact repeats\n",
-                (long long)raw.searches, (long long)win.windows, (long long)win.predicted, (long long)win.exact);
-    // (the loop polled the kernels' own completion counts: drain the stream before the buffers go away)
-    const hipError_t drained = hipStreamSynchronize(g_ctx[dev].stream);
-    if (rc == DQ_OK && drained != hipSuccess) return fail(DQ_ERR_HIP, "scan loop: stream did not drain", drained);
-    return rc;
+    return diff_index_scan(ix, nw, m, raw);
 }
 
 // one bzip2 stream; the Burrows-Wheeler transform of each block through the suffix sorter
@@ -1877,6 +2047,45 @@ int bz2_stream(const std::vector<uint8_t> &src, std::vector<uint8_t> &out, int d
     return DQ_OK;
 }
 
+// header + the three streams (Diff.cs:54-70 / :196-252).  The streams are framed side by side on three host threads:
+// their run-length / MTF / Huffman work overlaps, the block sorts take turns on the device.
+int frame_patch(const bsdiff::RawStreams &raw, int64_t m, int dev, std::vector<uint8_t> &patch)
+{
+    std::vector<uint8_t> z[3];
+    const std::vector<uint8_t> *src[3] = {&raw.ctrl, &raw.diff, &raw.extra};
+    int rcs[3] = {DQ_OK, DQ_OK, DQ_OK};
+    std::string errs[3];
+    auto work = [&](int k) {
+        try {
+            rcs[k] = bz2_stream(*src[k], z[k], dev);
+            if (rcs[k] != DQ_OK) errs[k] = t_err;
+        } catch (const std::exception &e) {
+            rcs[k] = DQ_ERR_OOM;
+            errs[k] = std::string("bsdiff: ") + e.what();
+        }
+    };
+    {
+        JoinAll threads;
+        // (streams of a few KB are not worth a thread)
+        const bool parallel = raw.ctrl.size() + raw.diff.size() + raw.extra.size() >= (1u << 16) && !env("DQ_BZ2_SERIAL");
+        for (int k = 1; k < 3; ++k) {
+            if (!parallel) { work(k); continue; }
+            try { threads.v.emplace_back(work, k); } catch (const std::exception &) { work(k); }
+        }
+        work(0);
+    }
+    for (int k = 0; k < 3; ++k)
+        if (rcs[k] != DQ_OK) { t_err = errs[k]; return rcs[k]; }
+    patch.assign((size_t)bsdiff::kHeaderSize, 0);                                  // Diff.cs:54-70 / :247-252
+    bsdiff::write_packed_long(&patch[0], bsdiff::kSignature);
+    bsdiff::write_packed_long(&patch[8], (int64_t)z[0].size());
+    bsdiff::write_packed_long(&patch[16], (int64_t)z[1].size());
+    bsdiff::write_packed_long(&patch[24], m);
+    patch.reserve(patch.size() + z[0].size() + z[1].size() + z[2].size());
+    for (int k = 0; k < 3; ++k) patch.insert(patch.end(), z[k].begin(), z[k].end());
+    return DQ_OK;
+}
+
 int bsdiff_create_host(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, std::vector<uint8_t> &patch)
 {
     bsdiff::RawStreams raw;
@@ -1885,19 +2094,7 @@ int bsdiff_create_host(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t
     int dev = 0;
     rc = resolve_device(device, &dev);
     if (rc != DQ_OK) return rc;
-    std::vector<uint8_t> zc, zd, ze;
-    if ((rc = bz2_stream(raw.ctrl, zc, dev)) != DQ_OK || (rc = bz2_stream(raw.diff, zd, dev)) != DQ_OK ||
-        (rc = bz2_stream(raw.extra, ze, dev)) != DQ_OK)
-        return rc;
-    patch.assign((size_t)bsdiff::kHeaderSize, 0);                                  // Diff.cs:54-70 / :247-252
-    bsdiff::write_packed_long(&patch[0], bsdiff::kSignature);
-    bsdiff::write_packed_long(&patch[8], (int64_t)zc.size());
-    bsdiff::write_packed_long(&patch[16], (int64_t)zd.size());
-    bsdiff::write_packed_long(&patch[24], m);
-    patch.insert(patch.end(), zc.begin(), zc.end());
-    patch.insert(patch.end(), zd.begin(), zd.end());
-    patch.insert(patch.end(), ze.begin(), ze.end());
-    return DQ_OK;
+    return frame_patch(raw, m, dev, patch);
 }
 
 // Patch.Apply (Patch.cs:52-168): host only (dq_bspatch.h)
@@ -1919,10 +2116,6 @@ int bspatch_apply_host(const uint8_t *old, int64_t n, const uint8_t *patch, int6
 // short-text path or that are larger than the slot size go through the plain host entry point.
 constexpr int kBatchSlots = 3;
 
-struct JoinAll {                        // joins whatever was started, also when leaving by exception
-    std::vector<std::thread> v;
-    ~JoinAll() { for (std::thread &t : v) if (t.joinable()) t.join(); }
-};
 
 int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *const *texts, const int64_t *lens,
                     int32_t *const *sas, std::string *err)
@@ -1943,7 +2136,7 @@ int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *con
     }
     if (hipSetDevice(device) != hipSuccess) { *err = "hipSetDevice failed"; return DQ_ERR_HIP; }
     // the three device slots and streams live in the device context: allocated once, grown on demand
-    DeviceCtx &bc = g_ctx[device];
+    DeviceCtx &bc = ctx0(device);
     std::lock_guard<std::mutex> batch_lock(bc.batch_mu);
     struct Slot { uint8_t *text = nullptr; int32_t *sa = nullptr; int job = -1; };
     Slot slots[kBatchSlots];
@@ -2074,27 +2267,32 @@ const char *dq_last_error(void) { return t_err.c_str(); }
 
 int32_t dq_sufsort_hip_i32(const uint8_t *text, int64_t n, int32_t *sa, int32_t device)
 {
+    EnvScope flags;
     return sufsort_host<int32_t>(text, n, sa, device);
 }
 
 int32_t dq_sufsort_hip_i64(const uint8_t *text, int64_t n, int64_t *sa, int32_t device)
 {
+    EnvScope flags;
     return sufsort_host<int64_t>(text, n, sa, device);
 }
 
 int32_t dq_sufsort_hip_dev_i32(const void *d_text, int64_t n, void *d_sa, int32_t device, void *stream)
 {
+    EnvScope flags;
     return sufsort_dev<int32_t>(d_text, n, d_sa, device, stream);
 }
 
 int32_t dq_sufsort_hip_dev_i64(const void *d_text, int64_t n, void *d_sa, int32_t device, void *stream)
 {
+    EnvScope flags;
     return sufsort_dev<int64_t>(d_text, n, d_sa, device, stream);
 }
 
 int32_t dq_sufsort_hip_batch_i32(int32_t count, const uint8_t *const *texts, const int64_t *lens,
                                  int32_t *const *sas, int32_t ndev, const int32_t *devs)
 {
+    EnvScope flags;
     if (count < 0 || ndev <= 0 || (count > 0 && (!texts || !lens || !sas)))
         return fail(DQ_ERR_BAD_ARGS, "bad batch arguments");
     if (count == 0) return DQ_OK;
@@ -2142,6 +2340,7 @@ int32_t dq_bsdiff_search_dev_i32(const void *d_old, int64_t n, const void *d_sa,
                                  const int64_t *d_scans, int64_t scan0, int64_t count, int64_t cap, void *d_pos,
                                  void *d_len, int32_t device, void *stream)
 {
+    EnvScope flags;
     return match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, d_scans, scan0, count, cap, d_pos, d_len, device, stream);
 }
 
@@ -2149,6 +2348,7 @@ int32_t dq_bsdiff_search_dev_i64(const void *d_old, int64_t n, const void *d_sa,
                                  const int64_t *d_scans, int64_t scan0, int64_t count, int64_t cap, void *d_pos,
                                  void *d_len, int32_t device, void *stream)
 {
+    EnvScope flags;
     return match_search_dev<int64_t>(d_old, n, d_sa, d_new, m, d_scans, scan0, count, cap, d_pos, d_len, device, stream);
 }
 
@@ -2156,6 +2356,7 @@ int32_t dq_bsdiff_search_i32(const uint8_t *old_data, int64_t n, const int32_t *
                              const int64_t *scans, int64_t scan0, int64_t count, int64_t cap, int32_t *pos, int32_t *len,
                              int32_t device)
 {
+    EnvScope flags;
     return match_search_host<int32_t>(old_data, n, sa, new_data, m, scans, scan0, count, cap, pos, len, device);
 }
 
@@ -2163,6 +2364,7 @@ int32_t dq_bsdiff_search_i64(const uint8_t *old_data, int64_t n, const int64_t *
                              const int64_t *scans, int64_t scan0, int64_t count, int64_t cap, int64_t *pos, int64_t *len,
                              int32_t device)
 {
+    EnvScope flags;
     return match_search_host<int64_t>(old_data, n, sa, new_data, m, scans, scan0, count, cap, pos, len, device);
 }
 
@@ -2170,6 +2372,7 @@ int32_t dq_bsdiff_scan_i32(const uint8_t *old_data, int64_t n, const uint8_t *ne
                            int64_t ctrl_cap, int64_t *nctrl, uint8_t *diff, int64_t *ndiff, uint8_t *extra, int64_t *nextra,
                            int64_t *stats, int32_t device)
 {
+    EnvScope flags;
     try {
         bsdiff::RawStreams raw;
         const int rc = bsdiff_raw(old_data, n, new_data, m, device, raw);
@@ -2192,6 +2395,7 @@ int32_t dq_bsdiff_scan_i32(const uint8_t *old_data, int64_t n, const uint8_t *ne
 int32_t dq_bsdiff_create(const uint8_t *old_data, int64_t n, const uint8_t *new_data, int64_t m, uint8_t *patch,
                          int64_t cap, int64_t *patch_len, int32_t device)
 {
+    EnvScope flags;
     try {
         std::vector<uint8_t> v;
         const int rc = bsdiff_create_host(old_data, n, new_data, m, device, v);
@@ -2205,6 +2409,72 @@ int32_t dq_bsdiff_create(const uint8_t *old_data, int64_t n, const uint8_t *new_
     } catch (const std::exception &e) {            // nothing may propagate through the C ABI
         return fail(DQ_ERR_HIP, e.what());
     }
+}
+
+int32_t dq_bsdiff_index_create(const uint8_t *old_data, int64_t n, const void *d_old, const void *d_sa, int32_t device,
+                               void **index_out)
+{
+    EnvScope flags;
+    if (!index_out) return fail(DQ_ERR_BAD_ARGS, "null index pointer");
+    *index_out = nullptr;
+    try {
+        DiffIndex *ix = new DiffIndex();
+        const int rc = diff_index_build(old_data, n, device, d_old, d_sa, /*cached=*/false, ix);
+        if (rc != DQ_OK) { diff_index_drop(ix); delete ix; return rc; }
+        *index_out = ix;
+        return DQ_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(DQ_ERR_OOM, "bsdiff: host allocation failed");
+    } catch (const std::exception &e) {
+        return fail(DQ_ERR_HIP, e.what());
+    }
+}
+
+int32_t dq_bsdiff_index_buffers(const void *index, const void **d_old, const void **d_sa, int64_t *n)
+{
+    if (!index) return fail(DQ_ERR_BAD_ARGS, "null index");
+    const DiffIndex *ix = static_cast<const DiffIndex *>(index);
+    if (d_old) *d_old = ix->d_old;
+    if (d_sa) *d_sa = ix->d_sa;
+    if (n) *n = ix->n;
+    return DQ_OK;
+}
+
+int32_t dq_bsdiff_index_diff(const void *index, const uint8_t *new_data, int64_t m, uint8_t *patch, int64_t cap,
+                             int64_t *patch_len)
+{
+    EnvScope flags;
+    if (!index) return fail(DQ_ERR_BAD_ARGS, "null index");
+    const DiffIndex *ix = static_cast<const DiffIndex *>(index);
+    try {
+        std::vector<uint8_t> v;
+        {
+            bsdiff::RawStreams raw;
+            {
+                std::lock_guard<std::mutex> one_diff(ctx0(ix->dev).diff_mu);      // scan loops take turns on a device
+                const int rc = diff_index_scan(*ix, new_data, m, raw);
+                if (rc != DQ_OK) return rc;
+            }
+            const int rc = frame_patch(raw, m, ix->dev, v);                        // (framing overlaps the next caller's scan loop)
+            if (rc != DQ_OK) return rc;
+        }
+        if (patch_len) *patch_len = (int64_t)v.size();
+        if ((int64_t)v.size() > cap || !patch) return fail(DQ_ERR_BAD_ARGS, "patch buffer too small (see dq_bsdiff_patch_bound)");
+        memcpy(patch, v.data(), v.size());
+        return DQ_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(DQ_ERR_OOM, "bsdiff: host allocation failed");
+    } catch (const std::exception &e) {
+        return fail(DQ_ERR_HIP, e.what());
+    }
+}
+
+void dq_bsdiff_index_free(void *index)
+{
+    if (!index) return;
+    DiffIndex *ix = static_cast<DiffIndex *>(index);
+    diff_index_drop(ix);
+    delete ix;
 }
 
 int64_t dq_bsdiff_patch_bound(int64_t n, int64_t m)
@@ -2238,34 +2508,45 @@ int64_t dq_sufsort_hip_workspace_bytes(int64_t n, int32_t index_bytes)
 
 void dq_sufsort_hip_release(void)
 {
-    for (int d = 0; d < kMaxDevices; ++d) {
-        DeviceCtx &c = g_ctx[d];
-        std::lock_guard<std::mutex> bl(c.batch_mu);        // lock order everywhere: batch_mu, then mu
-        std::lock_guard<std::mutex> lk(c.mu);
-        if (c.dev < 0) continue;
-        if (hipSetDevice(c.dev) != hipSuccess) continue;
-        if (c.ws) (void)hipFree(c.ws);
-        c.ws = nullptr; c.ws_bytes = 0;
-        {
-            for (int k = 0; k < 3; ++k) {
-                if (c.bslot_text[k]) (void)hipFree(c.bslot_text[k]);
-                if (c.bslot_sa[k]) (void)hipFree(c.bslot_sa[k]);
-                c.bslot_text[k] = nullptr; c.bslot_sa[k] = nullptr;
-            }
-            c.bslot_cap = 0;
-            for (hipStream_t *st : {&c.b_in, &c.b_sort, &c.b_out}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
+    for (int d = 0; d < kMaxDevices && d < count; ++d) {
+        DeviceCtx &c0 = ctx0(d);
+        // lock order everywhere: batch_mu, then diff_mu, then a slot's mu
+        std::lock_guard<std::mutex> bl(c0.batch_mu);
+        std::lock_guard<std::mutex> dl(c0.diff_mu);
+        bool any = c0.diff_dev || c0.diff_idx || c0.diff_pinned || c0.bslot_cap;
+        for (int k = 0; k < kCtxSlots; ++k) any = any || g_dev[d].slot[k].dev >= 0;
+        if (!any || hipSetDevice(d) != hipSuccess) continue;
+        for (int k = 0; k < 3; ++k) {
+            if (c0.bslot_text[k]) (void)hipFree(c0.bslot_text[k]);
+            if (c0.bslot_sa[k]) (void)hipFree(c0.bslot_sa[k]);
+            c0.bslot_text[k] = nullptr; c0.bslot_sa[k] = nullptr;
         }
-        for (hipEvent_t e : c.pool) (void)hipEventDestroy(e);
-        c.pool.clear();
-        if (c.pinned) (void)hipHostFree(c.pinned);
-        c.pinned = nullptr;
-        if (c.pinned_io) (void)hipHostFree(c.pinned_io);
-        c.pinned_io = nullptr;
-        if (c.readback) (void)hipEventDestroy(c.readback);
-        c.readback = nullptr;
-        if (c.stream) (void)hipStreamDestroy(c.stream);
-        c.stream = nullptr;
-        c.dev = -1;
+        c0.bslot_cap = 0;
+        for (hipStream_t *st : {&c0.b_in, &c0.b_sort, &c0.b_out}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
+        if (c0.diff_dev) (void)hipFree(c0.diff_dev);
+        if (c0.diff_idx) (void)hipFree(c0.diff_idx);
+        if (c0.diff_pinned) (void)hipHostFree(c0.diff_pinned);
+        c0.diff_dev = nullptr; c0.diff_idx = nullptr; c0.diff_pinned = nullptr;
+        c0.diff_dev_bytes = 0; c0.diff_idx_bytes = 0;
+        for (int k = 0; k < kCtxSlots; ++k) {
+            DeviceCtx &c = g_dev[d].slot[k];
+            std::lock_guard<std::mutex> lk(c.mu);
+            if (c.ws) (void)hipFree(c.ws);
+            c.ws = nullptr; c.ws_bytes = 0;
+            for (hipEvent_t e : c.pool) (void)hipEventDestroy(e);
+            c.pool.clear();
+            if (c.pinned) (void)hipHostFree(c.pinned);
+            c.pinned = nullptr;
+            if (c.pinned_io) (void)hipHostFree(c.pinned_io);
+            c.pinned_io = nullptr;
+            if (c.readback) (void)hipEventDestroy(c.readback);
+            c.readback = nullptr;
+            if (c.stream) (void)hipStreamDestroy(c.stream);
+            c.stream = nullptr;
+            c.dev = -1;
+        }
     }
 }
 

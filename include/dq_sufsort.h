@@ -108,12 +108,33 @@ int32_t dq_bsdiff_search_i64(const uint8_t *old_data, int64_t n, const int64_t *
  * dq_bsdiff_scan_i32 = the same up to the raw streams: ctrl receives *nctrl (add, copy, seek) triples (capacity
  *   ctrl_cap triples; m + 1 always suffices), diff / extra the raw bytes (capacity m each); stats (optional,
  *   3 entries): Search calls of the loop, windows requested from the device, positions asked again exactly.
+ *   (diff and extra are written without a capacity argument: together they never exceed m bytes.)
  * dq_bspatch_apply   = Patch.Apply(input, openPatchStream, output)                src/DeltaQ.BsDiff/Patch.cs:52-168
  *   host code only (no device needed).  out == NULL: only *out_len = size of the new file.  A patch the
  *   reference would reject with "Corrupt patch" returns DQ_ERR_BAD_ARGS with that message in dq_last_error(). */
 int32_t dq_bsdiff_create(const uint8_t *old_data, int64_t n, const uint8_t *new_data, int64_t m, uint8_t *patch,
                          int64_t cap, int64_t *patch_len, int32_t device);
 int64_t dq_bsdiff_patch_bound(int64_t n, int64_t m);
+
+/* ---- one old file, many new files (the many-files bsdiff path of the batch mode) --------------------------------
+ * Diff.Create sorts oldData on every call (Diff.cs:89-90); the suffix array depends on the old file alone.  An index
+ * holds (old, suffix array, the match search's prefix table) on one device; any number of new files are diffed
+ * against it, each call returning the patch dq_bsdiff_create(old, new) returns.
+ *   dq_bsdiff_index_create   d_old == d_sa == NULL: uploads old_data and sorts it (the index owns the buffers).
+ *                            Otherwise d_old / d_sa are the caller's device-resident text (n bytes) and suffix array
+ *                            (n int32) -- e.g. received by RCCL broadcast from the rank that sorted -- and must stay
+ *                            valid until dq_bsdiff_index_free.  old_data (host) is read by every diff (the scan loop
+ *                            walks it, Diff.cs:129-191) and must stay valid as long as the index.
+ *   dq_bsdiff_index_buffers  the device pointers (for a broadcast / gather by the caller) and n.
+ *   dq_bsdiff_index_diff     = Diff.Create(oldData, newData, ...) without its suffix sort.  Thread-safe: scan loops of
+ *                            concurrent callers take turns on the device, their bzip2 framing overlaps.
+ *   dq_bsdiff_index_free     releases the index (not the caller's buffers). */
+int32_t dq_bsdiff_index_create(const uint8_t *old_data, int64_t n, const void *d_old, const void *d_sa, int32_t device,
+                               void **index_out);
+int32_t dq_bsdiff_index_buffers(const void *index, const void **d_old, const void **d_sa, int64_t *n);
+int32_t dq_bsdiff_index_diff(const void *index, const uint8_t *new_data, int64_t m, uint8_t *patch, int64_t cap,
+                             int64_t *patch_len);
+void dq_bsdiff_index_free(void *index);
 int32_t dq_bsdiff_scan_i32(const uint8_t *old_data, int64_t n, const uint8_t *new_data, int64_t m, int64_t *ctrl,
                            int64_t ctrl_cap, int64_t *nctrl, uint8_t *diff, int64_t *ndiff, uint8_t *extra, int64_t *nextra,
                            int64_t *stats, int32_t device);

@@ -76,6 +76,80 @@ def test_scatter_sort_gather_world_size_2_gloo():
     assert max(r[1] for r in res) == 8
 
 
+def _packed(y):
+    import struct
+    b = bytearray(struct.pack("<Q", abs(y)))
+    if y < 0:
+        b[7] |= 0x80
+    return bytes(b)
+
+
+def _diff_worker(rank, world, port, q):
+    """diff_many_distributed on the CPU: the oracle stands in for the sorter and for the scan loop (the product has
+    no CPU path); what is under test is the plan, the broadcast of (text, suffix array), the scatter of the new
+    files and the gather of the patches."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import bz2
+    import torch.distributed as dist
+    import oracle
+    from deltaq_amd.batch import diff_many_distributed
+
+    class OracleSorter:
+        def Sort(self, text):
+            return oracle.divsufsort(np.asarray(text, dtype=np.uint8))
+
+    class OracleIndex:                       # Diff.Create from the BROADCAST suffix array: a wrong one gives wrong patches
+        def __init__(self, old, text_t, sa_t):
+            self.old = np.asarray(old, dtype=np.uint8)
+            assert np.array_equal(text_t.numpy(), self.old)
+            self.sa = sa_t.numpy().astype(np.int32)
+
+        def Create(self, new):
+            new = np.asarray(new, dtype=np.uint8)
+            ctrl, diff, extra, _ = oracle.bsdiff_scan(self.old, self.sa, new)
+            c = b"".join(_packed(int(v)) for v in ctrl.reshape(-1))
+            zc, zd, ze = bz2.compress(c), bz2.compress(diff.tobytes()), bz2.compress(extra.tobytes())
+            return b"BSDIFF40" + _packed(len(zc)) + _packed(len(zd)) + _packed(new.size) + zc + zd + ze
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        old = news = None
+        if rank == 0:
+            old = oracle.gen_enwik_like(30000, 7, 2048)
+            news = []
+            for j in range(7):
+                x = old.copy()
+                x[1000 * j:1000 * j + 50] = oracle.gen_uniform(50, j)
+                news.append(np.concatenate([x[:20000 - 1500 * j], oracle.gen_uniform(100 * j, 50 + j), x[20000 - 1500 * j:]]))
+            news += [np.zeros(0, np.uint8), old.copy(), oracle.gen_uniform(500, 99)]
+        out = diff_many_distributed(old, news, sorter_factory=OracleSorter, index_factory=OracleIndex)
+        if rank == 0:
+            from deltaq_amd import Patch        # Patch.Apply is host code: it runs without a GPU
+            ok = len(out) == len(news) and all(Patch.Apply(old, p) == x.tobytes() for p, x in zip(out, news))
+            q.put(("ok" if ok else "mismatch", len(out)))
+        else:
+            q.put(("ok" if out is None else "non-root returned data", 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_old_many_new_world_size_2_gloo(backend_lib):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_diff_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[0] == "ok" for r in res), res
+    assert max(r[1] for r in res) == 10
+
+
 def _gpu_worker(rank, world, port, q, backend):
     """The same plumbing with the PRODUCT's sorter: every rank is its own process with its own HIP context
     (the box has one GPU: with gloo both ranks use device 0; with nccl, world size 1)."""
@@ -119,6 +193,66 @@ def test_scatter_sort_gather_with_the_hip_sorter(backend, world):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[0] == "ok" for r in res), res
+    assert max(r[1] for r in res) == 9
+
+
+def _gpu_diff_worker(rank, world, port, q, backend):
+    """diff_many_distributed with the PRODUCT's pieces in every rank: rank 0 sorts on the device, text and suffix
+    array are broadcast (RCCL under nccl), every rank builds a DiffIndex on the received buffers."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from deltaq_amd import Diff, Patch
+    from deltaq_amd.batch import diff_many_distributed
+
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        old = news = None
+        if rank == 0:
+            old = oracle.gen_enwik_like(1_500_000, 7, 16384)
+            news = []
+            for j in range(6):
+                x = old.copy()
+                for e in range(40):
+                    a = (j * 7919 + e * 36_000) % (old.size - 100)
+                    x[a:a + 8] = oracle.gen_uniform(8, 100 * j + e)
+                news.append(np.concatenate([x[:700_000 - 9000 * j], oracle.gen_uniform(300 * j, 50 + j), x[700_000 - 9000 * j:]]))
+            news += [np.zeros(0, np.uint8), old.copy(), oracle.gen_uniform(70_000, 99)]
+        out = diff_many_distributed(old, news)
+        if rank == 0:
+            ok = len(out) == len(news)
+            for p, x in zip(out, news):
+                ok = ok and Patch.Apply(old, p) == x.tobytes()
+                ok = ok and p == Diff.CreateBytes(old, x, 0)             # the patch Diff.Create writes, byte for byte
+            q.put(("ok" if ok else "mismatch", len(out)))
+        else:
+            q.put(("ok" if out is None else "non-root returned data", 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
+def test_one_old_many_new_with_the_hip_pieces(backend, world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_diff_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]

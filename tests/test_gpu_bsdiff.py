@@ -92,3 +92,83 @@ def test_bzip2_blocks_through_the_device_sorter(backend_lib, oracle_mod):
     assert np.array_equal(reference_style_apply(oracle_mod, old, patch), new)
     assert Patch.Apply(old, patch) == new.tobytes()
     assert len(patch) < new.size // 2                                     # text compresses: the framing does its job
+
+
+def test_one_old_many_new_index(backend_lib, oracle_mod):
+    """DiffIndex: the old file is sorted once; every Create returns the patch Diff.Create writes for that pair.
+    Also built on device-resident (text, suffix array) tensors of the caller, as a broadcast receiver holds them."""
+    import torch
+    from deltaq_amd import Diff, DiffIndex, HipSuffixSort, Patch
+    rng = np.random.default_rng(5)
+    for old in (oracle_mod.gen_enwik_like(5_000_000, 4, 16384), oracle_mod.gen_uniform(300_000, 21),
+                oracle_mod.net_random_bytes(4096), np.zeros(0, np.uint8)):
+        news = [edited(rng, old, k) for k in (3, 40)] if old.size else []
+        news += [old.copy(), oracle_mod.gen_uniform(50_000, 3), np.zeros(0, np.uint8)]
+        want = [Diff.CreateBytes(old, x) for x in news]
+        with DiffIndex(old, 0) as ix:
+            for x, w in zip(news, want):
+                p = ix.Create(x)
+                assert p == w
+                assert Patch.Apply(old, p) == x.tobytes()
+        if old.size > 8192:
+            dT = torch.from_numpy(old).cuda()
+            dSA = HipSuffixSort(0).Sort(dT)
+            with DiffIndex(old, 0, device_text=dT, device_sa=dSA) as ix:
+                assert [ix.Create(x) for x in news] == want
+
+
+def test_concurrent_callers_on_one_device(backend_lib, oracle_mod):
+    """Four threads on one device at once: dq_bsdiff_create, diffs against a shared index, batched match searches
+    and plain sorts -- the scan-loop windows (polled pinned answers, second-stage mailbox, cached buffers) are one
+    per device, so callers must take turns without mixing their answers up."""
+    import threading
+    from deltaq_amd import Diff, DiffIndex, HipMatchSearch, HipSuffixSort, Patch
+    rng = np.random.default_rng(11)
+    old = oracle_mod.gen_enwik_like(2_000_000, 9, 16384)
+    news = [edited(rng, old, 25 + 5 * k) for k in range(4)]
+    want = [Diff.CreateBytes(old, x) for x in news]
+    sa = oracle_mod.divsufsort(old)
+    scans = np.sort(rng.integers(0, news[0].size, 20000)).astype(np.int64)
+    pos_w, len_w = oracle_mod.bsdiff_search(old, sa, news[0], scans)
+    index = DiffIndex(old, 0)
+    errs = []
+
+    def create(k):
+        for _ in range(3):
+            if Diff.CreateBytes(old, news[k]) != want[k]:
+                errs.append(("create", k))
+
+    def via_index(k):
+        for _ in range(3):
+            if index.Create(news[k]) != want[k]:
+                errs.append(("index", k))
+
+    def searches():
+        ms = HipMatchSearch(0)
+        for _ in range(3):
+            p, l = ms.Search(sa, old, news[0], scans)
+            if not (np.array_equal(p, pos_w) and np.array_equal(l, len_w)):
+                errs.append(("search",))
+
+    def sorts():
+        s = HipSuffixSort(0)
+        for _ in range(3):
+            if not np.array_equal(s.Sort(old), sa):
+                errs.append(("sort",))
+
+    def guarded(f, *a):
+        try:
+            f(*a)
+        except Exception as e:                                            # noqa: BLE001
+            errs.append((f.__name__, repr(e)))
+
+    ths = [threading.Thread(target=guarded, args=(create, 0)), threading.Thread(target=guarded, args=(via_index, 1)),
+           threading.Thread(target=guarded, args=(via_index, 2)), threading.Thread(target=guarded, args=(create, 3)),
+           threading.Thread(target=guarded, args=(searches,)), threading.Thread(target=guarded, args=(sorts,))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    index.close()
+    assert not errs, errs
+    assert Patch.Apply(old, want[2]) == news[2].tobytes()

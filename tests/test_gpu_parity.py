@@ -544,3 +544,41 @@ def test_shared_provider_from_many_threads(ldss, oracle_mod):
     assert not errs, errs
     for T, SA in zip(inputs, outs):
         assert np.array_equal(SA, oracle_mod.divsufsort(T))
+
+
+def test_shared_provider_overlaps_small_sorts(ldss, oracle_mod):
+    """A device has several contexts (stream + workspace each) for texts of up to 4 MiB, so the threads of a host
+    that shares one provider overlap their sorts instead of queueing behind one mutex: 8 threads x 4 KiB ... 1 MiB
+    inputs must get through faster together than one after the other (and every result must be right)."""
+    import threading
+    import time
+    sizes = [4096, 20_000, 65_536, 200_000, 300_000, 500_000, 800_000, 1 << 20]
+    inputs = [oracle_mod.gen_enwik_like(n, 300 + i, 8192) if i % 2 else oracle_mod.gen_uniform(n, 400 + i) for i, n in enumerate(sizes)]
+    expect = [oracle_mod.divsufsort(T) for T in inputs]
+    reps = 12
+    for T in inputs:
+        ldss.Sort(T)                                         # warm: workspaces of every slot size class
+    bad = []
+
+    def work(i):
+        for _ in range(reps):
+            if not np.array_equal(ldss.Sort(inputs[i]), expect[i]):
+                bad.append(i)
+
+    t0 = time.perf_counter()
+    for i in range(len(inputs)):
+        work(i)
+    serial = time.perf_counter() - t0
+    best = None
+    for _ in range(3):
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(inputs))]
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    assert not bad, bad
+    print(f"8 inputs x {reps}: one thread {serial*1e3:.1f} ms, 8 threads {best*1e3:.1f} ms ({serial/best:.2f}x)")
+    assert best < serial, (serial, best)
