@@ -187,9 +187,7 @@ def main() -> int:
                 "avg_launch_us": round(rs["ms"] / rs["launches"] * 1e3, 2),
                 "alg_bytes_per_launch": rs["alg_bytes"] // rs["launches"],
             }
-        kernels = {k: {"launches_per_step": v["launches"] / all_steps, "ms_per_step": round(v["ms"] / all_steps, 4),
-                       "alg_GBps": round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
-                   for k, v in prof_all.items() if v["launches"]}
+        kernels = kernel_table(prof_all, all_steps)
         out = {
             "metric": "MB of text suffix-sorted per second (bit-exact SA)",
             "value": round(value, 2), "unit": "MB/s",
@@ -219,6 +217,33 @@ def main() -> int:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def kernel_table(snapshot, steps):
+    """Per kernel category: launches and time per step, algorithmic GB/s (DESIGN.md section 4's bytes per element x
+    the elements of each launch, summed by the library) and its fraction of the 8 TB/s HBM peak."""
+    return {k: {"launches_per_step": round(v["launches"] / steps, 2), "ms_per_step": round(v["ms"] / steps, 4),
+                "alg_GBps": round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                "frac_of_hbm_peak": round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}
+            for k, v in snapshot.items() if v["launches"]}
+
+
+def profiled_kernels(sorter, host, dev, steps=2):
+    """kernel_table() of `steps` sorts of `host` with every launch bracketed by hipEvents (a pass of its own: the
+    events cost ~6 % of a step, so this is never the timed region)."""
+    import torch
+    from deltaq_amd import _abi
+    L = _abi.load()
+    text = torch.from_numpy(host).to(dev)
+    sa = torch.empty(host.size, dtype=torch.int32, device=dev)
+    sorter.Sort(text, sa)
+    L.dq_profile_reset()
+    L.dq_profile_enable(1)
+    for _ in range(steps):
+        sorter.Sort(text, sa)
+    torch.cuda.synchronize(dev)
+    L.dq_profile_enable(0)
+    return kernel_table(_abi.profile_snapshot(), steps)
 
 
 def pmc_traffic(kernel, args):
@@ -284,6 +309,8 @@ def other_configs(sorter, dev):
         abi = time_through_abi(sorter, host, None, reps=2)
         recs.append({"config": name, "device_resident_ms": round(ms, 3), "device_resident_MBps": round(host.size / 1e3 / ms, 1),
                      "through_abi_ms": abi["ms"], "through_abi_MBps": abi["MBps"], "rounds": rounds})
+        if "enwik" in name:
+            recs[-1]["kernels"] = profiled_kernels(sorter, host, dev)
         del host
     recs.append(match_search_record(sorter, dev))
     recs.append(reference_benchmark_shape(sorter))
@@ -355,7 +382,26 @@ def reference_benchmark_shape(sorter):
         ct = time.perf_counter() - t0
         rows.append({"bytes": size, "through_abi_us": round(sorted(ts)[len(ts) // 2] * 1e6, 1),
                      "cpu_oracle_us": round(ct * 1e6, 1), "bit_exact": bool(np.array_equal(ref, sa))})
-    return {"config": "reference benchmark shape: Sort(new Random(670761).NextBytes(size)), host interface", "sizes": rows}
+    # the same sizes with text-like content (the reference's users diff executables and text, not noise): device-wide
+    # pipeline with its doubling rounds instead of one radix sort
+    from tools import datagen
+    text_rows = []
+    for size in (65536, 262144, 1048576, 4194304):
+        T = datagen.gen_enwik_like(size, SEED_ENWIK, 65536)
+        sa = np.ones(size, np.int32)
+        sorter.Sort(T, sa)
+        ts = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            sorter.Sort(T, sa)
+            ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        ref = oracle.divsufsort(T)
+        ct = time.perf_counter() - t0
+        text_rows.append({"bytes": size, "through_abi_us": round(sorted(ts)[len(ts) // 2] * 1e6, 1),
+                          "cpu_oracle_us": round(ct * 1e6, 1), "bit_exact": bool(np.array_equal(ref, sa))})
+    return {"config": "reference benchmark shape: Sort(new Random(670761).NextBytes(size)), host interface", "sizes": rows,
+            "text_like_sizes": text_rows}
 
 
 def match_search_record(sorter, dev):
@@ -392,8 +438,11 @@ def match_search_record(sorter, dev):
 
 def batch_config4(world, rank, local_rank, dev, backend, sorter):
     """BASELINE configs[4]: 128 x 16 MiB independent buffers, LPT-sharded over the ranks, host buffers in
-    and out through dq_sufsort_hip_batch_i32 on each rank's GPU; no data-path collective.  Then, for
-    N > 1, once through the scatter / sort / gather layer over RCCL with a small batch, checked on rank 0."""
+    and out through dq_sufsort_hip_batch_i32 on each rank's GPU; no data-path collective.  Timed twice: with the
+    pageable buffers a P/Invoke caller hands over, and with page-locked ones (what separates PCIe / host-memory
+    contention between the ranks of a node from GPU time: per-rank host-copy GB/s are listed).  Then, for N > 1, the
+    two exchange layers once each over the process group (RCCL under nccl): scatter / sort / gather of a small
+    batch, and one old file + many new files (broadcast of text and suffix array, deltaq_amd.batch)."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -403,39 +452,67 @@ def batch_config4(world, rank, local_rank, dev, backend, sorter):
     L = _abi.load()
     plan = plan_shards([BATCH_BYTES] * BATCH_COUNT, world)
     mine = plan[rank]
+    cnt = len(mine)
     texts = [datagen.gen_uniform(BATCH_BYTES, SEED_BATCH + j) for j in mine]
     sas = [np.ones(BATCH_BYTES, np.int32) for _ in mine]           # pre-touched output pages
-    cnt = len(mine)
-    tp = (ctypes.c_void_p * cnt)(*[t.ctypes.data for t in texts])
-    sp = (ctypes.c_void_p * cnt)(*[a.ctypes.data for a in sas])
-    ln = (ctypes.c_int64 * cnt)(*[BATCH_BYTES] * cnt)
     devs = (ctypes.c_int32 * 1)(local_rank)
-    # warm the pipeline's slots and the workspace with two buffers
-    _abi.check(L.dq_sufsort_hip_batch_i32(min(cnt, 3), tp, ln, sp, 1, devs))
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    _abi.check(L.dq_sufsort_hip_batch_i32(cnt, tp, ln, sp, 1, devs))
-    wall = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    ln = (ctypes.c_int64 * cnt)(*[BATCH_BYTES] * cnt)
+    cdev = dev if backend == "nccl" else "cpu"
+
+    def run(tx, sx):
+        tp = (ctypes.c_void_p * cnt)(*[t.ctypes.data for t in tx])
+        sp = (ctypes.c_void_p * cnt)(*[a.ctypes.data for a in sx])
+        # warm the pipeline's slots and the workspace
+        _abi.check(L.dq_sufsort_hip_batch_i32(min(cnt, 3), tp, ln, sp, 1, devs))
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        _abi.check(L.dq_sufsort_hip_batch_i32(cnt, tp, ln, sp, 1, devs))
+        mine_s = time.perf_counter() - t0
+        walls = [mine_s]
+        if world > 1:
+            t = torch.zeros(world, dtype=torch.float64, device=cdev)
+            t[rank] = mine_s
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            walls = [float(x) for x in t.tolist()]
+        return walls
+
+    walls = run(texts, sas)
+    wall = max(walls)
+    # the same call on page-locked buffers (torch's pinned allocator; the library sees plain pointers)
+    pin_walls = None
+    try:
+        ptexts = [torch.from_numpy(t).pin_memory() for t in texts]
+        psas = [torch.empty(BATCH_BYTES, dtype=torch.int32).pin_memory() for _ in mine]
+        pin_walls = run([t.numpy() for t in ptexts], [a.numpy() for a in psas])
+        pinned_ok = all(np.array_equal(a.numpy(), b) for a, b in list(zip(psas, sas))[:2])
+        del ptexts, psas
+    except Exception as e:                              # pinned memory exhausted on a small host: report, go on
+        pinned_ok = repr(e)[:200]
     # device-resident rate of the same buffers (what `value` would be for this shape)
     dms = time_device(sorter, texts[0], dev, 8) if cnt else 0.0
     rec = None
     if rank == 0:
         import oracle
         ok = all(oracle.sufcheck_mt(texts[k], sas[k]) == 0 for k in range(min(cnt, 4)))
+        per_rank_bytes = [len(p) * BATCH_BYTES * 5 for p in plan]                      # text in + SA out
         rec = {"workload": "BASELINE configs[4]: 128 x 16 MiB uniform random (seeds 0x5EED0500+j), int32 SA",
                "entry": "dq_sufsort_hip_batch_i32 per rank (host pointers in/out, PCIe-inclusive)",
                "sharding": {"policy": "LPT over ranks (deltaq_amd.batch.plan_shards)",
                             "buffers_per_rank": [len(p) for p in plan]},
                "wall_ms": round(wall * 1e3, 2), "MBps": round(BATCH_COUNT * BATCH_BYTES / 1e6 / wall, 1),
+               "host_copy_GBps_per_rank": [round(b / w / 1e9, 2) for b, w in zip(per_rank_bytes, walls)],
                "device_resident_ms_per_buffer": round(dms, 3),
                "device_resident_MBps_per_gpu": round(BATCH_BYTES / 1e3 / dms, 1) if dms else None,
                "sufcheck_first_buffers": bool(ok)}
+        if pin_walls is not None:
+            rec["pinned_buffers"] = {"wall_ms": round(max(pin_walls) * 1e3, 2),
+                                     "MBps": round(BATCH_COUNT * BATCH_BYTES / 1e6 / max(pin_walls), 1),
+                                     "host_copy_GBps_per_rank": [round(b / w / 1e9, 2) for b, w in zip(per_rank_bytes, pin_walls)],
+                                     "same_suffix_arrays": pinned_ok}
+        if world == 1:
+            rec["cpu_replicas"] = cpu_replica_baseline(texts)
     del texts, sas
     if world > 1:
         # the gather layer over RCCL (torch.distributed "nccl"): 2 small buffers per rank, SAs to rank 0
@@ -451,7 +528,81 @@ def batch_config4(world, rank, local_rank, dev, backend, sorter):
         except Exception as e:                      # report, do not lose the bench line
             if rank == 0:
                 rec["rccl_scatter_sort_gather"] = {"backend": backend, "error": repr(e)[:300]}
+    many = one_old_many_new(world, rank, dev, backend)
+    if rank == 0 and many is not None:
+        rec["one_old_many_new"] = many
     return rec
+
+
+def one_old_many_new(world, rank, dev, backend):
+    """The many-files bsdiff path with its one exchange step: a 16 MiB old file, 4 new files per rank (copies with
+    ~200 small edits).  Rank 0 sorts the old file once, text + suffix array are broadcast (RCCL under nccl), every
+    rank diffs its share against a DiffIndex on the received buffers, patches are gathered and applied on rank 0.
+    Beside it: the same diffs with the old file sorted again for every pair (Diff.Create as the reference calls it)."""
+    import numpy as np
+    import torch.distributed as dist
+    from deltaq_amd import Diff, DiffIndex, Patch
+    from deltaq_amd.batch import diff_many_distributed
+    from tools import datagen
+    per_rank = 4
+    old = news = None
+    if rank == 0:
+        rng = np.random.default_rng(9)
+        old = datagen.gen_uniform(16 << 20, SEED_BATCH + 77)
+        news = []
+        for j in range(per_rank * world):
+            x = bytearray(old.tobytes())
+            for _ in range(200):
+                k, a, ln = int(rng.integers(0, 3)), int(rng.integers(0, len(x))), int(rng.integers(1, 300))
+                if k == 0:
+                    x[a:a] = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+                elif k == 1:
+                    del x[a:a + ln]
+                else:
+                    x[a:a + ln] = rng.integers(0, 256, min(ln, len(x) - a), dtype=np.uint8).tobytes()
+            news.append(np.frombuffer(bytes(x), dtype=np.uint8))
+    try:
+        if world > 1:
+            dist.barrier()
+            t0 = time.perf_counter()
+            patches = diff_many_distributed(old, news)
+            dt = time.perf_counter() - t0
+        else:
+            Diff.CreateBytes(old[:4096], news[0][:4096], dev.index)
+            t0 = time.perf_counter()
+            with DiffIndex(old, dev.index) as ix:
+                patches = [ix.Create(x) for x in news]
+            dt = time.perf_counter() - t0
+        if rank != 0:
+            return None
+        t0 = time.perf_counter()
+        again = [Diff.CreateBytes(old, x, dev.index) for x in news[:per_rank]]
+        per_pair = (time.perf_counter() - t0) / per_rank
+        ok = all(Patch.Apply(old, p) == x.tobytes() for p, x in zip(patches, news))
+        return {"old_bytes": int(old.size), "new_files": len(news), "exchange": "broadcast of text + suffix array, gather of patches"
+                if world > 1 else "none (one rank): DiffIndex built once",
+                "backend": backend if world > 1 else None, "wall_ms": round(dt * 1e3, 1),
+                "ms_per_new_file": round(dt * 1e3 / len(news), 1),
+                "ms_per_pair_with_its_own_sort": round(per_pair * 1e3, 1),
+                "patches_equal_per_pair_create": bool(patches[:per_rank] == again), "patches_apply": bool(ok)}
+    except Exception as e:                              # report, do not lose the bench line
+        return {"error": repr(e)[:300]} if rank == 0 else None
+
+
+def cpu_replica_baseline(texts):
+    """the generous CPU figure for the batch shape -- one 16 MiB buffer per host core at the
+    same time (the oracle's LibDivSufSort restatement releases the GIL inside its C call), as many replicas as cores,
+    at most the 128 buffers of the config."""
+    import concurrent.futures as cf
+    import oracle
+    k = max(1, min(os.cpu_count() or 1, len(texts), BATCH_COUNT))
+    oracle.divsufsort(texts[0][:1 << 16])
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(max_workers=k) as ex:
+        list(ex.map(oracle.divsufsort, texts[:k]))
+    dt = time.perf_counter() - t0
+    return {"replicas": k, "cores": k, "seconds": round(dt, 3), "MBps": round(k * BATCH_BYTES / 1e6 / dt, 1),
+            "kind": "port", "note": "oracle/divsufsort.c, one buffer per core concurrently"}
 
 
 def cpu_baseline(host, sa_dev):

@@ -43,8 +43,13 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
     uint64_t *__restrict__ t_rank, IdxT *__restrict__ t_suf,
     uint64_t *__restrict__ l_key, IdxT *__restrict__ l_suf,
     uint64_t *__restrict__ u_rank_end, IdxT *__restrict__ u_suf_end,      // U grows DOWNWARD from these
-    SmallGroupCounters *__restrict__ ctr)
+    SmallGroupCounters *__restrict__ ctr, const SmallGroupCounters *__restrict__ prev = nullptr)
 {
+    // chained rounds (no host round trip in between): the list length is what the previous round appended to T
+    if (prev) {
+        const int64_t real = (int64_t)(prev->tied_moved & 0xffffffffull);
+        m = real < m ? real : m;
+    }
     constexpr int kTile = mg_tile<kG>();
     constexpr int kScan = kG + kMgSpan;                 // scan coordinates c = e + kG, e = span position
     constexpr int kPer = (kScan + kMgThreads - 1) / kMgThreads;       // consecutive scan positions per thread

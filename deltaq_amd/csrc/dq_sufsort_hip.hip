@@ -735,8 +735,6 @@ struct SuffixSorter {
     int64_t fin_cap = 0, fin_left = 0;
     // round 0 was bucketed: however many suffixes are tied, they are tied shallowly (random-like text)
     bool shallow_ties = false;
-    // the next long-list round takes mid_group_round_kernel (see doubling_round_small)
-    bool mid_wanted = true;
     // largest group the LDS class finishes: 0 = off; DQ_MID_GROUPS = 0 | 256 | 512 | 1024 forces it (and keeps it on)
     static int mid_group_cap()
     {
@@ -744,7 +742,7 @@ struct SuffixSorter {
             const int g = atoi(v);
             return g >= 1024 ? 1024 : g >= 512 ? 512 : g >= 256 ? 256 : 0;
         }
-        return 512;         // (256 MiB of enwik-style text: 31.95 / 31.86 / 32.30 ms with 256 / 512 / 1024, 34.65 without)
+        return 1024;        // (256 MiB of enwik-style text: 34.65 ms without it, ~32 ms with 256 / 512 / 1024; 16 MiB: 5.15 -> 4.08 ms)
     }
 
     SuffixSorter(DeviceCtx &c_, hipStream_t st_, Workspace<IdxT> &w_, int64_t n_, IdxT *sa_)
@@ -1158,25 +1156,13 @@ struct SuffixSorter {
         SmallGroupCounters *ctr = reinterpret_cast<SmallGroupCounters *>(w.totals + 4);
         HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(SmallGroupCounters), st));
         const bool cap32 = m < kSgShortList;           // (cap 32 on long lists measured: radix -2.4 ms, this kernel +2.8 ms)
-        // Long lists whose groups still reach beyond 8 members (the first rounds of a text-like input): the groups of
-        // up to kG members are finished inside LDS by mid_group_round_kernel (dq_mid_groups.h), only longer ones
-        // take the radix passes.  Chosen while the previous round still sent a good part of its list to the radix
-        // path (unknown before the first round: tried there).
+        // The groups of up to mid_g members are finished inside LDS by mid_group_round_kernel (dq_mid_groups.h); only
+        // longer ones take the radix passes.  DQ_MID_GROUPS=0: the two-class scheme of before (groups of <= 8, or
+        // <= 32 on short lists, in small_group_round_kernel; everything else through the radix passes).
         const int mid_g = mid_group_cap();
-        // (forced by DQ_MID_GROUPS: on lists of any length, so that the tests reach it with small inputs)
-        const bool use_mid = mid_g > 0 && mid_wanted && (!cap32 || env("DQ_MID_GROUPS") || env("DQ_MID_SHORT"));
+        const bool use_mid = mid_g > 0;
         if (use_mid) {
-            const int64_t tile = mid_g == 256 ? mg_tile<256>() : mid_g == 512 ? mg_tile<512>() : mg_tile<1024>();
-            const dim3 grid((unsigned)((m + tile - 1) / tile));
-            auto go = [&](auto kern) -> int {
-                LAUNCH(L, DQ_K_MID_ROUND, m, m * (8 + wb + wb + wb + 8 + wb),
-                       hipLaunchKernelGGL(kern, grid, dim3(kMgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
-                                          (const IdxT *)w.ISA, m, n, h, kbits, d_sa, B, Bs, B + half, Bs + half, B + top,
-                                          Bs + top, ctr));
-                return DQ_OK;
-            };
-            const int rc = mid_g == 256 ? go(mid_group_round_kernel<IdxT, 256>)
-                         : mid_g == 512 ? go(mid_group_round_kernel<IdxT, 512>) : go(mid_group_round_kernel<IdxT, 1024>);
+            int rc = launch_mid_round(mid_g, m, A, As, B, Bs, h, kbits, ctr, nullptr, m * (8 + wb + wb + wb + 8 + wb));
             if (rc != DQ_OK) return rc;
         } else if (cap32) {
             constexpr int kTile = sg_tile<kSgMaxGShort>();
@@ -1200,9 +1186,6 @@ struct SuffixSorter {
             fprintf(stderr, "[dq] %s round h=%lld m=%lld -> tied %lld, to radix %lld, moved %lld\n",
                     use_mid ? "mid-group" : "small", (long long)h,
                     (long long)m, (long long)m1, (long long)mL, (long long)mU);
-        // the LDS class pays while a round has many groups beyond 8; once one sends less than 1/16 of its list to the
-        // radix path the small-group kernel (lighter per entry) takes over again
-        if (use_mid && !env("DQ_MID_GROUPS")) mid_wanted = mL * 16 >= m;
         if (mU > 0) {
             LAUNCH(L, DQ_K_ISA_UPDATE, mU, mU * (8 + wb + wb),
                    hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(mU)), dim3(kBlock), 0, st,
@@ -1223,9 +1206,8 @@ struct SuffixSorter {
         rcur ^= 1;
         m = m1 + mLs;
         // groups only ever split: once nothing went to the radix list, every group fits this round's cap
-        // (a mid-group round that sent nothing there says only that every group has <= kG members)
-        if (mL == 0 && !use_mid) small_cap = cap32 ? kSgMaxGShort : kSgMaxG;
-        only_small_groups = mL == 0 && !use_mid;
+        if (mL == 0) small_cap = use_mid ? mid_g : cap32 ? kSgMaxGShort : kSgMaxG;
+        only_small_groups = mL == 0;
         return DQ_OK;
     }
 
@@ -1234,7 +1216,24 @@ struct SuffixSorter {
     //      the current m, which is an upper bound for all later rounds.
     int doubling_rounds_small_chain()
     {
-        return small_cap == kSgMaxGShort ? small_chain<kSgMaxGShort>() : small_chain<kSgMaxG>();
+        return small_cap > kSgMaxGShort ? small_chain<0>() : small_cap == kSgMaxGShort ? small_chain<kSgMaxGShort>() : small_chain<kSgMaxG>();
+    }
+
+    // one round of mid_group_round_kernel<kG> on the list (A, As)[0, mm); prev: the previous chained round's counters
+    int launch_mid_round(int g, int64_t mm, const uint64_t *A, const IdxT *As, uint64_t *B, IdxT *Bs, int64_t hh, int kbits,
+                         SmallGroupCounters *ctr, const SmallGroupCounters *prev, int64_t alg_bytes)
+    {
+        const int64_t half = sg_half(), top = sg_top();
+        const int64_t tile = g == 256 ? mg_tile<256>() : g == 512 ? mg_tile<512>() : mg_tile<1024>();
+        const dim3 grid((unsigned)((mm + tile - 1) / tile));
+        auto go = [&](auto kern) -> int {
+            LAUNCH(L, DQ_K_MID_ROUND, mm, alg_bytes,
+                   hipLaunchKernelGGL(kern, grid, dim3(kMgThreads), 0, st, A, As, (const IdxT *)w.ISA, mm, n, hh, kbits, d_sa, B, Bs,
+                                      B + half, Bs + half, B + top, Bs + top, ctr, prev));
+            return DQ_OK;
+        };
+        return g == 256 ? go(mid_group_round_kernel<IdxT, 256>) : g == 512 ? go(mid_group_round_kernel<IdxT, 512>)
+                                                                            : go(mid_group_round_kernel<IdxT, 1024>);
     }
 
     template <int kCap>
@@ -1248,12 +1247,18 @@ struct SuffixSorter {
             uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
             IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
             const int kbits = std::min(bit_length((uint64_t)(n - 1) + (uint64_t)hr), 64 - rbits);   // (no radix keys are made)
-            constexpr int kTile = sg_tile<kCap>();                           // (every group has <= kCap members here)
-            LAUNCH(L, DQ_K_SMALL_ROUND, m_in, 0,
-                   hipLaunchKernelGGL((small_group_round_kernel<IdxT, kCap>), dim3((unsigned)((m_in + kTile - 1) / kTile)),
-                                      dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
-                                      (const IdxT *)w.ISA, m_in, n, hr, kbits, d_sa, B, Bs, B + half, Bs + half, B + top,
-                                      Bs + top, w.sg_ctr + r, r == 0 ? (const SmallGroupCounters *)nullptr : w.sg_ctr + r - 1));
+            if constexpr (kCap == 0) {                                       // (every group has <= small_cap members here)
+                const int rc = launch_mid_round(small_cap, m_in, A, As, B, Bs, hr, kbits, w.sg_ctr + r,
+                                                r == 0 ? (const SmallGroupCounters *)nullptr : w.sg_ctr + r - 1, 0);
+                if (rc != DQ_OK) return rc;
+            } else {
+                constexpr int kTile = sg_tile<kCap>();                       // (every group has <= kCap members here)
+                LAUNCH(L, DQ_K_SMALL_ROUND, m_in, 0,
+                       hipLaunchKernelGGL((small_group_round_kernel<IdxT, kCap>), dim3((unsigned)((m_in + kTile - 1) / kTile)),
+                                          dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
+                                          (const IdxT *)w.ISA, m_in, n, hr, kbits, d_sa, B, Bs, B + half, Bs + half, B + top,
+                                          Bs + top, w.sg_ctr + r, r == 0 ? (const SmallGroupCounters *)nullptr : w.sg_ctr + r - 1));
+            }
             LAUNCH(L, DQ_K_ISA_UPDATE, m_in, 0,
                    hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(m_in)), dim3(kBlock), 0, st,
                                       (const uint64_t *)(B + top), (const IdxT *)(Bs + top), (int64_t)0, w.ISA,

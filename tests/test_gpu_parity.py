@@ -346,6 +346,7 @@ FUZZ_ENVS = [
     {"DQ_FORCE_RSHIFT": "1", "DQ_SMALL_N": "0"},           # composite keys carry rank >> 1, true rank read from the ISA (n near 2^32)
     {"DQ_BUCKET": "1", "DQ_SMALL_N": "0"},                 # bucketed round 0 wherever packed words are chosen (+ its fallbacks)
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SMALL_N": "0"},   # round-0 keys from alphabetic codewords
+    {"DQ_MID_GROUPS": "0", "DQ_SMALL_N": "0"},             # doubling rounds with the small-group kernel + radix passes only
     {"DQ_MID_GROUPS": "256", "DQ_SMALL_N": "0"},           # doubling rounds through the LDS class for groups of up to 256 ...
     {"DQ_MID_GROUPS": "1024", "DQ_SMALL_N": "0", "DQ_PAIR_CHAINS": "0", "DQ_NO_BINNED_ISA": "1"},   # ... 1024 members
     {"DQ_PAIR_CHAINS": "2", "DQ_SMALL_N": "0"},            # tied pairs decided chain by chain as early and as often as allowed
@@ -485,7 +486,9 @@ FORCED_PATHS = [
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8"},    # coded round-0 keys (dq_alpha_code.h), dense doubling
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "1"},
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_NO_BINNED_ISA": "1", "DQ_NO_SMALL": "1"},
-    {"DQ_MID_GROUPS": "256"},                                    # tie groups of up to 256 / 1024 members finished in LDS (dq_mid_groups.h)
+    {"DQ_MID_GROUPS": "0"},                                      # the two-class rounds: small_group_round_kernel (<= 8 / 32) + radix passes
+    {"DQ_MID_GROUPS": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_NO_CHAIN": "1"},
+    {"DQ_MID_GROUPS": "256"},                                    # tie groups of up to 256 / 512 / 1024 members finished in LDS (dq_mid_groups.h; 1024 is the default)
     {"DQ_MID_GROUPS": "1024", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
     {"DQ_MID_GROUPS": "512", "DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_NO_CHAIN": "1"},
     {"DQ_PAIR_CHAINS": "2"},                                     # pair chains (dq_pair_chains.h) before / after every round
