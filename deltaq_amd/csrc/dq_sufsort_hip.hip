@@ -286,6 +286,17 @@ constexpr int64_t kSgShortList = 1 << 20;     // below this many tied suffixes a
 // ------------------------------------------------------------------ workspace carving
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// radix_rank_kernel tile geometry by list length (RankCfg below): status rows a sort of m entries may need
+// (2048-key tiles measured: 64 KiB 16.7 -> 11 us per pass, 256 KiB ~18 -> ~14; break-even at 2^20 entries, where 512 tiles
+// make the look-back chain as long as 85 big tiles are slow)
+constexpr int64_t kSmallTileMaxM = 1ll << 20;
+inline bool small_tiles(int64_t m) { return m <= kSmallTileMaxM; }
+inline size_t status_tiles(size_t m)
+{
+    const size_t small = (m < (size_t)kSmallTileMaxM ? m : (size_t)kSmallTileMaxM) / 2048;
+    return std::max(m / 8192, small) + 2;
+}
+
 template <typename IdxT>
 struct Workspace {
     uint8_t *text;
@@ -330,8 +341,9 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.codetab = (uint16_t *)take(512);
     w.pc_tiles = (uint32_t *)take((un / 2048 + 4) * 8);
     w.bytehist = (int64_t *)take((size_t)(kRadixSize + 16) * 8);       // + the 8 k-gram sample counters + the long-run flag
-    // smallest tile is 8192 keys; 8-byte status words once a list reaches 2^30 entries
-    w.ctl_status_bytes = (size_t)kMaxPasses * align_up(256 + (un / 8192 + 2) * kRadixSize * (un >= (1ull << 30) ? 8 : 4));
+    // smallest tile is 8192 keys (2048 for lists of up to kSmallTileMaxM entries, see RankCfg); 8-byte status words
+    // once a list reaches 2^30 entries
+    w.ctl_status_bytes = (size_t)kMaxPasses * align_up(256 + status_tiles(un) * kRadixSize * (un >= (1ull << 30) ? 8 : 4));
     w.ctl_status = take(w.ctl_status_bytes);
     w.seg_status_bytes = 256 + 3 * (un / kSegFusedTile + 2) * 8;
     w.seg_status = take(w.seg_status_bytes);
@@ -346,11 +358,15 @@ inline int bit_length(uint64_t x) { return x == 0 ? 1 : 64 - __builtin_clzll(x);
 // (tools/kbench, 64 Mi keys, random digits): 512 threads; packed-word passes 24 keys/thread
 // (12288-key tiles, ~48-key runs per digit), LDS match tables; pair passes 20 keys/thread,
 // ballot match; the tile is staged through LDS in 2 position ranges (half the LDS footprint).
-template <typename IdxT, int kMode> struct RankCfg {
+//
+// Lists of up to kSmallTileMaxM entries are launch-bound, and what a pass costs there is the LIFE of one tile (load,
+// ranking, exchange, look-back, stores: ~17-22 us for the big tiles whatever their number -- 64 KiB ... 1 MiB of
+// text spend half their sort in these passes): they take 2048-key tiles (256 threads x 8), several per CU at once.
+template <typename IdxT, int kMode, bool kSmall = false> struct RankCfg {
     static constexpr bool kWords = (kMode == kTextPacked || kMode == kKeys || kMode == kKeysLast || kMode == kKeysLastTies);
     // (a 1024-thread tile for the tie-recording last pass, whose runs are 4-byte SA entries, measured +18 %)
-    static constexpr int kThreads = 512;
-    static constexpr int kItems = kWords ? 24 : (sizeof(IdxT) == 4 ? 20 : 16);
+    static constexpr int kThreads = kSmall ? 256 : 512;
+    static constexpr int kItems = kSmall ? 8 : kWords ? 24 : (sizeof(IdxT) == 4 ? 20 : 16);
     static constexpr int kMinWaves = 2;
     static constexpr int kRounds = 2;
     // LDS match tables beat 8 ballots on near-uniform digits (words: -6%), but equal digits in a wave are
@@ -366,20 +382,20 @@ template <typename IdxT>
 int prepare_status(Launcher &L, Workspace<IdxT> &w, int64_t m, int passes, int from = 0)
 {
     const size_t word = m < (1ll << 30) ? 4 : 8;
-    const size_t stride = align_up(256 + ((size_t)m / 8192 + 2) * kRadixSize * word);
+    const size_t stride = align_up(256 + status_tiles((size_t)m) * kRadixSize * word);
     if ((size_t)passes * stride > w.ctl_status_bytes) return fail(DQ_ERR_HIP, "status buffer too small");
     w.ctl_status_stride = stride;
     if (passes > from) HIP_TRY(hipMemsetAsync(w.ctl_status + (size_t)from * stride, 0, (size_t)(passes - from) * stride, L.st));
     return DQ_OK;
 }
 
-template <typename IdxT, typename StatusT, int kMode, bool kCoded = false>
+template <typename IdxT, typename StatusT, int kMode, bool kCoded = false, bool kSmall = false>
 int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin,
                      uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb, int ib,
                      uint32_t *ebits = nullptr, uint64_t *seam_tab = nullptr, int shift_override = -1,
                      int keybits = 0)
 {
-    using Cfg = RankCfg<IdxT, kMode>;
+    using Cfg = RankCfg<IdxT, kMode, kSmall>;
     constexpr int kItems = Cfg::kItems;
     constexpr int kThreads = Cfg::kThreads;
     constexpr int kTileN = kThreads * kItems;
@@ -412,6 +428,9 @@ int rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *
               IdxT *vout, int64_t m, int pass, int kb, int ib = 0, uint32_t *ebits = nullptr,
               uint64_t *seam_tab = nullptr, int shift_override = -1, int keybits = 0)
 {
+    if (small_tiles(m))
+        return launch_rank_pass<IdxT, uint32_t, kMode, kCoded, true>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits,
+                                                                     seam_tab, shift_override, keybits);
     if (m < (1ll << 30))
         return launch_rank_pass<IdxT, uint32_t, kMode, kCoded>(L, w, kin, vin, kout, vout, m, pass, kb, ib, ebits,
                                                                seam_tab, shift_override, keybits);
@@ -633,7 +652,9 @@ int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int k
                  bool seams = true, int64_t h_fin = -1)
 {
     using Cfg = RankCfg<IdxT, kKeysLastTies>;
-    const int64_t ntiles = (n + Cfg::kThreads * Cfg::kItems - 1) / (Cfg::kThreads * Cfg::kItems);
+    using CfgS = RankCfg<IdxT, kKeysLastTies, true>;
+    const int64_t tile_keys = small_tiles(n) ? CfgS::kThreads * CfgS::kItems : Cfg::kThreads * Cfg::kItems;
+    const int64_t ntiles = (n + tile_keys - 1) / tile_keys;
     const int pass = kb - 1;
     char *area = w.ctl_status + (size_t)pass * w.ctl_status_stride;
     const int64_t *dofs = w.digit_offset + pass * kRadixSize;
@@ -735,14 +756,17 @@ struct SuffixSorter {
     int64_t fin_cap = 0, fin_left = 0;
     // round 0 was bucketed: however many suffixes are tied, they are tied shallowly (random-like text)
     bool shallow_ties = false;
-    // largest group the LDS class finishes: 0 = off; DQ_MID_GROUPS = 0 | 256 | 512 | 1024 forces it (and keeps it on)
-    static int mid_group_cap()
+    // largest group the LDS class finishes: 0 = off; DQ_MID_GROUPS = 0 | 256 | 512 | 1024 forces it.  The walk over a
+    // group costs its members ~group size each, the radix passes cost launches: 512 on long lists (256 MiB of
+    // enwik-style text: 31.2 ms, 32.3 with 1024, 33.9 without the class), 1024 on the launch-bound short ones
+    // (16 MiB: 4.1 - 4.3 ms against 5.2; 64 KiB: 0.56 against 0.76).
+    static int mid_group_cap(int64_t list_len)
     {
         if (const char *v = env("DQ_MID_GROUPS")) {
             const int g = atoi(v);
             return g >= 1024 ? 1024 : g >= 512 ? 512 : g >= 256 ? 256 : 0;
         }
-        return 1024;        // (256 MiB of enwik-style text: 34.65 ms without it, ~32 ms with 256 / 512 / 1024; 16 MiB: 5.15 -> 4.08 ms)
+        return list_len >= kSgShortList ? 512 : 1024;
     }
 
     SuffixSorter(DeviceCtx &c_, hipStream_t st_, Workspace<IdxT> &w_, int64_t n_, IdxT *sa_)
@@ -1159,7 +1183,7 @@ struct SuffixSorter {
         // The groups of up to mid_g members are finished inside LDS by mid_group_round_kernel (dq_mid_groups.h); only
         // longer ones take the radix passes.  DQ_MID_GROUPS=0: the two-class scheme of before (groups of <= 8, or
         // <= 32 on short lists, in small_group_round_kernel; everything else through the radix passes).
-        const int mid_g = mid_group_cap();
+        const int mid_g = mid_group_cap(m);
         const bool use_mid = mid_g > 0;
         if (use_mid) {
             int rc = launch_mid_round(mid_g, m, A, As, B, Bs, h, kbits, ctr, nullptr, m * (8 + wb + wb + wb + 8 + wb));
