@@ -29,6 +29,23 @@ def test_hostile_patches_under_asan_ubsan():
     assert "ok" in r.stdout
 
 
+def test_host_pieces_from_six_threads_under_tsan():
+    """dq_bz2.h / dq_bspatch.h / dq_alpha_code.h run on the callers' threads (three framing threads per Diff.Create):
+    six threads at once under ThreadSanitizer -- no shared mutable state (the CRC table is a compile-time constant,
+    the codeword tables are per call)."""
+    exe = os.path.join(NATIVE, "host_tsan")
+    src = os.path.join(NATIVE, "host_tsan.cpp")
+    deps = [src] + [os.path.join(CSRC, h) for h in ("dq_bspatch.h", "dq_bsdiff.h", "dq_bz2.h", "dq_alpha_code.h")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", src, "-o", exe, "-pthread"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    if "unexpected memory mapping" in r.stderr:                    # (a kernel whose ASLR layout TSan cannot shadow)
+        import pytest
+        pytest.skip("ThreadSanitizer cannot run on this kernel")
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    assert "ThreadSanitizer" not in r.stderr, r.stderr
+
+
 def packed(y):
     b = bytearray(struct.pack("<Q", abs(y)))
     if y < 0:
