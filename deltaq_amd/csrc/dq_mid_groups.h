@@ -26,6 +26,7 @@
 #include <type_traits>
 #include "dq_device_utils.h"
 #include "dq_small_groups.h"
+#include "dq_runs.h"
 
 namespace dq {
 
@@ -43,7 +44,9 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
     uint64_t *__restrict__ t_rank, IdxT *__restrict__ t_suf,
     uint64_t *__restrict__ l_key, IdxT *__restrict__ l_suf,
     uint64_t *__restrict__ u_rank_end, IdxT *__restrict__ u_suf_end,      // U grows DOWNWARD from these
-    SmallGroupCounters *__restrict__ ctr, const SmallGroupCounters *__restrict__ prev = nullptr)
+    SmallGroupCounters *__restrict__ ctr, const SmallGroupCounters *__restrict__ prev = nullptr,
+    const uint32_t *__restrict__ RL = nullptr /* run lengths of the text (dq_runs.h), or none */,
+    const uint8_t *__restrict__ text = nullptr, int run_order = 0 /* 1: this is the run-order round */)
 {
     // chained rounds (no host round trip in between): the list length is what the previous round appended to T
     if (prev) {
@@ -153,8 +156,19 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
     for (int k = 0; k < kMgItems; ++k) {
         k2[k] = 0;
         if (own[k] || own_large[k]) {
-            const int64_t q = (int64_t)s[k] + h;
-            k2[k] = q < n ? (ElemT)((int64_t)ISA[q] + h) : (ElemT)(n - 1 - (int64_t)s[k]);     // as gather_key2_kernel
+            // (dq_runs.h: a member that starts with a run of >= h equal bytes takes the rank behind its run; in the
+            // run-order round its key is the run's own order, and everybody else's 0 -- no split)
+            int64_t off = h;
+            bool keyed = false;
+            if (RL) {
+                const uint32_t r = RL[s[k]];
+                if (run_order) { k2[k] = (int64_t)r >= h ? (ElemT)run_order_key(text, n, (int64_t)s[k], r) : (ElemT)0; keyed = true; }
+                else if ((int64_t)r > h) off = (int64_t)r;
+            }
+            if (!keyed) {
+                const int64_t q = (int64_t)s[k] + off;
+                k2[k] = q < n ? (ElemT)((int64_t)ISA[q] + h) : (off > h ? (ElemT)0 : (ElemT)(n - 1 - (int64_t)s[k]));   // as gather_key2_kernel
+            }
         }
     }
 #pragma unroll

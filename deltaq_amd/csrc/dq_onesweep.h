@@ -734,6 +734,7 @@ __global__ __launch_bounds__(kBlock) void text_hist_kernel(const uint8_t *__rest
     const uint4 *t16 = reinterpret_cast<const uint4 *>(text);      // text is 16-byte aligned
     const int64_t chunks = n >> 4;
     bool long_run = false;
+    unsigned long long flat_chunks = 0;                  // 16-byte chunks made of one byte value (wave-uniform count)
     for (int64_t i = hblock * kBlock + tid; i < chunks; i += nblocks * kBlock) {
         const uint4 v = t16[i];
         const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
@@ -742,6 +743,7 @@ __global__ __launch_bounds__(kBlock) void text_hist_kernel(const uint8_t *__rest
         const bool flat = v.x == v.y && v.y == v.z && v.z == v.w && v.x == (v.x & 0xffu) * 0x01010101u;
         const uint64_t fb = __ballot(flat);
         long_run |= (fb & (fb >> 1) & (fb >> 2) & (fb >> 3)) != 0;
+        flat_chunks += (unsigned long long)__popcll(fb);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -755,6 +757,8 @@ __global__ __launch_bounds__(kBlock) void text_hist_kernel(const uint8_t *__rest
     const uint32_t c = hist[tid * 4] + hist[tid * 4 + 1] + hist[tid * 4 + 2] + hist[tid * 4 + 3];
     if (c) atomicAdd(&bytehist[tid], (unsigned long long)c);
     if (kgram_coll && long_run && lane_id() == 0) atomicOr(&kgram_coll[8], 1ull);      // (wave-uniform flag)
+    // kgram_coll[9]: how much of the text lies in runs -- dq_runs.h pays where that is a good part of it
+    if (kgram_coll && flat_chunks && lane_id() == 0) atomicAdd(&kgram_coll[9], flat_chunks);
 }
 
 // digit_offset[p][d] for p < kb (one workgroup per digit place p)

@@ -8,6 +8,7 @@
 // a proper prefix sorts first): suffixes that run off the end of the text are
 // resolved by gather_key2's "past the end" rule, never by the zero padding.
 #pragma once
+#include "dq_runs.h"
 #include "dq_device_utils.h"
 
 namespace dq {
@@ -25,13 +26,27 @@ __global__ __launch_bounds__(kBlock) void gather_key2_kernel(uint64_t *__restric
                                                              const IdxT *__restrict__ suf,
                                                              const IdxT *__restrict__ ISA,
                                                              int64_t m, int64_t n, int64_t h, int kbits,
-                                                             int rshift = 0)
+                                                             int rshift = 0,
+                                                             const uint32_t *__restrict__ RL = nullptr /* dq_runs.h, or none */,
+                                                             const uint8_t *__restrict__ text = nullptr, int run_order = 0)
 {
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < m;
          j += (int64_t)gridDim.x * kBlock) {
         const int64_t s = (int64_t)suf[j];
-        const int64_t q = s + h;
-        const uint64_t k2 = q < n ? (uint64_t)((int64_t)ISA[q] + h) : (uint64_t)(n - 1 - s);
+        int64_t off = h;
+        uint64_t k2 = 0;
+        bool keyed = false;
+        if (RL) {
+            // a suffix that starts with a run of >= h equal bytes: the run's own order (run-order round), or the rank
+            // behind the run (every later round); the text ending behind the run sorts first
+            const uint32_t r = RL[s];
+            if (run_order) { k2 = (int64_t)r >= h ? (uint64_t)run_order_key(text, n, s, r) : 0ull; keyed = true; }
+            else if ((int64_t)r > h) off = (int64_t)r;
+        }
+        if (!keyed) {
+            const int64_t q = s + off;
+            k2 = q < n ? (uint64_t)((int64_t)ISA[q] + h) : (off > h ? 0ull : (uint64_t)(n - 1 - s));
+        }
         comp[j] = ((comp[j] >> rshift) << kbits) | k2;        // rshift = 1: see seg_fused_kernel's rank_from_isa
     }
 }

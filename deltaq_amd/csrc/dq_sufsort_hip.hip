@@ -39,6 +39,7 @@
 #include "dq_small.h"
 #include "dq_small_groups.h"
 #include "dq_mid_groups.h"
+#include "dq_runs.h"
 #include "dq_ties.h"
 #include "dq_isa_pairs.h"
 #include "dq_bucket_sort.h"
@@ -115,7 +116,7 @@ const char *const kKernelNames[DQ_K_COUNT] = {
     "tie_seam_kernel", "tie_collect_kernel", "small_group_finish_kernel", "small_group_round_kernel",
     "isa_update_kernel", "isa_from_pairs_kernel", "key2_from_pairs_kernel", "gather_key2_kernel",
     "gather_text_key_kernel", "isa_from_sa_kernel", "small_sufsort_kernel", "bucket_sort_kernel",
-    "match_search_kernel", "pair_chain_kernels", "mid_group_round_kernel"};
+    "match_search_kernel", "pair_chain_kernels", "mid_group_round_kernel", "runlen_kernels"};
 
 struct ProfRec { int cat; hipEvent_t a, b; int64_t elems, bytes; };
 
@@ -308,6 +309,9 @@ struct Workspace {
     uint32_t *hist_partial;     // [kHistBlocks][8][256]
     uint16_t *codetab;          // [256] codewords of the coded round 0 (dq_alpha_code.h)
     uint32_t *pc_tiles;         // per-tile counts / prefix sums of the pair-chain phase (dq_pair_chains.h)
+    uint32_t *RL;               // run lengths of the text (dq_runs.h; int32 indices only)
+    uint32_t *run_lead, *run_carry;   // per 4096-byte chunk
+    uint8_t *run_link;
     int64_t *digit_offset;      // [8][256]
     int64_t *bytehist;          // [256]
     char *ctl_status;           // per digit pass: OnesweepCtl (256 B) + the tiles' status words
@@ -340,6 +344,13 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.digit_offset = (int64_t *)take((size_t)kMaxPasses * kRadixSize * 8);
     w.codetab = (uint16_t *)take(512);
     w.pc_tiles = (uint32_t *)take((un / 2048 + 4) * 8);
+    if (sizeof(IdxT) == 4) {
+        const size_t nchunks = un / kRunChunk + 2;
+        w.RL = (uint32_t *)take(un * 4);
+        w.run_lead = (uint32_t *)take(nchunks * 4);
+        w.run_carry = (uint32_t *)take(nchunks * 4);
+        w.run_link = (uint8_t *)take(nchunks);
+    }
     w.bytehist = (int64_t *)take((size_t)(kRadixSize + 16) * 8);       // + the 8 k-gram sample counters + the long-run flag
     // smallest tile is 8192 keys (2048 for lists of up to kSmallTileMaxM entries, see RankCfg); 8-byte status words
     // once a list reaches 2^30 entries
@@ -531,7 +542,7 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
 {
     *coded_out = false;
     const int blocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 4) + kBlock - 1) / kBlock + 1);
-    HIP_TRY(hipMemsetAsync(w.bytehist, 0, (256 + 9) * 8, L.st));
+    HIP_TRY(hipMemsetAsync(w.bytehist, 0, (256 + 10) * 8, L.st));
     // (+1 workgroup: the k-gram sample, whose 8 counters sit right behind the byte histogram: one readback)
     LAUNCH(L, DQ_K_TEXT_HIST, n, n,
            hipLaunchKernelGGL(text_hist_kernel, dim3(blocks + 1), dim3(kBlock), 0, L.st,
@@ -539,7 +550,7 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
                               reinterpret_cast<unsigned long long *>(w.bytehist + 256)));
     int kb = 8;
     bool packed = false;
-    HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, (256 + 9) * 8, hipMemcpyDeviceToHost, L.st));
+    HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, (256 + 10) * 8, hipMemcpyDeviceToHost, L.st));
     HIP_TRY(hipEventRecord(c.readback, L.st));
     // While the host waits for the histogram and picks the key width, the device zeroes what the passes
     // need whatever that choice is: the look-back state of the first 3 passes (all the bucketed round 0 runs;
@@ -748,6 +759,9 @@ struct SuffixSorter {
     int rbits = 0;
     // the list already holds composite keys (rank << kbits | key2) for the next doubling round
     bool keys_ready = false;
+    // the list came out of the suffix-binned words in TEXT order (build_isa_binned): the members of a group are not
+    // adjacent until a radix round has sorted it, so no small-group / LDS-class round and no pair chains before that
+    bool list_ungrouped = false;
     // the last small-group round sent nothing to the radix list: every group has <= small_cap members
     bool only_small_groups = false;
     int small_cap = kSgMaxG;
@@ -756,6 +770,11 @@ struct SuffixSorter {
     int64_t fin_cap = 0, fin_left = 0;
     // round 0 was bucketed: however many suffixes are tied, they are tied shallowly (random-like text)
     bool shallow_ties = false;
+    // runs of one byte (dq_runs.h): text_hist_kernel saw a run of >= 64 equal bytes; the doubling rounds then order
+    // the suffixes inside runs by the run's own structure (w.RL) instead of log2(run length) rounds
+    bool runs_wanted = false, runs_on = false;
+    int run_order = 0;                  // 1 while the run-order round is being launched
+    const uint32_t *rl() const { return runs_on ? w.RL : nullptr; }
     // largest group the LDS class finishes: 0 = off; DQ_MID_GROUPS = 0 | 256 | 512 | 1024 forces it.  The walk over a
     // group costs its members ~group size each, the radix passes cost launches: 512 on long lists (256 MiB of
     // enwik-style text: 31.2 ms, 32.3 with 1024, 33.9 without the class), 1024 on the launch-bound short ones
@@ -858,7 +877,7 @@ struct SuffixSorter {
         }
         // Otherwise the list is taken from the words: it comes out in suffix order, not with the members of a
         // group adjacent, so the first doubling round takes the radix path (which sorts it); key2 is gathered here.
-        const bool with_key2 = true;
+        const bool with_key2 = !runs_wanted;               // (runs: the first round's keys are not ISA[s + h], see run())
         const int kbits = bit_length((uint64_t)(n - 1) + (uint64_t)kb);
         unsigned long long *cnt = reinterpret_cast<unsigned long long *>(w.totals + 3);
         HIP_TRY(hipMemsetAsync(cnt, 0, 8, st));
@@ -868,6 +887,7 @@ struct SuffixSorter {
                                   0, st, (const uint64_t *)P0, n, ib, (const IdxT *)w.ISA, (int64_t)kb, kbits, with_key2,
                                   keys, w.Va, cnt));
         keys_ready = with_key2;
+        list_ungrouped = true;
         return DQ_OK;
     }
 
@@ -995,6 +1015,13 @@ struct SuffixSorter {
         // must be the caller's SA, which is why the key width is chosen first
         rc = onesweep_sort_text_prepare<IdxT>(L, c, w, n, &kb, &packed, &coded);
         if (rc != DQ_OK) return rc;
+        // (c.pinned still holds the byte histogram, the k-gram sample and the long-run flag of text_hist_kernel)
+        // (run lengths + the run-order round cost about one doubling round: worth it where a good part of the text lies
+        // in runs -- padded images, sparse files; measured on the image's shared libraries, whose long tie tails are
+        // code repeated for several targets, not runs: 5-20 % slower with it.  1/16 of the text in 16-byte chunks of one value)
+        runs_wanted = sizeof(IdxT) == 4 && c.pinned[256 + 8] != 0 && n >= (1 << 16) && c.pinned[256 + 9] * 16 * 16 >= n;
+        if (const char *v = env("DQ_RUNS")) runs_wanted = sizeof(IdxT) == 4 && atoi(v) != 0;
+        if (const char *v = env("DQ_MID_GROUPS")) runs_wanted = runs_wanted && atoi(v) >= 256;   // (the LDS class carries the run offsets)
         V[kb & 1] = d_sa;
         V[(kb & 1) ^ 1] = w.Va;
         // Random-like input (packed words = few ties expected) of a size whose 2-byte buckets fit a workgroup's
@@ -1150,10 +1177,12 @@ struct SuffixSorter {
         } else {
             LAUNCH(L, DQ_K_GATHER_KEY2, m, m * (8 + wb + wb + 8),
                    hipLaunchKernelGGL(gather_key2_kernel<IdxT>, dim3(grid_for(m)), dim3(kBlock), 0, st, Kr[rcur],
-                                      (const IdxT *)Vr[rcur], (const IdxT *)w.ISA, m, n, h, kbits, rshift));
+                                      (const IdxT *)Vr[rcur], (const IdxT *)w.ISA, m, n, h, kbits, rshift, rl(),
+                                      (const uint8_t *)w.text, run_order));
         }
         int rc = sort_pairs(Kr, Vr, m, kbits + rbits - rshift, rcur);
         if (rc != DQ_OK) return rc;
+        list_ungrouped = false;
         int64_t m2 = 0;
         rc = rebucket<IdxT, false, true, true>(L, c, w, Kr[rcur], (const IdxT *)Vr[rcur], m, kbits, 0, d_sa,
                                                Kr[rcur ^ 1], Vr[rcur ^ 1], &m2, rshift);
@@ -1253,7 +1282,7 @@ struct SuffixSorter {
         auto go = [&](auto kern) -> int {
             LAUNCH(L, DQ_K_MID_ROUND, mm, alg_bytes,
                    hipLaunchKernelGGL(kern, grid, dim3(kMgThreads), 0, st, A, As, (const IdxT *)w.ISA, mm, n, hh, kbits, d_sa, B, Bs,
-                                      B + half, Bs + half, B + top, Bs + top, ctr, prev));
+                                      B + half, Bs + half, B + top, Bs + top, ctr, prev, rl(), (const uint8_t *)w.text, run_order));
             return DQ_OK;
         };
         return g == 256 ? go(mid_group_round_kernel<IdxT, 256>) : g == 512 ? go(mid_group_round_kernel<IdxT, 512>)
@@ -1405,6 +1434,25 @@ struct SuffixSorter {
         return DQ_OK;
     }
 
+    // RL[i] = number of equal bytes the text has from position i on (dq_runs.h): chunk pass, carry across chunks, final pass
+    int compute_run_lengths()
+    {
+        if constexpr (sizeof(IdxT) != 4) {
+            return fail(DQ_ERR_HIP, "run lengths: int32 indices only");
+        } else {
+            const int64_t nchunks = (n + kRunChunk - 1) / kRunChunk;
+            LAUNCH(L, DQ_K_RUNS, n, 2 * n + 4 * n,
+                   hipLaunchKernelGGL(runlen_chunk_kernel<false>, dim3((unsigned)nchunks), dim3(kRunThreads), 0, st,
+                                      (const uint8_t *)w.text, n, w.run_lead, w.run_link, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+                   hipLaunchKernelGGL(runlen_carry_kernel, dim3(1), dim3(kRunScanThreads), 0, st, (const uint32_t *)w.run_lead,
+                                      (const uint8_t *)w.run_link, nchunks, w.run_carry);
+                   hipLaunchKernelGGL(runlen_chunk_kernel<true>, dim3((unsigned)nchunks), dim3(kRunThreads), 0, st,
+                                      (const uint8_t *)w.text, n, (uint32_t *)nullptr, (uint8_t *)nullptr,
+                                      (const uint32_t *)w.run_carry, w.RL));
+            return DQ_OK;
+        }
+    }
+
     int run()
     {
         t_info[0] = t_info[1] = t_info[2] = 0;
@@ -1417,10 +1465,25 @@ struct SuffixSorter {
 
         bool sparse = m * 6 <= n || shallow_ties;
         if (const char *v = env("DQ_SPARSE")) sparse = atoi(v) != 0;
-        if (keys_ready) sparse = false;      // the ISA exists and the list is already keyed for a doubling round
+        if (keys_ready || list_ungrouped) sparse = false;      // the ISA exists and the list is keyed / laid out for a radix round
         if (sparse) rc = finish_sparse();
         else if (!dense_built) rc = build_isa(Kr[rcur], Vr[rcur], m);
         if (rc != DQ_OK) return rc;
+
+        // Runs of one byte (dq_runs.h): run lengths of the text, then ONE round that orders the members of every
+        // group inside a run by the run's own structure; from then on they gather the rank behind their run.
+        if (runs_wanted && m > 0 && 32 + rbits <= 64 && ((uses_small_round(m) && !list_ungrouped) ? mid_group_cap(m) > 0 : true)) {
+            rc = compute_run_lengths();
+            if (rc != DQ_OK) return rc;
+            runs_on = true;
+            run_order = 1;
+            t_info[0] += 1;
+            t_info[2] += m;
+            if (env("DQ_TRACE")) fprintf(stderr, "[dq] run-order round at h=%lld on %lld tied suffixes\n", (long long)h, (long long)m);
+            rc = (uses_small_round(m) && !list_ungrouped) ? doubling_round_small(32) : doubling_round_radix(32, 0);
+            run_order = 0;
+            if (rc != DQ_OK) return rc;
+        }
 
         int64_t m_before = 0;             // list length before the last round (0: no round yet)
         int pair_tries = 0, pair_aborts = 0;
@@ -1441,7 +1504,7 @@ struct SuffixSorter {
                                    (pair_tries == 0 || (pair_paid ? stagnant : h >= 16 * pair_h));
             const int max_tries = env("DQ_PAIR_TRIES") ? atoi(env("DQ_PAIR_TRIES")) : kPairChainTries;
             if (want && pair_tries < max_tries && pair_aborts < 2 * kPairChainTries && !env("DQ_NO_SMALL") && n < (1ll << 32) &&
-                m < n && !keys_ready) {
+                m < n && !keys_ready && !list_ungrouped) {
                 int outcome = 0;
                 m_before = 0;
                 const int64_t m_try = m;
@@ -1452,7 +1515,7 @@ struct SuffixSorter {
                 continue;
             }
             m_before = m;
-            if (only_small_groups && uses_small_round(m) && !keys_ready && !env("DQ_NO_CHAIN")) {
+            if (only_small_groups && uses_small_round(m) && !keys_ready && !list_ungrouped && !env("DQ_NO_CHAIN")) {
                 rc = doubling_rounds_small_chain();           // several rounds, one host round trip; updates h
                 if (rc != DQ_OK) return rc;
                 continue;
@@ -1473,7 +1536,7 @@ struct SuffixSorter {
                        hipLaunchKernelGGL(keys_to_ranks_kernel, dim3(grid_for(m)), dim3(kBlock), 0, st, Kr[rcur], m, kbits));
                 keys_ready = false;
             }
-            rc = (uses_small_round(m) && !keys_ready && !rshift) ? doubling_round_small(kbits)
+            rc = (uses_small_round(m) && !keys_ready && !rshift && !list_ungrouped) ? doubling_round_small(kbits)
                                                                  : doubling_round_radix(kbits, rshift);
             if (rc != DQ_OK) return rc;
             h *= 2;

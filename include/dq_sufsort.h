@@ -172,7 +172,8 @@ void dq_sufsort_hip_release(void);
 #define DQ_K_MATCH_SEARCH        16   /* match_search_kernel: Diff.cs Search for a batch of scan positions              */
 #define DQ_K_PAIR_CHAINS         17   /* dq_pair_chains.h: tied pairs inside long repeats decided chain by chain    */
 #define DQ_K_MID_ROUND           18   /* dq_mid_groups.h: a doubling round for tie groups of up to 1024 members, inside LDS */
-#define DQ_K_COUNT               19
+#define DQ_K_RUNS                19   /* dq_runs.h: run lengths of the text (three small kernels)                          */
+#define DQ_K_COUNT               20
 
 /* 0 off, 1 every kernel, 2 only radix_rank_kernel, 100 + c only category c (cheapest: the timed region) */
 int32_t dq_profile_enable(int32_t on);

@@ -349,6 +349,8 @@ FUZZ_ENVS = [
     {"DQ_MID_GROUPS": "0", "DQ_SMALL_N": "0"},             # doubling rounds with the small-group kernel + radix passes only
     {"DQ_MID_GROUPS": "256", "DQ_SMALL_N": "0"},           # doubling rounds through the LDS class for groups of up to 256 ...
     {"DQ_MID_GROUPS": "1024", "DQ_SMALL_N": "0", "DQ_PAIR_CHAINS": "0", "DQ_NO_BINNED_ISA": "1"},   # ... 1024 members
+    {"DQ_RUNS": "1", "DQ_SMALL_N": "0"},                   # run lengths + run-order round on every input
+    {"DQ_RUNS": "1", "DQ_SMALL_N": "0", "DQ_NO_SMALL": "1", "DQ_NO_BINNED_ISA": "1"},
     {"DQ_PAIR_CHAINS": "2", "DQ_SMALL_N": "0"},            # tied pairs decided chain by chain as early and as often as allowed
     {"DQ_PAIR_CHAINS": "2", "DQ_NO_BINNED_ISA": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0"},
 ]
@@ -491,6 +493,10 @@ FORCED_PATHS = [
     {"DQ_MID_GROUPS": "256"},                                    # tie groups of up to 256 / 512 / 1024 members finished in LDS (dq_mid_groups.h; 1024 is the default)
     {"DQ_MID_GROUPS": "1024", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
     {"DQ_MID_GROUPS": "512", "DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_NO_CHAIN": "1"},
+    {"DQ_RUNS": "1"},                                            # runs of one byte ordered by their own structure (dq_runs.h), forced on
+    {"DQ_RUNS": "1", "DQ_NO_SMALL": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},   # ... through the radix rounds
+    {"DQ_RUNS": "1", "DQ_MID_GROUPS": "256", "DQ_NO_CHAIN": "1", "DQ_PAIR_CHAINS": "0"},
+    {"DQ_RUNS": "0"},
     {"DQ_PAIR_CHAINS": "2"},                                     # pair chains (dq_pair_chains.h) before / after every round
     {"DQ_PAIR_CHAINS": "2", "DQ_NO_BINNED_ISA": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
     {"DQ_PAIR_CHAINS": "1", "DQ_PACKED": "1", "DQ_KEY_BYTES": "2"},
@@ -521,6 +527,49 @@ def test_every_code_path_is_bit_exact(ldss, oracle_mod, monkeypatch, env):
         assert np.array_equal(SA, oracle_mod.divsufsort(T)), (env, T.size)
     T = oracle_mod.gen_uniform(1_000_003, 7)
     assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
+
+
+def run_heavy_texts(oracle_mod):
+    """Texts made of runs: what dq_runs.h is for, and every edge of its run-length passes (16-byte segments,
+    4096-byte chunks, runs that cross them, reach the end of the text, are followed by smaller / larger bytes)."""
+    rng = np.random.default_rng(77)
+    out = [np.zeros(70_001, np.uint8), np.full(1 << 20, 255, np.uint8), np.full(65_536, 7, np.uint8)]
+    for total in (70_000, 300_000, 2_000_000):
+        parts, size = [], 0
+        while size < total:
+            kind = int(rng.integers(0, 6))
+            if kind <= 2:                                            # a run: lengths around the segment / chunk sizes and long ones
+                ln = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 255, 4095, 4096, 4097, 8192, 12_289, 40_000, 100_003]))
+                parts.append(np.full(ln, int(rng.choice([0, 0, 0, 1, 127, 255])), np.uint8))
+            elif kind == 3:
+                parts.append(rng.integers(0, 256, int(rng.integers(1, 3000)), dtype=np.uint8))
+            elif kind == 4:                                          # a few bytes between runs (what follows a run decides its place)
+                parts.append(rng.integers(0, 3, int(rng.integers(1, 4)), dtype=np.uint8))
+            else:                                                    # an earlier stretch again (runs inside repeats)
+                if parts:
+                    src = np.concatenate(parts[-8:])
+                    a = int(rng.integers(0, src.size))
+                    parts.append(src[a:a + int(rng.integers(1, 50_000))].copy())
+            size = sum(p.size for p in parts)
+        out.append(np.concatenate(parts)[:total])
+    T = oracle_mod.gen_uniform(600_000, 3)
+    T[100_000:233_000] = 0
+    T[400_000:400_100] = 0
+    T[-5000:] = 9                                                    # a run into the end of the text
+    out.append(T)
+    return out
+
+
+@pytest.mark.parametrize("env", [{}, {"DQ_RUNS": "1"}, {"DQ_RUNS": "0"}, {"DQ_RUNS": "1", "DQ_NO_SMALL": "1"},
+                                 {"DQ_RUNS": "1", "DQ_SPARSE": "1"}, {"DQ_RUNS": "1", "DQ_MID_GROUPS": "256", "DQ_NO_BINNED_ISA": "1"}],
+                         ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
+def test_runs_of_one_byte(ldss, oracle_mod, monkeypatch, env):
+    monkeypatch.setenv("DQ_SMALL_N", "0")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for T in run_heavy_texts(oracle_mod):
+        T = np.ascontiguousarray(T, dtype=np.uint8)
+        assert np.array_equal(ldss.Sort(T), oracle_mod.divsufsort(T)), (env, T.size)
 
 
 def test_shared_provider_from_many_threads(ldss, oracle_mod):

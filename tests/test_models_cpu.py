@@ -203,3 +203,134 @@ def test_pair_chains_decide_like_the_suffix_array(oracle_mod):
                         decided += 1
                         assert (st == 1) == (isa[a] < isa[b]), (h, maxg, a, b, st)
     assert decided > total // 2                        # (and it is worth it: most pairs of these inputs are decided)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dq_runs.h: runs of one byte decided by their own structure.  A numpy model of the doubling rounds with the run
+# lengths, the run-order round and the per-member offsets, validated against the oracle BEFORE any kernel runs.
+def run_lengths(T):
+    n = T.size
+    RL = np.ones(n, np.int64)
+    for i in range(n - 2, -1, -1):
+        if T[i] == T[i + 1]:
+            RL[i] = RL[i + 1] + 1
+    return RL
+
+
+def doubling_with_runs(T, h0=2):
+    """Prefix doubling from depth h0 (ranks = group starts of the h0-byte keys), with the run rules of dq_runs.h."""
+    n = T.size
+    P = np.concatenate([T, np.zeros(h0, np.uint8)]).astype(np.uint64)
+    key = np.zeros(n, np.uint64)
+    for b in range(h0):
+        key = (key << np.uint64(8)) | P[b:b + n]
+    # (zero padding can tie a suffix that ends with one that goes on with zero bytes: the valid length breaks it)
+    ln = np.minimum(n - np.arange(n), h0)
+    order = np.lexsort((ln, key))
+    k = key[order]
+    l = ln[order]
+    head = np.ones(n, bool)
+    head[1:] = (k[1:] != k[:-1]) | (l[1:] != l[:-1])
+    rank_sorted = np.maximum.accumulate(np.where(head, np.arange(n), 0))
+    ISA = np.empty(n, np.int64)
+    ISA[order] = rank_sorted
+    RL = run_lengths(T)
+    Tx = np.concatenate([T.astype(np.int64), [-1]])                    # the end of the text sorts before every byte
+
+    def rebucket(r, k2):
+        o = np.lexsort((k2, r))
+        return o, r[o], k2[o]
+
+    h = h0
+    s = np.arange(n)
+    rounds = 0
+    special = True
+    while True:
+        r = ISA[s]
+        if special:                                                   # the run-order round: depth h stays
+            e = s + RL[s]
+            down = Tx[np.minimum(e, n)] < Tx[s]
+            enc = np.where(down, RL[s], (1 << 31) | ((1 << 31) - 1 - RL[s]))
+            k2 = np.where(RL[s] >= h, enc, 0)
+        else:
+            off = np.where(RL[s] > h, RL[s], h)
+            q = s + off
+            k2 = np.where(q < n, ISA[np.minimum(q, n - 1)] + h, np.where(off > h, 0, n - 1 - s))
+        o, rs, ks = rebucket(r, k2)
+        ss = s[o]
+        m = ss.size
+        newhead = np.ones(m, bool)
+        newhead[1:] = (rs[1:] != rs[:-1]) | (ks[1:] != ks[:-1])
+        ghead = np.ones(m, bool)
+        ghead[1:] = rs[1:] != rs[:-1]
+        j = np.arange(m)
+        nh = np.maximum.accumulate(np.where(newhead, j, -1))
+        gh = np.maximum.accumulate(np.where(ghead, j, -1))
+        ISA[ss] = rs + (nh - gh)
+        rounds += 1
+        if special:
+            special = False
+        else:
+            h *= 2
+        # stop when every rank is unique
+        if np.unique(ISA).size == n:
+            break
+        assert h < 4 * n + 8, "no progress"
+    SA = np.empty(n, np.int64)
+    SA[ISA] = np.arange(n)
+    return SA, rounds
+
+
+def test_run_order_rule_and_offsets_give_the_suffix_array(oracle_mod):
+    rng = np.random.default_rng(5)
+    texts = [np.zeros(300, np.uint8), np.array([1] * 40 + [0] + [1] * 50 + [2] + [1] * 45, np.uint8)]
+    for _ in range(40):
+        parts = []
+        for _ in range(int(rng.integers(2, 14))):
+            if rng.random() < 0.6:
+                parts.append(np.full(int(rng.integers(1, 120)), int(rng.choice([0, 1, 1, 2])), np.uint8))
+            else:
+                parts.append(rng.integers(0, 3, int(rng.integers(1, 6)), dtype=np.uint8))
+        texts.append(np.concatenate(parts))
+    for T in texts:
+        for h0 in (1, 2, 4, 8):
+            SA, rounds = doubling_with_runs(T, h0)
+            assert np.array_equal(SA, oracle_mod.divsufsort(T).astype(np.int64)), (T.size, h0)
+    # one long run needs a constant number of rounds, not log2(length)
+    T = np.concatenate([np.zeros(5000, np.uint8), [3], np.zeros(4000, np.uint8), [1, 2]]).astype(np.uint8)
+    SA, rounds = doubling_with_runs(T, 2)
+    assert np.array_equal(SA, oracle_mod.divsufsort(T).astype(np.int64))
+    assert rounds <= 4, rounds
+
+
+def test_run_length_passes_model():
+    """The three-pass run-length computation of dq_runs.h (segments of 16, chunks of 4096, carry across chunks) in numpy."""
+    rng = np.random.default_rng(9)
+
+    def three_pass(T, seg=16, chunk=64):
+        n = T.size
+        nch = (n + chunk - 1) // chunk
+        lead = np.zeros(nch, np.int64)
+        link = np.zeros(nch, bool)
+        local = np.zeros(n, np.int64)
+        for c in range(nch):
+            lo, hi = c * chunk, min((c + 1) * chunk, n)
+            for i in range(hi - 1, lo - 1, -1):
+                local[i] = local[i + 1] + 1 if i + 1 < hi and T[i + 1] == T[i] else 1
+            lead[c] = local[lo]
+            link[c] = lo + lead[c] == hi and hi < n and T[hi] == T[lo]
+        carry = np.zeros(nch + 1, np.int64)
+        for c in range(nch - 1, -1, -1):
+            carry[c] = lead[c] + (carry[c + 1] if link[c] else 0)
+        RL = local.copy()
+        for c in range(nch):
+            lo, hi = c * chunk, min((c + 1) * chunk, n)
+            for i in range(lo, hi):
+                if i + local[i] == hi and hi < n and T[hi] == T[i]:
+                    RL[i] += carry[c + 1]
+        return RL
+
+    for _ in range(30):
+        parts = [np.full(int(rng.integers(1, 200)), int(rng.integers(0, 2)), np.uint8) for _ in range(int(rng.integers(1, 9)))]
+        T = np.concatenate(parts)
+        assert np.array_equal(three_pass(T), run_lengths(T))
