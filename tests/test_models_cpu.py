@@ -334,3 +334,69 @@ def test_run_length_passes_model():
         parts = [np.full(int(rng.integers(1, 200)), int(rng.integers(0, 2)), np.uint8) for _ in range(int(rng.integers(1, 9)))]
         T = np.concatenate(parts)
         assert np.array_equal(three_pass(T), run_lengths(T))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dq_mid_groups.h: which workgroup finishes / forwards which list entry.  A numpy model of the kernel's ownership
+# rules (left halo of ranks, right overhang, group closed iff its closer is seen) run over random group layouts:
+# every list entry must be claimed by exactly one tile, as a member of a group finished in LDS or as a member of a
+# large group handed to the radix list -- and both sides of a tile boundary must agree on which.
+def mid_kernel_claims(ranks, span=64, G=16):
+    m = ranks.size
+    tile = span - G
+    scan = G + span
+    mid = np.zeros(m, np.int64)          # times claimed as a member of a group finished in LDS
+    large = np.zeros(m, np.int64)        # times forwarded to the radix list
+    NONE = -1
+    for b in range((m + tile - 1) // tile):
+        j0 = b * tile
+        r = np.array([ranks[j] if 0 <= j < m else NONE for j in range(j0 - G, j0 - G + scan + 1)])   # [scan] = the closer
+        head = np.zeros(scan, bool)
+        for c in range(scan):
+            head[c] = (j0 - G <= 0) if c == 0 else r[c] != r[c - 1]
+        hp = np.full(scan, -1)
+        run = -1
+        for c in range(scan):
+            run = c if head[c] else run
+            hp[c] = run
+        gsize = {}
+        for c in range(1, scan):
+            if head[c] and hp[c - 1] >= 0:
+                gsize[hp[c - 1]] = c - hp[c - 1]
+        if hp[scan - 1] >= 0:
+            gsize[hp[scan - 1]] = (scan - hp[scan - 1]) if r[scan] != r[scan - 1] else None      # None: open
+        for e in range(span):
+            j = j0 + e
+            if not (0 <= j < m):
+                continue
+            hc = hp[G + e]
+            gs = gsize.get(hc) if hc >= 0 else None
+            is_large = hc < 0 or gs is None or gs > G
+            ghead = hc - G
+            if not is_large and 0 <= ghead < tile:
+                mid[j] += 1
+            if is_large and e < tile:
+                large[j] += 1
+    return mid, large
+
+
+def test_mid_group_tiles_claim_every_entry_exactly_once():
+    rng = np.random.default_rng(21)
+    for trial in range(60):
+        sizes = []
+        total = int(rng.integers(1, 700))
+        while sum(sizes) < total:
+            u = rng.random()
+            sizes.append(int(rng.integers(2, 6)) if u < 0.5 else int(rng.integers(6, 17)) if u < 0.8
+                         else int(rng.integers(17, 40)) if u < 0.95 else int(rng.integers(40, 300)))
+        ranks = np.concatenate([np.full(s, 1000 * i) for i, s in enumerate(sizes)])
+        mid, large = mid_kernel_claims(ranks)
+        assert np.all(mid + large == 1), (trial, sizes)
+        # a group of <= G members is finished in LDS, a longer one goes to the radix list -- whole groups either way
+        pos = 0
+        for s in sizes:
+            if s <= 16:
+                assert np.all(mid[pos:pos + s] == 1), (trial, pos, s)
+            else:
+                assert np.all(large[pos:pos + s] == 1), (trial, pos, s)
+            pos += s
