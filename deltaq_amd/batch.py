@@ -8,12 +8,13 @@ Three layers:
 
 * ``plan_shards``            longest-processing-time-first assignment of inputs to ranks
                              (the same rule as dq_sufsort_hip_batch_i32 uses for devices).
-* ``sort_batch_distributed`` one process per GPU under ``torch.distributed``: every rank
-                             sorts its share; results are optionally gathered to rank 0
-                             (``nccl`` == RCCL over xGMI on the GPU box, ``gloo`` in the CPU
-                             tests).  The sorter is injected, so the CPU tests exercise the
-                             sharding / gather plumbing without a GPU; on a GPU box it
-                             defaults to ``HipSuffixSort``.
+* ``sort_batch_distributed`` one process per GPU under ``torch.distributed``: the inputs are dealt out
+                             with one broadcast (every rank slices its LPT share), every rank sorts its
+                             share, the suffix arrays come back to rank 0 with one padded gather
+                             (``nccl`` == RCCL over xGMI on the GPU box, ``gloo`` in the CPU tests).
+                             Collectives only: no point-to-point pairs.  The sorter is injected, so the
+                             CPU tests exercise the plumbing without a GPU; on a GPU box it defaults to
+                             ``HipSuffixSort``.
 * ``diff_many_distributed``  the one exchange step the path has: ONE old file, many new files.  Rank 0 sorts the
                              old file once, text and suffix array are BROADCAST (``ncclBroadcast`` over xGMI under
                              ``nccl``), every rank builds a ``DiffIndex`` on the received buffers and diffs its LPT
@@ -47,13 +48,93 @@ def sort_batch_local(texts: Sequence, sorter) -> List[np.ndarray]:
     return [sorter.Sort(t) for t in texts]
 
 
+def _announce(rank, arrs, world, group, extra=None):
+    """rank 0 -> everybody: the lengths of the inputs, the LPT plan, and anything else that is small."""
+    import torch.distributed as dist
+    if rank == 0:
+        lengths = [int(a.size) for a in arrs]
+        meta = [lengths, plan_shards(lengths, world), extra]
+    else:
+        meta = None
+    box = [meta]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return box[0]
+
+
+def _deal_out(rank, arrs, lengths, plan, dev, group):
+    """The inputs to their owners with ONE collective: rank 0 lays them out share after share in a single buffer,
+    the buffer is broadcast (`ncclBroadcast` over xGMI under nccl) and every rank slices its own share out of it.
+    (Collectives only on the data path: no point-to-point pairs whose lazily built communicators have to meet.)
+    Returns {input index: uint8 tensor on `dev`} for this rank's share."""
+    import torch
+    import torch.distributed as dist
+    order = [j for share in plan for j in share]
+    total = sum(lengths[j] for j in order)
+    if rank == 0:
+        flat = np.empty(total, dtype=np.uint8)
+        pos = 0
+        for j in order:
+            flat[pos:pos + lengths[j]] = arrs[j]
+            pos += lengths[j]
+        buf = torch.from_numpy(flat).to(dev)
+    else:
+        buf = torch.empty(total, dtype=torch.uint8, device=dev)
+    if total > 0:
+        dist.broadcast(buf, src=0, group=group)
+    mine, pos = {}, 0
+    for r, share in enumerate(plan):
+        for j in share:
+            if r == rank:
+                mine[j] = buf[pos:pos + lengths[j]]
+            pos += lengths[j]
+    return mine
+
+
+def _all_ok(err, dev, group) -> None:
+    """Every rank reports whether its local work succeeded BEFORE the result collective: a rank that failed would
+    otherwise leave the others waiting in it.  Raises on every rank if any failed."""
+    import torch
+    import torch.distributed as dist
+    flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()) != 0:
+        raise RuntimeError(f"a rank failed in its share of the batch (this rank: {err!r})")
+
+
+def _collect(rank, world, plan, sizes, parts, dtype, dev, group):
+    """Variable-length results to rank 0 with ONE collective: every rank concatenates its results (in plan order),
+    pads to the longest share and takes part in `dist.gather` (grouped sends / receives inside RCCL).
+    sizes[j] = elements of result j; parts = {j: tensor} of this rank.  Returns {j: tensor on dev} on rank 0."""
+    import torch
+    import torch.distributed as dist
+    share_len = [sum(sizes[j] for j in share) for share in plan]
+    cap = max(max(share_len), 1)
+    mine = torch.zeros(cap, dtype=dtype, device=dev)
+    pos = 0
+    for j in plan[rank]:
+        if sizes[j]:
+            mine[pos:pos + sizes[j]] = parts[j].to(dev).reshape(-1)
+        pos += sizes[j]
+    bins = [torch.empty(cap, dtype=dtype, device=dev) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, bins, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = {}
+    for r, share in enumerate(plan):
+        pos = 0
+        for j in share:
+            out[j] = bins[r][pos:pos + sizes[j]]
+            pos += sizes[j]
+    return out
+
+
 def sort_batch_distributed(texts: Optional[Sequence], *, sorter_factory: Optional[Callable] = None,
                            gather_to_root: bool = True, group=None) -> Optional[List[np.ndarray]]:
     """Sort a batch across the ranks of an initialised ``torch.distributed`` process group.
 
-    ``texts`` must be given on rank 0 (other ranks may pass ``None``); inputs are
-    scattered to their owners, sorted there, and -- if ``gather_to_root`` -- the suffix
-    arrays are returned on rank 0 in input order (other ranks return ``None``).
+    ``texts`` must be given on rank 0 (other ranks may pass ``None``); inputs are dealt out to their owners (one
+    broadcast), sorted there, and -- if ``gather_to_root`` -- the suffix arrays are returned on rank 0 in input
+    order (one gather; other ranks return ``None``).
     """
     import torch
     import torch.distributed as dist
@@ -63,37 +144,12 @@ def sort_batch_distributed(texts: Optional[Sequence], *, sorter_factory: Optiona
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
 
-    # ---- rank 0 announces the plan ----
+    arrs = None
     if rank == 0:
         arrs = [np.ascontiguousarray(np.frombuffer(memoryview(t).cast("B"), dtype=np.uint8)
                                      if not isinstance(t, np.ndarray) else t) for t in texts]
-        lengths = [int(a.size) for a in arrs]
-        plan = plan_shards(lengths, world)
-        meta = [lengths, plan]
-    else:
-        arrs, meta = None, None
-    box = [meta]
-    dist.broadcast_object_list(box, src=0, group=group)
-    lengths, plan = box[0]
-
-    # ---- scatter inputs to their owners (point-to-point; rank 0 keeps its own share) ----
-    mine = {}
-    if rank == 0:
-        reqs = []
-        for r in range(world):
-            for j in plan[r]:
-                if r == 0:
-                    mine[j] = arrs[j]
-                elif lengths[j] > 0:
-                    reqs.append(dist.isend(torch.from_numpy(arrs[j]).to(dev), dst=r, group=group))
-        for q in reqs:
-            q.wait()
-    else:
-        for j in plan[rank]:
-            buf = torch.empty(lengths[j], dtype=torch.uint8, device=dev)
-            if lengths[j] > 0:
-                dist.recv(buf, src=0, group=group)
-            mine[j] = buf
+    lengths, plan, _ = _announce(rank, arrs, world, group)
+    mine = _deal_out(rank, arrs, lengths, plan, dev, group)
 
     # ---- sort the local share ----
     if sorter_factory is None:
@@ -101,39 +157,31 @@ def sort_batch_distributed(texts: Optional[Sequence], *, sorter_factory: Optiona
         sorter = HipSuffixSort(dev.index if dev.type == "cuda" else -1)
     else:
         sorter = sorter_factory()
-    results = {}
-    for j in plan[rank]:
-        t = mine[j]
-        if isinstance(t, torch.Tensor) and not t.is_cuda:
-            t = t.numpy()
-        sa = sorter.Sort(t)
-        results[j] = sa
+    results, err = {}, None
+    try:
+        for j in plan[rank]:
+            t = mine[j]
+            if not t.is_cuda:
+                t = t.numpy()
+            elif lengths[j] == 0:
+                t = np.zeros(0, np.uint8)
+            results[j] = sorter.Sort(t.contiguous() if isinstance(t, torch.Tensor) else t)
+    except Exception as e:                      # noqa: BLE001 -- reported to every rank below
+        err = e
+    _all_ok(err, dev, group)
 
     if not gather_to_root:
         return [results[j] for j in plan[rank]]
 
-    # ---- gather the suffix arrays to rank 0 ----
     def as_tensor(x):
         if isinstance(x, torch.Tensor):
-            return x.to(dev)
-        return torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(dev)
+            return x.to(torch.int32)
+        return torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32))
 
-    if rank == 0:
-        out: List[Optional[np.ndarray]] = [None] * len(lengths)
-        for j in plan[0]:
-            r0 = results[j]
-            out[j] = r0.cpu().numpy() if isinstance(r0, torch.Tensor) else np.asarray(r0)
-        for r in range(1, world):
-            for j in plan[r]:
-                buf = torch.empty(lengths[j], dtype=torch.int32, device=dev)
-                if lengths[j] > 0:
-                    dist.recv(buf, src=r, group=group)
-                out[j] = buf.cpu().numpy()
-        return out
-    for j in plan[rank]:
-        if lengths[j] > 0:
-            dist.send(as_tensor(results[j]), dst=0, group=group)
-    return None
+    got = _collect(rank, world, plan, lengths, {j: as_tensor(v) for j, v in results.items()}, torch.int32, dev, group)
+    if rank != 0:
+        return None
+    return [got[j].cpu().numpy() for j in range(len(lengths))]
 
 
 def diff_many_distributed(old, news: Optional[Sequence], *, sorter_factory: Optional[Callable] = None,
@@ -161,16 +209,11 @@ def diff_many_distributed(old, news: Optional[Sequence], *, sorter_factory: Opti
         return x if isinstance(x, np.ndarray) else np.frombuffer(memoryview(x).cast("B"), dtype=np.uint8)
 
     # ---- plan: new files to ranks by length (the scan loop's cost grows with the new file) ----
+    old_np = new_np = None
     if rank == 0:
         old_np = np.ascontiguousarray(as_u8(old), dtype=np.uint8)
         new_np = [np.ascontiguousarray(as_u8(x), dtype=np.uint8) for x in news]
-        lengths = [int(a.size) for a in new_np]
-        meta = [int(old_np.size), lengths, plan_shards(lengths, world)]
-    else:
-        old_np, new_np, meta = None, None, None
-    box = [meta]
-    dist.broadcast_object_list(box, src=0, group=group)
-    n, lengths, plan = box[0]
+    lengths, plan, n = _announce(rank, new_np, world, group, extra=int(old_np.size) if rank == 0 else None)
 
     # ---- rank 0 sorts the old file; text + suffix array go to every rank in two broadcasts ----
     if rank == 0:
@@ -191,36 +234,25 @@ def diff_many_distributed(old, news: Optional[Sequence], *, sorter_factory: Opti
     if rank != 0:
         old_np = text_t.cpu().numpy()                  # the scan loop walks the old file on the host
 
-    # ---- new files to their owners (point-to-point; rank 0 keeps its own share) ----
-    mine = {}
-    if rank == 0:
-        reqs = []
-        for r in range(world):
-            for j in plan[r]:
-                if r == 0:
-                    mine[j] = new_np[j]
-                elif lengths[j] > 0:
-                    reqs.append(dist.isend(torch.from_numpy(new_np[j]).to(dev), dst=r, group=group))
-        for q in reqs:
-            q.wait()
-    else:
-        for j in plan[rank]:
-            buf = torch.empty(lengths[j], dtype=torch.uint8, device=dev)
-            if lengths[j] > 0:
-                dist.recv(buf, src=0, group=group)
-            mine[j] = buf.cpu().numpy()
+    # ---- new files to their owners (one more broadcast; every rank slices its share) ----
+    mine = {j: t.cpu().numpy() for j, t in _deal_out(rank, new_np, lengths, plan, dev, group).items()}
 
     # ---- every rank: one index on the broadcast buffers, then its share of the diffs ----
-    if index_factory is None:
-        from .bsdiff import DiffIndex
-        if not text_t.is_cuda:                         # gloo on a GPU box: upload once
-            text_t, sa_t = text_t.cuda(), sa_t.cuda()
-        index = DiffIndex(old_np, device_text=text_t, device_sa=sa_t)
-    else:
-        index = index_factory(old_np, text_t, sa_t)
-    patches = {j: index.Create(mine[j]) for j in plan[rank]}
-    if hasattr(index, "close"):
-        index.close()
+    patches, err = {}, None
+    try:
+        if index_factory is None:
+            from .bsdiff import DiffIndex
+            if not text_t.is_cuda:                     # gloo on a GPU box: upload once
+                text_t, sa_t = text_t.cuda(), sa_t.cuda()
+            index = DiffIndex(old_np, device_text=text_t, device_sa=sa_t)
+        else:
+            index = index_factory(old_np, text_t, sa_t)
+        patches = {j: index.Create(mine[j]) for j in plan[rank]}
+        if hasattr(index, "close"):
+            index.close()
+    except Exception as e:                      # noqa: BLE001 -- reported to every rank below
+        err = e
+    _all_ok(err, dev, group)
 
     # ---- patches (small: three bzip2 streams) to rank 0 ----
     gathered = [None] * world if rank == 0 else None

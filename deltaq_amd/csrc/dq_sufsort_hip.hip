@@ -1793,7 +1793,9 @@ struct SearchWindows {
     int32_t *h_pos = nullptr, *h_len = nullptr;
     uint64_t *h_packed = nullptr;                        // pinned: (len << 32 | pos) of the wave windows, polled by the loop
     void *d_mail = nullptr;                              // device: mailbox of the window kernel's second stage
-    static constexpr int64_t kSecond = 128;              // positions of the predicted next window
+    static constexpr int64_t kSecond = 1024;             // slots of the predicted next window (second <= kSecond are used)
+    int64_t second = 128;                                // positions of the predicted next window
+    int64_t min_window = 128;                            // first window after a jump
     static constexpr int64_t kSecondMaxFirst = 1024;     // ... behind first stages of up to this many positions
     int64_t sec_region = 0, predicted = 0;               // slot region (offset into h_packed) of the pending second stage
     bool sec_pending = false, no_second = false;
@@ -1802,7 +1804,7 @@ struct SearchWindows {
     unsigned long long ticket = 0, done_total = 0;       // of the launches with a second stage (the mailbox is never reset)
     const void *d_ptab = nullptr;                        // prefix table (prefix_bounds_kernel), or none
     int pk = 0;
-    int64_t w0 = -1, wc = 0, next_size = kMinWindow;
+    int64_t w0 = -1, wc = 0, next_size = 128;
     int64_t windows = 0, exact = 0;
     static constexpr int64_t kMinWindow = 128, kMaxWindow = 65536, kCap = 64, kWaveWindow = 2048;
     static constexpr uint64_t kPending = 0x8000000080000000ull;   // (no answer looks like this: len >= -1)
@@ -1837,7 +1839,7 @@ struct SearchWindows {
             if (rc != DQ_OK) return rc;
             if (hdr != kMsSkipped && (int64_t)hdr == scan) {
                 int64_t got = 0;
-                for (; got < kSecond; ++got) {
+                for (; got < second; ++got) {
                     uint64_t v = 0;
                     rc = await_slot(&reg[1 + got], c.stream, &v);
                     if (rc != DQ_OK) return rc;
@@ -1848,7 +1850,7 @@ struct SearchWindows {
                 if (got > 0) {
                     w0 = scan;
                     wc = got;
-                    next_size = kMinWindow;
+                    next_size = min_window;
                     ++windows;
                     ++predicted;
                     return DQ_OK;
@@ -1859,7 +1861,7 @@ struct SearchWindows {
         if (!from_capped && !(w0 >= 0 && scan == w0 + wc)) capped_streak = 0;
         from_capped = false;
         // the previous window was used up to its end: the loop is walking byte by byte -> a larger one
-        next_size = (w0 >= 0 && scan == w0 + wc) ? std::min(next_size * 2, kMaxWindow) : kMinWindow;
+        next_size = (w0 >= 0 && scan == w0 + wc) ? std::min(next_size * 2, kMaxWindow) : min_window;
         const int64_t count = std::min(next_size, m - scan);
         if (count <= kWaveWindow && !env("DQ_NO_WAVE_WINDOWS")) {
             // short windows (the loop is hopping from match to match: every launch is a dependent round trip): one WAVE
@@ -1873,14 +1875,14 @@ struct SearchWindows {
             // second stage: the window the loop will want after its next jump (dq_match_search.h), windows of up to 1024 positions.
             // Its answers are looked at when the loop gets there, not now; two slot regions take turns, so that a
             // region is written by one launch at a time (the launch in between has answered: the older one is over).
-            const int64_t count2 = (poll_now && d_mail && count <= kSecondMaxFirst && !no_second && ticket < (1ull << 20) - 2) ? kSecond : 0;
+            const int64_t count2 = (poll_now && d_mail && count <= kSecondMaxFirst && !no_second && ticket < (1ull << 20) - 2) ? second : 0;
             uint64_t *reg2 = nullptr;
             if (count2) {
                 ++ticket;
                 done_total += (unsigned long long)count;
                 sec_region = kWaveWindow + (int64_t)(ticket & 1) * (kSecond + 1);
                 reg2 = h_packed + sec_region;
-                for (int64_t i = 0; i < kSecond + 1; ++i) reg2[i] = kPending;
+                for (int64_t i = 0; i < second + 1; ++i) reg2[i] = kPending;
             }
             auto launch = [&]() -> int {
                 LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * 4 * (4 + 64) * 64,
@@ -1978,7 +1980,7 @@ struct DiffIndex {
     int pk = 0;
 };
 
-constexpr size_t kDiffPinnedBytes = 2 * ((size_t)(65536 + 2) * 4 + 256) + (size_t)(2048 + 2 * (128 + 1)) * 8 + 256;
+constexpr size_t kDiffPinnedBytes = 2 * ((size_t)(65536 + 2) * 4 + 256) + (size_t)(2048 + 2 * (1024 + 1)) * 8 + 256;
 
 size_t diff_tab_bytes(int64_t n, int *pk_out)
 {
@@ -2095,6 +2097,9 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
     win.d_mail = d_new + b_new;
     HIP_TRY(hipMemset(win.d_mail, 0, 16));
     win.no_second = env("DQ_NO_SECOND_STAGE") != nullptr;
+    if (const char *v = env("DQ_WIN_MIN")) win.min_window = std::min<int64_t>(std::max(16, atoi(v)), SearchWindows::kWaveWindow);
+    if (const char *v = env("DQ_WIN_SECOND")) win.second = std::min<int64_t>(std::max(16, atoi(v)), SearchWindows::kSecond);
+    win.next_size = win.min_window;
     rc = bsdiff::scan_loop(ix.old, ix.n, nw, m, win, raw);
     raw.windows = win.windows;
     raw.exact = win.exact;
