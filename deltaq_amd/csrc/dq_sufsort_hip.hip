@@ -1350,6 +1350,11 @@ struct SuffixSorter {
         // up to 3 when the list is longer than n/3: the records (1.5 per entry for groups of 4, at most 1 for
         // pairs and triples) must fit behind `half`.
         int maxg = m >= kSgShortList ? 2 : (m * 3 <= n ? kPcMaxG : (m * 2 <= n ? 3 : 2));
+        // (experiment knob: groups of 3 / 4 as their pairs on long lists too, where the records fit)
+        if (const char *v = env("DQ_PAIR_MAXG_LONG")) {
+            const int g = atoi(v);
+            if (m >= kSgShortList && g >= 3) maxg = (m * 3 <= n && g >= 4) ? kPcMaxG : (m * 2 <= n ? 3 : 2);
+        }
         if (const char *v = env("DQ_PAIR_MAXG")) maxg = std::min(maxg >= 3 ? maxg : 2, std::max(2, atoi(v)));
         // record = d << xbits | x.  Pairs only: x padded to whole digits, so that the digit passes over x see nothing of d
         const int xbits = maxg == 2 ? (ib + 7) / 8 * 8 : ib;
