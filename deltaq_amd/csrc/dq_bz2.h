@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstring>
 #include <functional>
+#include <thread>
 #include <vector>
 
 namespace dq {
@@ -64,6 +65,59 @@ inline uint32_t crc_update(uint32_t crc, const uint8_t *p, size_t n)
     }
     for (; i < n; ++i) crc = (crc << 8) ^ T[0][(crc >> 24) ^ p[i]];
     return crc;
+}
+
+// ---- the same CRC over a long buffer on several threads.  The register update is linear over GF(2): the state after
+// A || B from state s is  Z^{len(B)}(state after A from s)  xor  (state after B from 0), Z = "one zero byte" as a 32 x 32
+// bit matrix (the construction of zlib's crc32_combine, for this polynomial and bit order).
+inline uint32_t gf2_times(const uint32_t *mat, uint32_t vec)
+{
+    uint32_t sum = 0;
+    for (int i = 0; vec; vec >>= 1, ++i)
+        if (vec & 1u) sum ^= mat[i];
+    return sum;
+}
+
+// state after nbytes zero bytes, from `state`
+inline uint32_t crc_shift(uint32_t state, uint64_t nbytes)
+{
+    uint32_t op[32], sq[32];
+    for (int i = 0; i < 32; ++i) {                       // column i: what one zero byte makes of the state 1 << i
+        const uint32_t c = 1u << i;
+        op[i] = (c << 8) ^ kCrcTable.v[0][c >> 24];
+    }
+    for (; nbytes; nbytes >>= 1) {
+        if (nbytes & 1u) state = gf2_times(op, state);
+        for (int i = 0; i < 32; ++i) sq[i] = gf2_times(op, op[i]);
+        memcpy(op, sq, sizeof op);
+    }
+    return state;
+}
+
+inline uint32_t crc_update_mt(uint32_t crc, const uint8_t *p, size_t n)
+{
+    constexpr size_t kMinPart = (size_t)1 << 20;
+    const unsigned parts = (unsigned)std::min<size_t>(4, n / kMinPart);
+    if (parts < 2) return crc_update(crc, p, n);
+    const size_t per = n / parts;
+    uint32_t raw[4] = {0, 0, 0, 0};
+    {
+        std::vector<std::thread> ts;
+        for (unsigned k = 1; k < parts; ++k) {
+            const uint8_t *q = p + k * per;
+            const size_t len = k + 1 == parts ? n - k * per : per;
+            try { ts.emplace_back([&raw, k, q, len] { raw[k] = crc_update(0, q, len); }); }
+            catch (...) { raw[k] = crc_update(0, q, len); }
+        }
+        raw[0] = crc_update(crc, p, per);
+        for (std::thread &t : ts) t.join();
+    }
+    uint32_t s = raw[0];
+    for (unsigned k = 1; k < parts; ++k) {
+        const size_t len = k + 1 == parts ? n - k * per : per;
+        s = crc_shift(s, len) ^ raw[k];
+    }
+    return s;
 }
 
 // ------------------------------------------------------------------ decoder
@@ -273,7 +327,7 @@ inline int bz2_decompress(const uint8_t *src, size_t n, std::vector<uint8_t> &ou
                 same = (ch == prev) ? same + 1 : 1;
                 prev = ch;
             }
-            uint32_t crc = crc_update(0xffffffffu, out.data() + out0, out.size() - out0);
+            uint32_t crc = crc_update_mt(0xffffffffu, out.data() + out0, out.size() - out0);
             crc = ~crc;
             if (crc != block_crc) return kCorrupt;
             combined = ((combined << 1) | (combined >> 31)) ^ crc;
@@ -551,7 +605,7 @@ inline int bz2_compress(const uint8_t *src, size_t n, std::vector<uint8_t> &out,
             }
             i += run;
         }
-        const uint32_t crc = ~crc_update(0xffffffffu, src + i0, i - i0);      // of the block's input bytes, in one sweep
+        const uint32_t crc = ~crc_update_mt(0xffffffffu, src + i0, i - i0);   // of the block's input bytes, in one sweep (4 threads from 2 MiB)
         const int rc = compress_block(bw, blk, crc, sorter);
         if (rc != 0) return rc;
         combined = ((combined << 1) | (combined >> 31)) ^ crc;

@@ -50,6 +50,19 @@ int32_t t_bspatch_apply(const uint8_t *old_data, int64_t n, const uint8_t *patch
     return dq::bsdiff::apply_patch(old_data, n, patch, plen, out, cap, out_len);
 }
 
+// the block CRC folded 8 bytes a step / on several threads, against the bit-by-bit definition
+uint32_t t_crc_bitwise(const uint8_t *p, int64_t n)
+{
+    uint32_t crc = 0xffffffffu;
+    for (int64_t i = 0; i < n; ++i) {
+        crc ^= (uint32_t)p[i] << 24;
+        for (int k = 0; k < 8; ++k) crc = (crc & 0x80000000u) ? (crc << 1) ^ 0x04c11db7u : crc << 1;
+    }
+    return ~crc;
+}
+uint32_t t_crc_sliced(const uint8_t *p, int64_t n) { return ~dq::bz2::crc_update(0xffffffffu, p, (size_t)n); }
+uint32_t t_crc_mt(const uint8_t *p, int64_t n) { return ~dq::bz2::crc_update_mt(0xffffffffu, p, (size_t)n); }
+
 int64_t t_bz2_decompress(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap)
 {
     std::vector<uint8_t> v;

@@ -22,7 +22,7 @@ def harness():
     src = os.path.join(NATIVE, "bz2_harness.cpp")
     hdr = os.path.join(ROOT, "deltaq_amd", "csrc", "dq_bz2.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", src, "-o", so], check=True)
     L = ctypes.CDLL(so)
     L.t_bz2_compress.restype = ctypes.c_int64
     L.t_bz2_compress.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
@@ -55,6 +55,22 @@ def sample_inputs(oracle_mod):
         cases.append((rng.integers(0, 256, n, dtype=np.uint8) * (rng.integers(0, 10, n) == 0)).astype(np.uint8).tobytes())
     cases.append(oracle_mod.gen_enwik_like(120_000, 3, 4096).tobytes())
     return cases
+
+
+def test_crc_variants_agree_with_the_definition(harness, oracle_mod):
+    so = os.path.join(NATIVE, "libbz2_harness.so")
+    L = ctypes.CDLL(so)
+    for f in (L.t_crc_bitwise, L.t_crc_sliced, L.t_crc_mt):
+        f.restype = ctypes.c_uint32
+        f.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 7, 8, 9, 63, 1000, (1 << 20) + 5, (2 << 20) - 1, 2 << 20, (5 << 20) + 123):
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        want = L.t_crc_bitwise(b, n) if n <= (1 << 20) + 5 else L.t_crc_sliced(b, n)
+        assert L.t_crc_sliced(b, n) == want and L.t_crc_mt(b, n) == want, n
+    z = bytes(9 << 20)                                       # a run of zeros with one byte set, split over four threads
+    z2 = z[:5_000_000] + b"\x01" + z[5_000_001:]
+    assert L.t_crc_mt(z2, len(z2)) == L.t_crc_sliced(z2, len(z2)) != L.t_crc_mt(z, len(z))
 
 
 def test_decoder_reads_libbz2_streams(harness, oracle_mod):

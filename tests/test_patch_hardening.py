@@ -23,7 +23,7 @@ def test_hostile_patches_under_asan_ubsan():
     deps = [src] + [os.path.join(CSRC, h) for h in ("dq_bspatch.h", "dq_bsdiff.h", "dq_bz2.h")]
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
         subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                        src, "-o", exe], check=True)
+                        "-pthread", src, "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ok" in r.stdout
