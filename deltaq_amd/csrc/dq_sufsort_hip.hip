@@ -2135,16 +2135,25 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     return diff_index_scan(ix, nw, m, raw);
 }
 
-// one bzip2 stream; the Burrows-Wheeler transform of each block through the suffix sorter
+// one bzip2 stream; the Burrows-Wheeler transform of each block through the suffix sorter (blocks of a long stream
+// are encoded on several threads: the sorter is called concurrently, each call leasing its own device context)
 int bz2_stream(const std::vector<uint8_t> &src, std::vector<uint8_t> &out, int dev)
 {
-    int sort_rc = DQ_OK;
+    std::atomic<int> sort_rc{DQ_OK};
+    std::mutex err_mu;
+    std::string err;
     const int rc = bz2::bz2_compress(src.data(), src.size(), out,
                                      [&](const uint8_t *t, int64_t n2, int32_t *sa) -> int {
-                                         sort_rc = sufsort_host<int32_t>(t, n2, sa, dev);
-                                         return sort_rc == DQ_OK ? 0 : -2;
+                                         const int r = sufsort_host<int32_t>(t, n2, sa, dev);
+                                         if (r == DQ_OK) return 0;
+                                         int expect = DQ_OK;
+                                         if (sort_rc.compare_exchange_strong(expect, r)) {
+                                             std::lock_guard<std::mutex> lk(err_mu);
+                                             err = t_err;                      // (thread-local on the worker: carried over)
+                                         }
+                                         return -2;
                                      });
-    if (rc == -2) return sort_rc;
+    if (rc == -2) { t_err = err; return sort_rc.load(); }
     if (rc != 0) return fail(DQ_ERR_HIP, "bzip2 block transform failed");
     return DQ_OK;
 }
