@@ -496,7 +496,11 @@ int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V
 // pass instead of 24 and no value array; the few extra ties go to the sparse finishing path.
 // pair chains (dq_pair_chains.h): tried when a doubling round left > 60% of its list tied, at most this often per sort
 constexpr int kPairChainTries = 3;
-constexpr int64_t kPairChainMinM = 1 << 11;
+// Lists shorter than this keep doubling: since the LDS class finishes a round for nearly every group in one cheap pass
+// (a round of a 1 MiB text: ~20 us + its rank updates), a chain phase (~20 launches) costs more than the rounds it
+// saves -- 64 KiB ... 16 MiB of text are 8-35 % faster without (1 MiB: 1.43 -> 0.94 ms), 64 MiB tar-like and 256 MiB
+// enwik-style (lists of 2e7 ... 4e7 entries) 9-10 % slower.  DQ_PAIR_CHAINS=1/2 forces the phases on lists of any length.
+constexpr int64_t kPairChainMinM = 1 << 23;
 
 // coded round 0 (dq_alpha_code.h): from this size on, and only if a byte costs at most this many bits on average
 constexpr int64_t kCodedMinN = 8ll << 20;
@@ -1503,9 +1507,10 @@ struct SuffixSorter {
             // is tried again once the list has halved or h has grown 16-fold.
             const bool stagnant = m_before > 0 && m * 5 > m_before * 3;
             const char *pc = env("DQ_PAIR_CHAINS");
+            const int64_t pair_chain_min = env("DQ_PAIR_CHAINS_MIN") ? std::max(1, atoi(env("DQ_PAIR_CHAINS_MIN"))) : kPairChainMinM;
             const bool after_abort = abort_h == 0 || m * 2 <= abort_m || h >= 16 * abort_h;
             const bool want = pc ? atoi(pc) != 0 && (m_before > 0 || atoi(pc) > 1)
-                                 : m_before > 0 && m >= kPairChainMinM && after_abort &&
+                                 : m_before > 0 && m >= pair_chain_min && after_abort &&
                                    (pair_tries == 0 || (pair_paid ? stagnant : h >= 16 * pair_h));
             const int max_tries = env("DQ_PAIR_TRIES") ? atoi(env("DQ_PAIR_TRIES")) : kPairChainTries;
             if (want && pair_tries < max_tries && pair_aborts < 2 * kPairChainTries && !env("DQ_NO_SMALL") && n < (1ll << 32) &&

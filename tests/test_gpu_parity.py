@@ -153,7 +153,9 @@ def test_tie_bits_of_the_last_pass(ldss, oracle_mod, backend_lib):
 
 def test_pair_chains(ldss, oracle_mod, backend_lib, monkeypatch):
     """dq_pair_chains.h: tied pairs inside long repeats take the answer of the end of their chain.  Taken on its own
-    when a doubling round leaves most of its list tied; forced here before and after every round."""
+    when a doubling round leaves most of a LONG list tied (>= 2^23 entries: shorter ones are cheaper to keep
+    doubling since the LDS class); here with the default triggers on lists of any length (DQ_PAIR_CHAINS_MIN=1), then
+    forced before and after every round."""
     import ctypes
     rnd = oracle_mod.gen_uniform
 
@@ -167,6 +169,8 @@ def test_pair_chains(ldss, oracle_mod, backend_lib, monkeypatch):
         assert np.array_equal(sa, oracle_mod.divsufsort(T).astype(dtype))
         return n.value
 
+    assert launches(oracle_mod.gen_enwik_like(6_000_000, 53, 65536)) == 0                     # a short list: no phase by default
+    monkeypatch.setenv("DQ_PAIR_CHAINS_MIN", "2048")
     base = rnd(3_000_000, 51)
     one_copy = np.concatenate([base, base[100_000:160_000], rnd(500_000, 52)])               # pairs only: one chain of 60000
     assert launches(one_copy) >= 2                                                            # split + link phases ran
@@ -176,6 +180,7 @@ def test_pair_chains(ldss, oracle_mod, backend_lib, monkeypatch):
     doubled = oracle_mod.gen_enwik_like(2_500_000, 55, 1 << 20)
     doubled = np.concatenate([doubled, rnd(100_000, 56), doubled, rnd(50_000, 57)])          # a whole file twice: more than n/2
     assert launches(doubled) >= 2                                                             # suffixes tied, the records still fit
+    monkeypatch.delenv("DQ_PAIR_CHAINS_MIN")
     for force in ("1", "2"):
         monkeypatch.setenv("DQ_PAIR_CHAINS", force)
         monkeypatch.setenv("DQ_SMALL_N", "0")
