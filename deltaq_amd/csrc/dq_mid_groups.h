@@ -46,7 +46,8 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
     uint64_t *__restrict__ u_rank_end, IdxT *__restrict__ u_suf_end,      // U grows DOWNWARD from these
     SmallGroupCounters *__restrict__ ctr, const SmallGroupCounters *__restrict__ prev = nullptr,
     const uint32_t *__restrict__ RL = nullptr /* run lengths of the text (dq_runs.h), or none */,
-    const uint8_t *__restrict__ text = nullptr, int run_order = 0 /* 1: this is the run-order round */)
+    const uint8_t *__restrict__ text = nullptr, int run_order = 0 /* 1: this is the run-order round */,
+    const uint32_t *__restrict__ rank32 = nullptr /* the ranks as 32-bit values instead of `rank` (first round) */)
 {
     // chained rounds (no host round trip in between): the list length is what the previous round appended to T
     if (prev) {
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
     // ---- load: ranks of the scan region (striped, coalesced), suffixes of the span ----
     for (int c = t; c < kScan + 1; c += kMgThreads) {
         const int64_t j = j0 - kG + c;
-        s_rank[c] = (j >= 0 && j < m) ? (ElemT)rank[j] : kNone;
+        s_rank[c] = (j >= 0 && j < m) ? (rank32 ? (ElemT)rank32[j] : (ElemT)rank[j]) : kNone;
     }
     IdxT s[kMgItems];
 #pragma unroll

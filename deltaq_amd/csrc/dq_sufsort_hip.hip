@@ -779,6 +779,8 @@ struct SuffixSorter {
     bool runs_wanted = false, runs_on = false;
     int run_order = 0;                  // 1 while the run-order round is being launched
     const uint32_t *rl() const { return runs_on ? w.RL : nullptr; }
+    // the first round's list carries its ranks as 32-bit values here (build_isa_binned), not in Kr[rcur]
+    const uint32_t *first_rank32 = nullptr;
     // largest group the LDS class finishes: 0 = off; DQ_MID_GROUPS = 0 | 256 | 512 | 1024 forces it.  The walk over a
     // group costs its members ~group size each, the radix passes cost launches: 512 on long lists (256 MiB of
     // enwik-style text: 31.2 ms, 32.3 with 1024, 33.9 without the class), 1024 on the launch-bound short ones
@@ -834,7 +836,11 @@ struct SuffixSorter {
         // The tied suffixes are also listed group by group (32-bit ranks in the idle Vb, suffixes in Va): if they
         // are at most n/2, the first doubling round is a small-group round on that list and only the groups of
         // more than 8 go through the radix passes.
-        uint32_t *list_rank = (uses_small_round(0) && !env("DQ_NO_FIRST_SMALL")) ? reinterpret_cast<uint32_t *>(w.Vb) : nullptr;
+        // (32-bit ranks: every 64-bit buffer is busy until the words have been binned.  They go to the run-length buffer
+        // when that is idle -- the first round's kernel reads them there -- else to Vb, to be widened into a key buffer)
+        const bool rank32_direct = sizeof(IdxT) == 4 && !runs_wanted && mid_group_cap(n) > 0 && !env("DQ_WIDEN_RANKS");
+        uint32_t *list_rank = (uses_small_round(0) && !env("DQ_NO_FIRST_SMALL"))
+                                  ? (rank32_direct ? w.RL : reinterpret_cast<uint32_t *>(w.Vb)) : nullptr;
         LAUNCH(L, DQ_K_SEG_FUSED, n, n * (8 + wb + 8),
                hipLaunchKernelGGL((seg_fused_kernel<IdxT, true, false, false, true>), dim3((unsigned)ntiles),
                                   dim3(kSegThreads), 0, st, (const uint64_t *)keys, (const IdxT *)d_sa, n, ib, kshift0,
@@ -872,6 +878,10 @@ struct SuffixSorter {
                                       dim3(kPairThreads), 0, st, (const uint64_t *)P0, n, ib, w.ISA));
         }
         if (list_rank && m == 0) return DQ_OK;
+        if (list_rank && uses_small_round(m) && rank32_direct) {
+            first_rank32 = list_rank;
+            return DQ_OK;
+        }
         if (list_rank && uses_small_round(m)) {
             // (the sorted keys are gone -- their buffer was the output of the first binning pass and is free now)
             LAUNCH(L, DQ_K_KEY2_FROM_PAIRS, m, m * 12,
@@ -1098,7 +1108,10 @@ struct SuffixSorter {
             predict_dense = c.pinned[0] * 12 > kSamples;
         }
         if (const char *v = env("DQ_SPARSE")) predict_dense = atoi(v) == 0;
-        const bool binned = predict_dense && n >= (1 << 16) &&
+        // (the suffix-binned build pays once the inverse suffix array outgrows the last-level cache: 4n > 128 MiB.  Below
+        // that the plain scatter is ahead -- 64 KiB ... 16 MiB of text: 1-6 %.  DQ_BINNED_ISA=1: from 64 KiB on, for the tests)
+        const bool binned_pays = env("DQ_BINNED_ISA") ? atoi(env("DQ_BINNED_ISA")) != 0 : n > (32ll << 20);
+        const bool binned = predict_dense && n >= (1 << 16) && binned_pays &&
                             2 * bit_length((uint64_t)(n - 1)) <= 63 && !env("DQ_NO_BINNED_ISA");
         if (binned) {
             rc = build_isa_binned(K[cur], K[cur ^ 1], kb, kshift0);
@@ -1221,6 +1234,7 @@ struct SuffixSorter {
         if (use_mid) {
             int rc = launch_mid_round(mid_g, m, A, As, B, Bs, h, kbits, ctr, nullptr, m * (8 + wb + wb + wb + 8 + wb));
             if (rc != DQ_OK) return rc;
+            first_rank32 = nullptr;
         } else if (cap32) {
             constexpr int kTile = sg_tile<kSgMaxGShort>();
             LAUNCH(L, DQ_K_SMALL_ROUND, m, m * (8 + wb + wb + wb + 8 + wb),
@@ -1286,7 +1300,8 @@ struct SuffixSorter {
         auto go = [&](auto kern) -> int {
             LAUNCH(L, DQ_K_MID_ROUND, mm, alg_bytes,
                    hipLaunchKernelGGL(kern, grid, dim3(kMgThreads), 0, st, A, As, (const IdxT *)w.ISA, mm, n, hh, kbits, d_sa, B, Bs,
-                                      B + half, Bs + half, B + top, Bs + top, ctr, prev, rl(), (const uint8_t *)w.text, run_order));
+                                      B + half, Bs + half, B + top, Bs + top, ctr, prev, rl(), (const uint8_t *)w.text, run_order,
+                                      first_rank32));
             return DQ_OK;
         };
         return g == 256 ? go(mid_group_round_kernel<IdxT, 256>) : g == 512 ? go(mid_group_round_kernel<IdxT, 512>)

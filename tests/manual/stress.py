@@ -24,6 +24,7 @@ ENVS = [{}, {}, {}, {"DQ_SMALL_N": "0"}, {"DQ_NO_FUSED_TIES": "1"}, {"DQ_NO_SMAL
         {"DQ_PAIR_CHAINS": "1"}, {"DQ_PAIR_CHAINS": "2", "DQ_SMALL_N": "0"}, {"DQ_PAIR_CHAINS": "2", "DQ_PAIR_MAXG": "4"},
         {"DQ_PAIR_CHAINS": "1", "DQ_PAIR_MAXG": "3", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2"},
         {"DQ_PAIR_CHAINS": "2", "DQ_PAIR_MAXG": "2", "DQ_NO_BINNED_ISA": "1"}, {"DQ_BUCKET": "1"}, {"DQ_NO_FIRST_SMALL": "1"},
+        {"DQ_BINNED_ISA": "1"}, {"DQ_BINNED_ISA": "1", "DQ_NO_FIRST_SMALL": "1"}, {"DQ_BINNED_ISA": "1", "DQ_RUNS": "1", "DQ_SMALL_N": "0"},
         {"DQ_RUNS": "1"}, {"DQ_RUNS": "1", "DQ_SMALL_N": "0"}, {"DQ_RUNS": "1", "DQ_NO_SMALL": "1"}, {"DQ_RUNS": "1", "DQ_SPARSE": "0", "DQ_PAIR_CHAINS": "2"},
         {"DQ_RUNS": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_MID_GROUPS": "256"}, {"DQ_RUNS": "0"},
         {"DQ_MID_GROUPS": "0"}, {"DQ_MID_GROUPS": "0", "DQ_SMALL_N": "0"}, {"DQ_MID_GROUPS": "256"}, {"DQ_MID_GROUPS": "512", "DQ_NO_CHAIN": "1"},

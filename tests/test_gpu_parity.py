@@ -343,6 +343,7 @@ def structured_text(rng, n):
 
 FUZZ_ENVS = [
     {},
+    {"DQ_BINNED_ISA": "1", "DQ_SMALL_N": "0"},             # suffix-binned first inverse suffix array on every dense input
     {"DQ_SMALL_N": "0"},                                   # everything through the device-wide pipeline
     {"DQ_NO_FUSED_TIES": "1", "DQ_NO_SMALL": "1"},         # general rebucket pass, radix-only doubling rounds
     {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2", "DQ_SMALL_N": "0"},   # tie bits with most suffixes tied
@@ -479,6 +480,8 @@ def test_batch_entry_point_two_device_slots(backend_lib, oracle_mod):
 
 FORCED_PATHS = [
     {},                                                       # defaults (adaptive)
+    {"DQ_BINNED_ISA": "1"},                                      # first inverse suffix array through suffix-binned words (default from 32 MiB on)
+    {"DQ_BINNED_ISA": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_NO_FIRST_SMALL": "1"},
     {"DQ_PACKED": "1", "DQ_KEY_BYTES": "3", "DQ_SPARSE": "1"},   # packed words, finisher, sparse rounds
     {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},   # packed words, dense doubling
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "3", "DQ_SPARSE": "1"},   # pairs, sparse + fallback to dense
@@ -489,7 +492,7 @@ FORCED_PATHS = [
     {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2"},                     # tie bits with MANY ties (dense doubling after them)
     {"DQ_FORCE_RSHIFT": "1"},                                    # doubling rounds with rank >> 1 in the composite key
     {"DQ_FORCE_RSHIFT": "1", "DQ_SPARSE": "1"},
-    {"DQ_FORCE_RSHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "0", "DQ_NO_FIRST_SMALL": "1", "DQ_NO_SMALL": "1"},   # ... on a list that came keyed from the binned first ISA
+    {"DQ_FORCE_RSHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "0", "DQ_NO_FIRST_SMALL": "1", "DQ_NO_SMALL": "1", "DQ_BINNED_ISA": "1"},   # ... on a list that came keyed from the binned first ISA
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8"},    # coded round-0 keys (dq_alpha_code.h), dense doubling
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "1"},
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_NO_BINNED_ISA": "1", "DQ_NO_SMALL": "1"},
@@ -566,6 +569,7 @@ def run_heavy_texts(oracle_mod):
 
 
 @pytest.mark.parametrize("env", [{}, {"DQ_RUNS": "1"}, {"DQ_RUNS": "0"}, {"DQ_RUNS": "1", "DQ_NO_SMALL": "1"},
+                                 {"DQ_RUNS": "1", "DQ_BINNED_ISA": "1"}, {"DQ_RUNS": "1", "DQ_BINNED_ISA": "1", "DQ_NO_FIRST_SMALL": "1"},
                                  {"DQ_RUNS": "1", "DQ_SPARSE": "1"}, {"DQ_RUNS": "1", "DQ_MID_GROUPS": "256", "DQ_NO_BINNED_ISA": "1"}],
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
 def test_runs_of_one_byte(ldss, oracle_mod, monkeypatch, env):
