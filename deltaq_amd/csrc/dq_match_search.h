@@ -387,7 +387,8 @@ __global__ __launch_bounds__(kMsThreads) void match_search_wave_kernel(
     const IdxT *__restrict__ ptab, int pk, uint64_t *__restrict__ packed_out /* (len << 32 | pos) per position, or null */,
     int64_t count2 = 0, uint64_t *__restrict__ packed2 = nullptr /* second stage: [0] its start, [1 + i] its answers */,
     unsigned long long *__restrict__ mail = nullptr /* [0] winner, [1] finished first-stage waves (cumulative) */,
-    unsigned long long ticket = 0 /* of this launch, < 2^20, growing */, unsigned long long done_target = 0 /* mail[1] when stage 1 is through */)
+    unsigned long long ticket = 0 /* of this launch, < 2^20, growing */, unsigned long long done_target = 0 /* mail[1] when stage 1 is through */,
+    int walk_on = 0 /* second stage without a winner: answer the positions behind the window */)
 {
     const int64_t qi = (int64_t)blockIdx.x * (kMsThreads / kWave) + (threadIdx.x >> 6);
     if (qi >= count + count2) return;                            // (whole waves)
@@ -404,8 +405,12 @@ __global__ __launch_bounds__(kMsThreads) void match_search_wave_kernel(
         if (ready) v = __hip_atomic_load(&mail[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // winner word: ticket << 44 | (4095 - position) << 32 | length, kept by atomic max: a newer launch beats an older
         // one, inside a launch the smallest position wins (no reset between launches)
-        const bool go = ready && (v >> 44) == ticket;
-        if (go) base = scan0 + (int64_t)(4095 - ((v >> 32) & 0xfff)) + (int64_t)(uint32_t)v;
+        // No winner: no position of the window met a long match -- the loop is walking through a stretch that differs
+        // (an inserted / replaced run of bytes longer than the window) and will ask for the positions right behind it.
+        const bool won = ready && (v >> 44) == ticket;
+        if (won) base = scan0 + (int64_t)(4095 - ((v >> 32) & 0xfff)) + (int64_t)(uint32_t)v;
+        else base = scan0 + count;
+        const bool go = ready && (won || walk_on);
         if (!go || base + idx >= m) {
             if (lane_id() == 0) {
                 if (idx == 0) __hip_atomic_store(&packed2[0], kMsSkipped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -1821,6 +1821,7 @@ struct SearchWindows {
     static constexpr int64_t kSecond = 1024;             // slots of the predicted next window (second <= kSecond are used)
     int64_t second = 128;                                // positions of the predicted next window
     int64_t min_window = 128;                            // first window after a jump
+    bool walk_on = true;                                 // second stage without a winner: the positions behind the window
     static constexpr int64_t kSecondMaxFirst = 1024;     // ... behind first stages of up to this many positions
     int64_t sec_region = 0, predicted = 0;               // slot region (offset into h_packed) of the pending second stage
     bool sec_pending = false, no_second = false;
@@ -1917,7 +1918,7 @@ struct SearchWindows {
                                           (const int32_t *)d_ptab, pk,
                                           poll_now ? h_packed : (uint64_t *)nullptr, count2, reg2,
                                           count2 ? reinterpret_cast<unsigned long long *>(d_mail) : (unsigned long long *)nullptr,
-                                          ticket, done_total));
+                                          ticket, done_total, walk_on ? 1 : 0));
                 return DQ_OK;
             };
             if (poll_now) for (int64_t i = 0; i < count; ++i) h_packed[i] = kPending;
@@ -2125,6 +2126,7 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
     if (const char *v = env("DQ_WIN_MIN")) win.min_window = std::min<int64_t>(std::max(16, atoi(v)), SearchWindows::kWaveWindow);
     if (const char *v = env("DQ_WIN_SECOND")) win.second = std::min<int64_t>(std::max(16, atoi(v)), SearchWindows::kSecond);
     win.next_size = win.min_window;
+    if (const char *v = env("DQ_WALK_ON")) win.walk_on = atoi(v) != 0;
     rc = bsdiff::scan_loop(ix.old, ix.n, nw, m, win, raw);
     raw.windows = win.windows;
     raw.exact = win.exact;
