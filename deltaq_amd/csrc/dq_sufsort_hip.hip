@@ -1489,7 +1489,9 @@ struct SuffixSorter {
 
         bool sparse = m * 6 <= n || shallow_ties;
         if (const char *v = env("DQ_SPARSE")) sparse = atoi(v) != 0;
-        if (keys_ready || list_ungrouped) sparse = false;      // the ISA exists and the list is keyed / laid out for a radix round
+        // the ISA exists and the list is keyed / laid out for a radix round -- or carries its ranks as 32-bit values
+        // for the first LDS-class round (first_rank32: nothing else may read Kr[rcur] as ranks before that round)
+        if (keys_ready || list_ungrouped || first_rank32) sparse = false;
         if (sparse) rc = finish_sparse();
         else if (!dense_built) rc = build_isa(Kr[rcur], Vr[rcur], m);
         if (rc != DQ_OK) return rc;
@@ -1529,7 +1531,7 @@ struct SuffixSorter {
                                    (pair_tries == 0 || (pair_paid ? stagnant : h >= 16 * pair_h));
             const int max_tries = env("DQ_PAIR_TRIES") ? atoi(env("DQ_PAIR_TRIES")) : kPairChainTries;
             if (want && pair_tries < max_tries && pair_aborts < 2 * kPairChainTries && !env("DQ_NO_SMALL") && n < (1ll << 32) &&
-                m < n && !keys_ready && !list_ungrouped) {
+                m < n && !keys_ready && !list_ungrouped && !first_rank32) {
                 int outcome = 0;
                 m_before = 0;
                 const int64_t m_try = m;

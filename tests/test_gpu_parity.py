@@ -581,6 +581,30 @@ def test_runs_of_one_byte(ldss, oracle_mod, monkeypatch, env):
         assert np.array_equal(ldss.Sort(T), oracle_mod.divsufsort(T)), (env, T.size)
 
 
+def test_regression_inputs_found_by_the_stress_runs(ldss, oracle_mod, monkeypatch):
+    """Inputs that tests/manual/stress.py caught a build on (tests/golden/regress/*.npy, each with the flags it ran under).
+    stress_332_18050: suffix-binned first ISA on an input that leaves fewer than n/6 suffixes tied -- the finisher of the
+    sparse path read a rank list that had been left in 32-bit form for the first LDS-class round (memory fault)."""
+    import glob
+    import os
+    from conftest import GOLDEN_DIR
+    cases = {"stress_332_18050_binned_isa_few_ties.npy": [{"DQ_BINNED_ISA": "1"}, {"DQ_BINNED_ISA": "1", "DQ_PAIR_CHAINS": "2"},
+                                                          {"DQ_BINNED_ISA": "1", "DQ_SPARSE": "1"}, {}]}
+    files = sorted(glob.glob(os.path.join(GOLDEN_DIR, "regress", "*.npy")))
+    assert files
+    for f in files:
+        T = np.ascontiguousarray(np.load(f), dtype=np.uint8)
+        ref = oracle_mod.divsufsort(T)
+        for env in cases.get(os.path.basename(f), [{}]):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            import torch
+            assert np.array_equal(ldss.Sort(torch.from_numpy(T).cuda()).cpu().numpy(), ref), (f, env, "device")
+            assert np.array_equal(ldss.Sort(T), ref), (f, env, "host")
+            for k in env:
+                monkeypatch.delenv(k)
+
+
 def test_shared_provider_from_many_threads(ldss, oracle_mod):
     """Providers are shared singletons in the reference's benchmark (SuffixSortingBenchmarks.cs:59-61):
     every entry point must be re-entrant.  8 threads, one shared instance, different inputs."""
