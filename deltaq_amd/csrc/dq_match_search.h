@@ -244,8 +244,12 @@ template <typename IdxT>
 __device__ __forceinline__ void ms_search_wave(const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa,
                                                const uint8_t *__restrict__ nw, int64_t m, int64_t scan, int64_t cap,
                                                const IdxT *__restrict__ ptab, int pk, int64_t *pos_res, int64_t *len_res,
-                                               int64_t *over_at = nullptr)
+                                               int64_t *over_at = nullptr, bool resume_first = false, bool *went_exact = nullptr)
 {
+    // resume_first: a comparison that runs over the cap normally ends the search (len = -1: "inside a long match").
+    // If the match it ran into does NOT cover the byte before the query (old[p - 1] != new[scan - 1]), this position is
+    // probably the FIRST of that match -- the one the scan loop will want exactly -- and the search goes on from where
+    // it stands with the cap lifted, instead of being repeated from the top by the caller.
     const int lane = lane_id();
     const uint8_t *q = nw + scan;
     const int64_t lq = m - scan;
@@ -323,7 +327,16 @@ __device__ __forceinline__ void ms_search_wave(const uint8_t *__restrict__ old, 
         const int64_t l = lcp_lanes(p, llcp < rlcp ? llcp : rlcp, act, &over);
         if (handed > 4) narrow = true;
         const uint64_t ov = __ballot(over);
-        if (ov) { gave_up = true; gave_up_at = (int64_t)ms_readlane64((uint64_t)p, __builtin_ctzll(ov)); break; }
+        if (ov) {
+            gave_up_at = (int64_t)ms_readlane64((uint64_t)p, __builtin_ctzll(ov));
+            if (resume_first && cap > 0 && !(gave_up_at > 0 && scan > 0 && old[gave_up_at - 1] == nw[scan - 1])) {
+                cap = 0;                                        // this level again, exactly; everything after it too
+                if (went_exact) *went_exact = true;
+                continue;
+            }
+            gave_up = true;
+            break;
+        }
         const uint64_t yes = __ballot(act && less_than_query(p, l));      // a prefix of the active lanes
         const int f = __popcll(yes);
         if (f > 0) {
@@ -347,8 +360,18 @@ __device__ __forceinline__ void ms_search_wave(const uint8_t *__restrict__ old, 
         int64_t lim = (n - p) < lq ? (n - p) : lq;
         bool capped = false;
         if (cap > 0 && lim > cap) { lim = cap; capped = true; }
-        const int64_t r = ms_wave_lcp(old + p, lim, q, lim, 0);
-        if (capped && r == lim) { gave_up = true; gave_up_at = p; }
+        int64_t r = ms_wave_lcp(old + p, lim, q, lim, 0);
+        if (capped && r == lim) {
+            if (resume_first && !(p > 0 && scan > 0 && old[p - 1] == nw[scan - 1])) {
+                cap = 0;
+                if (went_exact) *went_exact = true;
+                const int64_t full = (n - p) < lq ? (n - p) : lq;
+                r = ms_wave_lcp(old + p, full, q, full, r);
+            } else {
+                gave_up = true;
+                gave_up_at = p;
+            }
+        }
         return r;
     };
     const bool x_known = g > 0 ? l_known : r_known;
@@ -424,11 +447,9 @@ __global__ __launch_bounds__(kMsThreads) void match_search_wave_kernel(
     int64_t pos = 0, len = 0, at = -1;
     const int64_t scan = base + idx;
     bool exact = idx == 0;
-    ms_search_wave<IdxT>(old, n, sa, nw, m, scan, exact ? 0 : cap, ptab, pk, &pos, &len, &at);
-    if (len < 0 && !(at > 0 && scan > 0 && old[at - 1] == nw[scan - 1])) {
-        ms_search_wave<IdxT>(old, n, sa, nw, m, scan, 0, ptab, pk, &pos, &len);
-        exact = true;
-    }
+    bool went_exact = false;
+    ms_search_wave<IdxT>(old, n, sa, nw, m, scan, exact ? 0 : cap, ptab, pk, &pos, &len, &at, /*resume_first=*/true, &went_exact);
+    exact = exact || went_exact;
     if (lane_id() == 0) {
         if (packed_out) {
             // polled by the host loop in pinned memory (a round trip of the scan loop is worth the ~10 us of
