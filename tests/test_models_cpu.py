@@ -400,3 +400,33 @@ def test_mid_group_tiles_claim_every_entry_exactly_once():
             else:
                 assert np.all(large[pos:pos + s] == 1), (trial, pos, s)
             pos += s
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dq_match_search.h, second stage of the window kernel: the mailbox word  ticket << 44 | (4095 - position) << 32 | length
+# kept by atomic max and never reset.  Model: whatever order the first-stage waves of several launches publish in,
+# the word a second stage reads is (a) of its own launch iff any wave of that launch published, with (b) the SMALLEST
+# position of that launch; an older launch's word never passes the ticket test; lengths never disturb the order.
+def mail_word(ticket, pos, length):
+    assert 0 <= pos < 4096 and 0 <= length < (1 << 32) and 0 < ticket < (1 << 20)
+    return (ticket << 44) | ((4095 - pos) << 32) | length
+
+
+def test_mailbox_word_orders_by_ticket_then_smallest_position():
+    rng = np.random.default_rng(8)
+    mail = 0
+    for ticket in range(1, 200):
+        k = int(rng.integers(0, 6))                                   # long matches found by this launch's waves
+        pubs = [(int(rng.integers(0, 4096)), int(rng.integers(32, 1 << 31))) for _ in range(k)]
+        order = rng.permutation(k)
+        for i in order:                                               # publication order is arbitrary
+            mail = max(mail, mail_word(ticket, *pubs[i]))
+        won = (mail >> 44) == ticket                                  # the second stage's test
+        assert won == (k > 0)
+        if won:
+            pos = 4095 - ((mail >> 32) & 0xfff)
+            length = mail & 0xffffffff
+            best = min(p for p, _ in pubs)
+            assert pos == best and length in [l for p, l in pubs if p == best]
+    # the host stops using the second stage before the ticket field would overflow (ticket < 2^20 - 2)
+    assert mail_word((1 << 20) - 3, 0, (1 << 32) - 1) < (1 << 64)
