@@ -96,10 +96,24 @@ __device__ __forceinline__ int64_t ms_wave_lcp(const uint8_t *a, int64_t la, con
     return lim;
 }
 
+// [ptab[v], ptab[v + 1]) holds the suffixes s with pattern(v) <= s < pattern(v + 1): the ones that start with the pk
+// bytes of v -- and, at its upper end, up to pk - 1 suffixes SHORTER than pk bytes that sort between the two patterns
+// without sharing them (old ending in the byte c puts the one-byte suffix "c" into the range of v = (c - 1, 255):
+// "c-1 255 ..." < "c" < "c 0").  The search below starts its comparisons behind the pk shared bytes, so those are cut
+// off first; they are larger than every suffix that does start with v, hence larger than the query.
+template <typename IdxT>
+__device__ __forceinline__ void ms_trim_short_suffixes(const IdxT *__restrict__ sa, int64_t n, int pk, int64_t L, int64_t *R)
+{
+    for (int t = 1; t < pk && *R > L; ++t) {
+        if (n - (int64_t)sa[*R - 1] < pk) --*R; else break;
+    }
+}
+
 // prefix_bounds_kernel: ptab[v] = number of suffixes of old below the pk-byte string with big-endian value v, for
 // v = 0 .. 256^pk (ptab[256^pk] = n); one thread per v, the same lower bound as below with a pk-byte pattern.
 // A query of >= pk bytes with prefix value v then has its lower bound inside [ptab[v], ptab[v + 1]], and every
-// suffix strictly inside that range shares those pk bytes with it: the search starts ~8 * pk probes further down.
+// suffix inside that range -- but for the short ones ms_trim_short_suffixes() removes -- shares those pk bytes with
+// it: the search starts ~8 * pk probes further down.
 // Built once per old file by the scan-loop driver (dq_sufsort_hip.hip::SearchWindows), where a Search is one
 // dependent round trip to the device and its ~log2(n) probes of ~1 us each are what the round trip costs.
 template <typename IdxT>
@@ -196,6 +210,7 @@ __device__ __forceinline__ void ms_search_one(const uint8_t *__restrict__ old, i
         for (int j = 0; j < pk; ++j) v = (v << 8) | q[j];
         L = (int64_t)ptab[v];
         R = (int64_t)ptab[v + 1];
+        ms_trim_short_suffixes(sa, n, pk, L, &R);
         llcp = rlcp = pk;
     }
     for (;;) {
@@ -310,6 +325,7 @@ __device__ __forceinline__ void ms_search_wave(const uint8_t *__restrict__ old, 
         for (int j = 0; j < pk; ++j) v = (v << 8) | q[j];
         L = (int64_t)ptab[v];
         R = (int64_t)ptab[v + 1];
+        ms_trim_short_suffixes(sa, n, pk, L, &R);
         llcp = rlcp = pk;
     }
     while (L < R && !gave_up) {
@@ -411,7 +427,8 @@ __global__ __launch_bounds__(kMsThreads) void match_search_wave_kernel(
     int64_t count2 = 0, uint64_t *__restrict__ packed2 = nullptr /* second stage: [0] its start, [1 + i] its answers */,
     unsigned long long *__restrict__ mail = nullptr /* [0] winner, [1] finished first-stage waves (cumulative) */,
     unsigned long long ticket = 0 /* of this launch, < 2^20, growing */, unsigned long long done_target = 0 /* mail[1] when stage 1 is through */,
-    int walk_on = 0 /* second stage without a winner: answer the positions behind the window */)
+    int walk_on = 0 /* second stage without a winner: answer the positions behind the window */,
+    int no_resume = 0 /* 1: a capped first position is searched again from the top (the older form) */)
 {
     const int64_t qi = (int64_t)blockIdx.x * (kMsThreads / kWave) + (threadIdx.x >> 6);
     if (qi >= count + count2) return;                            // (whole waves)
@@ -448,8 +465,12 @@ __global__ __launch_bounds__(kMsThreads) void match_search_wave_kernel(
     const int64_t scan = base + idx;
     bool exact = idx == 0;
     bool went_exact = false;
-    ms_search_wave<IdxT>(old, n, sa, nw, m, scan, exact ? 0 : cap, ptab, pk, &pos, &len, &at, /*resume_first=*/true, &went_exact);
+    ms_search_wave<IdxT>(old, n, sa, nw, m, scan, exact ? 0 : cap, ptab, pk, &pos, &len, &at, /*resume_first=*/!no_resume, &went_exact);
     exact = exact || went_exact;
+    if (no_resume && len < 0 && !(at > 0 && scan > 0 && old[at - 1] == nw[scan - 1])) {
+        ms_search_wave<IdxT>(old, n, sa, nw, m, scan, 0, ptab, pk, &pos, &len);
+        exact = true;
+    }
     if (lane_id() == 0) {
         if (packed_out) {
             // polled by the host loop in pinned memory (a round trip of the scan loop is worth the ~10 us of

@@ -1734,6 +1734,18 @@ int match_search_dev(const void *d_old, int64_t n, const void *d_sa, const void 
     // (DQ_SEARCH_WAVE=1: consecutive positions through the one-wave-per-position kernel of the scan-loop driver, so
     // that the tests can compare its answers one by one; position 0 is answered exactly whatever the cap)
     const bool wave = env("DQ_SEARCH_WAVE") && !d_scans && count <= 4096;
+    // (DQ_SEARCH_PTAB = 2 | 3: the search starts from a prefix table of that many bytes, as the scan-loop driver's
+    // windows do -- built here for the call, so that the tests can compare the answers of both kernels with it)
+    struct TmpTab { void *p = nullptr; ~TmpTab() { if (p) (void)hipFree(p); } } tmp_tab;
+    if (!d_ptab && env("DQ_SEARCH_PTAB") && n > 0) {
+        pk = atoi(env("DQ_SEARCH_PTAB")) >= 3 ? 3 : 2;
+        const int64_t total = (1ll << (8 * pk)) + 1;
+        HIP_TRY(hipMalloc(&tmp_tab.p, (size_t)total * sizeof(IdxT)));
+        hipLaunchKernelGGL(prefix_bounds_kernel<IdxT>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           (const uint8_t *)d_old, n, (const IdxT *)d_sa, pk, (IdxT *)tmp_tab.p);
+        HIP_TRY(hipGetLastError());
+        d_ptab = tmp_tab.p;
+    }
     auto launch = [&]() -> int {
         if (wave) {
             constexpr int kPer = kMsThreads / kWave;
@@ -1824,6 +1836,7 @@ struct SearchWindows {
     int64_t second = 128;                                // positions of the predicted next window
     int64_t min_window = 128;                            // first window after a jump
     bool walk_on = true;                                 // second stage without a winner: the positions behind the window
+    bool no_resume = false;                              // DQ_NO_RESUME: capped first positions searched again from the top
     static constexpr int64_t kSecondMaxFirst = 1024;     // ... behind first stages of up to this many positions
     int64_t sec_region = 0, predicted = 0;               // slot region (offset into h_packed) of the pending second stage
     bool sec_pending = false, no_second = false;
@@ -1920,7 +1933,7 @@ struct SearchWindows {
                                           (const int32_t *)d_ptab, pk,
                                           poll_now ? h_packed : (uint64_t *)nullptr, count2, reg2,
                                           count2 ? reinterpret_cast<unsigned long long *>(d_mail) : (unsigned long long *)nullptr,
-                                          ticket, done_total, walk_on ? 1 : 0));
+                                          ticket, done_total, walk_on ? 1 : 0, no_resume ? 1 : 0));
                 return DQ_OK;
             };
             if (poll_now) for (int64_t i = 0; i < count; ++i) h_packed[i] = kPending;
@@ -2129,6 +2142,7 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
     if (const char *v = env("DQ_WIN_SECOND")) win.second = std::min<int64_t>(std::max(16, atoi(v)), SearchWindows::kSecond);
     win.next_size = win.min_window;
     if (const char *v = env("DQ_WALK_ON")) win.walk_on = atoi(v) != 0;
+    win.no_resume = env("DQ_NO_RESUME") != nullptr;
     rc = bsdiff::scan_loop(ix.old, ix.n, nw, m, win, raw);
     raw.windows = win.windows;
     raw.exact = win.exact;

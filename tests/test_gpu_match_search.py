@@ -162,3 +162,50 @@ def test_wave_per_position_kernel(ms, oracle_mod, monkeypatch):
     want = oracle_mod.bsdiff_search(old, sa64, new, scan0=1000, count=500)
     got = ms.Search(sa64, old, new, scan0=1000, count=500)
     assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+
+
+def test_prefix_table_ranges_and_the_last_suffixes(backend_lib, oracle_mod, monkeypatch):
+    """The scan-loop driver starts its searches from a prefix table (2 or 3 bytes): [ptab[v], ptab[v + 1]) also holds,
+    at its upper end, the suffixes SHORTER than the prefix that sort between the two patterns (old ending in byte c: the
+    one-byte suffix "c" lies in the range of (c - 1, 255)).  Every position, both kernels, with the table forced on
+    (DQ_SEARCH_PTAB); queries built to start with exactly those prefixes.  Found by tests/manual/stress_bsdiff.py
+    (seed 373, pair 7459: a pre-existing slip of round 2), kept in tests/golden/regress/."""
+    import os
+    from conftest import GOLDEN_DIR
+    from deltaq_amd import Diff, HipMatchSearch
+    ms = HipMatchSearch(0)
+    rng = np.random.default_rng(3)
+    pairs = []
+    for tail in ([239], [7, 0], [200, 255], [0], [255], [9, 9]):
+        c = tail[0]
+        body = rng.integers(0, 256, 70_000, dtype=np.uint8)
+        for k in range(0, 60_000, 997):                          # plant the critical prefixes in old, followed by noise
+            body[k:k + 3] = [(c - 1) % 256, 255, 255]
+            body[k + 500:k + 503] = [c, tail[1] if len(tail) > 1 else 0, 0]
+        old = np.concatenate([body, np.array(tail, np.uint8)])
+        new = rng.integers(0, 256, 20_000, dtype=np.uint8)
+        for k in range(0, 19_000, 211):                          # ... and queries that start with them
+            new[k:k + 3] = [(c - 1) % 256, 255, int(rng.integers(0, 256))]
+            new[k + 100:k + 102] = [(c - 1) % 256, 255]
+            new[k + 150:k + 153] = [c, tail[1] if len(tail) > 1 else 0, 0]
+        new[-2:] = [(c - 1) % 256, 255]
+        pairs.append((old, new))
+    pairs.append((np.load(os.path.join(GOLDEN_DIR, "regress", "bsdiff_373_7459_old.npy")),
+                  np.load(os.path.join(GOLDEN_DIR, "regress", "bsdiff_373_7459_new.npy"))))
+    for old, new in pairs:
+        sa = oracle_mod.divsufsort(old)
+        wp, wl = oracle_mod.bsdiff_search(old, sa, new, scan0=0, count=new.size)
+        for tab in ("2", "3"):
+            monkeypatch.setenv("DQ_SEARCH_PTAB", tab)
+            p, l = ms.Search(sa, old, new, scan0=0, count=new.size)
+            assert np.array_equal(p, wp) and np.array_equal(l, wl), ("lane kernel", tab, old.size)
+            monkeypatch.setenv("DQ_SEARCH_WAVE", "1")
+            for s0 in range(0, new.size, 4096):
+                cnt = min(4096, new.size - s0)
+                p, l = ms.Search(sa, old, new, scan0=s0, count=cnt)
+                assert np.array_equal(p, wp[s0:s0 + cnt]) and np.array_equal(l, wl[s0:s0 + cnt]), ("wave kernel", tab, old.size, s0)
+            monkeypatch.delenv("DQ_SEARCH_WAVE")
+            monkeypatch.delenv("DQ_SEARCH_PTAB")
+        ctrl, diff, extra, _ = Diff.Scan(old, new)
+        wc, wd, we, _ = oracle_mod.bsdiff_scan(old, sa, new)
+        assert np.array_equal(ctrl, wc) and np.array_equal(diff, wd) and np.array_equal(extra, we), old.size
