@@ -281,7 +281,7 @@ int flush_profile(DeviceCtx &c)
         if (rc_ != DQ_OK) return rc_;                     \
     } while (0)
 
-constexpr int kSgChain = 4;       // small-group rounds chained without a host round trip
+constexpr int kSgChain = 8;       // small-group rounds chained without a host round trip (4 -> 8: see DESIGN section 5)
 constexpr int64_t kSgShortList = 1 << 20;     // below this many tied suffixes a round is launch-bound
 
 // ------------------------------------------------------------------ workspace carving
