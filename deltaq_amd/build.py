@@ -2,20 +2,29 @@
 
 The shared library is built IN-TREE (deltaq_amd/libdq_sufsort_hip.so) so that it
 travels with the repository snapshot; it is git-ignored.
+
+Four translation units, compiled side by side and linked into one library:
+    dq_sorter_i32.hip / dq_sorter_i64.hip   the suffix sorter and its kernels per index width
+    dq_diff.hip                             match search, Diff.Create / Patch.Apply
+    dq_abi.hip                              the C ABI and the batch pipeline (host code only)
+Objects live in deltaq_amd/csrc/obj/ with the compiler's own dependency files, so an edit
+rebuilds only the units that include what changed.
 """
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "obj")
 LIB_NAME = "libdq_sufsort_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["dq_sufsort_hip.hip"]
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "dq_sufsort.h")]
+SOURCES = ["dq_sorter_i32.hip", "dq_sorter_i64.hip", "dq_diff.hip", "dq_abi.hip"]
 ARCH = "gfx950"
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-pthread"]
 
 
 def _hipcc() -> str:
@@ -25,11 +34,40 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the MI355X backend cannot be built")
 
 
+def _obj(src: str) -> str:
+    return os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+
+
+def _deps(src: str) -> list[str]:
+    """Files the object was compiled from, as recorded by the compiler (-MD); none recorded = unknown."""
+    dep = _obj(src)[:-2] + ".d"
+    if not os.path.exists(dep):
+        return []
+    text = open(dep).read().replace("\\\n", " ")
+    return [p for p in text.split(":", 1)[-1].split() if p.startswith(CSRC) or p.startswith(os.path.dirname(HERE))]
+
+
+def _obj_stale(src: str) -> bool:
+    obj = _obj(src)
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = _deps(src)
+    if not deps:
+        return True
+    return any((not os.path.exists(p)) or os.path.getmtime(p) > t for p in deps + [os.path.join(CSRC, src)])
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    if os.path.isdir(OBJ) and all(os.path.exists(_obj(s)) for s in SOURCES):
+        return any(_obj_stale(s) or os.path.getmtime(_obj(s)) > t for s in SOURCES)
+    # a snapshot that carries the library but not the objects (the GPU box): compare with every source
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
+    srcs.append(os.path.join(os.path.dirname(HERE), "include", "dq_sufsort.h"))
+    return any(os.path.getmtime(p) > t for p in srcs)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -42,16 +80,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not is_stale():
             return LIB_PATH
-        return _build_locked(verbose)
+        return _build_locked(force, verbose)
 
 
-def _build_locked(verbose: bool) -> str:
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-pthread"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH + ".tmp"]
+def _compile(src: str, verbose: bool) -> None:
+    obj = _obj(src)
+    cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-MD", "-MF", obj[:-2] + ".d", "-o", obj]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    todo = [s for s in SOURCES if force or _obj_stale(s)]
+    with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as pool:
+        list(pool.map(lambda s: _compile(s, verbose), todo))
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-pthread", *[_obj(s) for s in SOURCES], "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH

@@ -40,7 +40,7 @@ struct BucketFlags {
 };
 
 // bounds[t] for t = 0..ntiles: first bucket boundary at or after t*C (bounds[ntiles] = n)
-__global__ __launch_bounds__(kBlock) void bucket_bounds_kernel(const uint64_t *__restrict__ W, int64_t n, int bshift,
+static __global__ __launch_bounds__(kBlock) void bucket_bounds_kernel(const uint64_t *__restrict__ W, int64_t n, int bshift,
                                                                int64_t C, int64_t X, int64_t ntiles,
                                                                int64_t *__restrict__ bounds,
                                                                BucketFlags *__restrict__ flags)

@@ -1,0 +1,631 @@
+// dq_diff.hip -- the consumers of the suffix array: match search on the device-resident SA (Diff.cs:267-298), Diff.Create
+// (Diff.cs:27-253: scan loop over windows of device answers, BSDIFF40 framing with the own bzip2 codec), Patch.Apply
+// (Patch.cs:52-168), and the one-old-file-many-new-files index.  The sorter is called through dq_runtime.h.
+#include "dq_runtime.h"
+#include "dq_match_search.h"
+#include "dq_bz2.h"
+#include "dq_bsdiff.h"
+#include "dq_bspatch.h"
+
+namespace dq {
+namespace {
+
+// ------------------------------------------------------------------ match search (Diff.cs:267-298) on the device
+template <typename IdxT>
+int match_search_dev(const void *d_old, int64_t n, const void *d_sa, const void *d_new, int64_t m,
+                     const int64_t *d_scans, int64_t scan0, int64_t count, int64_t cap, void *d_pos, void *d_len,
+                     int32_t device, void *stream, const void *d_ptab = nullptr, int pk = 0, int exact_first = 0)
+{
+    if (n < 0 || m < 0 || count < 0 || cap < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
+    if ((n > 0 && (!d_old || !d_sa)) || (m > 0 && !d_new) || (count > 0 && (!d_pos || !d_len)))
+        return fail(DQ_ERR_BAD_ARGS, "null buffer");
+    if (!d_scans && (scan0 < 0 || scan0 + count > m + 1)) return fail(DQ_ERR_BAD_ARGS, "scan range outside the new data");
+    if (sizeof(IdxT) == 4 && (n > 0x7fffffffLL || m > 0x7fffffffLL))
+        return fail(DQ_ERR_TOO_LARGE, "n or m exceeds 2^31-1; use the i64 entry point");
+    int dev = 0;
+    int rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    if (count == 0) return DQ_OK;
+    DeviceCtx &c = ctx0(dev);
+    std::lock_guard<std::mutex> lk(c.mu);
+    rc = init_ctx(c, dev);
+    if (rc != DQ_OK) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : c.stream;
+    Launcher L{c, st, g_prof_on.load()};
+    // per query: ~log2(n) probes of one SA entry and one 64-byte sector of old, + the match itself
+    const int64_t probes = bit_length((uint64_t)std::max<int64_t>(n, 1));
+    // (DQ_SEARCH_WAVE=1: consecutive positions through the one-wave-per-position kernel of the scan-loop driver, so
+    // that the tests can compare its answers one by one; position 0 is answered exactly whatever the cap)
+    const bool wave = env("DQ_SEARCH_WAVE") && !d_scans && count <= 4096;
+    // (DQ_SEARCH_PTAB = 2 | 3: the search starts from a prefix table of that many bytes, as the scan-loop driver's
+    // windows do -- built here for the call, so that the tests can compare the answers of both kernels with it)
+    struct TmpTab { void *p = nullptr; ~TmpTab() { if (p) (void)hipFree(p); } } tmp_tab;
+    if (!d_ptab && env("DQ_SEARCH_PTAB") && n > 0) {
+        pk = atoi(env("DQ_SEARCH_PTAB")) >= 3 ? 3 : 2;
+        const int64_t total = (1ll << (8 * pk)) + 1;
+        HIP_TRY(hipMalloc(&tmp_tab.p, (size_t)total * sizeof(IdxT)));
+        hipLaunchKernelGGL(prefix_bounds_kernel<IdxT>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           (const uint8_t *)d_old, n, (const IdxT *)d_sa, pk, (IdxT *)tmp_tab.p);
+        HIP_TRY(hipGetLastError());
+        d_ptab = tmp_tab.p;
+    }
+    auto launch = [&]() -> int {
+        if (wave) {
+            constexpr int kPer = kMsThreads / kWave;
+            LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * 4 * ((int64_t)sizeof(IdxT) + 64) * 64,
+                   hipLaunchKernelGGL(match_search_wave_kernel<IdxT>, dim3((unsigned)((count + kPer - 1) / kPer)),
+                                      dim3(kMsThreads), 0, st, (const uint8_t *)d_old, n, (const IdxT *)d_sa,
+                                      (const uint8_t *)d_new, m, scan0, count, cap, (IdxT *)d_pos, (IdxT *)d_len,
+                                      (const IdxT *)d_ptab, pk, 0));
+            return DQ_OK;
+        }
+        LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * probes * ((int64_t)sizeof(IdxT) + 64),
+               hipLaunchKernelGGL(match_search_kernel<IdxT>, dim3((unsigned)((count + kMsThreads - 1) / kMsThreads)),
+                                  dim3(kMsThreads), 0, st, (const uint8_t *)d_old, n, (const IdxT *)d_sa,
+                                  (const uint8_t *)d_new, m, d_scans, scan0, count, cap, (IdxT *)d_pos, (IdxT *)d_len,
+                                  (const IdxT *)d_ptab, pk, exact_first));
+        return DQ_OK;
+    };
+    rc = launch();
+    if (rc != DQ_OK) { drop_pending(c, st); return rc; }
+    HIP_TRY(hipStreamSynchronize(st));
+    return flush_profile(c);
+}
+
+// host buffers in / out: what a P/Invoke caller without device memory of its own uses (and the tests)
+template <typename IdxT>
+int match_search_host(const uint8_t *old, int64_t n, const IdxT *sa, const uint8_t *nw, int64_t m, const int64_t *scans,
+                      int64_t scan0, int64_t count, int64_t cap, IdxT *pos, IdxT *len, int32_t device)
+{
+    if (n < 0 || m < 0 || count < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
+    if ((n > 0 && (!old || !sa)) || (m > 0 && !nw) || (count > 0 && (!pos || !len))) return fail(DQ_ERR_BAD_ARGS, "null buffer");
+    // host-resident scan positions are checked here (a position outside [0, m] would be a device read out of bounds);
+    // the device forms take them as they are (include/dq_sufsort.h says so)
+    if (scans)
+        for (int64_t q = 0; q < count; ++q)
+            if (scans[q] < 0 || scans[q] > m) return fail(DQ_ERR_BAD_ARGS, "scan position outside the new data");
+    int dev = 0;
+    int rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    if (count == 0) return DQ_OK;
+    HIP_TRY(hipSetDevice(dev));
+    char *base = nullptr;
+    const size_t b_old = align_up((size_t)n + 16), b_sa = align_up((size_t)n * sizeof(IdxT) + 16), b_new = align_up((size_t)m + 16);
+    const size_t b_sc = scans ? align_up((size_t)count * 8) : 0, b_out = align_up((size_t)count * sizeof(IdxT));
+    hipError_t e = hipMalloc((void **)&base, b_old + b_sa + b_new + b_sc + 2 * b_out);
+    if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(match search buffers)", e);
+    char *d_old = base, *d_sa = d_old + b_old, *d_new = d_sa + b_sa, *d_sc = d_new + b_new, *d_pos = d_sc + b_sc,
+         *d_len = d_pos + b_out;
+    auto done = [&](int code) { (void)hipFree(base); return code; };
+    if (n > 0) {
+        if (hipMemcpy(d_old, old, (size_t)n, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_sa, sa, (size_t)n * sizeof(IdxT), hipMemcpyHostToDevice) != hipSuccess)
+            return done(fail(DQ_ERR_HIP, "match search: copy-in failed"));
+    }
+    if (m > 0 && hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice) != hipSuccess)
+        return done(fail(DQ_ERR_HIP, "match search: copy-in failed"));
+    if (scans && hipMemcpy(d_sc, scans, (size_t)count * 8, hipMemcpyHostToDevice) != hipSuccess)
+        return done(fail(DQ_ERR_HIP, "match search: copy-in failed"));
+    rc = match_search_dev<IdxT>(d_old, n, d_sa, d_new, m, scans ? (const int64_t *)d_sc : nullptr, scan0, count, cap, d_pos,
+                                d_len, dev, nullptr);
+    if (rc != DQ_OK) return done(rc);
+    if (hipMemcpy(pos, d_pos, (size_t)count * sizeof(IdxT), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(len, d_len, (size_t)count * sizeof(IdxT), hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(DQ_ERR_HIP, "match search: copy-out failed"));
+    return done(DQ_OK);
+}
+
+// ------------------------------------------------------------------ BSDIFF40: Diff.Create / Patch.Apply (dq_bsdiff.h)
+// Answers of the match search for a window of scan positions ahead of the scan loop.  Windows start small after a
+// jump and double while the loop consumes them to the end (a region where old and new differ: one Search per
+// byte, the regime the device is for: 4.2 M searches in 31 ms against 5.4 s on one host core; the one-query-per-lane
+// kernel).  The cap is low: the positions of a window that lie inside the next long match would each cost `cap` byte
+// comparisons for nothing (the loop leaves the window with its next jump).  Between nearly identical files the
+// loop hops from match to match and every launch is a dependent round trip (~1 per edit): windows of up to 2048
+// positions go to the one-wave-per-position kernel (65-ary search; the position the loop stands on and the probable
+// start of the next long match answered exactly), whose answers are polled in pinned memory, whose second stage
+// answers the window behind the predicted jump, and which answers exactly throughout while positions keep coming
+// back capped (dq_match_search.h; DESIGN.md section 2c has the measurements).
+struct SearchWindows {
+    const void *d_old, *d_sa, *d_new;
+    int64_t n, m;
+    int device;
+    // kMaxWindow + 2 entries each in PINNED HOST memory that the kernel writes directly (no copy back: between
+    // similar files the loop is a chain of dependent round trips, and two small hipMemcpy cost more than the kernel)
+    int32_t *h_pos = nullptr, *h_len = nullptr;
+    uint64_t *h_packed = nullptr;                        // pinned: (len << 32 | pos) of the wave windows, polled by the loop
+    void *d_mail = nullptr;                              // device: mailbox of the window kernel's second stage
+    static constexpr int64_t kSecond = 1024;             // slots of the predicted next window (second <= kSecond are used)
+    int64_t second = 128;                                // positions of the predicted next window
+    int64_t min_window = 128;                            // first window after a jump
+    bool walk_on = true;                                 // second stage without a winner: the positions behind the window
+    bool no_resume = false;                              // DQ_NO_RESUME: capped first positions searched again from the top
+    static constexpr int64_t kSecondMaxFirst = 1024;     // ... behind first stages of up to this many positions
+    int64_t sec_region = 0, predicted = 0;               // slot region (offset into h_packed) of the pending second stage
+    bool sec_pending = false, no_second = false;
+    int64_t last_capped = -2, capped_streak = 0;         // consecutive positions that came back capped
+    bool from_capped = false;
+    unsigned long long ticket = 0, done_total = 0;       // of the launches with a second stage (the mailbox is never reset)
+    const void *d_ptab = nullptr;                        // prefix table (prefix_bounds_kernel), or none
+    int pk = 0;
+    int64_t w0 = -1, wc = 0, next_size = 128;
+    int64_t windows = 0, exact = 0;
+    static constexpr int64_t kMinWindow = 128, kMaxWindow = 65536, kCap = 64, kWaveWindow = 2048;
+    static constexpr uint64_t kPending = 0x8000000080000000ull;   // (no answer looks like this: len >= -1)
+
+    // wait for one pinned slot to leave the "pending" state (bounded polling, then the ordinary stream wait)
+    int await_slot(const uint64_t *slot, hipStream_t st, uint64_t *value)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0;; ++spins) {
+            const uint64_t v = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
+            if (v != kPending) { *value = v; return DQ_OK; }
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+        HIP_TRY(hipStreamSynchronize(st));               // (a slow window -- megabytes of equal text)
+        *value = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
+        if (*value == kPending) return fail(DQ_ERR_HIP, "match search: a window position was left unanswered");
+        return DQ_OK;
+    }
+
+    int refill(int64_t scan)
+    {
+        int dev = 0;
+        int rc = resolve_device(device, &dev);
+        if (rc != DQ_OK) return rc;
+        DeviceCtx &c = ctx0(dev);
+        // the window the device was asked to answer ahead (second stage of the previous launch): is it this one?
+        if (sec_pending) {
+            sec_pending = false;
+            const uint64_t *reg = h_packed + sec_region;
+            uint64_t hdr = 0;
+            rc = await_slot(&reg[0], c.stream, &hdr);
+            if (rc != DQ_OK) return rc;
+            if (hdr != kMsSkipped && (int64_t)hdr == scan) {
+                int64_t got = 0;
+                for (; got < second; ++got) {
+                    uint64_t v = 0;
+                    rc = await_slot(&reg[1 + got], c.stream, &v);
+                    if (rc != DQ_OK) return rc;
+                    if (v == kMsSkipped) break;
+                    h_pos[got] = (int32_t)(uint32_t)v;
+                    h_len[got] = (int32_t)(uint32_t)(v >> 32);
+                }
+                if (got > 0) {
+                    w0 = scan;
+                    wc = got;
+                    next_size = min_window;
+                    ++windows;
+                    ++predicted;
+                    return DQ_OK;
+                }
+            }
+        }
+        // (the loop jumped: whatever made positions come back capped in a row is behind it)
+        if (!from_capped && !(w0 >= 0 && scan == w0 + wc)) capped_streak = 0;
+        from_capped = false;
+        // the previous window was used up to its end: the loop is walking byte by byte -> a larger one
+        next_size = (w0 >= 0 && scan == w0 + wc) ? std::min(next_size * 2, kMaxWindow) : min_window;
+        const int64_t count = std::min(next_size, m - scan);
+        if (count <= kWaveWindow && !env("DQ_NO_WAVE_WINDOWS")) {
+            // short windows (the loop is hopping from match to match: every launch is a dependent round trip): one WAVE
+            // per position, 65-ary search; the position the loop stands on exactly, the ones behind it with the cap
+            std::lock_guard<std::mutex> lk(c.mu);
+            rc = init_ctx(c, dev);
+            if (rc != DQ_OK) return rc;
+            Launcher L{c, c.stream, g_prof_on.load()};
+            constexpr int kPer = kMsThreads / kWave;
+            const bool poll_now = h_packed != nullptr && !L.prof;
+            // second stage: the window the loop will want after its next jump (dq_match_search.h), windows of up to 1024 positions.
+            // Its answers are looked at when the loop gets there, not now; two slot regions take turns, so that a
+            // region is written by one launch at a time (the launch in between has answered: the older one is over).
+            const int64_t count2 = (poll_now && d_mail && count <= kSecondMaxFirst && !no_second && ticket < (1ull << 20) - 2) ? second : 0;
+            uint64_t *reg2 = nullptr;
+            if (count2) {
+                ++ticket;
+                done_total += (unsigned long long)count;
+                sec_region = kWaveWindow + (int64_t)(ticket & 1) * (kSecond + 1);
+                reg2 = h_packed + sec_region;
+                for (int64_t i = 0; i < second + 1; ++i) reg2[i] = kPending;
+            }
+            auto launch = [&]() -> int {
+                LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * 4 * (4 + 64) * 64,
+                       hipLaunchKernelGGL(match_search_wave_kernel<int32_t>, dim3((unsigned)((count + count2 + kPer - 1) / kPer)),
+                                          dim3(kMsThreads), 0, c.stream, (const uint8_t *)d_old, n, (const int32_t *)d_sa,
+                                          (const uint8_t *)d_new, m, scan, count, capped_streak >= 2 ? (int64_t)0 : kCap, h_pos, h_len,
+                                          (const int32_t *)d_ptab, pk,
+                                          poll_now ? h_packed : (uint64_t *)nullptr, count2, reg2,
+                                          count2 ? reinterpret_cast<unsigned long long *>(d_mail) : (unsigned long long *)nullptr,
+                                          ticket, done_total, walk_on ? 1 : 0, no_resume ? 1 : 0));
+                return DQ_OK;
+            };
+            if (poll_now) for (int64_t i = 0; i < count; ++i) h_packed[i] = kPending;
+            rc = launch();
+            if (rc != DQ_OK) { drop_pending(c, c.stream); return rc; }
+            if (poll_now) {
+                for (int64_t i = 0; i < count; ++i) {
+                    uint64_t v = 0;
+                    rc = await_slot(&h_packed[i], c.stream, &v);
+                    if (rc != DQ_OK) return rc;
+                    h_pos[i] = (int32_t)(uint32_t)v;
+                    h_len[i] = (int32_t)(uint32_t)(v >> 32);
+                }
+                sec_pending = count2 > 0;
+            } else {
+                HIP_TRY(hipStreamSynchronize(c.stream));
+            }
+            rc = flush_profile(c);
+        } else {
+            rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, count, kCap, h_pos, h_len, device, nullptr,
+                                           d_ptab, pk, /*exact_first=*/1);
+        }
+        if (rc != DQ_OK) return rc;                      // (the answers are there)
+        w0 = scan;
+        wc = count;
+        ++windows;
+        return DQ_OK;
+    }
+    int operator()(int64_t scan, int64_t *pos, int64_t *len)
+    {
+        if (scan < w0 || scan >= w0 + wc) {
+            const int rc = refill(scan);
+            if (rc != DQ_OK) return rc;
+        }
+        int64_t p = h_pos[(size_t)(scan - w0)], l = h_len[(size_t)(scan - w0)];
+        if (l < 0) {
+            // undecided within the cap (the loop has reached the next long match): a new window from here, whose first
+            // position is answered exactly -- and whose other positions are there if the match turns out not to be taken.
+            // When that happens at one position after the other (the loop is walking through text that matches far
+            // everywhere -- periodic data, runs -- without jumping), the windows are answered exactly throughout:
+            // one launch per 128 positions instead of one per position.
+            capped_streak = (scan == last_capped + 1) ? capped_streak + 1 : 1;
+            last_capped = scan;
+            w0 = -1;
+            from_capped = true;
+            int rc = refill(scan);
+            if (rc != DQ_OK) return rc;
+            p = h_pos[0];
+            l = h_len[0];
+            ++exact;
+            if (l < 0) {                                 // (a long window: its exact position may not be this one)
+                rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, 1, 0, h_pos + kMaxWindow,
+                                               h_len + kMaxWindow, device, nullptr, d_ptab, pk);
+                if (rc != DQ_OK) return rc;
+                p = h_pos[kMaxWindow];
+                l = h_len[kMaxWindow];
+                h_pos[0] = (int32_t)p;
+                h_len[0] = (int32_t)l;
+            }
+        }
+        *pos = p;
+        *len = l;
+        return DQ_OK;
+    }
+};
+
+
+// ---- "one old file, many new files": the suffix array of old (Diff.cs:89-90) is what a diff costs before its scan loop,
+// and it depends on old alone.  A DiffIndex holds (old, suffix array, prefix table of the match search) on the
+// device; any number of new files are diffed against it (dq_bsdiff_index_*; the reference pays the sort once per
+// Diff.Create call).  The buffers are either the index's own (built here) or the caller's (a rank that received
+// text + suffix array by RCCL broadcast, deltaq_amd/batch.py: diff_many_distributed).
+struct DiffIndex {
+    int dev = 0;
+    int64_t n = 0;
+    const uint8_t *old = nullptr;       // host copy the scan loop walks: the caller's, valid while the index lives
+    char *own = nullptr;                // device allocation of this index (old + SA if built here, prefix table)
+    bool own_cached = false;            // ... which is the device context's cached one-shot buffer (not freed)
+    const char *d_old = nullptr, *d_sa = nullptr;
+    const char *d_tab = nullptr;
+    int pk = 0;
+};
+
+constexpr size_t kDiffPinnedBytes = 2 * ((size_t)(65536 + 2) * 4 + 256) + (size_t)(2048 + 2 * (1024 + 1)) * 8 + 256;
+
+size_t diff_tab_bytes(int64_t n, int *pk_out)
+{
+    // prefix table of the match search: 3 bytes (64 MiB of entries) for old files from 4 MiB, 2 bytes from 64 KiB
+    const int pk = n >= (4 << 20) ? 3 : n >= (1 << 16) ? 2 : 0;
+    *pk_out = pk;
+    return pk ? align_up(((size_t)1 << (8 * pk)) * 4 + 16) : 0;
+}
+
+int grow_cached(char **buf, size_t *have, size_t want, const char *what)
+{
+    if (*have >= want) return DQ_OK;
+    if (*buf) { (void)hipFree(*buf); *buf = nullptr; *have = 0; }
+    hipError_t e = hipMalloc((void **)buf, want);
+    if (e != hipSuccess) return fail(DQ_ERR_OOM, what, e);
+    *have = want;
+    return DQ_OK;
+}
+
+// d_old_in / d_sa_in: device-resident text and suffix array of the caller (both or neither).  cached: build into the
+// device context's reusable buffer (the one-shot dq_bsdiff_create; the caller holds diff_mu).
+int diff_index_build(const uint8_t *old, int64_t n, int32_t device, const void *d_old_in, const void *d_sa_in, bool cached,
+                     DiffIndex *ix)
+{
+    if (n < 0 || (n > 0 && !old)) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
+    if ((d_old_in == nullptr) != (d_sa_in == nullptr)) return fail(DQ_ERR_BAD_ARGS, "device text and suffix array go together");
+    if (n > 0x7fffffffLL) return fail(DQ_ERR_TOO_LARGE, "the BSDIFF40 path takes files below 2 GiB (int indices, as the reference)");
+    int dev = 0;
+    int rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    HIP_TRY(hipSetDevice(dev));
+    ix->dev = dev; ix->n = n; ix->old = old;
+    int pk = 0;
+    const size_t b_tab = diff_tab_bytes(n, &pk);
+    const size_t b_old = d_old_in ? 0 : align_up((size_t)n + 16), b_sa = d_old_in ? 0 : align_up((size_t)n * 4 + 16);
+    const size_t total = b_old + b_sa + b_tab;
+    if (total > 0) {
+        if (cached) {
+            DeviceCtx &c = ctx0(dev);
+            rc = grow_cached(&c.diff_idx, &c.diff_idx_bytes, total, "hipMalloc(bsdiff index)");
+            if (rc != DQ_OK) return rc;
+            ix->own = c.diff_idx;
+            ix->own_cached = true;
+        } else {
+            hipError_t e = hipMalloc((void **)&ix->own, total);
+            if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(bsdiff index)", e);
+        }
+    }
+    if (d_old_in) {
+        ix->d_old = (const char *)d_old_in;
+        ix->d_sa = (const char *)d_sa_in;
+    } else {
+        ix->d_old = ix->own;
+        ix->d_sa = ix->own + b_old;
+        if (n > 0) HIP_TRY(hipMemcpy(ix->own, old, (size_t)n, hipMemcpyHostToDevice));
+        rc = sufsort_dev<int32_t>(ix->d_old, n, const_cast<char *>(ix->d_sa), dev, nullptr);     // Diff.cs:90; the SA never leaves the device
+        if (rc != DQ_OK) return rc;
+    }
+    ix->pk = pk;
+    if (pk) {
+        char *tab = ix->own + b_old + b_sa;
+        const int64_t total_e = (1ll << (8 * pk)) + 1;
+        hipLaunchKernelGGL(prefix_bounds_kernel<int32_t>, dim3((unsigned)((total_e + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           nullptr, (const uint8_t *)ix->d_old, n, (const int32_t *)ix->d_sa, pk, (int32_t *)tab);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        ix->d_tab = tab;
+    }
+    return DQ_OK;
+}
+
+void diff_index_drop(DiffIndex *ix)
+{
+    if (ix->own && !ix->own_cached) { (void)hipSetDevice(ix->dev); (void)hipFree(ix->own); }
+    ix->own = nullptr;
+}
+
+// Diff.Create's data path up to the raw streams for one new file: upload it, run the scan loop over windows of answers
+int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::RawStreams &raw)
+{
+    if (m < 0 || (m > 0 && !nw)) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
+    if (m > 0x7fffffffLL) return fail(DQ_ERR_TOO_LARGE, "the BSDIFF40 path takes files below 2 GiB (int indices, as the reference)");
+    if (m == 0) return DQ_OK;
+    const int dev = ix.dev;
+    HIP_TRY(hipSetDevice(dev));
+    DeviceCtx &c = ctx0(dev);
+    const bool trace = env("DQ_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) {
+        if (trace) fprintf(stderr, "[dq] bsdiff %-14s at %8.3f ms\n", what,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    const size_t b_new = align_up((size_t)m + 16);
+    int rc = grow_cached(&c.diff_dev, &c.diff_dev_bytes, b_new + 256, "hipMalloc(bsdiff buffers)");      // (+ the mailbox of the window kernel)
+    if (rc != DQ_OK) return rc;
+    if (!c.diff_pinned) {
+        hipError_t e = hipHostMalloc((void **)&c.diff_pinned, kDiffPinnedBytes, hipHostMallocCoherent);   // (windows + the packed answers the loop polls)
+        if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipHostMalloc(search windows)", e);
+    }
+    char *pinned = c.diff_pinned;
+    const size_t b_win = align_up((size_t)(SearchWindows::kMaxWindow + 2) * 4);
+    static_assert(kDiffPinnedBytes >= 2 * ((size_t)(SearchWindows::kMaxWindow + 2) * 4 + 256) +
+                  (size_t)(SearchWindows::kWaveWindow + 2 * (SearchWindows::kSecond + 1)) * 8 + 256, "pinned window area");
+    char *d_new = c.diff_dev;
+    stamp("buffers");
+    HIP_TRY(hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice));
+    stamp("new on device");
+    SearchWindows win{ix.d_old, ix.d_sa, d_new, ix.n, m, dev};
+    win.d_ptab = ix.d_tab;
+    win.pk = ix.pk;
+    win.h_pos = reinterpret_cast<int32_t *>(pinned);
+    win.h_len = reinterpret_cast<int32_t *>(pinned + b_win);
+    win.h_packed = env("DQ_NO_POLL") ? nullptr : reinterpret_cast<uint64_t *>(pinned + 2 * b_win);
+    win.d_mail = d_new + b_new;
+    HIP_TRY(hipMemset(win.d_mail, 0, 16));
+    win.no_second = env("DQ_NO_SECOND_STAGE") != nullptr;
+    if (const char *v = env("DQ_WIN_MIN")) win.min_window = std::min<int64_t>(std::max(16, atoi(v)), SearchWindows::kWaveWindow);
+    if (const char *v = env("DQ_WIN_SECOND")) win.second = std::min<int64_t>(std::max(16, atoi(v)), SearchWindows::kSecond);
+    win.next_size = win.min_window;
+    if (const char *v = env("DQ_WALK_ON")) win.walk_on = atoi(v) != 0;
+    win.no_resume = env("DQ_NO_RESUME") != nullptr;
+    rc = bsdiff::scan_loop(ix.old, ix.n, nw, m, win, raw);
+    raw.windows = win.windows;
+    raw.exact = win.exact;
+    stamp("scan loop");
+    if (trace)
+        fprintf(stderr, "[dq] scan loop: %lld searches, %lld windows (%lld of them answered ahead by the second stage), %lld exact repeats\n",
+                (long long)raw.searches, (long long)win.windows, (long long)win.predicted, (long long)win.exact);
+    // (the loop polled the kernels' own completion counts: drain the stream before the buffers are reused)
+    const hipError_t drained = hipStreamSynchronize(c.stream);
+    if (rc == DQ_OK && drained != hipSuccess) return fail(DQ_ERR_HIP, "scan loop: stream did not drain", drained);
+    return rc;
+}
+
+// Diff.Create's data path up to the raw streams: sort old on the device, keep the SA there, run the scan loop
+int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, bsdiff::RawStreams &raw)
+{
+    if (n < 0 || m < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
+    if ((n > 0 && !old) || (m > 0 && !nw)) return fail(DQ_ERR_BAD_ARGS, "null buffer");
+    if (n > 0x7fffffffLL || m > 0x7fffffffLL) return fail(DQ_ERR_TOO_LARGE, "the BSDIFF40 path takes files below 2 GiB (int indices, as the reference)");
+    int dev = 0;
+    int rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    if (m == 0) return DQ_OK;
+    std::lock_guard<std::mutex> one_diff(ctx0(dev).diff_mu);
+    DiffIndex ix;
+    rc = diff_index_build(old, n, dev, nullptr, nullptr, /*cached=*/true, &ix);
+    if (rc != DQ_OK) return rc;
+    return diff_index_scan(ix, nw, m, raw);
+}
+
+// one bzip2 stream; the Burrows-Wheeler transform of each block through the suffix sorter (blocks of a long stream
+// are encoded on several threads: the sorter is called concurrently, each call leasing its own device context)
+int bz2_stream(const std::vector<uint8_t> &src, std::vector<uint8_t> &out, int dev)
+{
+    std::atomic<int> sort_rc{DQ_OK};
+    std::mutex err_mu;
+    std::string err;
+    const int rc = bz2::bz2_compress(src.data(), src.size(), out,
+                                     [&](const uint8_t *t, int64_t n2, int32_t *sa) -> int {
+                                         const int r = sufsort_host<int32_t>(t, n2, sa, dev);
+                                         if (r == DQ_OK) return 0;
+                                         int expect = DQ_OK;
+                                         if (sort_rc.compare_exchange_strong(expect, r)) {
+                                             std::lock_guard<std::mutex> lk(err_mu);
+                                             err = t_err;                      // (thread-local on the worker: carried over)
+                                         }
+                                         return -2;
+                                     });
+    if (rc == -2) { t_err = err; return sort_rc.load(); }
+    if (rc != 0) return fail(DQ_ERR_HIP, "bzip2 block transform failed");
+    return DQ_OK;
+}
+
+// header + the three streams (Diff.cs:54-70 / :196-252).  The streams are framed side by side on three host threads:
+// their run-length / MTF / Huffman work overlaps, the block sorts take turns on the device.
+int frame_patch(const bsdiff::RawStreams &raw, int64_t m, int dev, std::vector<uint8_t> &patch)
+{
+    std::vector<uint8_t> z[3];
+    const std::vector<uint8_t> *src[3] = {&raw.ctrl, &raw.diff, &raw.extra};
+    int rcs[3] = {DQ_OK, DQ_OK, DQ_OK};
+    std::string errs[3];
+    auto work = [&](int k) {
+        try {
+            rcs[k] = bz2_stream(*src[k], z[k], dev);
+            if (rcs[k] != DQ_OK) errs[k] = t_err;
+        } catch (const std::exception &e) {
+            rcs[k] = DQ_ERR_OOM;
+            errs[k] = std::string("bsdiff: ") + e.what();
+        }
+    };
+    {
+        JoinAll threads;
+        // (streams of a few KB are not worth a thread)
+        const bool parallel = raw.ctrl.size() + raw.diff.size() + raw.extra.size() >= (1u << 16) && !env("DQ_BZ2_SERIAL");
+        for (int k = 1; k < 3; ++k) {
+            if (!parallel) { work(k); continue; }
+            try { threads.v.emplace_back(work, k); } catch (const std::exception &) { work(k); }
+        }
+        work(0);
+    }
+    for (int k = 0; k < 3; ++k)
+        if (rcs[k] != DQ_OK) { t_err = errs[k]; return rcs[k]; }
+    patch.assign((size_t)bsdiff::kHeaderSize, 0);                                  // Diff.cs:54-70 / :247-252
+    bsdiff::write_packed_long(&patch[0], bsdiff::kSignature);
+    bsdiff::write_packed_long(&patch[8], (int64_t)z[0].size());
+    bsdiff::write_packed_long(&patch[16], (int64_t)z[1].size());
+    bsdiff::write_packed_long(&patch[24], m);
+    patch.reserve(patch.size() + z[0].size() + z[1].size() + z[2].size());
+    for (int k = 0; k < 3; ++k) patch.insert(patch.end(), z[k].begin(), z[k].end());
+    return DQ_OK;
+}
+}  // namespace
+
+int bsdiff_create_host(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, std::vector<uint8_t> &patch)
+{
+    bsdiff::RawStreams raw;
+    int rc = bsdiff_raw(old, n, nw, m, device, raw);
+    if (rc != DQ_OK) return rc;
+    int dev = 0;
+    rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    return frame_patch(raw, m, dev, patch);
+}
+
+// Patch.Apply (Patch.cs:52-168): host only (dq_bspatch.h)
+int bspatch_apply_host(const uint8_t *old, int64_t n, const uint8_t *patch, int64_t plen, uint8_t *out, int64_t cap, int64_t *out_len)
+{
+    if (n < 0 || plen < 0 || cap < 0 || (n > 0 && !old) || !patch) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
+    const int rc = bsdiff::apply_patch(old, n, patch, plen, out, cap, out_len);
+    if (rc == bsdiff::kPatchSmallBuffer) return fail(DQ_ERR_BAD_ARGS, "output buffer too small");
+    if (rc != bsdiff::kPatchOk) return fail(DQ_ERR_BAD_ARGS, "Corrupt patch");
+    return DQ_OK;
+}
+
+int match_search_dev_i32(const void *d_old, int64_t n, const void *d_sa, const void *d_new, int64_t m, const int64_t *d_scans,
+                         int64_t scan0, int64_t count, int64_t cap, void *d_pos, void *d_len, int32_t device, void *stream)
+{
+    return match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, d_scans, scan0, count, cap, d_pos, d_len, device, stream);
+}
+int match_search_dev_i64(const void *d_old, int64_t n, const void *d_sa, const void *d_new, int64_t m, const int64_t *d_scans,
+                         int64_t scan0, int64_t count, int64_t cap, void *d_pos, void *d_len, int32_t device, void *stream)
+{
+    return match_search_dev<int64_t>(d_old, n, d_sa, d_new, m, d_scans, scan0, count, cap, d_pos, d_len, device, stream);
+}
+int match_search_host_i32(const uint8_t *old, int64_t n, const int32_t *sa, const uint8_t *nw, int64_t m, const int64_t *scans,
+                          int64_t scan0, int64_t count, int64_t cap, int32_t *pos, int32_t *len, int32_t device)
+{
+    return match_search_host<int32_t>(old, n, sa, nw, m, scans, scan0, count, cap, pos, len, device);
+}
+int match_search_host_i64(const uint8_t *old, int64_t n, const int64_t *sa, const uint8_t *nw, int64_t m, const int64_t *scans,
+                          int64_t scan0, int64_t count, int64_t cap, int64_t *pos, int64_t *len, int32_t device)
+{
+    return match_search_host<int64_t>(old, n, sa, nw, m, scans, scan0, count, cap, pos, len, device);
+}
+
+// the raw streams of Diff.Create (dq_bsdiff_scan_i32: what the tests compare with the oracle's restated loop)
+int bsdiff_scan_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, std::vector<int64_t> &ctrl,
+                    std::vector<uint8_t> &diff, std::vector<uint8_t> &extra, int64_t stats[3])
+{
+    bsdiff::RawStreams raw;
+    const int rc = bsdiff_raw(old, n, nw, m, device, raw);
+    if (rc != DQ_OK) return rc;
+    ctrl.resize(raw.ctrl.size() / 8);
+    for (size_t i = 0; i < ctrl.size(); ++i) ctrl[i] = bsdiff::read_packed_long(&raw.ctrl[i * 8]);
+    diff.swap(raw.diff); extra.swap(raw.extra);
+    stats[0] = raw.searches; stats[1] = raw.windows; stats[2] = raw.exact;
+    return DQ_OK;
+}
+
+int diff_index_new(const uint8_t *old, int64_t n, int32_t device, const void *d_old, const void *d_sa, void **index_out)
+{
+    DiffIndex *ix = new DiffIndex();
+    const int rc = diff_index_build(old, n, device, d_old, d_sa, /*cached=*/false, ix);
+    if (rc != DQ_OK) { diff_index_drop(ix); delete ix; return rc; }
+    *index_out = ix;
+    return DQ_OK;
+}
+
+int diff_index_buffers(const void *index, const void **d_old, const void **d_sa, int64_t *n)
+{
+    const DiffIndex *ix = static_cast<const DiffIndex *>(index);
+    if (d_old) *d_old = ix->d_old;
+    if (d_sa) *d_sa = ix->d_sa;
+    if (n) *n = ix->n;
+    return DQ_OK;
+}
+
+int diff_index_diff(const void *index, const uint8_t *nw, int64_t m, std::vector<uint8_t> &patch)
+{
+    const DiffIndex *ix = static_cast<const DiffIndex *>(index);
+    bsdiff::RawStreams raw;
+    {
+        std::lock_guard<std::mutex> one_diff(ctx0(ix->dev).diff_mu);      // scan loops take turns on a device
+        const int rc = diff_index_scan(*ix, nw, m, raw);
+        if (rc != DQ_OK) return rc;
+    }
+    return frame_patch(raw, m, ix->dev, patch);                            // (framing overlaps the next caller's scan loop)
+}
+
+void diff_index_delete(void *index)
+{
+    DiffIndex *ix = static_cast<DiffIndex *>(index);
+    diff_index_drop(ix);
+    delete ix;
+}
+
+}  // namespace dq

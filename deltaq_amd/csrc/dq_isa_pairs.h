@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kPairThreads) void key2_from_pairs_kernel(
 }
 
 // ranks of the tied list, written as 32-bit values while every 64-bit buffer was busy, into their 64-bit slots
-__global__ __launch_bounds__(kBlock) void widen_ranks_kernel(const uint32_t *__restrict__ in, int64_t m,
+static __global__ __launch_bounds__(kBlock) void widen_ranks_kernel(const uint32_t *__restrict__ in, int64_t m,
                                                              uint64_t *__restrict__ out)
 {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock)

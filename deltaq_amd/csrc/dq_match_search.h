@@ -114,7 +114,7 @@ __device__ __forceinline__ void ms_trim_short_suffixes(const IdxT *__restrict__ 
 // A query of >= pk bytes with prefix value v then has its lower bound inside [ptab[v], ptab[v + 1]], and every
 // suffix inside that range -- but for the short ones ms_trim_short_suffixes() removes -- shares those pk bytes with
 // it: the search starts ~8 * pk probes further down.
-// Built once per old file by the scan-loop driver (dq_sufsort_hip.hip::SearchWindows), where a Search is one
+// Built once per old file by the scan-loop driver (dq_diff.hip::SearchWindows), where a Search is one
 // dependent round trip to the device and its ~log2(n) probes of ~1 us each are what the round trip costs.
 template <typename IdxT>
 __global__ __launch_bounds__(kBlock) void prefix_bounds_kernel(const uint8_t *__restrict__ old, int64_t n,

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kHistThreads) void radix_hist_kernel(const uint64_t
 
 // Same 8 histograms for the CODED round-0 keys (dq_coded_keys.h), which exist nowhere in memory yet: every lane
 // builds the keys of 4 consecutive suffixes from 20 text bytes, as the first digit pass will.
-__global__ __launch_bounds__(kHistThreads) void text_coded_hist_kernel(const uint32_t *__restrict__ t32, int64_t n,
+static __global__ __launch_bounds__(kHistThreads) void text_coded_hist_kernel(const uint32_t *__restrict__ t32, int64_t n,
                                                                        const uint16_t *__restrict__ codetab,
                                                                        uint32_t *__restrict__ partial)
 {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kHistThreads) void text_coded_hist_kernel(const uin
 // The partial sums are a latency chain (nblocks dependent-free but serial loads per digit), so
 // 4 slices of the workgroups are summed side by side and combined through LDS.
 constexpr int kHistScanThreads = 1024;
-__global__ __launch_bounds__(kHistScanThreads) void radix_hist_scan_kernel(const uint32_t *__restrict__ partial,
+static __global__ __launch_bounds__(kHistScanThreads) void radix_hist_scan_kernel(const uint32_t *__restrict__ partial,
                                                                            int nblocks,
                                                                            int64_t *__restrict__ digit_offset)
 {
@@ -714,7 +714,7 @@ __device__ __forceinline__ void sample_kgrams(const uint8_t *__restrict__ text, 
     if (t < 8) coll[t] = (unsigned long long)cnt[t];
 }
 
-__global__ __launch_bounds__(kBlock) void text_hist_kernel(const uint8_t *__restrict__ text, int64_t n,
+static __global__ __launch_bounds__(kBlock) void text_hist_kernel(const uint8_t *__restrict__ text, int64_t n,
                                                            unsigned long long *__restrict__ bytehist /*[256], zeroed*/,
                                                            unsigned long long *__restrict__ kgram_coll = nullptr)
 {
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(kBlock) void text_hist_kernel(const uint8_t *__rest
 }
 
 // digit_offset[p][d] for p < kb (one workgroup per digit place p)
-__global__ __launch_bounds__(kBlock) void text_digit_offsets_kernel(const int64_t *__restrict__ bytehist,
+static __global__ __launch_bounds__(kBlock) void text_digit_offsets_kernel(const int64_t *__restrict__ bytehist,
                                                                     const uint8_t *__restrict__ text,
                                                                     int64_t n, int kb,
                                                                     int64_t *__restrict__ digit_offset)

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kPcThreads) void pair_split_kernel(const uint64_t *
 
 // tile_cnt[2t], tile_cnt[2t+1] -> exclusive prefix sums over the tiles (two independent sums), totals to ctr.
 // One workgroup: every thread sums a contiguous run of tiles, the runs are scanned, the run is rewritten.
-__global__ __launch_bounds__(kPcScanThreads) void pair_scan_kernel(uint32_t *__restrict__ tile_cnt, int64_t ntiles,
+static __global__ __launch_bounds__(kPcScanThreads) void pair_scan_kernel(uint32_t *__restrict__ tile_cnt, int64_t ntiles,
                                                                    PairCounters *__restrict__ ctr)
 {
     __shared__ unsigned long long part[2][kPcScanThreads / kWave];
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kPcThreads) void pair_link_kernel(const uint64_t *_
 }
 
 // carry[t] = first chain end of the tiles behind tile t (one workgroup, as pair_scan_kernel)
-__global__ __launch_bounds__(kPcScanThreads) void pair_carry_kernel(const uint32_t *__restrict__ tile_head, int64_t ntiles,
+static __global__ __launch_bounds__(kPcScanThreads) void pair_carry_kernel(const uint32_t *__restrict__ tile_head, int64_t ntiles,
                                                                     uint32_t *__restrict__ carry)
 {
     __shared__ uint32_t wave_first[kPcScanThreads / kWave];
@@ -348,7 +348,7 @@ __device__ __forceinline__ uint32_t pc_chain_end(const uint32_t *__restrict__ nt
 // One pointer-jumping step for the FAR chain ends: take the answer of the chain the link points into, or, if
 // that chain ends FAR as well, point where it points.  (Links only lead to the right, so racing reads see either
 // the old or the new link of a neighbour, both valid.)
-__global__ __launch_bounds__(kPcThreads) void pair_resolve_kernel(const uint32_t *__restrict__ nt,
+static __global__ __launch_bounds__(kPcThreads) void pair_resolve_kernel(const uint32_t *__restrict__ nt,
                                                                   const uint32_t *__restrict__ carry, int64_t cnt,
                                                                   uint8_t *__restrict__ tstat, uint32_t *__restrict__ far)
 {

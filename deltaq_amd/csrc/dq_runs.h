@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kRunThreads) void runlen_chunk_kernel(const uint8_t
 }
 
 // pass 2: carry[c] = true run length at the first byte of chunk c = lead[c] + (link[c] ? carry[c + 1] : 0); one workgroup
-__global__ __launch_bounds__(kRunScanThreads) void runlen_carry_kernel(const uint32_t *__restrict__ lead,
+static __global__ __launch_bounds__(kRunScanThreads) void runlen_carry_kernel(const uint32_t *__restrict__ lead,
                                                                        const uint8_t *__restrict__ link, int64_t nchunks,
                                                                        uint32_t *__restrict__ carry /*[nchunks + 1]*/)
 {

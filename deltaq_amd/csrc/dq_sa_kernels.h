@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void gather_key2_kernel(uint64_t *__restric
 
 // A list that came keyed for a round (rank << kbits | key2) back to plain group ranks: the round was found to
 // need the shifted-rank form of its keys (64-bit composite near n = 2^32, or DQ_FORCE_RSHIFT in the tests).
-__global__ __launch_bounds__(kBlock) void keys_to_ranks_kernel(uint64_t *__restrict__ comp, int64_t m, int kbits)
+static __global__ __launch_bounds__(kBlock) void keys_to_ranks_kernel(uint64_t *__restrict__ comp, int64_t m, int kbits)
 {
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < m; j += (int64_t)gridDim.x * kBlock)
         comp[j] >>= kbits;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kFinishThreads) void small_group_finish_kernel(
 // Estimate of the tie fraction after round 0: kSamples evenly spaced adjacent pairs of the
 // sorted key list; *count = pairs with equal keys.  Decides whether the rebucket pass should
 // write the full inverse suffix array right away (dense doubling expected).
-__global__ __launch_bounds__(kBlock) void sample_ties_kernel(const uint64_t *__restrict__ keys, int64_t m,
+static __global__ __launch_bounds__(kBlock) void sample_ties_kernel(const uint64_t *__restrict__ keys, int64_t m,
                                                              int kshift, int samples, int64_t *__restrict__ count)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
                 const uint64_t hm = Hk & le, gm = Gk & le;
                 const IdxT rn = hm ? wb_i + (IdxT)(k * kWave + 63 - __builtin_clzll(hm)) : cn;
                 const IdxT rg = gm ? wb_i + (IdxT)(k * kWave + 63 - __builtin_clzll(gm)) : cg;
-                // rank_from_isa: the composite key carries rank >> 1 (n close to 2^32, dq_sufsort_hip.hip::run);
+                // rank_from_isa: the composite key carries rank >> 1 (n close to 2^32, dq_sorter_impl.h::run);
                 // a tied suffix's own ISA entry is its parent rank
                 const IdxT rank = kInitial ? (IdxT)0 : (kWriteISA && rank_from_isa) ? ISA[suf[k]] : (IdxT)(ck[k] >> kbits);
                 const IdxT nr = rank + (rn - rg);

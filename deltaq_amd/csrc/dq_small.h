@@ -13,10 +13,11 @@
 // (ReadOnlySpan<byte>.SequenceCompareTo, LibDivSufSortTests.cs:43-59).
 #pragma once
 #include "dq_device_utils.h"
+#include "dq_runtime.h"
 
 namespace dq {
 
-constexpr int kSmallMaxN = 8192;
+// (kSmallMaxN = 8192 lives in dq_runtime.h: the host runtime sizes its pinned areas by it)
 constexpr int kSmallThreads = 1024;
 constexpr int kSmallWaves = kSmallThreads / kWave;
 constexpr int kSmallItems = kSmallMaxN / kSmallThreads;       // positions per thread at the largest n

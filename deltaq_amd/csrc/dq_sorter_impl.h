@@ -1,4 +1,6 @@
-// dq_sufsort_hip.hip -- host runtime + C ABI of libdq_sufsort_hip.so.
+// dq_sorter_impl.h -- the suffix sorter: host driver of the HIP kernels, templated on the index type.
+// Included by dq_sorter_i32.hip and dq_sorter_i64.hip, which instantiate the entry points of dq_runtime.h.
+//
 //
 // Suffix-array construction for byte text on one MI355X (gfx950), prefix doubling on ranks:
 //   round 0   byte histogram of the text -> key width kb (3..8 bytes); kb stable LSD digit passes
@@ -15,22 +17,8 @@
 // LibDivSufSort.Sort() (LibDivSufSort.cs:12-29; order = LibDivSufSortTests.cs:43-59).
 //
 // This file contains no CPU sorting path: if HIP is unusable the entry points fail.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <condition_variable>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <chrono>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "../../include/dq_sufsort.h"
+#pragma once
+#include "dq_runtime.h"
 #include "dq_alpha_code.h"
 #include "dq_onesweep.h"
 #include "dq_radix.h"
@@ -43,249 +31,14 @@
 #include "dq_ties.h"
 #include "dq_isa_pairs.h"
 #include "dq_bucket_sort.h"
-#include "dq_match_search.h"
 #include "dq_pair_chains.h"
-#include "dq_bz2.h"
-#include "dq_bsdiff.h"
-#include "dq_bspatch.h"
 
+namespace dq {
 namespace {
-
-using namespace dq;
-
-// ------------------------------------------------------------------ errors
-thread_local std::string t_err;
-thread_local int64_t t_info[3] = {0, 0, 0};
-
-int fail(int code, const char *what, hipError_t e = hipSuccess)
-{
-    char buf[512];
-    if (e != hipSuccess)
-        snprintf(buf, sizeof buf, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
-    else
-        snprintf(buf, sizeof buf, "%s", what);
-    t_err = buf;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                   \
-    do {                                                                                \
-        hipError_t e_ = (expr);                                                         \
-        if (e_ != hipSuccess)                                                           \
-            return fail(e_ == hipErrorOutOfMemory ? DQ_ERR_OOM : DQ_ERR_HIP, #expr, e_); \
-    } while (0)
-
-// ------------------------------------------------------------------ DQ_* flags
-// Every entry point reads the DQ_* environment flags through env(): the first lookup of a name inside a call asks
-// the process environment, later ones get the same answer -- a call sees ONE consistent set of flags, each variable
-// is read once per call and thread, and nothing on the per-kernel path touches the environment.  (The tests flip
-// flags between calls, so the answers are not kept beyond the outermost call on this thread.)
-struct EnvCache {
-    struct Entry { const char *name; bool set; std::string val; };
-    static constexpr int kMax = 64;
-    Entry e[kMax];
-    int count = 0, depth = 0;
-};
-thread_local EnvCache t_env;
-
-const char *env(const char *name)
-{
-    EnvCache &c = t_env;
-    for (int i = 0; i < c.count; ++i)
-        if (c.e[i].name == name || strcmp(c.e[i].name, name) == 0) return c.e[i].set ? c.e[i].val.c_str() : nullptr;
-    const char *v = getenv(name);
-    if (c.depth == 0 || c.count == EnvCache::kMax) return v;          // outside an entry point: nothing is kept
-    EnvCache::Entry &x = c.e[c.count++];
-    x.name = name; x.set = v != nullptr; x.val = v ? v : "";
-    return x.set ? x.val.c_str() : nullptr;
-}
-
-struct EnvScope {
-    EnvScope() { if (t_env.depth++ == 0) t_env.count = 0; }
-    ~EnvScope() { --t_env.depth; }
-};
-
-// ------------------------------------------------------------------ profiling
-struct KernelStat { int64_t launches = 0; double ms = 0; int64_t elems = 0; int64_t bytes = 0; };
-std::mutex g_prof_mu;
-KernelStat g_prof[DQ_K_COUNT];
-std::atomic<int> g_prof_on{0};
-
-const char *const kKernelNames[DQ_K_COUNT] = {
-    "text_hist_kernel", "radix_hist_kernel", "radix_rank_kernel", "seg_fused_kernel",
-    "tie_seam_kernel", "tie_collect_kernel", "small_group_finish_kernel", "small_group_round_kernel",
-    "isa_update_kernel", "isa_from_pairs_kernel", "key2_from_pairs_kernel", "gather_key2_kernel",
-    "gather_text_key_kernel", "isa_from_sa_kernel", "small_sufsort_kernel", "bucket_sort_kernel",
-    "match_search_kernel", "pair_chain_kernels", "mid_group_round_kernel", "runlen_kernels"};
-
-struct ProfRec { int cat; hipEvent_t a, b; int64_t elems, bytes; };
-
-// ------------------------------------------------------------------ per-device context
-struct DeviceCtx {
-    std::mutex mu;
-    int dev = -1;
-    int ncu = 0;                        // compute units of the device (grid of the persistent kernels)
-    hipStream_t stream = nullptr;
-    char *ws = nullptr;
-    size_t ws_bytes = 0;
-    int64_t *pinned = nullptr;          // 8 KiB pinned: readback area [0, 4 KiB), upload staging [4 KiB, 8 KiB)
-    uint8_t *pinned_io = nullptr;       // short texts: text in / SA out, read and written by the kernel itself
-    hipEvent_t readback = nullptr;      // "the pinned readback has landed" (work queued behind it keeps running)
-    std::vector<ProfRec> pending;
-    std::vector<hipEvent_t> pool;
-    // batch pipeline (dq_sufsort_hip_batch_i32): device slots and streams, kept between calls
-    std::mutex batch_mu;                // one batch at a time per device
-    uint8_t *bslot_text[3] = {nullptr, nullptr, nullptr};
-    int32_t *bslot_sa[3] = {nullptr, nullptr, nullptr};
-    size_t bslot_cap = 0;               // bytes of text each slot holds
-    hipStream_t b_in = nullptr, b_sort = nullptr, b_out = nullptr;
-    // Diff.Create (dq_bsdiff_create / dq_bsdiff_index_diff): one diff at a time per device; its device scratch
-    // (new file + mailbox; for the one-shot form also old file, suffix array and prefix table) and the pinned
-    // answer windows are kept between calls -- hipMalloc / hipHostMalloc / hipFree are synchronous driver calls
-    std::mutex diff_mu;
-    char *diff_dev = nullptr;           // per-diff scratch
-    size_t diff_dev_bytes = 0;
-    char *diff_idx = nullptr;           // index buffers of the one-shot form
-    size_t diff_idx_bytes = 0;
-    char *diff_pinned = nullptr;        // fixed size (SearchWindows)
-};
-constexpr int kMaxDevices = 64;
-// A device has several contexts ("slots": stream + workspace + pinned areas each).  Texts of up to kSlotSmallN bytes
-// take whichever slot is free, so that the threads of a host sharing one provider (the reference's benchmark keeps
-// static singletons, SuffixSortingBenchmarks.cs:59-61) overlap their sorts instead of queueing behind one mutex;
-// anything larger, the match search, the batch pipeline and the diffs use slot 0 (a large sort fills the device anyway).
-constexpr int kCtxSlots = 4;
-constexpr int64_t kSlotSmallN = 4ll << 20;
-constexpr size_t kSmallTextArea = kSmallMaxN + 64;
-constexpr size_t kSmallIoBytes = kSmallTextArea + (size_t)kSmallMaxN * 8;
-struct DeviceState {
-    DeviceCtx slot[kCtxSlots];
-    std::atomic<unsigned> next{0};
-};
-DeviceState g_dev[kMaxDevices];
-inline DeviceCtx &ctx0(int dev) { return g_dev[dev].slot[0]; }
-
-// holds one slot of a device for the duration of a sort
-struct SlotLease {
-    DeviceCtx *c = nullptr;
-    SlotLease(int dev, int64_t n)
-    {
-        DeviceState &d = g_dev[dev];
-        if (n > kSlotSmallN) { c = &d.slot[0]; c->mu.lock(); return; }
-        for (int k = 1; k < kCtxSlots && !c; ++k)
-            if (d.slot[k].mu.try_lock()) c = &d.slot[k];
-        if (!c && d.slot[0].mu.try_lock()) c = &d.slot[0];
-        if (!c) {
-            c = &d.slot[1 + d.next.fetch_add(1u, std::memory_order_relaxed) % (unsigned)(kCtxSlots - 1)];
-            c->mu.lock();
-        }
-    }
-    ~SlotLease() { c->mu.unlock(); }
-    SlotLease(const SlotLease &) = delete;
-    SlotLease &operator=(const SlotLease &) = delete;
-};
-
-int init_ctx(DeviceCtx &c, int dev)
-{
-    HIP_TRY(hipSetDevice(dev));
-    if (c.dev == dev) return DQ_OK;
-    // c.dev is published only once every resource exists: a failure half way (e.g. pinned memory
-    // exhausted) frees what was made and leaves the context unbuilt, so the next call retries
-    hipError_t e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c.pinned, 8192, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c.pinned_io, kSmallIoBytes, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c.readback, hipEventDisableTiming);
-    if (e != hipSuccess) {
-        if (c.readback) (void)hipEventDestroy(c.readback);
-        if (c.pinned_io) (void)hipHostFree(c.pinned_io);
-        if (c.pinned) (void)hipHostFree(c.pinned);
-        if (c.stream) (void)hipStreamDestroy(c.stream);
-        c.readback = nullptr; c.pinned_io = nullptr; c.pinned = nullptr; c.stream = nullptr;
-        return fail(e == hipErrorOutOfMemory ? DQ_ERR_OOM : DQ_ERR_HIP, "device context setup", e);
-    }
-    c.dev = dev;
-    return DQ_OK;
-}
-
-// A sort that failed half way leaves timing events queued in c.pending: hand them back to the pool
-// (after the stream has drained, so none is still being recorded).
-void drop_pending(DeviceCtx &c, hipStream_t st)
-{
-    (void)hipStreamSynchronize(st);
-    for (ProfRec &r : c.pending) {
-        if (r.a) c.pool.push_back(r.a);
-        if (r.b) c.pool.push_back(r.b);
-    }
-    c.pending.clear();
-}
-
-int ensure_ws(DeviceCtx &c, size_t bytes)
-{
-    if (c.ws_bytes >= bytes) return DQ_OK;
-    if (c.ws) { (void)hipFree(c.ws); c.ws = nullptr; c.ws_bytes = 0; }
-    hipError_t e = hipMalloc((void **)&c.ws, bytes);
-    if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(workspace)", e);
-    c.ws_bytes = bytes;
-    return DQ_OK;
-}
-
-struct Launcher {
-    DeviceCtx &c;
-    hipStream_t st;
-    int prof;                         // 0 off, 1 every kernel, 2 only radix_rank_kernel, 100 + c only category c
-    bool active = false;
-    int begin(int cat, int64_t elems, int64_t bytes)
-    {
-        active = prof == 1 || (prof == 2 && cat == DQ_K_RADIX_RANK) || prof == 100 + cat;
-        if (!active) return DQ_OK;
-        c.pending.push_back(ProfRec{cat, nullptr, nullptr, elems, bytes});      // queued first: an error below leaks nothing
-        ProfRec &r = c.pending.back();
-        for (hipEvent_t *ev : {&r.a, &r.b}) {
-            if (!c.pool.empty()) { *ev = c.pool.back(); c.pool.pop_back(); }
-            else HIP_TRY(hipEventCreate(ev));
-        }
-        HIP_TRY(hipEventRecord(r.a, st));
-        return DQ_OK;
-    }
-    int end()
-    {
-        if (!active) return DQ_OK;
-        HIP_TRY(hipEventRecord(c.pending.back().b, st));
-        return DQ_OK;
-    }
-};
-
-int flush_profile(DeviceCtx &c)
-{
-    if (c.pending.empty()) return DQ_OK;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (ProfRec &r : c.pending) {
-        float ms = 0;
-        HIP_TRY(hipEventSynchronize(r.b));
-        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
-        KernelStat &s = g_prof[r.cat];
-        s.launches += 1; s.ms += ms; s.elems += r.elems; s.bytes += r.bytes;
-        c.pool.push_back(r.a); c.pool.push_back(r.b);
-    }
-    c.pending.clear();
-    return DQ_OK;
-}
-
-#define LAUNCH(L, cat, elems, bytes, ...)                 \
-    do {                                                  \
-        int rc_ = (L).begin(cat, elems, bytes);           \
-        if (rc_ != DQ_OK) return rc_;                     \
-        __VA_ARGS__;                                      \
-        HIP_TRY(hipGetLastError());                       \
-        rc_ = (L).end();                                  \
-        if (rc_ != DQ_OK) return rc_;                     \
-    } while (0)
 
 constexpr int kSgChain = 8;       // small-group rounds chained without a host round trip (4 -> 8: see DESIGN section 5)
 constexpr int64_t kSgShortList = 1 << 20;     // below this many tied suffixes a round is launch-bound
 
-// ------------------------------------------------------------------ workspace carving
-inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // radix_rank_kernel tile geometry by list length (RankCfg below): status rows a sort of m entries may need
 // (2048-key tiles measured: 64 KiB 16.7 -> 11 us per pass, 256 KiB ~18 -> ~14; break-even at 2^20 entries, where 512 tiles
@@ -362,7 +115,6 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     return w;
 }
 
-inline int bit_length(uint64_t x) { return x == 0 ? 1 : 64 - __builtin_clzll(x); }
 
 // ------------------------------------------------------------------ onesweep driver
 // Tile geometry of radix_rank_kernel per (index type, pass kind), from the kbench sweep
@@ -1580,15 +1332,6 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
     return sorter.run();
 }
 
-// ------------------------------------------------------------------ short texts: one launch
-// Largest n the single-workgroup sorter takes (DQ_SMALL_N=0 sends everything down the
-// device-wide pipeline; the tests use that to keep the pipeline covered on the fixtures).
-int64_t small_limit()
-{
-    if (const char *v = env("DQ_SMALL_N")) return std::min<int64_t>(std::max(0, atoi(v)), kSmallMaxN);
-    return kSmallMaxN;
-}
-
 template <typename IdxT>
 int sufsort_small(DeviceCtx &c, hipStream_t st, const uint8_t *text, int64_t n, IdxT *sa)
 {
@@ -1598,21 +1341,6 @@ int sufsort_small(DeviceCtx &c, hipStream_t st, const uint8_t *text, int64_t n, 
            hipLaunchKernelGGL(small_sufsort_kernel<IdxT>, dim3(1), dim3(kSmallThreads), 0, st, text, (int)n, sa));
     HIP_TRY(hipStreamSynchronize(st));
     return flush_profile(c);
-}
-
-int resolve_device(int32_t device, int *out)
-{
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0) return fail(DQ_ERR_NO_DEVICE, "no HIP device available", e);
-    if (device < 0) {
-        const char *v = env("DQ_HIP_DEVICE");
-        device = v ? atoi(v) : 0;
-    }
-    if (device < 0 || device >= count || device >= kMaxDevices)
-        return fail(DQ_ERR_BAD_ARGS, "device ordinal out of range");
-    *out = device;
-    return DQ_OK;
 }
 
 template <typename IdxT>
@@ -1627,6 +1355,8 @@ int check_args(const void *text, int64_t n, const void *sa)
         return fail(DQ_ERR_TOO_LARGE, "n exceeds 2^32: the 64-bit entry points take texts of up to 4 GiB");
     return DQ_OK;
 }
+
+}  // namespace
 
 // host buffers in / out  (ISuffixSort.Sort(text, suffixes))
 template <typename IdxT>
@@ -1707,1036 +1437,6 @@ int sufsort_dev(const void *d_text, int64_t n, void *d_sa, int32_t device, void 
     return DQ_OK;
 }
 
-// ------------------------------------------------------------------ match search (Diff.cs:267-298) on the device
-template <typename IdxT>
-int match_search_dev(const void *d_old, int64_t n, const void *d_sa, const void *d_new, int64_t m,
-                     const int64_t *d_scans, int64_t scan0, int64_t count, int64_t cap, void *d_pos, void *d_len,
-                     int32_t device, void *stream, const void *d_ptab = nullptr, int pk = 0, int exact_first = 0)
-{
-    if (n < 0 || m < 0 || count < 0 || cap < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
-    if ((n > 0 && (!d_old || !d_sa)) || (m > 0 && !d_new) || (count > 0 && (!d_pos || !d_len)))
-        return fail(DQ_ERR_BAD_ARGS, "null buffer");
-    if (!d_scans && (scan0 < 0 || scan0 + count > m + 1)) return fail(DQ_ERR_BAD_ARGS, "scan range outside the new data");
-    if (sizeof(IdxT) == 4 && (n > 0x7fffffffLL || m > 0x7fffffffLL))
-        return fail(DQ_ERR_TOO_LARGE, "n or m exceeds 2^31-1; use the i64 entry point");
-    int dev = 0;
-    int rc = resolve_device(device, &dev);
-    if (rc != DQ_OK) return rc;
-    if (count == 0) return DQ_OK;
-    DeviceCtx &c = ctx0(dev);
-    std::lock_guard<std::mutex> lk(c.mu);
-    rc = init_ctx(c, dev);
-    if (rc != DQ_OK) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : c.stream;
-    Launcher L{c, st, g_prof_on.load()};
-    // per query: ~log2(n) probes of one SA entry and one 64-byte sector of old, + the match itself
-    const int64_t probes = bit_length((uint64_t)std::max<int64_t>(n, 1));
-    // (DQ_SEARCH_WAVE=1: consecutive positions through the one-wave-per-position kernel of the scan-loop driver, so
-    // that the tests can compare its answers one by one; position 0 is answered exactly whatever the cap)
-    const bool wave = env("DQ_SEARCH_WAVE") && !d_scans && count <= 4096;
-    // (DQ_SEARCH_PTAB = 2 | 3: the search starts from a prefix table of that many bytes, as the scan-loop driver's
-    // windows do -- built here for the call, so that the tests can compare the answers of both kernels with it)
-    struct TmpTab { void *p = nullptr; ~TmpTab() { if (p) (void)hipFree(p); } } tmp_tab;
-    if (!d_ptab && env("DQ_SEARCH_PTAB") && n > 0) {
-        pk = atoi(env("DQ_SEARCH_PTAB")) >= 3 ? 3 : 2;
-        const int64_t total = (1ll << (8 * pk)) + 1;
-        HIP_TRY(hipMalloc(&tmp_tab.p, (size_t)total * sizeof(IdxT)));
-        hipLaunchKernelGGL(prefix_bounds_kernel<IdxT>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           (const uint8_t *)d_old, n, (const IdxT *)d_sa, pk, (IdxT *)tmp_tab.p);
-        HIP_TRY(hipGetLastError());
-        d_ptab = tmp_tab.p;
-    }
-    auto launch = [&]() -> int {
-        if (wave) {
-            constexpr int kPer = kMsThreads / kWave;
-            LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * 4 * ((int64_t)sizeof(IdxT) + 64) * 64,
-                   hipLaunchKernelGGL(match_search_wave_kernel<IdxT>, dim3((unsigned)((count + kPer - 1) / kPer)),
-                                      dim3(kMsThreads), 0, st, (const uint8_t *)d_old, n, (const IdxT *)d_sa,
-                                      (const uint8_t *)d_new, m, scan0, count, cap, (IdxT *)d_pos, (IdxT *)d_len,
-                                      (const IdxT *)d_ptab, pk, 0));
-            return DQ_OK;
-        }
-        LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * probes * ((int64_t)sizeof(IdxT) + 64),
-               hipLaunchKernelGGL(match_search_kernel<IdxT>, dim3((unsigned)((count + kMsThreads - 1) / kMsThreads)),
-                                  dim3(kMsThreads), 0, st, (const uint8_t *)d_old, n, (const IdxT *)d_sa,
-                                  (const uint8_t *)d_new, m, d_scans, scan0, count, cap, (IdxT *)d_pos, (IdxT *)d_len,
-                                  (const IdxT *)d_ptab, pk, exact_first));
-        return DQ_OK;
-    };
-    rc = launch();
-    if (rc != DQ_OK) { drop_pending(c, st); return rc; }
-    HIP_TRY(hipStreamSynchronize(st));
-    return flush_profile(c);
-}
+template <typename IdxT> int64_t sufsort_workspace_bytes(int64_t n) { return (int64_t)carve<IdxT>(nullptr, n, false).bytes; }
 
-// host buffers in / out: what a P/Invoke caller without device memory of its own uses (and the tests)
-template <typename IdxT>
-int match_search_host(const uint8_t *old, int64_t n, const IdxT *sa, const uint8_t *nw, int64_t m, const int64_t *scans,
-                      int64_t scan0, int64_t count, int64_t cap, IdxT *pos, IdxT *len, int32_t device)
-{
-    if (n < 0 || m < 0 || count < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
-    if ((n > 0 && (!old || !sa)) || (m > 0 && !nw) || (count > 0 && (!pos || !len))) return fail(DQ_ERR_BAD_ARGS, "null buffer");
-    // host-resident scan positions are checked here (a position outside [0, m] would be a device read out of bounds);
-    // the device forms take them as they are (include/dq_sufsort.h says so)
-    if (scans)
-        for (int64_t q = 0; q < count; ++q)
-            if (scans[q] < 0 || scans[q] > m) return fail(DQ_ERR_BAD_ARGS, "scan position outside the new data");
-    int dev = 0;
-    int rc = resolve_device(device, &dev);
-    if (rc != DQ_OK) return rc;
-    if (count == 0) return DQ_OK;
-    HIP_TRY(hipSetDevice(dev));
-    char *base = nullptr;
-    const size_t b_old = align_up((size_t)n + 16), b_sa = align_up((size_t)n * sizeof(IdxT) + 16), b_new = align_up((size_t)m + 16);
-    const size_t b_sc = scans ? align_up((size_t)count * 8) : 0, b_out = align_up((size_t)count * sizeof(IdxT));
-    hipError_t e = hipMalloc((void **)&base, b_old + b_sa + b_new + b_sc + 2 * b_out);
-    if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(match search buffers)", e);
-    char *d_old = base, *d_sa = d_old + b_old, *d_new = d_sa + b_sa, *d_sc = d_new + b_new, *d_pos = d_sc + b_sc,
-         *d_len = d_pos + b_out;
-    auto done = [&](int code) { (void)hipFree(base); return code; };
-    if (n > 0) {
-        if (hipMemcpy(d_old, old, (size_t)n, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(d_sa, sa, (size_t)n * sizeof(IdxT), hipMemcpyHostToDevice) != hipSuccess)
-            return done(fail(DQ_ERR_HIP, "match search: copy-in failed"));
-    }
-    if (m > 0 && hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice) != hipSuccess)
-        return done(fail(DQ_ERR_HIP, "match search: copy-in failed"));
-    if (scans && hipMemcpy(d_sc, scans, (size_t)count * 8, hipMemcpyHostToDevice) != hipSuccess)
-        return done(fail(DQ_ERR_HIP, "match search: copy-in failed"));
-    rc = match_search_dev<IdxT>(d_old, n, d_sa, d_new, m, scans ? (const int64_t *)d_sc : nullptr, scan0, count, cap, d_pos,
-                                d_len, dev, nullptr);
-    if (rc != DQ_OK) return done(rc);
-    if (hipMemcpy(pos, d_pos, (size_t)count * sizeof(IdxT), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(len, d_len, (size_t)count * sizeof(IdxT), hipMemcpyDeviceToHost) != hipSuccess)
-        return done(fail(DQ_ERR_HIP, "match search: copy-out failed"));
-    return done(DQ_OK);
-}
-
-// ------------------------------------------------------------------ BSDIFF40: Diff.Create / Patch.Apply (dq_bsdiff.h)
-// Answers of the match search for a window of scan positions ahead of the scan loop.  Windows start small after a
-// jump and double while the loop consumes them to the end (a region where old and new differ: one Search per
-// byte, the regime the device is for: 4.2 M searches in 31 ms against 5.4 s on one host core; the one-query-per-lane
-// kernel).  The cap is low: the positions of a window that lie inside the next long match would each cost `cap` byte
-// comparisons for nothing (the loop leaves the window with its next jump).  Between nearly identical files the
-// loop hops from match to match and every launch is a dependent round trip (~1 per edit): windows of up to 2048
-// positions go to the one-wave-per-position kernel (65-ary search; the position the loop stands on and the probable
-// start of the next long match answered exactly), whose answers are polled in pinned memory, whose second stage
-// answers the window behind the predicted jump, and which answers exactly throughout while positions keep coming
-// back capped (dq_match_search.h; DESIGN.md section 2c has the measurements).
-struct SearchWindows {
-    const void *d_old, *d_sa, *d_new;
-    int64_t n, m;
-    int device;
-    // kMaxWindow + 2 entries each in PINNED HOST memory that the kernel writes directly (no copy back: between
-    // similar files the loop is a chain of dependent round trips, and two small hipMemcpy cost more than the kernel)
-    int32_t *h_pos = nullptr, *h_len = nullptr;
-    uint64_t *h_packed = nullptr;                        // pinned: (len << 32 | pos) of the wave windows, polled by the loop
-    void *d_mail = nullptr;                              // device: mailbox of the window kernel's second stage
-    static constexpr int64_t kSecond = 1024;             // slots of the predicted next window (second <= kSecond are used)
-    int64_t second = 128;                                // positions of the predicted next window
-    int64_t min_window = 128;                            // first window after a jump
-    bool walk_on = true;                                 // second stage without a winner: the positions behind the window
-    bool no_resume = false;                              // DQ_NO_RESUME: capped first positions searched again from the top
-    static constexpr int64_t kSecondMaxFirst = 1024;     // ... behind first stages of up to this many positions
-    int64_t sec_region = 0, predicted = 0;               // slot region (offset into h_packed) of the pending second stage
-    bool sec_pending = false, no_second = false;
-    int64_t last_capped = -2, capped_streak = 0;         // consecutive positions that came back capped
-    bool from_capped = false;
-    unsigned long long ticket = 0, done_total = 0;       // of the launches with a second stage (the mailbox is never reset)
-    const void *d_ptab = nullptr;                        // prefix table (prefix_bounds_kernel), or none
-    int pk = 0;
-    int64_t w0 = -1, wc = 0, next_size = 128;
-    int64_t windows = 0, exact = 0;
-    static constexpr int64_t kMinWindow = 128, kMaxWindow = 65536, kCap = 64, kWaveWindow = 2048;
-    static constexpr uint64_t kPending = 0x8000000080000000ull;   // (no answer looks like this: len >= -1)
-
-    // wait for one pinned slot to leave the "pending" state (bounded polling, then the ordinary stream wait)
-    int await_slot(const uint64_t *slot, hipStream_t st, uint64_t *value)
-    {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t spins = 0;; ++spins) {
-            const uint64_t v = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
-            if (v != kPending) { *value = v; return DQ_OK; }
-            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
-        }
-        HIP_TRY(hipStreamSynchronize(st));               // (a slow window -- megabytes of equal text)
-        *value = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
-        if (*value == kPending) return fail(DQ_ERR_HIP, "match search: a window position was left unanswered");
-        return DQ_OK;
-    }
-
-    int refill(int64_t scan)
-    {
-        int dev = 0;
-        int rc = resolve_device(device, &dev);
-        if (rc != DQ_OK) return rc;
-        DeviceCtx &c = ctx0(dev);
-        // the window the device was asked to answer ahead (second stage of the previous launch): is it this one?
-        if (sec_pending) {
-            sec_pending = false;
-            const uint64_t *reg = h_packed + sec_region;
-            uint64_t hdr = 0;
-            rc = await_slot(&reg[0], c.stream, &hdr);
-            if (rc != DQ_OK) return rc;
-            if (hdr != kMsSkipped && (int64_t)hdr == scan) {
-                int64_t got = 0;
-                for (; got < second; ++got) {
-                    uint64_t v = 0;
-                    rc = await_slot(&reg[1 + got], c.stream, &v);
-                    if (rc != DQ_OK) return rc;
-                    if (v == kMsSkipped) break;
-                    h_pos[got] = (int32_t)(uint32_t)v;
-                    h_len[got] = (int32_t)(uint32_t)(v >> 32);
-                }
-                if (got > 0) {
-                    w0 = scan;
-                    wc = got;
-                    next_size = min_window;
-                    ++windows;
-                    ++predicted;
-                    return DQ_OK;
-                }
-            }
-        }
-        // (the loop jumped: whatever made positions come back capped in a row is behind it)
-        if (!from_capped && !(w0 >= 0 && scan == w0 + wc)) capped_streak = 0;
-        from_capped = false;
-        // the previous window was used up to its end: the loop is walking byte by byte -> a larger one
-        next_size = (w0 >= 0 && scan == w0 + wc) ? std::min(next_size * 2, kMaxWindow) : min_window;
-        const int64_t count = std::min(next_size, m - scan);
-        if (count <= kWaveWindow && !env("DQ_NO_WAVE_WINDOWS")) {
-            // short windows (the loop is hopping from match to match: every launch is a dependent round trip): one WAVE
-            // per position, 65-ary search; the position the loop stands on exactly, the ones behind it with the cap
-            std::lock_guard<std::mutex> lk(c.mu);
-            rc = init_ctx(c, dev);
-            if (rc != DQ_OK) return rc;
-            Launcher L{c, c.stream, g_prof_on.load()};
-            constexpr int kPer = kMsThreads / kWave;
-            const bool poll_now = h_packed != nullptr && !L.prof;
-            // second stage: the window the loop will want after its next jump (dq_match_search.h), windows of up to 1024 positions.
-            // Its answers are looked at when the loop gets there, not now; two slot regions take turns, so that a
-            // region is written by one launch at a time (the launch in between has answered: the older one is over).
-            const int64_t count2 = (poll_now && d_mail && count <= kSecondMaxFirst && !no_second && ticket < (1ull << 20) - 2) ? second : 0;
-            uint64_t *reg2 = nullptr;
-            if (count2) {
-                ++ticket;
-                done_total += (unsigned long long)count;
-                sec_region = kWaveWindow + (int64_t)(ticket & 1) * (kSecond + 1);
-                reg2 = h_packed + sec_region;
-                for (int64_t i = 0; i < second + 1; ++i) reg2[i] = kPending;
-            }
-            auto launch = [&]() -> int {
-                LAUNCH(L, DQ_K_MATCH_SEARCH, count, count * 4 * (4 + 64) * 64,
-                       hipLaunchKernelGGL(match_search_wave_kernel<int32_t>, dim3((unsigned)((count + count2 + kPer - 1) / kPer)),
-                                          dim3(kMsThreads), 0, c.stream, (const uint8_t *)d_old, n, (const int32_t *)d_sa,
-                                          (const uint8_t *)d_new, m, scan, count, capped_streak >= 2 ? (int64_t)0 : kCap, h_pos, h_len,
-                                          (const int32_t *)d_ptab, pk,
-                                          poll_now ? h_packed : (uint64_t *)nullptr, count2, reg2,
-                                          count2 ? reinterpret_cast<unsigned long long *>(d_mail) : (unsigned long long *)nullptr,
-                                          ticket, done_total, walk_on ? 1 : 0, no_resume ? 1 : 0));
-                return DQ_OK;
-            };
-            if (poll_now) for (int64_t i = 0; i < count; ++i) h_packed[i] = kPending;
-            rc = launch();
-            if (rc != DQ_OK) { drop_pending(c, c.stream); return rc; }
-            if (poll_now) {
-                for (int64_t i = 0; i < count; ++i) {
-                    uint64_t v = 0;
-                    rc = await_slot(&h_packed[i], c.stream, &v);
-                    if (rc != DQ_OK) return rc;
-                    h_pos[i] = (int32_t)(uint32_t)v;
-                    h_len[i] = (int32_t)(uint32_t)(v >> 32);
-                }
-                sec_pending = count2 > 0;
-            } else {
-                HIP_TRY(hipStreamSynchronize(c.stream));
-            }
-            rc = flush_profile(c);
-        } else {
-            rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, count, kCap, h_pos, h_len, device, nullptr,
-                                           d_ptab, pk, /*exact_first=*/1);
-        }
-        if (rc != DQ_OK) return rc;                      // (the answers are there)
-        w0 = scan;
-        wc = count;
-        ++windows;
-        return DQ_OK;
-    }
-    int operator()(int64_t scan, int64_t *pos, int64_t *len)
-    {
-        if (scan < w0 || scan >= w0 + wc) {
-            const int rc = refill(scan);
-            if (rc != DQ_OK) return rc;
-        }
-        int64_t p = h_pos[(size_t)(scan - w0)], l = h_len[(size_t)(scan - w0)];
-        if (l < 0) {
-            // undecided within the cap (the loop has reached the next long match): a new window from here, whose first
-            // position is answered exactly -- and whose other positions are there if the match turns out not to be taken.
-            // When that happens at one position after the other (the loop is walking through text that matches far
-            // everywhere -- periodic data, runs -- without jumping), the windows are answered exactly throughout:
-            // one launch per 128 positions instead of one per position.
-            capped_streak = (scan == last_capped + 1) ? capped_streak + 1 : 1;
-            last_capped = scan;
-            w0 = -1;
-            from_capped = true;
-            int rc = refill(scan);
-            if (rc != DQ_OK) return rc;
-            p = h_pos[0];
-            l = h_len[0];
-            ++exact;
-            if (l < 0) {                                 // (a long window: its exact position may not be this one)
-                rc = match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, nullptr, scan, 1, 0, h_pos + kMaxWindow,
-                                               h_len + kMaxWindow, device, nullptr, d_ptab, pk);
-                if (rc != DQ_OK) return rc;
-                p = h_pos[kMaxWindow];
-                l = h_len[kMaxWindow];
-                h_pos[0] = (int32_t)p;
-                h_len[0] = (int32_t)l;
-            }
-        }
-        *pos = p;
-        *len = l;
-        return DQ_OK;
-    }
-};
-
-struct JoinAll {                        // joins whatever was started, also when leaving by exception
-    std::vector<std::thread> v;
-    ~JoinAll() { for (std::thread &t : v) if (t.joinable()) t.join(); }
-};
-
-// ---- "one old file, many new files": the suffix array of old (Diff.cs:89-90) is what a diff costs before its scan loop,
-// and it depends on old alone.  A DiffIndex holds (old, suffix array, prefix table of the match search) on the
-// device; any number of new files are diffed against it (dq_bsdiff_index_*; the reference pays the sort once per
-// Diff.Create call).  The buffers are either the index's own (built here) or the caller's (a rank that received
-// text + suffix array by RCCL broadcast, deltaq_amd/batch.py: diff_many_distributed).
-struct DiffIndex {
-    int dev = 0;
-    int64_t n = 0;
-    const uint8_t *old = nullptr;       // host copy the scan loop walks: the caller's, valid while the index lives
-    char *own = nullptr;                // device allocation of this index (old + SA if built here, prefix table)
-    bool own_cached = false;            // ... which is the device context's cached one-shot buffer (not freed)
-    const char *d_old = nullptr, *d_sa = nullptr;
-    const char *d_tab = nullptr;
-    int pk = 0;
-};
-
-constexpr size_t kDiffPinnedBytes = 2 * ((size_t)(65536 + 2) * 4 + 256) + (size_t)(2048 + 2 * (1024 + 1)) * 8 + 256;
-
-size_t diff_tab_bytes(int64_t n, int *pk_out)
-{
-    // prefix table of the match search: 3 bytes (64 MiB of entries) for old files from 4 MiB, 2 bytes from 64 KiB
-    const int pk = n >= (4 << 20) ? 3 : n >= (1 << 16) ? 2 : 0;
-    *pk_out = pk;
-    return pk ? align_up(((size_t)1 << (8 * pk)) * 4 + 16) : 0;
-}
-
-int grow_cached(char **buf, size_t *have, size_t want, const char *what)
-{
-    if (*have >= want) return DQ_OK;
-    if (*buf) { (void)hipFree(*buf); *buf = nullptr; *have = 0; }
-    hipError_t e = hipMalloc((void **)buf, want);
-    if (e != hipSuccess) return fail(DQ_ERR_OOM, what, e);
-    *have = want;
-    return DQ_OK;
-}
-
-// d_old_in / d_sa_in: device-resident text and suffix array of the caller (both or neither).  cached: build into the
-// device context's reusable buffer (the one-shot dq_bsdiff_create; the caller holds diff_mu).
-int diff_index_build(const uint8_t *old, int64_t n, int32_t device, const void *d_old_in, const void *d_sa_in, bool cached,
-                     DiffIndex *ix)
-{
-    if (n < 0 || (n > 0 && !old)) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
-    if ((d_old_in == nullptr) != (d_sa_in == nullptr)) return fail(DQ_ERR_BAD_ARGS, "device text and suffix array go together");
-    if (n > 0x7fffffffLL) return fail(DQ_ERR_TOO_LARGE, "the BSDIFF40 path takes files below 2 GiB (int indices, as the reference)");
-    int dev = 0;
-    int rc = resolve_device(device, &dev);
-    if (rc != DQ_OK) return rc;
-    HIP_TRY(hipSetDevice(dev));
-    ix->dev = dev; ix->n = n; ix->old = old;
-    int pk = 0;
-    const size_t b_tab = diff_tab_bytes(n, &pk);
-    const size_t b_old = d_old_in ? 0 : align_up((size_t)n + 16), b_sa = d_old_in ? 0 : align_up((size_t)n * 4 + 16);
-    const size_t total = b_old + b_sa + b_tab;
-    if (total > 0) {
-        if (cached) {
-            DeviceCtx &c = ctx0(dev);
-            rc = grow_cached(&c.diff_idx, &c.diff_idx_bytes, total, "hipMalloc(bsdiff index)");
-            if (rc != DQ_OK) return rc;
-            ix->own = c.diff_idx;
-            ix->own_cached = true;
-        } else {
-            hipError_t e = hipMalloc((void **)&ix->own, total);
-            if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(bsdiff index)", e);
-        }
-    }
-    if (d_old_in) {
-        ix->d_old = (const char *)d_old_in;
-        ix->d_sa = (const char *)d_sa_in;
-    } else {
-        ix->d_old = ix->own;
-        ix->d_sa = ix->own + b_old;
-        if (n > 0) HIP_TRY(hipMemcpy(ix->own, old, (size_t)n, hipMemcpyHostToDevice));
-        rc = sufsort_dev<int32_t>(ix->d_old, n, const_cast<char *>(ix->d_sa), dev, nullptr);     // Diff.cs:90; the SA never leaves the device
-        if (rc != DQ_OK) return rc;
-    }
-    ix->pk = pk;
-    if (pk) {
-        char *tab = ix->own + b_old + b_sa;
-        const int64_t total_e = (1ll << (8 * pk)) + 1;
-        hipLaunchKernelGGL(prefix_bounds_kernel<int32_t>, dim3((unsigned)((total_e + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                           nullptr, (const uint8_t *)ix->d_old, n, (const int32_t *)ix->d_sa, pk, (int32_t *)tab);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
-        ix->d_tab = tab;
-    }
-    return DQ_OK;
-}
-
-void diff_index_drop(DiffIndex *ix)
-{
-    if (ix->own && !ix->own_cached) { (void)hipSetDevice(ix->dev); (void)hipFree(ix->own); }
-    ix->own = nullptr;
-}
-
-// Diff.Create's data path up to the raw streams for one new file: upload it, run the scan loop over windows of answers
-int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::RawStreams &raw)
-{
-    if (m < 0 || (m > 0 && !nw)) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
-    if (m > 0x7fffffffLL) return fail(DQ_ERR_TOO_LARGE, "the BSDIFF40 path takes files below 2 GiB (int indices, as the reference)");
-    if (m == 0) return DQ_OK;
-    const int dev = ix.dev;
-    HIP_TRY(hipSetDevice(dev));
-    DeviceCtx &c = ctx0(dev);
-    const bool trace = env("DQ_TRACE") != nullptr;
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto stamp = [&](const char *what) {
-        if (trace) fprintf(stderr, "[dq] bsdiff %-14s at %8.3f ms\n", what,
-                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
-    };
-    const size_t b_new = align_up((size_t)m + 16);
-    int rc = grow_cached(&c.diff_dev, &c.diff_dev_bytes, b_new + 256, "hipMalloc(bsdiff buffers)");      // (+ the mailbox of the window kernel)
-    if (rc != DQ_OK) return rc;
-    if (!c.diff_pinned) {
-        hipError_t e = hipHostMalloc((void **)&c.diff_pinned, kDiffPinnedBytes, hipHostMallocCoherent);   // (windows + the packed answers the loop polls)
-        if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipHostMalloc(search windows)", e);
-    }
-    char *pinned = c.diff_pinned;
-    const size_t b_win = align_up((size_t)(SearchWindows::kMaxWindow + 2) * 4);
-    static_assert(kDiffPinnedBytes >= 2 * ((size_t)(SearchWindows::kMaxWindow + 2) * 4 + 256) +
-                  (size_t)(SearchWindows::kWaveWindow + 2 * (SearchWindows::kSecond + 1)) * 8 + 256, "pinned window area");
-    char *d_new = c.diff_dev;
-    stamp("buffers");
-    HIP_TRY(hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice));
-    stamp("new on device");
-    SearchWindows win{ix.d_old, ix.d_sa, d_new, ix.n, m, dev};
-    win.d_ptab = ix.d_tab;
-    win.pk = ix.pk;
-    win.h_pos = reinterpret_cast<int32_t *>(pinned);
-    win.h_len = reinterpret_cast<int32_t *>(pinned + b_win);
-    win.h_packed = env("DQ_NO_POLL") ? nullptr : reinterpret_cast<uint64_t *>(pinned + 2 * b_win);
-    win.d_mail = d_new + b_new;
-    HIP_TRY(hipMemset(win.d_mail, 0, 16));
-    win.no_second = env("DQ_NO_SECOND_STAGE") != nullptr;
-    if (const char *v = env("DQ_WIN_MIN")) win.min_window = std::min<int64_t>(std::max(16, atoi(v)), SearchWindows::kWaveWindow);
-    if (const char *v = env("DQ_WIN_SECOND")) win.second = std::min<int64_t>(std::max(16, atoi(v)), SearchWindows::kSecond);
-    win.next_size = win.min_window;
-    if (const char *v = env("DQ_WALK_ON")) win.walk_on = atoi(v) != 0;
-    win.no_resume = env("DQ_NO_RESUME") != nullptr;
-    rc = bsdiff::scan_loop(ix.old, ix.n, nw, m, win, raw);
-    raw.windows = win.windows;
-    raw.exact = win.exact;
-    stamp("scan loop");
-    if (trace)
-        fprintf(stderr, "[dq] scan loop: %lld searches, %lld windows (%lld of them answered ahead by the second stage), %lld exact repeats\n",
-                (long long)raw.searches, (long long)win.windows, (long long)win.predicted, (long long)win.exact);
-    // (the loop polled the kernels' own completion counts: drain the stream before the buffers are reused)
-    const hipError_t drained = hipStreamSynchronize(c.stream);
-    if (rc == DQ_OK && drained != hipSuccess) return fail(DQ_ERR_HIP, "scan loop: stream did not drain", drained);
-    return rc;
-}
-
-// Diff.Create's data path up to the raw streams: sort old on the device, keep the SA there, run the scan loop
-int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, bsdiff::RawStreams &raw)
-{
-    if (n < 0 || m < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
-    if ((n > 0 && !old) || (m > 0 && !nw)) return fail(DQ_ERR_BAD_ARGS, "null buffer");
-    if (n > 0x7fffffffLL || m > 0x7fffffffLL) return fail(DQ_ERR_TOO_LARGE, "the BSDIFF40 path takes files below 2 GiB (int indices, as the reference)");
-    int dev = 0;
-    int rc = resolve_device(device, &dev);
-    if (rc != DQ_OK) return rc;
-    if (m == 0) return DQ_OK;
-    std::lock_guard<std::mutex> one_diff(ctx0(dev).diff_mu);
-    DiffIndex ix;
-    rc = diff_index_build(old, n, dev, nullptr, nullptr, /*cached=*/true, &ix);
-    if (rc != DQ_OK) return rc;
-    return diff_index_scan(ix, nw, m, raw);
-}
-
-// one bzip2 stream; the Burrows-Wheeler transform of each block through the suffix sorter (blocks of a long stream
-// are encoded on several threads: the sorter is called concurrently, each call leasing its own device context)
-int bz2_stream(const std::vector<uint8_t> &src, std::vector<uint8_t> &out, int dev)
-{
-    std::atomic<int> sort_rc{DQ_OK};
-    std::mutex err_mu;
-    std::string err;
-    const int rc = bz2::bz2_compress(src.data(), src.size(), out,
-                                     [&](const uint8_t *t, int64_t n2, int32_t *sa) -> int {
-                                         const int r = sufsort_host<int32_t>(t, n2, sa, dev);
-                                         if (r == DQ_OK) return 0;
-                                         int expect = DQ_OK;
-                                         if (sort_rc.compare_exchange_strong(expect, r)) {
-                                             std::lock_guard<std::mutex> lk(err_mu);
-                                             err = t_err;                      // (thread-local on the worker: carried over)
-                                         }
-                                         return -2;
-                                     });
-    if (rc == -2) { t_err = err; return sort_rc.load(); }
-    if (rc != 0) return fail(DQ_ERR_HIP, "bzip2 block transform failed");
-    return DQ_OK;
-}
-
-// header + the three streams (Diff.cs:54-70 / :196-252).  The streams are framed side by side on three host threads:
-// their run-length / MTF / Huffman work overlaps, the block sorts take turns on the device.
-int frame_patch(const bsdiff::RawStreams &raw, int64_t m, int dev, std::vector<uint8_t> &patch)
-{
-    std::vector<uint8_t> z[3];
-    const std::vector<uint8_t> *src[3] = {&raw.ctrl, &raw.diff, &raw.extra};
-    int rcs[3] = {DQ_OK, DQ_OK, DQ_OK};
-    std::string errs[3];
-    auto work = [&](int k) {
-        try {
-            rcs[k] = bz2_stream(*src[k], z[k], dev);
-            if (rcs[k] != DQ_OK) errs[k] = t_err;
-        } catch (const std::exception &e) {
-            rcs[k] = DQ_ERR_OOM;
-            errs[k] = std::string("bsdiff: ") + e.what();
-        }
-    };
-    {
-        JoinAll threads;
-        // (streams of a few KB are not worth a thread)
-        const bool parallel = raw.ctrl.size() + raw.diff.size() + raw.extra.size() >= (1u << 16) && !env("DQ_BZ2_SERIAL");
-        for (int k = 1; k < 3; ++k) {
-            if (!parallel) { work(k); continue; }
-            try { threads.v.emplace_back(work, k); } catch (const std::exception &) { work(k); }
-        }
-        work(0);
-    }
-    for (int k = 0; k < 3; ++k)
-        if (rcs[k] != DQ_OK) { t_err = errs[k]; return rcs[k]; }
-    patch.assign((size_t)bsdiff::kHeaderSize, 0);                                  // Diff.cs:54-70 / :247-252
-    bsdiff::write_packed_long(&patch[0], bsdiff::kSignature);
-    bsdiff::write_packed_long(&patch[8], (int64_t)z[0].size());
-    bsdiff::write_packed_long(&patch[16], (int64_t)z[1].size());
-    bsdiff::write_packed_long(&patch[24], m);
-    patch.reserve(patch.size() + z[0].size() + z[1].size() + z[2].size());
-    for (int k = 0; k < 3; ++k) patch.insert(patch.end(), z[k].begin(), z[k].end());
-    return DQ_OK;
-}
-
-int bsdiff_create_host(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, std::vector<uint8_t> &patch)
-{
-    bsdiff::RawStreams raw;
-    int rc = bsdiff_raw(old, n, nw, m, device, raw);
-    if (rc != DQ_OK) return rc;
-    int dev = 0;
-    rc = resolve_device(device, &dev);
-    if (rc != DQ_OK) return rc;
-    return frame_patch(raw, m, dev, patch);
-}
-
-// Patch.Apply (Patch.cs:52-168): host only (dq_bspatch.h)
-int bspatch_apply_host(const uint8_t *old, int64_t n, const uint8_t *patch, int64_t plen, uint8_t *out, int64_t cap, int64_t *out_len)
-{
-    if (n < 0 || plen < 0 || cap < 0 || (n > 0 && !old) || !patch) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
-    const int rc = bsdiff::apply_patch(old, n, patch, plen, out, cap, out_len);
-    if (rc == bsdiff::kPatchSmallBuffer) return fail(DQ_ERR_BAD_ARGS, "output buffer too small");
-    if (rc != bsdiff::kPatchOk) return fail(DQ_ERR_BAD_ARGS, "Corrupt patch");
-    return DQ_OK;
-}
-
-// ------------------------------------------------------------------ batch: one device's share, pipelined
-// Three stages on three host threads and three streams, kBatchSlots device buffers in flight:
-//   copy-in   text j -> slot          (pageable host memory: the copy blocks its thread, not the others)
-//   sort      slot's text -> slot's SA (device-resident sorter; one sort at a time per device anyway)
-//   copy-out  slot's SA -> sas[j]
-// so the PCIe transfers of neighbouring inputs overlap the sort.  Inputs that need the
-// short-text path or that are larger than the slot size go through the plain host entry point.
-constexpr int kBatchSlots = 3;
-
-
-int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *const *texts, const int64_t *lens,
-                    int32_t *const *sas, std::string *err)
-{
-    auto plain = [&](int j) -> int {
-        int rc = sufsort_host<int32_t>(texts[j], lens[j], sas[j], device);
-        if (rc != DQ_OK) *err = t_err;
-        return rc;
-    };
-    const int64_t direct = std::max<int64_t>(small_limit(), 2);             // these bypass the pipeline
-    int64_t cap = 0;
-    int big = 0;
-    for (int j : jobs)
-        if (lens[j] > direct) { cap = std::max(cap, lens[j]); ++big; }
-    if (big < 3 || cap > (1ll << 30)) {                       // nothing to overlap / slots would be huge
-        for (int j : jobs) { int rc = plain(j); if (rc != DQ_OK) return rc; }
-        return DQ_OK;
-    }
-    if (hipSetDevice(device) != hipSuccess) { *err = "hipSetDevice failed"; return DQ_ERR_HIP; }
-    // the three device slots and streams live in the device context: allocated once, grown on demand
-    DeviceCtx &bc = ctx0(device);
-    std::lock_guard<std::mutex> batch_lock(bc.batch_mu);
-    struct Slot { uint8_t *text = nullptr; int32_t *sa = nullptr; int job = -1; };
-    Slot slots[kBatchSlots];
-    {
-        bool ok = true;
-        for (hipStream_t *st : {&bc.b_in, &bc.b_sort, &bc.b_out})
-            if (!*st) ok = ok && hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
-        if (ok && bc.bslot_cap < (size_t)cap) {
-            for (int k = 0; k < kBatchSlots; ++k) {
-                if (bc.bslot_text[k]) (void)hipFree(bc.bslot_text[k]);
-                if (bc.bslot_sa[k]) (void)hipFree(bc.bslot_sa[k]);
-                bc.bslot_text[k] = nullptr; bc.bslot_sa[k] = nullptr;
-            }
-            bc.bslot_cap = 0;
-            for (int k = 0; k < kBatchSlots; ++k)
-                ok = ok && hipMalloc((void **)&bc.bslot_text[k], (size_t)cap + 64) == hipSuccess &&
-                     hipMalloc((void **)&bc.bslot_sa[k], (size_t)cap * sizeof(int32_t)) == hipSuccess;
-            if (ok) bc.bslot_cap = (size_t)cap;
-        }
-        if (!ok) { *err = "batch slot allocation failed"; return DQ_ERR_OOM; }
-        for (int k = 0; k < kBatchSlots; ++k) { slots[k].text = bc.bslot_text[k]; slots[k].sa = bc.bslot_sa[k]; }
-    }
-    hipStream_t s_in = bc.b_in, s_sort = bc.b_sort, s_out = bc.b_out;
-
-    // slot hand-over: free -> filled (text on the device) -> sorted (SA on the device) -> free
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<int> filled, sorted, freeq;
-    for (int k = 0; k < kBatchSlots; ++k) freeq.push_back(k);
-    bool in_done = false, sort_done = false;
-    std::atomic<int> failed{DQ_OK};
-    std::string errs[3];
-    auto take = [&](std::vector<int> &q, const bool *producer_done) -> int {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !q.empty() || (producer_done && *producer_done) || failed.load() != DQ_OK; });
-        if (q.empty()) return -1;
-        const int k = q.front();
-        q.erase(q.begin());
-        return k;
-    };
-    auto give = [&](std::vector<int> &q, int k) { { std::lock_guard<std::mutex> lk(mu); q.push_back(k); } cv.notify_all(); };
-    auto fail_stage = [&](int stage, int rc, const std::string &what) {
-        {   // under the mutex: a waiter between its predicate check and its block must not miss this
-            std::lock_guard<std::mutex> lk(mu);
-            errs[stage] = what;
-            int expect = DQ_OK;
-            failed.compare_exchange_strong(expect, rc);
-        }
-        cv.notify_all();
-    };
-
-    auto stage_in = [&]() {
-        (void)hipSetDevice(device);
-        for (int j : jobs) {
-            if (lens[j] <= direct) continue;                                // handled after the pipeline
-            const int k = take(freeq, nullptr);
-            if (k < 0 || failed.load() != DQ_OK) break;
-            slots[k].job = j;
-            hipError_t e = hipMemcpyAsync(slots[k].text, texts[j], (size_t)lens[j], hipMemcpyHostToDevice, s_in);
-            if (e == hipSuccess) e = hipStreamSynchronize(s_in);
-            if (e != hipSuccess) { fail_stage(0, DQ_ERR_HIP, std::string("batch copy-in: ") + hipGetErrorString(e)); break; }
-            give(filled, k);
-        }
-        { std::lock_guard<std::mutex> lk(mu); in_done = true; }
-        cv.notify_all();
-    };
-    auto stage_sort = [&]() {
-        (void)hipSetDevice(device);
-        for (;;) {
-            const int k = take(filled, &in_done);
-            if (k < 0 || failed.load() != DQ_OK) break;
-            const int j = slots[k].job;
-            int rc = sufsort_dev<int32_t>(slots[k].text, lens[j], slots[k].sa, device, s_sort);
-            if (rc != DQ_OK) { fail_stage(1, rc, t_err); break; }
-            give(sorted, k);
-        }
-        { std::lock_guard<std::mutex> lk(mu); sort_done = true; }
-        cv.notify_all();
-    };
-    auto stage_out = [&]() {
-        (void)hipSetDevice(device);
-        for (;;) {
-            const int k = take(sorted, &sort_done);
-            if (k < 0 || failed.load() != DQ_OK) break;
-            const int j = slots[k].job;
-            hipError_t e = hipMemcpyAsync(sas[j], slots[k].sa, (size_t)lens[j] * sizeof(int32_t), hipMemcpyDeviceToHost, s_out);
-            if (e == hipSuccess) e = hipStreamSynchronize(s_out);
-            if (e != hipSuccess) { fail_stage(2, DQ_ERR_HIP, std::string("batch copy-out: ") + hipGetErrorString(e)); break; }
-            give(freeq, k);
-        }
-    };
-    {
-        // a thread that cannot be started (std::system_error) fails the batch instead of terminating:
-        // the stages already running are woken through fail_stage and joined
-        JoinAll stages;
-        try {
-            stages.v.emplace_back(stage_in);
-            stages.v.emplace_back(stage_sort);
-            stages.v.emplace_back(stage_out);
-        } catch (const std::exception &e) {
-            fail_stage(0, DQ_ERR_OOM, std::string("batch: cannot start a pipeline thread: ") + e.what());
-        }
-    }
-    if (failed.load() != DQ_OK) {
-        for (const std::string &e : errs) if (!e.empty()) { *err = e; break; }
-        return failed.load();
-    }
-    for (int j : jobs)
-        if (lens[j] <= direct) { int rc = plain(j); if (rc != DQ_OK) return rc; }
-    return DQ_OK;
-}
-
-}  // namespace
-
-// ====================================================================== C ABI
-extern "C" {
-
-int32_t dq_abi_version(void) { return DQ_ABI_VERSION; }
-
-int32_t dq_device_count(void)
-{
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
-    return count;
-}
-
-const char *dq_last_error(void) { return t_err.c_str(); }
-
-int32_t dq_sufsort_hip_i32(const uint8_t *text, int64_t n, int32_t *sa, int32_t device)
-{
-    EnvScope flags;
-    return sufsort_host<int32_t>(text, n, sa, device);
-}
-
-int32_t dq_sufsort_hip_i64(const uint8_t *text, int64_t n, int64_t *sa, int32_t device)
-{
-    EnvScope flags;
-    return sufsort_host<int64_t>(text, n, sa, device);
-}
-
-int32_t dq_sufsort_hip_dev_i32(const void *d_text, int64_t n, void *d_sa, int32_t device, void *stream)
-{
-    EnvScope flags;
-    return sufsort_dev<int32_t>(d_text, n, d_sa, device, stream);
-}
-
-int32_t dq_sufsort_hip_dev_i64(const void *d_text, int64_t n, void *d_sa, int32_t device, void *stream)
-{
-    EnvScope flags;
-    return sufsort_dev<int64_t>(d_text, n, d_sa, device, stream);
-}
-
-int32_t dq_sufsort_hip_batch_i32(int32_t count, const uint8_t *const *texts, const int64_t *lens,
-                                 int32_t *const *sas, int32_t ndev, const int32_t *devs)
-{
-    EnvScope flags;
-    if (count < 0 || ndev <= 0 || (count > 0 && (!texts || !lens || !sas)))
-        return fail(DQ_ERR_BAD_ARGS, "bad batch arguments");
-    if (count == 0) return DQ_OK;
-    try {
-    // longest-processing-time-first assignment of inputs to devices
-    std::vector<int> order(count);
-    for (int i = 0; i < count; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
-    std::vector<std::vector<int>> share(ndev);
-    std::vector<int64_t> load(ndev, 0);
-    for (int j : order) {
-        int best = 0;
-        for (int d = 1; d < ndev; ++d)
-            if (load[d] < load[best]) best = d;
-        share[best].push_back(j);
-        load[best] += lens[j];
-    }
-    std::vector<int> rcs(ndev, DQ_OK);
-    std::vector<std::string> errs(ndev);
-    {
-        JoinAll threads;
-        for (int d = 0; d < ndev; ++d) {
-            threads.v.emplace_back([&, d]() {
-                const int device = devs ? devs[d] : d;
-                try {
-                    rcs[d] = batch_on_device(device, share[d], texts, lens, sas, &errs[d]);
-                } catch (const std::exception &e) {
-                    rcs[d] = DQ_ERR_OOM;
-                    errs[d] = std::string("batch: ") + e.what();
-                }
-            });
-        }
-    }
-    for (int d = 0; d < ndev; ++d)
-        if (rcs[d] != DQ_OK) { t_err = errs[d]; return rcs[d]; }
-    return DQ_OK;
-    } catch (const std::bad_alloc &) {             // nothing may propagate through the C ABI
-        return fail(DQ_ERR_OOM, "batch: host allocation failed");
-    } catch (const std::exception &e) {            // std::system_error from std::thread, ...
-        return fail(DQ_ERR_HIP, e.what());
-    }
-}
-
-int32_t dq_bsdiff_search_dev_i32(const void *d_old, int64_t n, const void *d_sa, const void *d_new, int64_t m,
-                                 const int64_t *d_scans, int64_t scan0, int64_t count, int64_t cap, void *d_pos,
-                                 void *d_len, int32_t device, void *stream)
-{
-    EnvScope flags;
-    return match_search_dev<int32_t>(d_old, n, d_sa, d_new, m, d_scans, scan0, count, cap, d_pos, d_len, device, stream);
-}
-
-int32_t dq_bsdiff_search_dev_i64(const void *d_old, int64_t n, const void *d_sa, const void *d_new, int64_t m,
-                                 const int64_t *d_scans, int64_t scan0, int64_t count, int64_t cap, void *d_pos,
-                                 void *d_len, int32_t device, void *stream)
-{
-    EnvScope flags;
-    return match_search_dev<int64_t>(d_old, n, d_sa, d_new, m, d_scans, scan0, count, cap, d_pos, d_len, device, stream);
-}
-
-int32_t dq_bsdiff_search_i32(const uint8_t *old_data, int64_t n, const int32_t *sa, const uint8_t *new_data, int64_t m,
-                             const int64_t *scans, int64_t scan0, int64_t count, int64_t cap, int32_t *pos, int32_t *len,
-                             int32_t device)
-{
-    EnvScope flags;
-    return match_search_host<int32_t>(old_data, n, sa, new_data, m, scans, scan0, count, cap, pos, len, device);
-}
-
-int32_t dq_bsdiff_search_i64(const uint8_t *old_data, int64_t n, const int64_t *sa, const uint8_t *new_data, int64_t m,
-                             const int64_t *scans, int64_t scan0, int64_t count, int64_t cap, int64_t *pos, int64_t *len,
-                             int32_t device)
-{
-    EnvScope flags;
-    return match_search_host<int64_t>(old_data, n, sa, new_data, m, scans, scan0, count, cap, pos, len, device);
-}
-
-int32_t dq_bsdiff_scan_i32(const uint8_t *old_data, int64_t n, const uint8_t *new_data, int64_t m, int64_t *ctrl,
-                           int64_t ctrl_cap, int64_t *nctrl, uint8_t *diff, int64_t *ndiff, uint8_t *extra, int64_t *nextra,
-                           int64_t *stats, int32_t device)
-{
-    EnvScope flags;
-    try {
-        bsdiff::RawStreams raw;
-        const int rc = bsdiff_raw(old_data, n, new_data, m, device, raw);
-        if (rc != DQ_OK) return rc;
-        const int64_t triples = (int64_t)raw.ctrl.size() / 24;
-        if (triples > ctrl_cap) return fail(DQ_ERR_BAD_ARGS, "control buffer too small");
-        for (int64_t i = 0; i < 3 * triples; ++i) ctrl[i] = bsdiff::read_packed_long(&raw.ctrl[(size_t)i * 8]);
-        if (!raw.diff.empty()) memcpy(diff, raw.diff.data(), raw.diff.size());
-        if (!raw.extra.empty()) memcpy(extra, raw.extra.data(), raw.extra.size());
-        *nctrl = triples; *ndiff = (int64_t)raw.diff.size(); *nextra = (int64_t)raw.extra.size();
-        if (stats) { stats[0] = raw.searches; stats[1] = raw.windows; stats[2] = raw.exact; }
-        return DQ_OK;
-    } catch (const std::bad_alloc &) {
-        return fail(DQ_ERR_OOM, "bsdiff: host allocation failed");
-    } catch (const std::exception &e) {            // nothing may propagate through the C ABI
-        return fail(DQ_ERR_HIP, e.what());
-    }
-}
-
-int32_t dq_bsdiff_create(const uint8_t *old_data, int64_t n, const uint8_t *new_data, int64_t m, uint8_t *patch,
-                         int64_t cap, int64_t *patch_len, int32_t device)
-{
-    EnvScope flags;
-    try {
-        std::vector<uint8_t> v;
-        const int rc = bsdiff_create_host(old_data, n, new_data, m, device, v);
-        if (rc != DQ_OK) return rc;
-        if (patch_len) *patch_len = (int64_t)v.size();
-        if ((int64_t)v.size() > cap || !patch) return fail(DQ_ERR_BAD_ARGS, "patch buffer too small (see dq_bsdiff_patch_bound)");
-        memcpy(patch, v.data(), v.size());
-        return DQ_OK;
-    } catch (const std::bad_alloc &) {
-        return fail(DQ_ERR_OOM, "bsdiff: host allocation failed");
-    } catch (const std::exception &e) {            // nothing may propagate through the C ABI
-        return fail(DQ_ERR_HIP, e.what());
-    }
-}
-
-int32_t dq_bsdiff_index_create(const uint8_t *old_data, int64_t n, const void *d_old, const void *d_sa, int32_t device,
-                               void **index_out)
-{
-    EnvScope flags;
-    if (!index_out) return fail(DQ_ERR_BAD_ARGS, "null index pointer");
-    *index_out = nullptr;
-    try {
-        DiffIndex *ix = new DiffIndex();
-        const int rc = diff_index_build(old_data, n, device, d_old, d_sa, /*cached=*/false, ix);
-        if (rc != DQ_OK) { diff_index_drop(ix); delete ix; return rc; }
-        *index_out = ix;
-        return DQ_OK;
-    } catch (const std::bad_alloc &) {
-        return fail(DQ_ERR_OOM, "bsdiff: host allocation failed");
-    } catch (const std::exception &e) {
-        return fail(DQ_ERR_HIP, e.what());
-    }
-}
-
-int32_t dq_bsdiff_index_buffers(const void *index, const void **d_old, const void **d_sa, int64_t *n)
-{
-    if (!index) return fail(DQ_ERR_BAD_ARGS, "null index");
-    const DiffIndex *ix = static_cast<const DiffIndex *>(index);
-    if (d_old) *d_old = ix->d_old;
-    if (d_sa) *d_sa = ix->d_sa;
-    if (n) *n = ix->n;
-    return DQ_OK;
-}
-
-int32_t dq_bsdiff_index_diff(const void *index, const uint8_t *new_data, int64_t m, uint8_t *patch, int64_t cap,
-                             int64_t *patch_len)
-{
-    EnvScope flags;
-    if (!index) return fail(DQ_ERR_BAD_ARGS, "null index");
-    const DiffIndex *ix = static_cast<const DiffIndex *>(index);
-    try {
-        std::vector<uint8_t> v;
-        {
-            bsdiff::RawStreams raw;
-            {
-                std::lock_guard<std::mutex> one_diff(ctx0(ix->dev).diff_mu);      // scan loops take turns on a device
-                const int rc = diff_index_scan(*ix, new_data, m, raw);
-                if (rc != DQ_OK) return rc;
-            }
-            const int rc = frame_patch(raw, m, ix->dev, v);                        // (framing overlaps the next caller's scan loop)
-            if (rc != DQ_OK) return rc;
-        }
-        if (patch_len) *patch_len = (int64_t)v.size();
-        if ((int64_t)v.size() > cap || !patch) return fail(DQ_ERR_BAD_ARGS, "patch buffer too small (see dq_bsdiff_patch_bound)");
-        memcpy(patch, v.data(), v.size());
-        return DQ_OK;
-    } catch (const std::bad_alloc &) {
-        return fail(DQ_ERR_OOM, "bsdiff: host allocation failed");
-    } catch (const std::exception &e) {
-        return fail(DQ_ERR_HIP, e.what());
-    }
-}
-
-void dq_bsdiff_index_free(void *index)
-{
-    if (!index) return;
-    DiffIndex *ix = static_cast<DiffIndex *>(index);
-    diff_index_drop(ix);
-    delete ix;
-}
-
-int64_t dq_bsdiff_patch_bound(int64_t n, int64_t m)
-{
-    if (n < 0 || m < 0) return -1;
-    // three bzip2 streams: 24 bytes of control per triple (at most m + 1 triples), m diff + extra bytes in total;
-    // bzip2 never grows its input by more than 1 % + 600 bytes per stream
-    const int64_t raw = 24 * (m + 1) + m;
-    return bsdiff::kHeaderSize + raw + raw / 100 + 3 * 600 + 64;
-}
-
-int32_t dq_bspatch_apply(const uint8_t *old_data, int64_t n, const uint8_t *patch, int64_t patch_len, uint8_t *out,
-                         int64_t cap, int64_t *out_len)
-{
-    try {
-        return bspatch_apply_host(old_data, n, patch, patch_len, out, cap, out_len);
-    } catch (const std::bad_alloc &) {
-        return fail(DQ_ERR_OOM, "bspatch: host allocation failed");
-    } catch (const std::exception &e) {
-        return fail(DQ_ERR_HIP, e.what());
-    }
-}
-
-int64_t dq_sufsort_hip_workspace_bytes(int64_t n, int32_t index_bytes)
-{
-    if (n < 0) return -1;
-    if (index_bytes == 4) return (int64_t)carve<int32_t>(nullptr, n, false).bytes;
-    if (index_bytes == 8) return (int64_t)carve<int64_t>(nullptr, n, false).bytes;
-    return -1;
-}
-
-void dq_sufsort_hip_release(void)
-{
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
-    for (int d = 0; d < kMaxDevices && d < count; ++d) {
-        DeviceCtx &c0 = ctx0(d);
-        // lock order everywhere: batch_mu, then diff_mu, then a slot's mu
-        std::lock_guard<std::mutex> bl(c0.batch_mu);
-        std::lock_guard<std::mutex> dl(c0.diff_mu);
-        bool any = c0.diff_dev || c0.diff_idx || c0.diff_pinned || c0.bslot_cap;
-        for (int k = 0; k < kCtxSlots; ++k) any = any || g_dev[d].slot[k].dev >= 0;
-        if (!any || hipSetDevice(d) != hipSuccess) continue;
-        for (int k = 0; k < 3; ++k) {
-            if (c0.bslot_text[k]) (void)hipFree(c0.bslot_text[k]);
-            if (c0.bslot_sa[k]) (void)hipFree(c0.bslot_sa[k]);
-            c0.bslot_text[k] = nullptr; c0.bslot_sa[k] = nullptr;
-        }
-        c0.bslot_cap = 0;
-        for (hipStream_t *st : {&c0.b_in, &c0.b_sort, &c0.b_out}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
-        if (c0.diff_dev) (void)hipFree(c0.diff_dev);
-        if (c0.diff_idx) (void)hipFree(c0.diff_idx);
-        if (c0.diff_pinned) (void)hipHostFree(c0.diff_pinned);
-        c0.diff_dev = nullptr; c0.diff_idx = nullptr; c0.diff_pinned = nullptr;
-        c0.diff_dev_bytes = 0; c0.diff_idx_bytes = 0;
-        for (int k = 0; k < kCtxSlots; ++k) {
-            DeviceCtx &c = g_dev[d].slot[k];
-            std::lock_guard<std::mutex> lk(c.mu);
-            if (c.ws) (void)hipFree(c.ws);
-            c.ws = nullptr; c.ws_bytes = 0;
-            for (hipEvent_t e : c.pool) (void)hipEventDestroy(e);
-            c.pool.clear();
-            if (c.pinned) (void)hipHostFree(c.pinned);
-            c.pinned = nullptr;
-            if (c.pinned_io) (void)hipHostFree(c.pinned_io);
-            c.pinned_io = nullptr;
-            if (c.readback) (void)hipEventDestroy(c.readback);
-            c.readback = nullptr;
-            if (c.stream) (void)hipStreamDestroy(c.stream);
-            c.stream = nullptr;
-            c.dev = -1;
-        }
-    }
-}
-
-int32_t dq_profile_enable(int32_t on)
-{
-    g_prof_on.store((on == 2 || (on >= 100 && on < 100 + DQ_K_COUNT)) ? on : (on ? 1 : 0));
-    return DQ_OK;
-}
-
-void dq_profile_reset(void)
-{
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto &s : g_prof) s = KernelStat{};
-}
-
-int32_t dq_profile_get(int32_t category, int64_t *launches, double *total_ms, int64_t *elements,
-                       int64_t *alg_bytes)
-{
-    if (category < 0 || category >= DQ_K_COUNT) return DQ_ERR_BAD_ARGS;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    const KernelStat &s = g_prof[category];
-    if (launches) *launches = s.launches;
-    if (total_ms) *total_ms = s.ms;
-    if (elements) *elements = s.elems;
-    if (alg_bytes) *alg_bytes = s.bytes;
-    return DQ_OK;
-}
-
-int32_t dq_profile_category_count(void) { return DQ_K_COUNT; }
-
-const char *dq_profile_kernel_name(int32_t category)
-{
-    return (category >= 0 && category < DQ_K_COUNT) ? kKernelNames[category] : "";
-}
-
-int32_t dq_last_sort_info(int64_t *rounds, int64_t *initial_active, int64_t *sum_active)
-{
-    if (rounds) *rounds = t_info[0];
-    if (initial_active) *initial_active = t_info[1];
-    if (sum_active) *sum_active = t_info[2];
-    return DQ_OK;
-}
-
-}  // extern "C"
+}  // namespace dq
