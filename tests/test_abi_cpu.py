@@ -89,3 +89,73 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "dq_oracle" not in src, f
+
+
+# ---- the never-compiled C# shim (no dotnet in any image): its [DllImport] signatures against the header
+C_WIDTH = {"int32_t": "i32", "int64_t": "i64", "void": "void", "double": "f64"}
+CS_WIDTH = {"int": "i32", "long": "i64", "void": "void", "double": "f64", "uint": "i32", "ulong": "i64"}
+
+
+def c_kind(decl: str) -> str:
+    """'i32' / 'i64' for integers by value, 'ptr' for any pointer, 'void'."""
+    decl = decl.replace("const", " ").strip()
+    if "*" in decl:
+        return "ptr"
+    base = decl.split()[0]
+    assert base in C_WIDTH, decl
+    return C_WIDTH[base]
+
+
+def cs_kind(decl: str) -> str:
+    decl = decl.strip()
+    if "*" in decl or decl.split()[0] in ("IntPtr", "UIntPtr") or decl.startswith(("ref ", "out ")):
+        return "ptr"
+    base = decl.split()[0]
+    assert base in CS_WIDTH, decl
+    return CS_WIDTH[base]
+
+
+def header_signatures():
+    text = open(os.path.join(ROOT, "include", "dq_sufsort.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    sigs = {}
+    for ret, name, args in re.findall(r"^\s*([A-Za-z_][\w \*]*?)\s*\b(dq_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text, flags=re.M):
+        params = [] if args.strip() in ("", "void") else [c_kind(a) for a in args.split(",")]
+        sigs[name] = (c_kind(ret), params)
+    return sigs
+
+
+def csharp_signatures():
+    sigs = {}
+    base = os.path.join(ROOT, "bindings", "csharp")
+    for dirpath, _, files in os.walk(base):
+        for f in files:
+            if not f.endswith(".cs"):
+                continue
+            text = re.sub(r"//[^\n]*", "", open(os.path.join(dirpath, f)).read())
+            for attrs, ret, name, args in re.findall(
+                    r"\[DllImport\(([^\]]*)\)\]\s*(?:(?:internal|private|public|static|extern|unsafe)\s+)+([\w\*]+)\s+(dq_\w+)\s*\(([^)]*)\)\s*;",
+                    text, flags=re.S):
+                assert "CallingConvention.Cdecl" in attrs, f"{f}: {name} must be Cdecl"
+                assert "EntryPoint" not in attrs, f"{f}: {name} renames its entry point"
+                params = [] if not args.strip() else [cs_kind(a) for a in args.split(",")]
+                sigs.setdefault(name, []).append((f, cs_kind(ret), params))
+    return sigs
+
+
+def test_csharp_dllimports_match_the_header():
+    """Every [DllImport] of bindings/csharp/**/*.cs names an export of include/dq_sufsort.h with the same arity, the same
+    integer widths by value (C# int = int32_t, long = int64_t) and pointers where the header has pointers."""
+    hdr, cs = header_signatures(), csharp_signatures()
+    assert len(hdr) == len(header_symbols())            # the signature parser sees every declaration
+    assert cs, "no [DllImport] found under bindings/csharp"
+    assert {"dq_sufsort_hip_i32", "dq_bsdiff_create", "dq_bspatch_apply", "dq_bsdiff_search_i32", "dq_bsdiff_index_create",
+            "dq_bsdiff_index_diff", "dq_bsdiff_index_free"} <= set(cs)
+    for name, uses in cs.items():
+        assert name in hdr, f"{name}: imported by {uses[0][0]} but not declared in include/dq_sufsort.h"
+        ret, params = hdr[name]
+        for f, cret, cparams in uses:
+            # `const char *` comes back as IntPtr
+            assert cret == ret, f"{f}: {name} returns {cret}, header says {ret}"
+            assert len(cparams) == len(params), f"{f}: {name} takes {len(cparams)} arguments, header says {len(params)}"
+            assert cparams == params, f"{f}: {name} argument kinds {cparams} differ from the header's {params}"
