@@ -39,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6300.0          # ... and the copy ceiling measured on it (same guide; SURVEY.md section 8(d): report against both)
 SEED_TARGET = 0x5EED0003       # 256 MiB uniform, the north-star run
 SEED_CONFIG1 = 0x5EED0002      # 64 MiB uniform
 SEED_ENWIK = 0xD17A0           # 256 MiB enwik-style text
@@ -81,6 +82,8 @@ def main() -> int:
         dq_build.build()                   # no-op when the in-tree .so is current
         oracle.build()
         datagen.build()
+
+    managed = managed_reference_probe() if rank == 0 else None      # (child processes: before anything touches the GPU)
 
     import numpy as np
     import torch
@@ -182,6 +185,7 @@ def main() -> int:
                 "kernel": dominant, "bound": "hbm",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_of_6p3": round(achieved / HBM_COPY_GBS, 4),      # against the measured copy ceiling
                 "traffic": traffic, "traffic_source": traffic_src,
                 "launches": rs["launches"],
                 "avg_launch_us": round(rs["ms"] / rs["launches"] * 1e3, 2),
@@ -208,6 +212,7 @@ def main() -> int:
             out["batch"] = batch
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(host, sa)
+            cb["managed_reference"] = managed
             out["cpu_baseline"] = cb
             if through_abi is not None:
                 through_abi["speedup_vs_cpu"] = round(through_abi["MBps"] / cb["value"], 1)
@@ -219,12 +224,39 @@ def main() -> int:
     return 0
 
 
+def managed_reference_probe():
+    """"if dotnet happens to exist on the GPU box, additionally time the real managed
+    LibDivSufSort".  The probe runs before the GPU runtime is initialised (it starts a child process).  The managed
+    provider's sources are the reference's (never copied into this repository, and /root/reference does not exist on
+    the GPU box), so a toolchain alone is not enough: the harness also needs DQ_REFERENCE_DIR to point at a checkout."""
+    import shutil
+    import subprocess
+    exe = shutil.which("dotnet") or shutil.which("mono")
+    rec = {"toolchain": exe, "timed": False}
+    if not exe:
+        rec["note"] = "no dotnet / mono on this host: the C restatement (kind 'port') is the CPU baseline"
+        return rec
+    try:
+        rec["version"] = subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=60).stdout.strip()[:80]
+    except Exception as e:              # noqa: BLE001
+        rec["version"] = repr(e)[:80]
+    ref = os.environ.get("DQ_REFERENCE_DIR")
+    proj = os.path.join(ref, "src", "DeltaQ.SuffixSorting.LibDivSufSort") if ref else None
+    if not (proj and os.path.isdir(proj)):
+        rec["note"] = "toolchain present, reference checkout absent (set DQ_REFERENCE_DIR): managed LibDivSufSort not timed"
+        return rec
+    rec["note"] = ("toolchain and reference checkout present: build bindings/csharp/DeltaQ.SuffixSorting.Hip.Tests against it and "
+                   "run its benchmark harness (INTEGRATION.md section 2); not automated in bench.py")
+    return rec
+
+
 def kernel_table(snapshot, steps):
     """Per kernel category: launches and time per step, algorithmic GB/s (DESIGN.md section 4's bytes per element x
     the elements of each launch, summed by the library) and its fraction of the 8 TB/s HBM peak."""
     return {k: {"launches_per_step": round(v["launches"] / steps, 2), "ms_per_step": round(v["ms"] / steps, 4),
                 "alg_GBps": round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
-                "frac_of_hbm_peak": round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}
+                "frac_of_hbm_peak": round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+                "frac_of_6p3": round(v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6 / HBM_COPY_GBS, 4)}
             for k, v in snapshot.items() if v["launches"]}
 
 
@@ -312,10 +344,42 @@ def other_configs(sorter, dev):
         if "enwik" in name:
             recs[-1]["kernels"] = profiled_kernels(sorter, host, dev)
         del host
+    recs.append(real_binary_record(sorter, dev))
     recs.append(match_search_record(sorter, dev))
     recs.append(reference_benchmark_shape(sorter))
     recs.append(bsdiff_create_record(dev))
     return recs
+
+
+def real_binary_record(sorter, dev, mib=128):
+    """What `dq bsdiff` is pointed at (the reference's README diffs executables): the first 128 MiB of a real shared
+    library of this image -- machine code, tables, strings, code built for several targets -- not generator output.
+    Device-resident time with its per-kernel table, and the suffix array bit-compared with the oracle's LibDivSufSort."""
+    import glob
+    import numpy as np
+    import oracle
+    from deltaq_amd import _abi
+    cands = sorted(glob.glob("/usr/local/lib/python3*/dist-packages/torch/lib/libtorch_cpu.so")) + \
+        sorted(glob.glob("/opt/rocm/lib/librocsparse.so.*"), key=os.path.getsize, reverse=True)
+    path = next((p for p in cands if os.path.getsize(p) >= (mib << 20)), None)
+    if path is None:
+        return {"config": "real binary: a shared library of the image", "skipped": "no library of >= %d MiB found" % mib}
+    host = np.fromfile(path, dtype=np.uint8, count=mib << 20)
+    ms = time_device(sorter, host, dev, 3)
+    info = _abi.last_sort_info()
+    rec = {"config": f"real binary: first {mib} MiB of {os.path.basename(path)} (a shared library of this image)",
+           "device_resident_ms": round(ms, 3), "device_resident_MBps": round(host.size / 1e3 / ms, 1),
+           "rounds": info["rounds"], "sum_active_over_n": round(info["sum_active"] / host.size, 2),
+           "kernels": profiled_kernels(sorter, host, dev)}
+    import torch
+    d = torch.from_numpy(host).to(dev)
+    got = sorter.Sort(d).cpu().numpy()
+    t0 = time.perf_counter()
+    ref = oracle.divsufsort(host)
+    ct = time.perf_counter() - t0
+    rec["cpu_oracle_s"] = round(ct, 2)
+    rec["bit_exact_vs_oracle"] = bool(np.array_equal(got, ref))
+    return rec
 
 
 def bsdiff_create_record(dev):

@@ -8,9 +8,9 @@ Three layers:
 
 * ``plan_shards``            longest-processing-time-first assignment of inputs to ranks
                              (the same rule as dq_sufsort_hip_batch_i32 uses for devices).
-* ``sort_batch_distributed`` one process per GPU under ``torch.distributed``: the inputs are dealt out
-                             with one broadcast (every rank slices its LPT share), every rank sorts its
-                             share, the suffix arrays come back to rank 0 with one padded gather
+* ``sort_batch_distributed`` one process per GPU under ``torch.distributed``: every rank is sent its LPT share
+                             (``dist.scatter`` of padded shares: no rank holds more than its own), sorts
+                             it, the suffix arrays come back to rank 0 with one padded gather
                              (``nccl`` == RCCL over xGMI on the GPU box, ``gloo`` in the CPU tests).
                              Collectives only: no point-to-point pairs.  The sorter is injected, so the
                              CPU tests exercise the plumbing without a GPU; on a GPU box it defaults to
@@ -61,32 +61,52 @@ def _announce(rank, arrs, world, group, extra=None):
     return box[0]
 
 
-def _deal_out(rank, arrs, lengths, plan, dev, group):
-    """The inputs to their owners with ONE collective: rank 0 lays them out share after share in a single buffer,
-    the buffer is broadcast (`ncclBroadcast` over xGMI under nccl) and every rank slices its own share out of it.
-    (Collectives only on the data path: no point-to-point pairs whose lazily built communicators have to meet.)
+# rank 0 stages at most this many bytes per rank and scatter step (the shares travel in rows of this width)
+_SCATTER_ROW_BYTES = 128 << 20
+
+
+def _deal_out(rank, arrs, lengths, plan, dev, group, row_bytes: int = _SCATTER_ROW_BYTES):
+    """The inputs to their owners: every rank receives ITS OWN share and nothing else.  Rank 0 lays each rank's
+    share out input after input, pads the shares to the longest one and scatters them (`dist.scatter`: grouped
+    sends / receives inside RCCL over xGMI under nccl) in rows of at most `row_bytes` per rank, so that a rank holds
+    its share (128 x 16 MiB over 8 ranks: 256 MiB each, where one broadcast of the whole batch put 2 GiB on every
+    device and moved world times the bytes) and rank 0 stages world x row_bytes at a time.
     Returns {input index: uint8 tensor on `dev`} for this rank's share."""
     import torch
     import torch.distributed as dist
-    order = [j for share in plan for j in share]
-    total = sum(lengths[j] for j in order)
+    world = len(plan)
+    share_len = [sum(lengths[j] for j in share) for share in plan]
+    cap = max(share_len) if share_len else 0
+    mine_flat = torch.empty(share_len[rank], dtype=torch.uint8, device=dev)
+    flats = None
     if rank == 0:
-        flat = np.empty(total, dtype=np.uint8)
-        pos = 0
-        for j in order:
-            flat[pos:pos + lengths[j]] = arrs[j]
-            pos += lengths[j]
-        buf = torch.from_numpy(flat).to(dev)
-    else:
-        buf = torch.empty(total, dtype=torch.uint8, device=dev)
-    if total > 0:
-        dist.broadcast(buf, src=0, group=group)
+        flats = []
+        for share in plan:
+            flat = np.empty(sum(lengths[j] for j in share), dtype=np.uint8)
+            pos = 0
+            for j in share:
+                flat[pos:pos + lengths[j]] = arrs[j]
+                pos += lengths[j]
+            flats.append(flat)
+    for lo in range(0, cap, max(1, row_bytes)):
+        w = min(row_bytes, cap - lo)
+        recv = torch.empty(w, dtype=torch.uint8, device=dev)
+        rows = None
+        if rank == 0:
+            rows = []
+            for r in range(world):
+                row = np.zeros(w, dtype=np.uint8)
+                part = flats[r][lo:lo + w]
+                row[:part.size] = part
+                rows.append(torch.from_numpy(row).to(dev))
+        dist.scatter(recv, rows, src=0, group=group)
+        take = max(0, min(w, share_len[rank] - lo))
+        if take:
+            mine_flat[lo:lo + take] = recv[:take]
     mine, pos = {}, 0
-    for r, share in enumerate(plan):
-        for j in share:
-            if r == rank:
-                mine[j] = buf[pos:pos + lengths[j]]
-            pos += lengths[j]
+    for j in plan[rank]:
+        mine[j] = mine_flat[pos:pos + lengths[j]]
+        pos += lengths[j]
     return mine
 
 
@@ -132,8 +152,8 @@ def sort_batch_distributed(texts: Optional[Sequence], *, sorter_factory: Optiona
                            gather_to_root: bool = True, group=None) -> Optional[List[np.ndarray]]:
     """Sort a batch across the ranks of an initialised ``torch.distributed`` process group.
 
-    ``texts`` must be given on rank 0 (other ranks may pass ``None``); inputs are dealt out to their owners (one
-    broadcast), sorted there, and -- if ``gather_to_root`` -- the suffix arrays are returned on rank 0 in input
+    ``texts`` must be given on rank 0 (other ranks may pass ``None``); inputs are dealt out to their owners (a
+    scatter of the shares), sorted there, and -- if ``gather_to_root`` -- the suffix arrays are returned on rank 0 in input
     order (one gather; other ranks return ``None``).
     """
     import torch
@@ -216,25 +236,32 @@ def diff_many_distributed(old, news: Optional[Sequence], *, sorter_factory: Opti
     lengths, plan, n = _announce(rank, new_np, world, group, extra=int(old_np.size) if rank == 0 else None)
 
     # ---- rank 0 sorts the old file; text + suffix array go to every rank in two broadcasts ----
-    if rank == 0:
-        if sorter_factory is None:
-            from .suffix_sort import HipSuffixSort
-            sorter = HipSuffixSort(dev.index if on_gpu else -1)
+    # (a sort that fails on rank 0 -- out of memory, a device error -- must not leave the others waiting in the broadcast)
+    err0 = None
+    text_t = sa_t = None
+    try:
+        if rank == 0:
+            if sorter_factory is None:
+                from .suffix_sort import HipSuffixSort
+                sorter = HipSuffixSort(dev.index if on_gpu else -1)
+            else:
+                sorter = sorter_factory()
+            text_t = torch.from_numpy(old_np).to(dev)
+            sa = sorter.Sort(text_t if (on_gpu and sorter_factory is None) else old_np)
+            sa_t = sa.to(dev) if isinstance(sa, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(sa, dtype=np.int32)).to(dev)
         else:
-            sorter = sorter_factory()
-        text_t = torch.from_numpy(old_np).to(dev)
-        sa = sorter.Sort(text_t if (on_gpu and sorter_factory is None) else old_np)
-        sa_t = sa.to(dev) if isinstance(sa, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(sa, dtype=np.int32)).to(dev)
-    else:
-        text_t = torch.empty(n, dtype=torch.uint8, device=dev)
-        sa_t = torch.empty(n, dtype=torch.int32, device=dev)
+            text_t = torch.empty(n, dtype=torch.uint8, device=dev)
+            sa_t = torch.empty(n, dtype=torch.int32, device=dev)
+    except Exception as e:                      # noqa: BLE001 -- reported to every rank below
+        err0 = e
+    _all_ok(err0, dev, group)
     if n > 0:
         dist.broadcast(text_t, src=0, group=group)
         dist.broadcast(sa_t, src=0, group=group)
     if rank != 0:
         old_np = text_t.cpu().numpy()                  # the scan loop walks the old file on the host
 
-    # ---- new files to their owners (one more broadcast; every rank slices its share) ----
+    # ---- new files to their owners (a scatter of the shares) ----
     mine = {j: t.cpu().numpy() for j, t in _deal_out(rank, new_np, lengths, plan, dev, group).items()}
 
     # ---- every rank: one index on the broadcast buffers, then its share of the diffs ----

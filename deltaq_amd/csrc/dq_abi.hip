@@ -404,7 +404,10 @@ void dq_sufsort_hip_release(void)
         std::lock_guard<std::mutex> bl(c0.batch_mu);
         std::lock_guard<std::mutex> dl(c0.diff_mu);
         bool any = c0.diff_dev || c0.diff_idx || c0.diff_pinned || c0.bslot_cap;
-        for (int k = 0; k < kCtxSlots; ++k) any = any || g_dev[d].slot[k].dev >= 0;
+        for (int k = 0; k < kCtxSlots; ++k) {
+            std::lock_guard<std::mutex> lk(g_dev[d].slot[k].mu);       // (a first use of the slot may be publishing dev right now)
+            any = any || g_dev[d].slot[k].dev >= 0;
+        }
         if (!any || hipSetDevice(d) != hipSuccess) continue;
         for (int k = 0; k < 3; ++k) {
             if (c0.bslot_text[k]) (void)hipFree(c0.bslot_text[k]);

@@ -23,14 +23,24 @@ inline int apply_patch(const uint8_t *old, int64_t n, const uint8_t *patch, int6
 {
     Header h;
     if (parse_header(patch, plen, &h) != 0) return kPatchCorrupt;
+    // The header's newSize is what a caller allocates BEFORE any stream has been looked at (the size query below), so a
+    // claim no patch of this length could honour is rejected here instead of becoming an out-of-memory error in the
+    // wrapper: every byte of the new file is decoded from the diff or the extra stream, and bzip2 cannot expand by
+    // more than ~10^6 (a 900 kB block of run-length pairs = 46 MB of one byte, in ~45 bytes); 2^21 leaves a margin.
+    if (h.new_size > ((int64_t)1 << 21) * (plen - kHeaderSize - h.ctrl_len + 64)) return kPatchCorrupt;
     if (out_len) *out_len = h.new_size;
     if (!out) return kPatchOk;
     if (cap < h.new_size) return kPatchSmallBuffer;
     std::vector<uint8_t> ctrl, diff, extra;
     const uint8_t *pc = patch + kHeaderSize, *pd = pc + h.ctrl_len, *pe = pd + h.diff_len;
     const size_t elen = (size_t)(plen - kHeaderSize - h.ctrl_len - h.diff_len);
-    // every triple but the zero-progress ones (never written by Diff.Create) produces at least one byte
-    const size_t ctrl_max = h.new_size < (int64_t)1 << 56 ? 24 * ((size_t)h.new_size + 1) : (size_t)-1;
+    // Triples the reader may look at.  Diff.Create's scan position advances with every triple, so its patches hold at
+    // most newSize + 1 of them -- but a triple may produce no byte at all (the first one routinely is (0, 0, seek)),
+    // and Patch.Apply accepts a third-party patch with any number of those.  The cut-off is therefore generous rather
+    // than exact: two triples per output byte + 4096; a control stream that decodes to more than that before the
+    // new file is complete is treated as corrupt (the one documented divergence from Patch.cs:115-160, which would
+    // keep reading: it is what keeps a few KB of bzip2 from asking for gigabytes of control data).
+    const size_t ctrl_max = h.new_size < (int64_t)1 << 55 ? 24 * (2 * (size_t)h.new_size + 4096) : (size_t)-1;
     int rc = bz2::bz2_decompress(pc, (size_t)h.ctrl_len, ctrl, ctrl_max);
     if (rc != bz2::kOk && rc != bz2::kTooLong) return kPatchCorrupt;
     rc = bz2::bz2_decompress(pd, (size_t)h.diff_len, diff, (size_t)h.new_size);

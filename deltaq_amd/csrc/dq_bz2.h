@@ -576,6 +576,27 @@ inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32
 // Burrows-Wheeler transform through the sorter, MTF / Huffman -- are independent and go to up to 4 threads (the extra
 // stream of two unrelated 4 MiB files is five blocks of random bytes: 250 ms of move-to-front on one thread); their
 // bit strings are then appended in order.  The sorter must be callable from several threads at once.
+// Process-wide budget of extra framing threads (block encoders of all streams of all concurrent Diff.Create calls):
+// one per hardware thread.  acquire() grants 0 ... want of them without waiting.
+inline std::atomic<int> &framing_threads_in_use()
+{
+    static std::atomic<int> v{0};
+    return v;
+}
+inline int framing_threads_acquire(int want)
+{
+    if (want <= 0) return 0;
+    const int cap = (int)std::max(2u, std::thread::hardware_concurrency());
+    std::atomic<int> &u = framing_threads_in_use();
+    int cur = u.load();
+    for (;;) {
+        const int grant = std::min(want, std::max(0, cap - cur));
+        if (grant == 0) return 0;
+        if (u.compare_exchange_weak(cur, cur + grant)) return grant;
+    }
+}
+inline void framing_threads_release(int n) { if (n > 0) framing_threads_in_use().fetch_sub(n); }
+
 inline int bz2_compress(const uint8_t *src, size_t n, std::vector<uint8_t> &out, const DoubledSorter &sorter, int level = 9)
 {
     BitWriter bw(out);
@@ -621,23 +642,37 @@ inline int bz2_compress(const uint8_t *src, size_t n, std::vector<uint8_t> &out,
         }
         blocks.back().crc = ~crc_update_mt(0xffffffffu, src + i0, i - i0);   // of the block's input bytes, in one sweep (4 threads from 2 MiB)
     }
+    // (nothing may leave a worker thread as an exception -- that would be std::terminate, not an error code: an
+    // allocation that fails inside a block's encoder becomes that block's rc)
     auto encode = [&](Block &b) {
-        BitWriter w(b.bytes);
-        b.rc = compress_block(w, b.rle, b.crc, sorter);
-        b.nbits = w.total;
-        w.flush();
-        std::vector<uint8_t>().swap(b.rle);
+        try {
+            BitWriter w(b.bytes);
+            b.rc = compress_block(w, b.rle, b.crc, sorter);
+            b.nbits = w.total;
+            w.flush();
+            std::vector<uint8_t>().swap(b.rle);
+        } catch (...) {
+            b.rc = -3;
+        }
     };
     if (blocks.size() >= 2) {
         std::atomic<size_t> next{0};
         auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < blocks.size();) encode(blocks[k]); };
-        std::vector<std::thread> ts;
-        const size_t extra = std::min<size_t>(blocks.size(), 4) - 1;
+        struct Joiner {                  // joins on every way out of this scope
+            std::vector<std::thread> ts;
+            ~Joiner() { for (std::thread &t : ts) if (t.joinable()) t.join(); }
+        } pool;
+        // at most kBlockThreads encoder threads per stream, and no more framing threads process-wide than the host
+        // has cores (several Diff.Create calls at once: 3 streams x 4 block threads each would oversubscribe it)
+        size_t extra = std::min<size_t>(blocks.size(), 4) - 1;
+        const int granted = framing_threads_acquire((int)extra);
+        extra = (size_t)granted;
         for (size_t t = 0; t < extra; ++t) {
-            try { ts.emplace_back(work); } catch (...) { break; }
+            try { pool.ts.emplace_back(work); } catch (...) { break; }
         }
         work();
-        for (std::thread &t : ts) t.join();
+        for (std::thread &t : pool.ts) t.join();
+        framing_threads_release(granted);
     } else {
         for (Block &b : blocks) encode(b);
     }

@@ -464,7 +464,13 @@ int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int k
     *overflow = c.pinned[7] != 0;
     if (*overflow && env("DQ_TRACE")) fprintf(stderr, "[dq] tie / bucket overflow flags: %lld\n", (long long)c.pinned[7]);
     *fin_left = c.pinned[3];
-    (void)wb;
+    // byte model of the speculative finisher, now that the list length is known: list entry in, one 64-byte
+    // sector of text per tied suffix, SA entry out
+    if (fin_cap > 0 && L.active && !c.pending.empty() && c.pending.back().cat == DQ_K_SMALL_FINISH) {
+        const int64_t cnt = std::min<int64_t>(*count, fin_cap);
+        c.pending.back().elems = cnt;
+        c.pending.back().bytes = cnt * (8 + wb + 64 + wb);
+    }
     return DQ_OK;
 }
 
@@ -1306,7 +1312,11 @@ struct SuffixSorter {
             // needs 33 + 32: the key then carries rank >> 1 (unique per group: tied groups have >= 2 members)
             // and the rebucket pass reads the true rank from the ISA.  check_args() keeps n <= 2^32.
             // (DQ_FORCE_RSHIFT: the tests take this path on small inputs)
-            const int rshift = (kbits + rbits > 64 || env("DQ_FORCE_RSHIFT")) ? 1 : 0;
+            // (a list that still carries its ranks as 32-bit values for the first LDS-class round -- first_rank32 -- has
+            // nothing in Kr[rcur] for the radix path to read: the test flag is ignored for that round; kbits + rbits > 64
+            // cannot coincide with it, n < 2^32 there)
+            const int rshift = (kbits + rbits > 64 || (env("DQ_FORCE_RSHIFT") && !first_rank32)) ? 1 : 0;
+            if (rshift && first_rank32) return fail(DQ_ERR_HIP, "rank-shift round on a list with 32-bit ranks");
             if (kbits + rbits - rshift > 64) return fail(DQ_ERR_TOO_LARGE, "composite key exceeds 64 bits");
             if (rshift && keys_ready) {
                 // the list came keyed from build_isa_binned() (rank << kbits | key2, unshifted): take the group

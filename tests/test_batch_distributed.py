@@ -49,7 +49,19 @@ def _worker(rank, world, port, q):
         if rank == 0:
             texts = [oracle.gen_uniform(5000 + 777 * j, 0x5EED0500 + j) for j in range(5)]
             texts += [np.zeros(0, np.uint8), oracle.gen_enwik_like(20000, 3, 2048), b"banana"]
+        # (rows of 3000 bytes: the shares travel in several scatter steps, the last one ragged)
+        from deltaq_amd import batch as batch_mod
+        batch_mod._SCATTER_ROW_BYTES = 3000
+        seen = []
+        deal = batch_mod._deal_out
+        def spy(rank_, arrs, lengths, plan, dev, group, row_bytes=None):
+            mine = deal(rank_, arrs, lengths, plan, dev, group, row_bytes=batch_mod._SCATTER_ROW_BYTES)
+            seen.append((sum(int(t.numel()) for t in mine.values()), sum(lengths[j] for j in plan[rank_]), sum(lengths)))
+            return mine
+        batch_mod._deal_out = spy
         out = sort_batch_distributed(texts, sorter_factory=OracleSorter)
+        # a rank holds its own share, not the batch
+        assert len(seen) == 1 and seen[0][0] == seen[0][1] < seen[0][2], seen
         if rank == 0:
             ok = all(np.array_equal(o, oracle.divsufsort(np.frombuffer(bytes(t), np.uint8) if isinstance(t, bytes) else t))
                      for o, t in zip(out, texts))
@@ -261,3 +273,33 @@ def test_one_old_many_new_with_the_hip_pieces(backend, world):
         assert p.exitcode == 0
     assert all(r[0] == "ok" for r in res), res
     assert max(r[1] for r in res) == 9
+
+
+@pytest.mark.gpu
+def test_bench_line_of_two_ranks_sharing_the_gpu():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), here with both ranks on
+    cuda:0 over gloo: the line must carry the N > 1 records -- configs[4] LPT-sharded 64 / 64, one run of the scatter /
+    sort / gather layer and one of the one-old-many-new layer -- without an error key."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in [k for k in env if k.startswith("DQ_")]:
+        env.pop(k)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--share-gpu", "--backend", "gloo", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak"
+    assert rec["roofline"]["frac_of_6p3"] > rec["roofline"]["frac"] > 0
+    b = rec["batch"]
+    assert b["sharding"]["buffers_per_rank"] == [64, 64]
+    assert b["sufcheck_first_buffers"] is True
+    assert len(b["host_copy_GBps_per_rank"]) == 2
+    ssg = b["rccl_scatter_sort_gather"]
+    assert "error" not in ssg and ssg["sufcheck"] is True and ssg["buffers"] == 4, ssg
+    many = b["one_old_many_new"]
+    assert "error" not in many and many["patches_apply"] is True and many["new_files"] == 8, many
