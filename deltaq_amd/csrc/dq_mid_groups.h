@@ -47,7 +47,8 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
     SmallGroupCounters *__restrict__ ctr, const SmallGroupCounters *__restrict__ prev = nullptr,
     const uint32_t *__restrict__ RL = nullptr /* run lengths of the text (dq_runs.h), or none */,
     const uint8_t *__restrict__ text = nullptr, int run_order = 0 /* 1: this is the run-order round */,
-    const uint32_t *__restrict__ rank32 = nullptr /* the ranks as 32-bit values instead of `rank` (first round) */)
+    const uint32_t *__restrict__ rank32 = nullptr /* the ranks as 32-bit values instead of `rank` (first round) */,
+    int u_ib = 0 /* > 0: update entries as single words (rank << u_ib | suffix) in u_rank_end, u_suf_end unused */)
 {
     // chained rounds (no host round trip in between): the list length is what the previous round appended to T
     if (prev) {
@@ -168,7 +169,11 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
             }
             if (!keyed) {
                 const int64_t q = (int64_t)s[k] + off;
+#ifdef DQ_EXPERIMENT_MG_NOGATHER        /* timing experiment only: no random read of the inverse suffix array */
+                k2[k] = (ElemT)(((uint64_t)q * 0x9E3779B97F4A7C15ull) >> 40);
+#else
                 k2[k] = q < n ? (ElemT)((int64_t)ISA[q] + h) : (off > h ? (ElemT)0 : (ElemT)(n - 1 - (int64_t)s[k]));   // as gather_key2_kernel
+#endif
             }
         }
     }
@@ -189,7 +194,11 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
         if (own[k]) {
             int less = 0, eq = 0, eq_before = 0;
             const int g0 = ghead[k], me = e - g0;
+#ifdef DQ_EXPERIMENT_MG_NOWALK          /* timing experiment only (tools/exp): what the kernel costs without the walk */
+            for (int i = 0; i < (gsize[k] > 2 ? 2 : gsize[k]); ++i) {
+#else
             for (int i = 0; i < gsize[k]; ++i) {
+#endif
                 const ElemT o = s_key2[g0 + i];
                 less += o < k2[k];
                 eq += o == k2[k];
@@ -266,8 +275,12 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
         }
         if (f[k] & 4) {
             const int64_t p = (int64_t)base[2] + wave_cnt[2][k][wv] + mask_rank_lt(bu[k]);
-            u_rank_end[-1 - p] = (uint64_t)slot_rank[e];
-            u_suf_end[-1 - p] = slot_suf[e];
+            if (u_ib > 0) {
+                u_rank_end[-1 - p] = ((uint64_t)slot_rank[e] << u_ib) | (uint64_t)(ElemT)slot_suf[e];
+            } else {
+                u_rank_end[-1 - p] = (uint64_t)slot_rank[e];
+                u_suf_end[-1 - p] = slot_suf[e];
+            }
         }
     }
 }

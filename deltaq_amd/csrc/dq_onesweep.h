@@ -36,7 +36,8 @@ constexpr uint32_t kSpinLimit = 1u << 24;
 // ---------------------------------------------------------------------------------
 template <int kPasses>
 __global__ __launch_bounds__(kHistThreads) void radix_hist_kernel(const uint64_t *__restrict__ keys,
-                                                            int64_t m, uint32_t *__restrict__ partial)
+                                                            int64_t m, uint32_t *__restrict__ partial,
+                                                            int shift0 = 0 /* digit p sits at bit shift0 + 8 p */)
 {
     __shared__ uint32_t hist[kPasses][kRadixSize * 4];     // kPasses * 4 KiB
     const int tid = threadIdx.x;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kHistThreads) void radix_hist_kernel(const uint64_t
         for (int p = 0; p < kPasses; ++p) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint32_t d = digit_of(h ? v.y : v.x, p * kRadixBits);
+                const uint32_t d = digit_of(h ? v.y : v.x, shift0 + p * kRadixBits);
                 const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
                 if (full && __all(d == d0)) {
                     if (lane == 0) atomicAdd(&hist[p][d0 << 2], (uint32_t)kWave);
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(kHistThreads) void radix_hist_kernel(const uint64_t
     }
     if ((m & 1) && blockIdx.x == 0 && tid == 0) {
         const uint64_t k = keys[m - 1];
-        for (int p = 0; p < kPasses; ++p) atomicAdd(&hist[p][digit_of(k, p * kRadixBits) << 2], 1u);
+        for (int p = 0; p < kPasses; ++p) atomicAdd(&hist[p][digit_of(k, shift0 + p * kRadixBits) << 2], 1u);
     }
     __syncthreads();
     for (int i = tid; i < kPasses * kRadixSize; i += kHistThreads) {

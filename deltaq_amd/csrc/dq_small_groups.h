@@ -220,16 +220,43 @@ __global__ __launch_bounds__(kSgThreads) void small_group_round_kernel(
     }
 }
 
-// ISA[s] = new rank for the entries of the update list (stored downward from the *_end pointers)
+// ISA[s] = new rank for the entries of the update list (stored downward from the *_end pointers).
+// u_ib > 0: the entries are single words (rank << u_ib | suffix) in the rank array (mid_group_round_kernel writes them
+// that way when two indices fit one word), the suffix array is not used.
 template <typename IdxT>
 __global__ __launch_bounds__(kBlock) void isa_update_kernel(const uint64_t *__restrict__ u_rank_end,
                                                             const IdxT *__restrict__ u_suf_end, int64_t count,
                                                             IdxT *__restrict__ ISA,
-                                                            const SmallGroupCounters *__restrict__ cnt_dev = nullptr)
+                                                            const SmallGroupCounters *__restrict__ cnt_dev = nullptr,
+                                                            int u_ib = 0)
 {
     if (cnt_dev) count = (int64_t)(cnt_dev->tied_moved >> 32);            // chained rounds: length from the device
+    if (u_ib > 0) {
+        const uint64_t mask = (1ull << u_ib) - 1;
+        for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < count; p += (int64_t)gridDim.x * kBlock) {
+            const uint64_t wd = u_rank_end[-1 - p];
+            ISA[wd & mask] = (IdxT)(wd >> u_ib);
+        }
+        return;
+    }
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < count; p += (int64_t)gridDim.x * kBlock)
         ISA[u_suf_end[-1 - p]] = (IdxT)u_rank_end[-1 - p];
+}
+
+// The same for update words that have been BINNED by the top bits of the suffix first (two word passes of the radix
+// sorter): consecutive words then fall into one window of 2^(ib-16) suffixes -- the 4-byte writes of a workgroup
+// land in a few KB of the array and leave its L2 as whole lines instead of one read-modify-write per entry.
+// A word whose suffix field is >= n is padding (an alignment filler in front of the list) and is skipped.
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void isa_update_words_kernel(const uint64_t *__restrict__ words, int64_t count,
+                                                                  int ib, int64_t n, IdxT *__restrict__ ISA)
+{
+    const uint64_t mask = (1ull << ib) - 1;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < count; p += (int64_t)gridDim.x * kBlock) {
+        const uint64_t wd = words[p];
+        const uint64_t sfx = wd & mask;
+        if ((int64_t)sfx < n) ISA[sfx] = (IdxT)(wd >> ib);
+    }
 }
 
 }  // namespace dq

@@ -202,9 +202,9 @@ int rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *
 }
 
 template <int kPasses>
-void launch_hist(hipStream_t st, int blocks, const uint64_t *keys, int64_t m, uint32_t *partial)
+void launch_hist(hipStream_t st, int blocks, const uint64_t *keys, int64_t m, uint32_t *partial, int shift0 = 0)
 {
-    hipLaunchKernelGGL(radix_hist_kernel<kPasses>, dim3(blocks), dim3(kHistThreads), 0, st, keys, m, partial);
+    hipLaunchKernelGGL(radix_hist_kernel<kPasses>, dim3(blocks), dim3(kHistThreads), 0, st, keys, m, partial, shift0);
 }
 
 // generic pairs: all digit histograms in one read, then one radix_rank_kernel per digit
@@ -535,6 +535,13 @@ struct SuffixSorter {
     // runs of one byte (dq_runs.h): text_hist_kernel saw a run of >= 64 equal bytes; the doubling rounds then order
     // the suffixes inside runs by the run's own structure (w.RL) instead of log2(run length) rounds
     bool runs_wanted = false, runs_on = false;
+    // ... or only once the rounds show them: text_hist_kernel saw a long run somewhere (long_run_seen), and the members
+    // of the large groups (last_large: what the last round sent to the radix list, prev_large the round before) stop
+    // getting fewer -- a run of L bytes keeps ~L - h of its suffixes in one group for log2(L / h) rounds.  The run
+    // lengths and the run-order round are then paid at that point, on the list as it is by then (libtorch_cpu.so:
+    // one 5.5 MB run of 'X' among 128 MiB kept 16 rounds of 8 radix passes over ~6 M entries alive).
+    bool long_run_seen = false, runs_late_tried = false;
+    int64_t last_large = -1, prev_large = -1;
     int run_order = 0;                  // 1 while the run-order round is being launched
     const uint32_t *rl() const { return runs_on ? w.RL : nullptr; }
     // the first round's list carries its ranks as 32-bit values here (build_isa_binned), not in Kr[rcur]
@@ -565,9 +572,61 @@ struct SuffixSorter {
         return onesweep_sort_pairs<IdxT>(L, w, K, V, cnt, bits, cur);
     }
 
-    // ISA[SA[p]] = p for everybody, then the tied suffixes get their group rank
+    // digit offsets of the two binning passes over the top 16 bits of the suffix, in closed form (every suffix
+    // 0..n-1 occurs once): staged in the pinned area, uploaded to w.digit_offset[0..1]
+    int upload_suffix_bin_offsets(int ib)
+    {
+        const int sh[2] = {ib - 16, ib - 8};
+        for (int p = 0; p < 2; ++p) {
+            const int64_t unit = 1ll << sh[p];                       // suffixes per digit value inside one cycle
+            const int64_t full = n >> (sh[p] + 8), rem = n & ((unit << 8) - 1);
+            int64_t acc = 0;
+            for (int d = 0; d < 256; ++d) {
+                c.pinned[p * 256 + d] = acc;
+                acc += full * unit + std::min<int64_t>(std::max<int64_t>(rem - d * unit, 0), unit);
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(w.digit_offset, c.pinned, 2 * 256 * 8, hipMemcpyHostToDevice, st));
+        return DQ_OK;
+    }
+
+    // ISA[SA[p]] = p for everybody, then the tied suffixes get their group rank.  (rank, suf) = (Kr[rcur], Vr[rcur])[0, cnt).
+    // Large texts: the n random 4-byte writes of the plain scatter (256 MiB: 9.9 ms) are replaced by the suffix-binned
+    // build of dq_isa_pairs.h -- words (p << ib | SA[p]), two word passes over the top 16 bits of the suffix, LDS
+    // images written coalesced (~3 ms) -- with the tied list's ranks parked in the idle index buffer meanwhile.
     int build_isa(const uint64_t *rank, const IdxT *suf, int64_t cnt)
     {
+        const int ib = bit_length((uint64_t)(n - 1));
+        const bool pays = env("DQ_BINNED_ISA") ? atoi(env("DQ_BINNED_ISA")) != 0 : n > (32ll << 20);
+        const bool fits = (size_t)cnt * 8 <= (size_t)(n + 2) * sizeof(IdxT) && rank == Kr[rcur] && suf == Vr[rcur];
+        if (pays && fits && n >= (1 << 16) && 2 * ib <= 63 && !env("DQ_NO_BINNED_ISA")) {
+            uint64_t *P0 = Kr[rcur ^ 1], *P1 = Kr[rcur];
+            uint64_t *stash = reinterpret_cast<uint64_t *>(Vr[rcur ^ 1]);
+            if (cnt > 0) HIP_TRY(hipMemcpyAsync(stash, P1, (size_t)cnt * 8, hipMemcpyDeviceToDevice, st));
+            LAUNCH(L, DQ_K_ISA_FROM_SA, n, n * (wb + 8),
+                   hipLaunchKernelGGL(sa_words_kernel<IdxT>, dim3(grid_for(n)), dim3(kBlock), 0, st, (const IdxT *)d_sa, n, ib, P0));
+            int rc = upload_suffix_bin_offsets(ib);
+            if (rc != DQ_OK) return rc;
+            rc = prepare_status<IdxT>(L, w, n, 2);
+            if (rc != DQ_OK) return rc;
+            rc = rank_pass<IdxT, kKeys>(L, w, P0, (const IdxT *)nullptr, P1, (IdxT *)nullptr, n, 0, 8, ib, nullptr, nullptr, ib - 16);
+            if (rc != DQ_OK) return rc;
+            rc = rank_pass<IdxT, kKeys>(L, w, P1, (const IdxT *)nullptr, P0, (IdxT *)nullptr, n, 1, 8, ib, nullptr, nullptr, ib - 8);
+            if (rc != DQ_OK) return rc;
+            if (ib - 16 <= 12) {
+                LAUNCH(L, DQ_K_ISA_FROM_PAIRS, n, n * (8 + wb),
+                       hipLaunchKernelGGL((isa_from_pairs_kernel<IdxT, 4096>), dim3((unsigned)((n + 4095) / 4096)),
+                                          dim3(kPairThreads), 0, st, (const uint64_t *)P0, n, ib, w.ISA));
+            } else {
+                LAUNCH(L, DQ_K_ISA_FROM_PAIRS, n, n * (8 + wb),
+                       hipLaunchKernelGGL((isa_from_pairs_kernel<IdxT, 32768>), dim3((unsigned)((n + 32767) / 32768)),
+                                          dim3(kPairThreads), 0, st, (const uint64_t *)P0, n, ib, w.ISA));
+            }
+            if (cnt > 0) HIP_TRY(hipMemcpyAsync(P1, stash, (size_t)cnt * 8, hipMemcpyDeviceToDevice, st));
+            LAUNCH(L, DQ_K_ISA_FROM_SA, cnt, cnt * (8 + 2 * wb),
+                   hipLaunchKernelGGL(isa_scatter_kernel<IdxT>, dim3(grid_for(cnt)), dim3(kBlock), 0, st, rank, suf, w.ISA, cnt));
+            return DQ_OK;
+        }
         LAUNCH(L, DQ_K_ISA_FROM_SA, n, n * 3 * wb,
                hipLaunchKernelGGL(isa_from_sa_kernel<IdxT>, dim3(grid_for(n)), dim3(kBlock), 0, st,
                                   (const IdxT *)d_sa, w.ISA, n);
@@ -610,17 +669,9 @@ struct SuffixSorter {
         HIP_TRY(hipStreamSynchronize(st));
         m = c.pinned[0];
         if (c.pinned[1] != 0) return fail(DQ_ERR_HIP, "device look-back timed out (spin bound hit)");
-        for (int p = 0; p < 2; ++p) {
-            const int64_t unit = 1ll << sh[p];                       // suffixes per digit value inside one cycle
-            const int64_t full = n >> (sh[p] + 8), rem = n & ((unit << 8) - 1);
-            int64_t acc = 0;
-            for (int d = 0; d < 256; ++d) {
-                c.pinned[p * 256 + d] = acc;
-                acc += full * unit + std::min<int64_t>(std::max<int64_t>(rem - d * unit, 0), unit);
-            }
-        }
-        HIP_TRY(hipMemcpyAsync(w.digit_offset, c.pinned, 2 * 256 * 8, hipMemcpyHostToDevice, st));
-        int rc = prepare_status<IdxT>(L, w, n, 2);
+        int rc = upload_suffix_bin_offsets(ib);
+        if (rc != DQ_OK) return rc;
+        rc = prepare_status<IdxT>(L, w, n, 2);
         if (rc != DQ_OK) return rc;
         rc = rank_pass<IdxT, kKeys>(L, w, P0, (const IdxT *)nullptr, keys, (IdxT *)nullptr, n, 0, kb, ib, nullptr, nullptr, sh[0]);
         if (rc != DQ_OK) return rc;
@@ -792,7 +843,8 @@ struct SuffixSorter {
         // in runs -- padded images, sparse files; measured on the image's shared libraries, whose long tie tails are
         // code repeated for several targets, not runs: 5-20 % slower with it.  1/16 of the text in 16-byte chunks of one value)
         runs_wanted = sizeof(IdxT) == 4 && c.pinned[256 + 8] != 0 && n >= (1 << 16) && c.pinned[256 + 9] * 16 * 16 >= n;
-        if (const char *v = env("DQ_RUNS")) runs_wanted = sizeof(IdxT) == 4 && atoi(v) != 0;
+        long_run_seen = sizeof(IdxT) == 4 && c.pinned[256 + 8] != 0 && n >= (1 << 16);
+        if (const char *v = env("DQ_RUNS")) { runs_wanted = sizeof(IdxT) == 4 && atoi(v) != 0; long_run_seen = long_run_seen && atoi(v) != 0; }
         if (const char *v = env("DQ_MID_GROUPS")) runs_wanted = runs_wanted && atoi(v) >= 256;   // (the LDS class carries the run offsets)
         V[kb & 1] = d_sa;
         V[(kb & 1) ^ 1] = w.Va;
@@ -976,6 +1028,67 @@ struct SuffixSorter {
     int64_t sg_half() const { return (n / 2 + 1) & ~(int64_t)1; }
     int64_t sg_top() const { return n + 2; }
 
+    // update entries of the LDS-class rounds as single words (rank << ib | suffix) where two indices fit one
+    int upd_ib() const
+    {
+        const int ib = bit_length((uint64_t)(n - 1));
+        return (2 * ib <= 64 && !env("DQ_NO_UPD_WORDS")) ? ib : 0;
+    }
+
+    // ISA[s] = new rank for the mU entries a round left in U (stored downward from B + top / Bs + top).  A long list of
+    // update words is first binned by the top 16 bits of the suffix with two word passes of the radix sorter (into
+    // the buffers of the round's input list, which is dead by now: A, then As seen as words), so that the 4-byte
+    // writes of a workgroup fall into a few KB of the array (isa_update_words_kernel); 256 MiB of enwik-style text,
+    // first doubling round: 75 M updates, 2.5 ms as random writes.  DQ_UPD_BIN = 0 | 1 | 2: passes (default 2).
+    static constexpr int64_t kUpdBinMin = 1ll << 22;
+    int apply_rank_updates(uint64_t *A, IdxT *As, uint64_t *B, IdxT *Bs, int64_t mU, int u_ib)
+    {
+        const int64_t top = sg_top();
+        int passes = env("DQ_UPD_BIN") ? std::max(0, std::min(2, atoi(env("DQ_UPD_BIN")))) : 2;
+        const int64_t min_len = env("DQ_UPD_BIN_MIN") ? std::max(1, atoi(env("DQ_UPD_BIN_MIN"))) : kUpdBinMin;
+        if (u_ib < 16 || mU < min_len || (size_t)(mU + 1) * 8 > (size_t)(n + 2) * sizeof(IdxT)) passes = 0;
+        if (passes == 0) {
+            LAUNCH(L, DQ_K_ISA_UPDATE, mU, mU * (u_ib ? 8 + wb : 8 + wb + wb),
+                   hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(mU)), dim3(kBlock), 0, st,
+                                      (const uint64_t *)(B + top), (const IdxT *)(Bs + top), mU, w.ISA,
+                                      (const SmallGroupCounters *)nullptr, u_ib));
+            return DQ_OK;
+        }
+        // the word list starts on an even entry (16-byte key loads of the histogram kernel): one filler word in
+        // front of it if need be -- all ones: a suffix field >= n, skipped by the update kernel
+        int64_t first = top - mU, cnt = mU;
+        if (first & 1) {
+            --first; ++cnt;
+            HIP_TRY(hipMemsetAsync(B + first, 0xff, 8, st));
+        }
+        const uint64_t *U = B + first;
+        const int sh0 = passes == 2 ? u_ib - 16 : u_ib - 8;
+        const int blocks = (int)std::min<int64_t>(kHistBlocks, ((cnt >> 1) + kHistThreads - 1) / kHistThreads + 1);
+        int rc = L.begin(DQ_K_RADIX_HIST, cnt, cnt * 8);
+        if (rc != DQ_OK) return rc;
+        if (passes == 2) launch_hist<2>(st, blocks, U, cnt, w.hist_partial, sh0);
+        else launch_hist<1>(st, blocks, U, cnt, w.hist_partial, sh0);
+        hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(passes), dim3(kHistScanThreads), 0, st,
+                           (const uint32_t *)w.hist_partial, blocks, w.digit_offset);
+        HIP_TRY(hipGetLastError());
+        rc = L.end();
+        if (rc != DQ_OK) return rc;
+        rc = prepare_status<IdxT>(L, w, cnt, passes);
+        if (rc != DQ_OK) return rc;
+        uint64_t *W1 = A, *W2 = reinterpret_cast<uint64_t *>(As);
+        rc = rank_pass<IdxT, kKeys>(L, w, U, (const IdxT *)nullptr, W1, (IdxT *)nullptr, cnt, 0, 8, u_ib, nullptr, nullptr, sh0);
+        if (rc != DQ_OK) return rc;
+        const uint64_t *binned = W1;
+        if (passes == 2) {
+            rc = rank_pass<IdxT, kKeys>(L, w, W1, (const IdxT *)nullptr, W2, (IdxT *)nullptr, cnt, 1, 8, u_ib, nullptr, nullptr, sh0 + 8);
+            if (rc != DQ_OK) return rc;
+            binned = W2;
+        }
+        LAUNCH(L, DQ_K_ISA_UPDATE, cnt, cnt * (8 + wb),
+               hipLaunchKernelGGL(isa_update_words_kernel<IdxT>, dim3(grid_for(cnt)), dim3(kBlock), 0, st, binned, cnt, u_ib, n, w.ISA));
+        return DQ_OK;
+    }
+
     int doubling_round_small(int kbits)
     {
         uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
@@ -1016,9 +1129,8 @@ struct SuffixSorter {
                     use_mid ? "mid-group" : "small", (long long)h,
                     (long long)m, (long long)m1, (long long)mL, (long long)mU);
         if (mU > 0) {
-            LAUNCH(L, DQ_K_ISA_UPDATE, mU, mU * (8 + wb + wb),
-                   hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(mU)), dim3(kBlock), 0, st,
-                                      (const uint64_t *)(B + top), (const IdxT *)(Bs + top), mU, w.ISA));
+            const int rc = apply_rank_updates(A, As, B, Bs, mU, use_mid ? upd_ib() : 0);
+            if (rc != DQ_OK) return rc;
         }
         int64_t mLs = 0;
         if (mL > 0) {
@@ -1037,6 +1149,8 @@ struct SuffixSorter {
         // groups only ever split: once nothing went to the radix list, every group fits this round's cap
         if (mL == 0) small_cap = use_mid ? mid_g : cap32 ? kSgMaxGShort : kSgMaxG;
         only_small_groups = mL == 0;
+        prev_large = last_large;
+        last_large = mL;
         return DQ_OK;
     }
 
@@ -1059,7 +1173,7 @@ struct SuffixSorter {
             LAUNCH(L, DQ_K_MID_ROUND, mm, alg_bytes,
                    hipLaunchKernelGGL(kern, grid, dim3(kMgThreads), 0, st, A, As, (const IdxT *)w.ISA, mm, n, hh, kbits, d_sa, B, Bs,
                                       B + half, Bs + half, B + top, Bs + top, ctr, prev, rl(), (const uint8_t *)w.text, run_order,
-                                      first_rank32));
+                                      first_rank32, upd_ib()));
             return DQ_OK;
         };
         return g == 256 ? go(mid_group_round_kernel<IdxT, 256>) : g == 512 ? go(mid_group_round_kernel<IdxT, 512>)
@@ -1092,7 +1206,7 @@ struct SuffixSorter {
             LAUNCH(L, DQ_K_ISA_UPDATE, m_in, 0,
                    hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(m_in)), dim3(kBlock), 0, st,
                                       (const uint64_t *)(B + top), (const IdxT *)(Bs + top), (int64_t)0, w.ISA,
-                                      (const SmallGroupCounters *)(w.sg_ctr + r)));
+                                      (const SmallGroupCounters *)(w.sg_ctr + r), kCap == 0 ? upd_ib() : 0));
             rcur ^= 1;
             hr *= 2;
         }
@@ -1274,7 +1388,10 @@ struct SuffixSorter {
         bool pair_paid = true;            // the last pair-chain phase finished at least half of its list
         int64_t pair_h = 0;               // h of the last phase
         int64_t abort_h = 0, abort_m = 0; // h and list length when a phase last gave up after its count
+        // (DQ_EXP_STOP_ROUNDS=k: timing experiments only -- leave after k doubling rounds with an unfinished suffix array)
+        const int64_t stop_rounds = env("DQ_EXP_STOP_ROUNDS") ? atoi(env("DQ_EXP_STOP_ROUNDS")) : -1;
         while (m > 0) {
+            if (stop_rounds >= 0 && t_info[0] >= stop_rounds) break;
             // Small tie groups inside long repeats are decided chain by chain (dq_pair_chains.h): tried once after the
             // first doubling round; again after a round that left most of its list tied if the phase before paid
             // off, or -- if it did not -- once h has grown 16-fold (chain ends step over larger groups h characters
@@ -1297,6 +1414,27 @@ struct SuffixSorter {
                 if (rc != DQ_OK) return rc;
                 if (outcome == 0) { ++pair_aborts; abort_h = h; abort_m = m_try; }
                 else { ++pair_tries; pair_paid = outcome == 2; pair_h = h; abort_h = 0; }
+                continue;
+            }
+            // runs seen late (see long_run_seen): the large groups have stopped shrinking -- run lengths now, one
+            // run-order round at the current depth on the current list, the rank behind the run from then on
+            if (long_run_seen && !runs_on && !runs_late_tried && !run_order && last_large >= (1 << 15) && prev_large > 0 &&
+                last_large * 8 >= prev_large * 7 && h >= 32 && 32 + rbits <= 64 && uses_small_round(m) && !keys_ready &&
+                !list_ungrouped && !first_rank32 && mid_group_cap(m) > 0 && !env("DQ_NO_LATE_RUNS")) {
+                runs_late_tried = true;
+                rc = compute_run_lengths();
+                if (rc != DQ_OK) return rc;
+                runs_on = true;
+                run_order = 1;
+                t_info[0] += 1;
+                t_info[2] += m;
+                if (env("DQ_TRACE"))
+                    fprintf(stderr, "[dq] late run-order round at h=%lld on %lld tied suffixes (%lld in large groups, %lld the round before)\n",
+                            (long long)h, (long long)m, (long long)last_large, (long long)prev_large);
+                rc = doubling_round_small(32);
+                run_order = 0;
+                if (rc != DQ_OK) return rc;
+                m_before = 0;
                 continue;
             }
             m_before = m;
