@@ -107,39 +107,29 @@ struct RawStreams {
 // `search(scan, &pos, &len)` stands for Search(I, old, new[scan..], 0, n, out pos): 0 or an error code.  Every
 // decision is the reference's, so the triples and both byte streams are the reference's (the tests compare them
 // with the oracle's restatement of the same lines).
-template <typename SearchFn>
-int scan_loop(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, SearchFn &&search, RawStreams &out)
-{
+// Steps 2 and 3 for one anchor: the state they carry from triple to triple is `prev`.
+struct TripleEmitter {
+    const uint8_t *old;
+    int64_t n;
+    const uint8_t *nw;
+    int64_t m;
+    RawStreams &out;
     struct Anchor { int64_t at = 0, in_old = 0; };          // a matched position of new and where it lies in old
     Anchor prev;                                             // end of the last emitted forward extension
-    int64_t shift = 0;                                       // old - new offset of the previous alignment
-    int64_t cursor = 0, hit_pos = 0, hit_len = 0;            // scan position, last Search answer
 
-    auto agrees = [&](int64_t i) { return i + shift < n && old[i + shift] == nw[i]; };     // previous alignment still right at i?
-    auto emit_packed = [&](int64_t v) {
+    TripleEmitter(const uint8_t *old_, int64_t n_, const uint8_t *nw_, int64_t m_, RawStreams &out_)
+        : old(old_), n(n_), nw(nw_), m(m_), out(out_) {}
+
+    void emit_packed(int64_t v)
+    {
         uint8_t b[8];
         write_packed_long(b, v);
         out.ctrl.insert(out.ctrl.end(), b, b + 8);
-    };
+    }
 
-    while (cursor < m) {
-        // ---- 1. next anchor ----
-        int64_t carried = 0;                                 // bytes of [.., cursor + hit_len) the previous alignment gets right
-        int64_t counted = cursor += hit_len;                 // ... counted up to here
-        for (; cursor < m; ++cursor) {
-            const int rc = search(cursor, &hit_pos, &hit_len);
-            if (rc != 0) return rc;
-            ++out.searches;
-            if (counted < cursor + hit_len) {                // bytes of the new match the previous alignment also gets right
-                const int64_t end = cursor + hit_len, upto = end < n - shift ? end : n - shift;
-                if (upto > counted) carried += count_equal(old + counted + shift, nw + counted, upto - counted);
-                counted = end;
-            }
-            if ((hit_len == carried && hit_len != 0) || hit_len > carried + 8) break;
-            carried -= agrees(cursor);
-        }
-        if (hit_len == carried && cursor != m) continue;     // the old alignment explains it: keep scanning behind it
-
+    // the anchor the loop broke on: position `cursor` of new matched at `hit_pos` of old (cursor == m: the end of new)
+    void take(int64_t cursor, int64_t hit_pos)
+    {
         // ---- 2. extensions ----
         int64_t fwd = 0;                                     // forward from prev, under prev's alignment
         for (int64_t i = 0, good = 0, best = 0; prev.at + i < cursor && prev.in_old + i < n;) {
@@ -197,9 +187,48 @@ int scan_loop(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, Searc
         emit_packed((hit_pos - back) - (prev.in_old + fwd));
         prev.at = cursor - back;
         prev.in_old = hit_pos - back;
+    }
+};
+
+template <typename SearchFn>
+int scan_loop(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, SearchFn &&search, RawStreams &out)
+{
+    TripleEmitter em(old, n, nw, m, out);
+    int64_t shift = 0;                                       // old - new offset of the previous alignment
+    int64_t cursor = 0, hit_pos = 0, hit_len = 0;            // scan position, last Search answer
+
+    auto agrees = [&](int64_t i) { return i + shift < n && old[i + shift] == nw[i]; };     // previous alignment still right at i?
+
+    while (cursor < m) {
+        // ---- 1. next anchor ----
+        int64_t carried = 0;                                 // bytes of [.., cursor + hit_len) the previous alignment gets right
+        int64_t counted = cursor += hit_len;                 // ... counted up to here
+        for (; cursor < m; ++cursor) {
+            const int rc = search(cursor, &hit_pos, &hit_len);
+            if (rc != 0) return rc;
+            ++out.searches;
+            if (counted < cursor + hit_len) {                // bytes of the new match the previous alignment also gets right
+                const int64_t end = cursor + hit_len, upto = end < n - shift ? end : n - shift;
+                if (upto > counted) carried += count_equal(old + counted + shift, nw + counted, upto - counted);
+                counted = end;
+            }
+            if ((hit_len == carried && hit_len != 0) || hit_len > carried + 8) break;
+            carried -= agrees(cursor);
+        }
+        if (hit_len == carried && cursor != m) continue;     // the old alignment explains it: keep scanning behind it
+        em.take(cursor, hit_pos);
         shift = hit_pos - cursor;
     }
     return 0;
+}
+
+// The same streams from the ANCHORS alone: step 1 runs on the device (dq_anchor_scan.h: the whole anchor search of
+// Diff.cs:100-125 without a host round trip per window) and hands over, per control triple, the position the loop
+// broke on and where its match lies in old -- (cursor, hit_pos) pairs in order, the last one with cursor == m.
+// The emitter keeps its state between calls, so the pairs may arrive in several batches.
+inline void scan_from_anchors(TripleEmitter &em, const int64_t *pairs, int64_t count)
+{
+    for (int64_t k = 0; k < count; ++k) em.take(pairs[2 * k], pairs[2 * k + 1]);
 }
 
 // Patch.cs:95-168 on the three decoded streams.  Returns 0, or -1 for what the reference reports as "Corrupt patch".

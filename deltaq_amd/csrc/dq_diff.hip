@@ -3,6 +3,7 @@
 // (Patch.cs:52-168), and the one-old-file-many-new-files index.  The sorter is called through dq_runtime.h.
 #include "dq_runtime.h"
 #include "dq_match_search.h"
+#include "dq_anchor_scan.h"
 #include "dq_bz2.h"
 #include "dq_bsdiff.h"
 #include "dq_bspatch.h"
@@ -398,6 +399,63 @@ void diff_index_drop(DiffIndex *ix)
     ix->own = nullptr;
 }
 
+// Step 1 of the scan loop on the device (dq_anchor_scan.h): one persistent launch walks the whole new file and leaves the
+// (cursor, hit_pos) pair of every control triple; steps 2 and 3 run here on those pairs.  The list has room for
+// kAnchorRecs pairs per launch -- a new file that needs more (text with a short match every few bytes) continues from
+// the state the kernel left.
+constexpr int64_t kAnchorRecs = 1 << 18;
+constexpr size_t kAnchorScratch = 256 + (size_t)kAsLaneWin * 8 + (size_t)kAnchorRecs * 16;
+
+int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch, const uint8_t *nw, int64_t m,
+                   bsdiff::RawStreams &raw)
+{
+    AnchorCtl *d_ctl = reinterpret_cast<AnchorCtl *>(scratch);
+    unsigned long long *d_ans = reinterpret_cast<unsigned long long *>(scratch + 256);
+    int64_t *d_rec = reinterpret_cast<int64_t *>(scratch + 256 + (size_t)kAsLaneWin * 8);
+    static_assert(sizeof(AnchorCtl) <= 256, "control block");
+    bsdiff::TripleEmitter em(ix.old, ix.n, nw, m, raw);
+    AnchorCtl st{};
+    std::vector<int64_t> pairs;
+    std::lock_guard<std::mutex> lk(c.mu);                 // (the device context's stream and pinned areas)
+    int rc = init_ctx(c, ix.dev);
+    if (rc != DQ_OK) return rc;
+    AnchorCtl *h_up = reinterpret_cast<AnchorCtl *>(c.pinned + 512), *h_back = reinterpret_cast<AnchorCtl *>(c.pinned);
+    for (;;) {
+        Launcher L{c, c.stream, g_prof_on.load()};
+        *h_up = AnchorCtl{};
+        h_up->cursor = st.cursor; h_up->hit_len = st.hit_len; h_up->hit_pos = st.hit_pos; h_up->shift = st.shift;
+        HIP_TRY(hipMemcpyAsync(d_ctl, h_up, sizeof(AnchorCtl), hipMemcpyHostToDevice, c.stream));
+        auto launch = [&]() -> int {
+            LAUNCH(L, DQ_K_MATCH_SEARCH, m, m * 2,
+                   hipLaunchKernelGGL(anchor_scan_kernel<int32_t>, dim3(kAsGroups), dim3(kAsThreads), 0, c.stream,
+                                      (const uint8_t *)ix.d_old, ix.n, (const int32_t *)ix.d_sa, (const uint8_t *)d_new, m,
+                                      (const int32_t *)ix.d_tab, ix.pk, d_ans, d_rec, kAnchorRecs, d_ctl));
+            return DQ_OK;
+        };
+        rc = launch();
+        if (rc != DQ_OK) { drop_pending(c, c.stream); return rc; }
+        HIP_TRY(hipMemcpyAsync(h_back, d_ctl, sizeof(AnchorCtl), hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        rc = flush_profile(c);
+        if (rc != DQ_OK) return rc;
+        st = *h_back;
+        if (st.error) return fail(DQ_ERR_HIP, "anchor scan: grid barrier timed out");
+        const int64_t got = (int64_t)st.nrec;
+        if (got < 0 || got > kAnchorRecs) return fail(DQ_ERR_HIP, "anchor scan: bad record count");
+        if (got > 0) {
+            pairs.resize((size_t)got * 2);
+            HIP_TRY(hipMemcpy(pairs.data(), d_rec, (size_t)got * 16, hipMemcpyDeviceToHost));
+            bsdiff::scan_from_anchors(em, pairs.data(), got);
+        }
+        raw.searches += (int64_t)st.searches;
+        raw.windows += (int64_t)st.windows;
+        raw.exact += (int64_t)st.stops;
+        if (st.done) break;
+        if (got == 0) return fail(DQ_ERR_HIP, "anchor scan: no progress");
+    }
+    return DQ_OK;
+}
+
 // Diff.Create's data path up to the raw streams for one new file: upload it, run the scan loop over windows of answers
 int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::RawStreams &raw)
 {
@@ -414,7 +472,8 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
     const size_t b_new = align_up((size_t)m + 16);
-    int rc = grow_cached(&c.diff_dev, &c.diff_dev_bytes, b_new + 256, "hipMalloc(bsdiff buffers)");      // (+ the mailbox of the window kernel)
+    // (+ the mailbox of the window kernel; + control block, answers and anchor list of the device's scan)
+    int rc = grow_cached(&c.diff_dev, &c.diff_dev_bytes, b_new + 256 + kAnchorScratch, "hipMalloc(bsdiff buffers)");
     if (rc != DQ_OK) return rc;
     if (!c.diff_pinned) {
         hipError_t e = hipHostMalloc((void **)&c.diff_pinned, kDiffPinnedBytes, hipHostMallocCoherent);   // (windows + the packed answers the loop polls)
@@ -428,6 +487,16 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
     stamp("buffers");
     HIP_TRY(hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice));
     stamp("new on device");
+    // the anchor search of the scan loop on the device (default), or the host loop over windows of device answers
+    const bool device_scan = env("DQ_SCAN_DEVICE") ? atoi(env("DQ_SCAN_DEVICE")) != 0 : false;
+    if (device_scan) {
+        rc = scan_on_device(ix, c, d_new, d_new + b_new + 256, nw, m, raw);
+        stamp("scan (device)");
+        if (trace)
+            fprintf(stderr, "[dq] device scan: %lld searches, %lld windows, %lld stop points, %zu triples\n", (long long)raw.searches,
+                    (long long)raw.windows, (long long)raw.exact, raw.ctrl.size() / 24);
+        return rc;
+    }
     SearchWindows win{ix.d_old, ix.d_sa, d_new, ix.n, m, dev};
     win.d_ptab = ix.d_tab;
     win.pk = ix.pk;

@@ -1036,15 +1036,16 @@ struct SuffixSorter {
     }
 
     // ISA[s] = new rank for the mU entries a round left in U (stored downward from B + top / Bs + top).  A long list of
-    // update words is first binned by the top 16 bits of the suffix with two word passes of the radix sorter (into
-    // the buffers of the round's input list, which is dead by now: A, then As seen as words), so that the 4-byte
-    // writes of a workgroup fall into a few KB of the array (isa_update_words_kernel); 256 MiB of enwik-style text,
-    // first doubling round: 75 M updates, 2.5 ms as random writes.  DQ_UPD_BIN = 0 | 1 | 2: passes (default 2).
-    static constexpr int64_t kUpdBinMin = 1ll << 22;
+    // update words is first binned by the top 8 bits of the suffix with one word pass of the radix sorter (into the
+    // buffer of the round's input list, which is dead by now), so that the 4-byte writes of the moment fall into one
+    // 1/256 of the array (isa_update_words_kernel).  Measured on 256 MiB of enwik-style text, first doubling round,
+    // 75 M updates: 2.75 ms as random writes; one pass 0.35 + 1.7 ms; two passes (16 bits, DQ_UPD_BIN=2) 0.75 + 1.07 ms
+    // -- the passes eat most of what the writes gain, and lists of a few million entries gain nothing.
+    static constexpr int64_t kUpdBinMin = 1ll << 24;
     int apply_rank_updates(uint64_t *A, IdxT *As, uint64_t *B, IdxT *Bs, int64_t mU, int u_ib)
     {
         const int64_t top = sg_top();
-        int passes = env("DQ_UPD_BIN") ? std::max(0, std::min(2, atoi(env("DQ_UPD_BIN")))) : 2;
+        int passes = env("DQ_UPD_BIN") ? std::max(0, std::min(2, atoi(env("DQ_UPD_BIN")))) : 1;
         const int64_t min_len = env("DQ_UPD_BIN_MIN") ? std::max(1, atoi(env("DQ_UPD_BIN_MIN"))) : kUpdBinMin;
         if (u_ib < 16 || mU < min_len || (size_t)(mU + 1) * 8 > (size_t)(n + 2) * sizeof(IdxT)) passes = 0;
         if (passes == 0) {
@@ -1418,7 +1419,8 @@ struct SuffixSorter {
             }
             // runs seen late (see long_run_seen): the large groups have stopped shrinking -- run lengths now, one
             // run-order round at the current depth on the current list, the rank behind the run from then on
-            if (long_run_seen && !runs_on && !runs_late_tried && !run_order && last_large >= (1 << 15) && prev_large > 0 &&
+            const int64_t late_min = env("DQ_LATE_RUNS_MIN") ? std::max(1, atoi(env("DQ_LATE_RUNS_MIN"))) : (1 << 15);   // (tests: small inputs)
+            if (long_run_seen && !runs_on && !runs_late_tried && !run_order && last_large >= late_min && prev_large > 0 &&
                 last_large * 8 >= prev_large * 7 && h >= 32 && 32 + rbits <= 64 && uses_small_round(m) && !keys_ready &&
                 !list_ungrouped && !first_rank32 && mid_group_cap(m) > 0 && !env("DQ_NO_LATE_RUNS")) {
                 runs_late_tried = true;

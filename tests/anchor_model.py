@@ -1,0 +1,147 @@
+"""CPU model of the device's anchor search (deltaq_amd/csrc/dq_anchor_scan.h): step 1 of the scan loop (Diff.cs:100-125)
+evaluated window by window, the way the persistent kernel does it.
+
+The reference's loop keeps two running numbers while it walks from `base` (the end of the last match): `oldscore`
+(here: carried) and `scsc` (counted).  With agree(k) = "the previous alignment still gets byte k right"
+(k + shift < n and old[k + shift] == new[k]) and  M_j = max(base, max_{k <= j} (k + len_k))  they satisfy, at the break
+test of position j,
+        carried_j = #{ k in [j, M_j) : agree(k) } = cnt(base, M_j) - cnt(base, j),
+so the tests of a whole window of positions can be evaluated from two running sums -- C = cnt(base, M) and
+S = cnt(base, j) -- and a prefix count of agree() over the bytes the window covers.  A position whose answer is not
+exact yet (the search hit its cap) or whose match reaches beyond the covered bytes is a STOP POINT: the window is
+evaluated up to it, then it is taken on its own (exact search, a count over its whole match), and a new window starts
+behind it.  test_models_cpu.py checks the anchors this gives against a literal transcription of the loop and the
+streams the product's emitter makes of them against the oracle's."""
+import numpy as np
+
+
+def literal_anchors(old, new, pos, ln):
+    """Diff.cs:100-125 as written (dq_bsdiff.h::scan_loop, step 1): the (cursor, hit_pos) of every emitted triple."""
+    n, m = len(old), len(new)
+    cursor = hit_pos = hit_len = shift = 0
+    out = []
+    while cursor < m:
+        carried = 0
+        cursor += hit_len
+        counted = cursor
+        while cursor < m:
+            hit_pos, hit_len = int(pos[cursor]), int(ln[cursor])
+            if counted < cursor + hit_len:
+                end = cursor + hit_len
+                upto = min(end, n - shift)
+                for k in range(counted, upto):
+                    carried += old[k + shift] == new[k]
+                counted = end
+            if (hit_len == carried and hit_len != 0) or hit_len > carried + 8:
+                break
+            carried -= int(cursor + shift < n and old[cursor + shift] == new[cursor])
+            cursor += 1
+        if hit_len == carried and cursor != m:
+            continue
+        out.append((cursor, hit_pos))
+        shift = hit_pos - cursor
+    return out
+
+
+def windowed_anchors(old, new, pos, ln, capped, w_first=8, w_next=32, extra=16, rng=None):
+    """The kernel's evaluation.  capped(j) -> True: the window's answer for position j comes back undecided (len < 0)
+    unless it is the window's first position; the exact answer (pos[j], ln[j]) is fetched when the position is taken on
+    its own.  Window sizes / coverage are parameters so that small inputs exercise every branch."""
+    n, m = len(old), len(new)
+    cursor = hit_pos = hit_len = shift = 0
+    out = []
+    stats = dict(windows=0, stops=0)
+
+    def agree(k):
+        return int(k + shift < n and old[k + shift] == new[k])
+
+    def cnt(a, b):
+        return sum(agree(k) for k in range(a, b))
+
+    while cursor < m:
+        cursor += hit_len
+        base = cursor
+        i, M, C, S = base, base, 0, 0                      # C = cnt(base, M), S = cnt(base, i); M >= i
+        found = False
+        first_window = True
+        streak = 0                                         # stop points in a row that did not break
+        last = None                                        # last position searched (exact answer)
+        while i < m and not found:
+            W = w_first if first_window else w_next
+            first_window = False
+            c = min(W, m - i)
+            stats["windows"] += 1
+            cover = i + c + extra                          # prefix counts exist for [i, cover]
+            agp = [0]
+            for k in range(i, min(cover, m) + 1):
+                agp.append(agp[-1] + (agree(k) if k < m else 0))
+            # agp[x - i] = cnt(i, x) for x in [i, min(cover, m)]; positions >= m never agree and are never asked for
+            lens = []
+            for j in range(i, i + c):
+                exact = (j == i) or streak >= 2 or not capped(j)
+                lens.append(int(ln[j]) if exact else -1)
+            # ---- stop point: first capped position, or first match that raises M beyond the covered bytes ----
+            s = None
+            for t, l in enumerate(lens):
+                j = i + t
+                if l < 0 or (j + l > M and j + l > cover):
+                    s = t
+                    break
+            upto = c if s is None else s
+            # ---- positions before it: prefix maximum of the match ends, the two running sums, the break test ----
+            f = None
+            Mj, Cj = M, C
+            for t in range(upto):
+                j = i + t
+                e = j + lens[t]
+                if e > Mj:                                 # (both inside the coverage, or the stop rule would have fired)
+                    assert M <= cover and e <= cover
+                    Cj = C + agp[e - i] - agp[M - i]
+                    Mj = e
+                Sj = S + agp[t]
+                carried = Cj - Sj
+                if (lens[t] == carried and lens[t] != 0) or lens[t] > carried + 8:
+                    f = t
+                    break
+            if f is not None:
+                cursor, hit_pos, hit_len, carried_at = i + f, int(pos[i + f]), lens[f], carried
+                found = True
+                break
+            if s is None:                                  # the whole window went by
+                last = i + c - 1
+                S += agp[c]
+                C, M = Cj, Mj
+                i += c
+            else:                                          # the stop point, on its own
+                stats["stops"] += 1
+                j = i + s
+                l = int(ln[j])                             # exact now
+                last = j
+                C, M = Cj, Mj                              # what the positions before it left
+                if j + l > M:
+                    C += cnt(M, j + l)
+                    M = j + l
+                Sj = S + agp[s]
+                carried = C - Sj
+                if (l == carried and l != 0) or l > carried + 8:
+                    cursor, hit_pos, hit_len, carried_at = j, int(pos[j]), l, carried
+                    found = True
+                    break
+                streak += 1
+                S = Sj + agree(j)
+                i = j + 1
+            if M < i:                                      # keep M >= i (every later M_j is >= j >= i anyway)
+                C += cnt(M, i)
+                M = i
+        if not found:
+            cursor = m
+            if last is not None:
+                hit_pos, hit_len = int(pos[last]), int(ln[last])
+            out.append((cursor, hit_pos))
+            shift = hit_pos - cursor
+            continue
+        if hit_len == carried_at and cursor != m:
+            continue
+        out.append((cursor, hit_pos))
+        shift = hit_pos - cursor
+    return out, stats

@@ -359,6 +359,12 @@ FUZZ_ENVS = [
     {"DQ_RUNS": "1", "DQ_SMALL_N": "0", "DQ_NO_SMALL": "1", "DQ_NO_BINNED_ISA": "1"},
     {"DQ_PAIR_CHAINS": "2", "DQ_SMALL_N": "0"},            # tied pairs decided chain by chain as early and as often as allowed
     {"DQ_PAIR_CHAINS": "2", "DQ_NO_BINNED_ISA": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0"},
+    {"DQ_LATE_RUNS_MIN": "1", "DQ_SMALL_N": "0"},          # run lengths + run-order round as soon as large groups stagnate
+    {"DQ_LATE_RUNS_MIN": "1", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "256", "DQ_PAIR_CHAINS": "0"},
+    {"DQ_UPD_BIN": "2", "DQ_UPD_BIN_MIN": "1", "DQ_SMALL_N": "0"},   # rank updates binned by suffix (two passes) before they are applied
+    {"DQ_UPD_BIN": "1", "DQ_UPD_BIN_MIN": "1", "DQ_SMALL_N": "0", "DQ_RUNS": "1"},   # ... one pass
+    {"DQ_NO_UPD_WORDS": "1", "DQ_SMALL_N": "0"},           # rank updates as (rank, suffix) in two arrays
+    {"DQ_SPARSE": "1", "DQ_BINNED_ISA": "1", "DQ_SMALL_N": "0"},     # suffix-binned inverse suffix array at the sparse-to-dense switch
 ]
 
 
@@ -565,12 +571,20 @@ def run_heavy_texts(oracle_mod):
     T[400_000:400_100] = 0
     T[-5000:] = 9                                                    # a run into the end of the text
     out.append(T)
+    # a few long runs in text that is otherwise not made of runs (a shared library with a padding area: too little of
+    # the text for the run lengths to be computed up front -- the rounds meet the runs' groups and switch to them late)
+    T = oracle_mod.gen_enwik_like(3_000_000, 11, 65536)
+    T[1_000_000:1_150_000] = 88
+    T[2_000_000:2_040_000] = 88
+    T[2_500_000:2_500_000 + 70_000] = np.resize(np.array([0, 255], np.uint8), 70_000)   # and a period-2 stretch, which stays with the rounds
+    out.append(T)
     return out
 
 
 @pytest.mark.parametrize("env", [{}, {"DQ_RUNS": "1"}, {"DQ_RUNS": "0"}, {"DQ_RUNS": "1", "DQ_NO_SMALL": "1"},
                                  {"DQ_RUNS": "1", "DQ_BINNED_ISA": "1"}, {"DQ_RUNS": "1", "DQ_BINNED_ISA": "1", "DQ_NO_FIRST_SMALL": "1"},
-                                 {"DQ_RUNS": "1", "DQ_SPARSE": "1"}, {"DQ_RUNS": "1", "DQ_MID_GROUPS": "256", "DQ_NO_BINNED_ISA": "1"}],
+                                 {"DQ_RUNS": "1", "DQ_SPARSE": "1"}, {"DQ_RUNS": "1", "DQ_MID_GROUPS": "256", "DQ_NO_BINNED_ISA": "1"},
+                                 {"DQ_LATE_RUNS_MIN": "1"}, {"DQ_LATE_RUNS_MIN": "64", "DQ_UPD_BIN_MIN": "1"}, {"DQ_NO_LATE_RUNS": "1"}],
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
 def test_runs_of_one_byte(ldss, oracle_mod, monkeypatch, env):
     monkeypatch.setenv("DQ_SMALL_N", "0")

@@ -430,3 +430,76 @@ def test_mailbox_word_orders_by_ticket_then_smallest_position():
             assert pos == best and length in [l for p, l in pubs if p == best]
     # the host stops using the second stage before the ticket field would overflow (ticket < 2^20 - 2)
     assert mail_word((1 << 20) - 3, 0, (1 << 32) - 1) < (1 << 64)
+
+
+# ---- the device's anchor search (dq_anchor_scan.h): windowed evaluation of Diff.cs:100-125 ----
+def _edited_pairs(oracle_mod, rng, trials):
+    for trial in range(trials):
+        n = int(rng.integers(1, 3000))
+        kind = trial % 4
+        old = oracle_mod.gen_enwik_like(n, 900 + trial, 512) if kind == 1 else oracle_mod.gen_uniform(n, 900 + trial)
+        if kind == 2:
+            old = np.tile(old[: max(1, n // 23)], 23)[:n].copy()               # periodic: alignments that carry on
+        if kind == 3:
+            old = (old & 1).astype(np.uint8)                                    # two symbols: long matches everywhere
+        new = bytearray(old.tobytes())
+        for _ in range(int(rng.integers(0, 8))):
+            a, ln, k = int(rng.integers(0, max(1, len(new)))), int(rng.integers(1, 120)), int(rng.integers(0, 4))
+            if k == 0:
+                new[a:a] = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+            elif k == 1:
+                del new[a:a + ln]
+            elif k == 2:
+                new[a:a + ln] = rng.integers(0, 256, min(ln, len(new) - a), dtype=np.uint8).tobytes()
+            else:
+                new[int(rng.integers(0, max(1, len(new)))):0] = new[a:a + ln]
+        if trial % 17 == 5:
+            new = bytearray(oracle_mod.gen_uniform(int(rng.integers(0, 400)), trial).tobytes())   # unrelated
+        yield trial, old, np.frombuffer(bytes(new), dtype=np.uint8)
+
+
+def test_windowed_anchor_search_equals_the_loop(oracle_mod):
+    import ctypes
+    import os
+    import subprocess
+    import anchor_model
+    from conftest import ROOT
+    native = os.path.join(ROOT, "tests", "native")
+    so, src = os.path.join(native, "libscan_harness.so"), os.path.join(native, "scan_harness.cpp")
+    hdr = os.path.join(ROOT, "deltaq_amd", "csrc", "dq_bsdiff.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", so], check=True)
+    L = ctypes.CDLL(so)
+    L.t_scan_from_anchors.restype = ctypes.c_int64
+    L.t_scan_from_anchors.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                      ctypes.c_int64] + [ctypes.c_void_p] * 6
+    rng = np.random.default_rng(2024)
+    stops = windows = 0
+    for trial, old, new in _edited_pairs(oracle_mod, rng, 120):
+        sa = oracle_mod.divsufsort(old)
+        pos, ln = oracle_mod.bsdiff_search(old, sa, new) if new.size else (np.zeros(0, np.int32), np.zeros(0, np.int32))
+        O, N = old.tolist(), new.tolist()
+        want = anchor_model.literal_anchors(O, N, pos, ln)
+        cap = int(rng.choice([0, 4, 16, 64]))
+        noise = set(rng.integers(0, max(1, new.size), new.size // 7).tolist())
+        capped = (lambda j: ln[j] > cap or j in noise) if cap else (lambda j: False)
+        for (w1, w2, ex) in ((8, 32, 16), (1, 1, 0), (128, 512, 64), (3, 5, 2)):
+            got, st = anchor_model.windowed_anchors(O, N, pos, ln, capped, w1, w2, ex)
+            assert got == want, (trial, w1, w2, ex, cap)
+            stops += st["stops"]; windows += st["windows"]
+        # the product's emitter on those anchors = the oracle's streams
+        pairs = np.array(want, dtype=np.int64).reshape(-1)
+        m = new.size
+        ctrl = np.empty(24 * (m + 2), np.uint8); diff = np.empty(max(m, 1), np.uint8); extra = np.empty(max(m, 1), np.uint8)
+        lens = np.zeros(3, np.int64)
+        oc, nc = np.ascontiguousarray(old), np.ascontiguousarray(new)
+        L.t_scan_from_anchors(oc.ctypes.data, oc.size, nc.ctypes.data if m else None, m, pairs.ctypes.data if pairs.size else None,
+                              pairs.size // 2, ctrl.ctypes.data, lens.ctypes.data, diff.ctypes.data, lens.ctypes.data + 8,
+                              extra.ctypes.data, lens.ctypes.data + 16)
+        wc, wd, we, _ = oracle_mod.bsdiff_scan(old, sa, new)
+        raw = ctrl[:lens[0]].reshape(-1, 8).astype(np.int64)
+        mag = sum((raw[:, i] & (0x7f if i == 7 else 0xff)) << (8 * i) for i in range(8))
+        trip = np.where(raw[:, 7] & 0x80, -mag, mag).reshape(-1, 3)
+        assert np.array_equal(trip, wc), trial
+        assert np.array_equal(diff[:lens[1]], wd) and np.array_equal(extra[:lens[2]], we), trial
+    assert stops > 100 and windows > 1000            # the stop-point path was exercised
