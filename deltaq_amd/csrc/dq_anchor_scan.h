@@ -2,23 +2,25 @@
 // last match, the oldscore bookkeeping, the break test) on the device, in ONE persistent launch per new file.
 //
 // The host loop of dq_bsdiff.h::scan_loop asks the device for a window of Search answers and waits: one dependent
-// round trip (~30 us) per window, ~1 per edit between similar files -- 90 of the 100 ms of a 16 MiB pair.  Here the
+// round trip (~30 us) per window, ~1.5 per edit between similar files -- 90 of the 100 ms of a 16 MiB pair.  Here the
 // loop itself runs on the device and hands the host only what steps 2 and 3 (extensions, emission:
 // dq_bsdiff.h::TripleEmitter) need: per control triple the position the loop broke on and where its match lies in
-// old.  tests/anchor_model.py is the CPU model of exactly this evaluation, checked against a literal transcription of
-// the reference's loop (tests/test_models_cpu.py).
+// old.  tests/anchor_model.py is the CPU model of this evaluation, checked against a literal transcription of the
+// reference's loop (tests/test_models_cpu.py).
 //
-// With agree(k) = "the previous alignment still gets byte k right" (k + shift < n and old[k + shift] == new[k]) and
-// M_j = max(base, max_{k <= j}(k + len_k)), the loop's oldscore at the break test of position j is
-//        carried_j = #{ k in [j, M_j) : agree(k) } = cnt(base, M_j) - cnt(base, j),
-// so a whole WINDOW of positions is tested at once from two running sums (C = cnt(base, M), S = cnt(base, j)), a
-// prefix count of agree() over the bytes the window covers and a prefix maximum of the match ends.  A position whose
-// answer is not exact (its search hit the cap) or whose match reaches beyond the covered bytes is a STOP POINT: the
-// window counts up to it, then it is taken on its own (exact search, a count over its whole match).
+// With agree(k) = "the previous alignment still gets byte k right" (k + shift < n and old[k + shift] == new[k]),
+// cnt(a, b) = #{ k in [a, b) : agree(k) } and M_j = max(base, max_{k <= j}(k + len_k)), the loop's oldscore at the
+// break test of position j is
+//        carried_j = cnt(j, M_j) = cnt(base, M_j) - cnt(base, j).
+// Every searching wave (lane) also counts cw_j = cnt(j, j + len_j) over its own match, so that
+// cnt(base, j + len_j) = S_j + cw_j with S_j = cnt(base, j) -- a prefix count over the window's POSITIONS only.  A
+// whole window is then tested at once: prefix maximum of the match ends j + len_j carrying cnt(base, .) of the end
+// that holds the maximum, minus S_j.  A position whose answer is not exact (its search hit the cap) is a STOP POINT:
+// the window counts up to it, then it is searched again exactly and taken on its own.
 //
-// Grid: kAsGroups workgroups of 4 waves, all resident.  A window's searches are dealt out one position per wave
-// (128 positions; 65-ary search, dq_match_search.h) or, while the loop walks through a long differing stretch, one per
-// lane (8192); the answers meet in device memory behind ONE grid barrier per window, and every workgroup then evaluates
+// Grid: G = kAsGroups workgroups of 4 waves, all resident.  A window's searches are dealt out one position per wave
+// (4 G = 128 positions; 65-ary search, dq_match_search.h) or, while the loop walks through a long differing stretch, one
+// per lane (256 G = 8192); the answers meet in device memory behind ONE grid barrier per window, and every workgroup then evaluates
 // the window on its own -- the same integer decisions everywhere, so no second exchange is needed.  The barrier is an
 // agent-scope counter (bounded spin, error flag); answers are agent-scope atomic stores / loads (the L2s of the 8 XCDs
 // are not coherent with each other).
@@ -29,11 +31,11 @@ namespace dq {
 
 constexpr int kAsThreads = 256;
 constexpr int kAsWaves = kAsThreads / kWave;
-constexpr int kAsGroups = 32;
-constexpr int kAsWaveWin = kAsGroups * kAsWaves;          // positions of a one-wave-per-position window
-constexpr int kAsLaneWin = kAsWaveWin * kWave;            // ... of a one-lane-per-position window
-constexpr int kAsExtra = 128;                             // bytes covered behind a window's last position
+constexpr int kAsGroups = 32;                             // workgroups of the persistent grid (DQ_SCAN_GROUPS: 8 .. kAsMaxGroups)
+constexpr int kAsMaxGroups = 64;
+constexpr int kAsMaxLaneWin = kAsMaxGroups * kAsWaves * kWave;   // positions of the largest one-lane-per-position window
 constexpr int64_t kAsCap = 64;                            // comparison cap of the speculative positions
+constexpr int kAsWaveWins = 3;                            // wave windows walked over before the lane windows take over
 
 struct AnchorCtl {
     unsigned long long arrive;                            // grid barrier: arrivals so far
@@ -43,18 +45,8 @@ struct AnchorCtl {
     unsigned long long searches, windows, stops;          // Search calls the reference's loop makes; windows; stop points
     unsigned int error;                                   // 1: the barrier timed out
     unsigned int pad;
+    unsigned long long t_search, t_wait, t_eval, t_stop;  // workgroup 0's time per phase, in 100 MHz ticks (DQ_TRACE prints them)
 };
-
-__device__ __forceinline__ int64_t as_wave_incl_max(int64_t v)
-{
-    const int l = lane_id();
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const int64_t t = __shfl_up(v, o, kWave);
-        if (l >= o) v = t > v ? t : v;
-    }
-    return v;
-}
 
 template <typename T>
 __device__ __forceinline__ T as_wave_min(T v)
@@ -67,17 +59,55 @@ __device__ __forceinline__ T as_wave_min(T v)
     return v;
 }
 
+// #{ k in [a, b) : po[k] == pn[k] } by one wave (wave-uniform arguments): 4 KiB a step, then 512 bytes a step, while 12
+// more bytes exist in both buffers behind every lane's 8 (ms_load8 touches whole dwords), then 64 bytes a step.  lim_o / lim_n: bytes that
+// exist in the two buffers counted from index 0 of po / pn.
+__device__ __forceinline__ int64_t as_wave_count_equal(const uint8_t *po, int64_t lim_o, const uint8_t *pn, int64_t lim_n,
+                                                       int64_t a, int64_t b)
+{
+    const int lane = lane_id();
+    constexpr uint64_t k7f = 0x7f7f7f7f7f7f7f7full;
+    uint32_t c = 0;
+    int64_t k = a;
+    while (k + 8 * 512 + 4 <= b && k + 8 * 512 + 4 <= lim_o && k + 8 * 512 + 4 <= lim_n) {      // 4 KiB a step, all in flight
+        uint64_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t q = k + u * 512 + 8 * lane;
+            x[u] = ms_load8(po + q) ^ ms_load8(pn + q);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c += (uint32_t)__popcll(~(((x[u] & k7f) + k7f) | x[u] | k7f));   // 0x80 in every byte of x that is zero
+        k += 8 * 512;
+    }
+    while (k + 512 + 4 <= b && k + 512 + 4 <= lim_o && k + 512 + 4 <= lim_n) {
+        const int64_t q = k + 8 * lane;
+        const uint64_t x = ms_load8(po + q) ^ ms_load8(pn + q);
+        c += (uint32_t)__popcll(~(((x & k7f) + k7f) | x | k7f));
+        k += 512;
+    }
+    for (; k < b; k += kWave) {
+        const int64_t q = k + lane;
+        c += (q < b && po[q] == pn[q]) ? 1u : 0u;
+    }
+    return (int64_t)__shfl(wave_incl_sum(c), kWave - 1, kWave);
+}
+
 template <typename IdxT>
 __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa, const uint8_t *__restrict__ nw, int64_t m,
-    const IdxT *__restrict__ ptab, int pk, unsigned long long *__restrict__ ans /* [kAsLaneWin]: len << 32 | pos */,
-    int64_t *__restrict__ rec /* [rec_cap][2] */, int64_t rec_cap, AnchorCtl *__restrict__ ctl)
+    const IdxT *__restrict__ ptab, int pk,
+    unsigned long long *__restrict__ ans /* [2][lane window][2]: len << 32 | pos, then cnt(j, j + len) */,
+    unsigned long long *__restrict__ rec /* [rec_cap] in PINNED HOST memory: cursor << 32 | hit_pos, one store each */,
+    int64_t rec_cap, AnchorCtl *__restrict__ ctl)
 {
-    __shared__ uint16_t agp[kAsLaneWin + kAsExtra + 2];   // agp[x] = #agree in [i, i + x)
-    __shared__ int64_t w_i64[kAsWaves];
+    __shared__ uint16_t agp[kAsMaxLaneWin + 2];           // agp[x] = cnt(i, i + x), x = 0 .. c
+    const int64_t kAsWaveWin = (int64_t)gridDim.x * kAsWaves;      // positions of a one-wave-per-position window
+    const int64_t kAsLaneWin = kAsWaveWin * kWave;                 // ... of a one-lane-per-position window
+    __shared__ int64_t w_e[kAsWaves], w_c[kAsWaves];
     __shared__ uint32_t w_u32[kAsWaves];
     __shared__ int32_t w_brk[kAsWaves], w_stp[kAsWaves];
-    __shared__ int64_t s_pos, s_len;
+    __shared__ int64_t s_v[4];
     __shared__ uint32_t s_err;
 
     const int tid = threadIdx.x;
@@ -91,47 +121,34 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     int64_t nrec = 0;
     unsigned long long n_search = 0, n_win = 0, n_stop = 0;
     bool failed = false;
+    unsigned long long t_search = 0, t_wait = 0, t_eval = 0, t_stop = 0, t0 = __builtin_readcyclecounter();
+    auto lap = [&](unsigned long long &acc) { const unsigned long long t1 = wall_clock64(); acc += t1 - t0; t0 = t1; };
+    t0 = wall_clock64();
 
     auto agree = [&](int64_t k) -> bool { return k + shift < n && old[k + shift] == nw[k]; };
-
-    // #agree in [a, b), by the whole workgroup (every byte of a long match is counted once per anchor search)
-    auto count_agree = [&](int64_t a, int64_t b) -> int64_t {
-        const int64_t upto = b < n - shift ? b : n - shift;
-        uint32_t c = 0;
-        if (upto > a) {
-            const uint8_t *po = old + shift, *pn = nw;
-            constexpr uint64_t k7f = 0x7f7f7f7f7f7f7f7full;
-            int64_t k = a + 8 * (int64_t)tid;
-            // 8 bytes a step while 12 bytes exist in both buffers behind k (ms_load8 touches whole dwords)
-            for (; k + 12 <= upto && k + shift + 12 <= n && k + 12 <= m; k += 8 * kAsThreads) {
-                const uint64_t x = ms_load8(po + k) ^ ms_load8(pn + k);
-                const uint64_t t = ~(((x & k7f) + k7f) | x | k7f);            // 0x80 in every byte of x that is zero
-                c += (uint32_t)__popcll(t);
-            }
-            // the words this thread did not take that way (the tail of the range): byte by byte
-            for (; k < upto; k += 8 * kAsThreads)
-                for (int64_t q = k; q < k + 8 && q < upto; ++q) c += po[q] == pn[q];
-        }
-        c = wave_incl_sum(c);
-        __syncthreads();
-        if (lane == kWave - 1) w_u32[wv] = c;
-        __syncthreads();
-        int64_t tot = 0;
-#pragma unroll
-        for (int q = 0; q < kAsWaves; ++q) tot += w_u32[q];
-        return tot;
+    // cnt(j, j + l) for the match (p, l) found at position j, by one wave: a match under the previous alignment agrees
+    // everywhere; otherwise the bytes are compared (the part of [j, j + l) that the shifted old file still covers)
+    auto wave_cw = [&](int64_t j, int64_t p, int64_t l) -> int64_t {
+        if (l <= 0) return 0;
+        if (p - j == shift) return l;
+        const int64_t upto = (j + l) < (n - shift) ? (j + l) : (n - shift);
+        if (upto <= j) return 0;
+        return as_wave_count_equal(old + shift, n - shift, nw, m, j, upto);
     };
 
+    // Grid barrier.  Everything the workgroups exchange goes through agent-scope relaxed atomics (answers: stores /
+    // loads that bypass the non-coherent cache levels; the arrival counter), as in radix_rank_kernel's status words:
+    // no fences, so the read-only data (old, new, suffix array, prefix table) stays cached from window to window.
+    // The answers of a wave are complete (s_waitcnt in __syncthreads) before its workgroup's arrival is counted.
     auto grid_barrier = [&]() {
-        __threadfence();
         __syncthreads();
         bar_target += gridDim.x;
         if (tid == 0) {
-            __hip_atomic_fetch_add(&ctl->arrive, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&ctl->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t spins = 0, bad = 0;
-            while (__hip_atomic_load(&ctl->arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < bar_target) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 26) || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            while (__hip_atomic_load(&ctl->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bar_target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24) || ((spins & 1023u) == 0 && __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                     __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     bad = 1;
                     break;
@@ -142,6 +159,15 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
         __syncthreads();
         if (s_err) failed = true;
     };
+    // (two answer buffers, taken in turn by the windows: a workgroup that is through with window k publishes window
+    // k + 1 while a slower one still reads window k; nobody reaches window k + 2 before everybody has left window k)
+    unsigned long long *ans_w = ans;
+    auto publish = [&](int64_t slot, int64_t p, int64_t l, int64_t cw) {
+        unsigned long long *ans = ans_w;
+        __hip_atomic_store(&ans[2 * slot], ((unsigned long long)(uint32_t)(int32_t)l << 32) | (uint32_t)(int32_t)p,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ans[2 * slot + 1], (unsigned long long)cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
 
     while (cursor < m && !failed) {
         if (nrec >= rec_cap) break;                       // the host empties the list and launches again from this state
@@ -150,50 +176,66 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
         int64_t i = base, M = base, C = 0, S = 0;         // C = cnt(base, M), S = cnt(base, i), M >= i
         bool found = false, lane_mode = false;
         int streak = 0;                                   // stop points in a row that did not break
+        int passed = 0;                                   // wave windows in a row that went by without a break
         int64_t carried_at = 0;
         bool any_search = false;
         int64_t last_pos = 0, last_len = 0;               // answer at the last position walked over
         while (i < m && !found && !failed) {
-            const int64_t c = (m - i) < (lane_mode ? kAsLaneWin : kAsWaveWin) ? (m - i) : (lane_mode ? kAsLaneWin : kAsWaveWin);
+            const int64_t win = lane_mode ? kAsLaneWin : kAsWaveWin;
+            const int64_t c = (m - i) < win ? (m - i) : win;
+            ans_w = ans + (size_t)(n_win & 1ull) * (2 * (size_t)kAsMaxLaneWin);
+            unsigned long long *ans = ans_w;              // (shadows the parameter: this window's buffer)
             ++n_win;
-            // ---- 0. the window's answers, one position per wave or per lane ----
+            // ---- 0. the window's answers (and each match's own agree count), one position per wave or per lane ----
             if (!lane_mode) {
                 if (gwave < c) {
                     const int64_t scan = i + gwave;
                     const bool exact = gwave == 0 || streak >= 2;
                     int64_t p = 0, l = 0;
                     ms_search_wave<IdxT>(old, n, sa, nw, m, scan, exact ? (int64_t)0 : kAsCap, ptab, pk, &p, &l, nullptr, /*resume_first=*/true);
-                    if (lane == 0)
-                        __hip_atomic_store(&ans[gwave], ((unsigned long long)(uint32_t)(int32_t)l << 32) | (uint32_t)(int32_t)p,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int64_t cw = wave_cw(scan, p, l);
+                    if (lane == 0) publish(gwave, p, l, cw);
                 }
             } else {
                 const int64_t idx = (int64_t)gwave * kWave + lane;
                 if ((int64_t)gwave * kWave < c) {          // (whole waves)
                     int64_t p = 0, l = 0;
-                    ms_search_one<IdxT>(old, n, sa, nw, m, idx < c ? i + idx : 0, idx < c, kAsCap, ptab, pk, &p, &l);
-                    if (idx < c)
-                        __hip_atomic_store(&ans[idx], ((unsigned long long)(uint32_t)(int32_t)l << 32) | (uint32_t)(int32_t)p,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool live = idx < c;
+                    ms_search_one<IdxT>(old, n, sa, nw, m, live ? i + idx : 0, live, kAsCap, ptab, pk, &p, &l);
+                    if (live) {
+                        const int64_t j = i + idx;
+                        int64_t cw = 0;
+                        if (l > 0) {
+                            if (p - j == shift) cw = l;
+                            else for (int64_t k = j; k < j + l; ++k) cw += agree(k) ? 1 : 0;
+                        }
+                        publish(idx, p, l, cw);
+                    }
                 }
             }
+            lap(t_search);
             grid_barrier();
+            lap(t_wait);
             if (failed) break;
 
-            // ---- 1. prefix counts of agree() over the covered bytes [i, cover] ----
-            const int64_t cover = (i + c + kAsExtra) < m ? (i + c + kAsExtra) : m;
-            const int lc = (int)(cover - i);               // agp[0 .. lc]
+            // ---- 1. prefix counts of agree() over the window's positions ----
             {
+                const int lc = (int)c;
                 const int seg = (lc + kAsThreads - 1) / kAsThreads;
                 const int k0 = tid * seg < lc ? tid * seg : lc, k1 = (tid + 1) * seg < lc ? (tid + 1) * seg : lc;
+                uint32_t bits[(kAsMaxLaneWin / kAsThreads + 31) / 32] = {0};
                 uint32_t mine = 0;
-                for (int k = k0; k < k1; ++k) mine += agree(i + k) ? 1u : 0u;
+                for (int k = k0; k < k1; ++k) {
+                    const uint32_t a = agree(i + k) ? 1u : 0u;
+                    bits[(k - k0) >> 5] |= a << ((k - k0) & 31);
+                    mine += a;
+                }
                 const uint32_t incl = wave_incl_sum(mine);
                 if (lane == kWave - 1) w_u32[wv] = incl;
                 __syncthreads();
                 uint32_t run = incl - mine;
                 for (int q = 0; q < wv; ++q) run += w_u32[q];
-                for (int k = k0; k < k1; ++k) { agp[k] = (uint16_t)run; run += agree(i + k) ? 1u : 0u; }
+                for (int k = k0; k < k1; ++k) { agp[k] = (uint16_t)run; run += (bits[(k - k0) >> 5] >> ((k - k0) & 31)) & 1u; }
                 if (tid == 0) {                            // the total closes the array
                     uint32_t tot = 0;
                     for (int q = 0; q < kAsWaves; ++q) tot += w_u32[q];
@@ -202,41 +244,46 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 __syncthreads();
             }
 
-            // ---- 2. the positions, 256 at a time: stop rule, prefix maximum of the match ends, break test ----
-            int64_t Mrun = M;                              // M after the positions walked over so far in this window
+            // ---- 2. the positions, 256 at a time: prefix maximum of the match ends (with cnt(base, end)), break test ----
+            int64_t Mrun = M, Crun = C;                    // (M, cnt(base, M)) after the positions walked over so far
             int brk = -1, stp = -1;                        // window index of the first break / stop point
-            const int64_t Cbase = C, Mbase = M;
-            auto C_of = [&](int64_t Mj) -> int64_t {       // cnt(base, Mj) for Mj inside the coverage (or Mj == Mbase)
-                return Mj > Mbase ? Cbase + (int64_t)agp[Mj - i] - (int64_t)agp[Mbase - i] : Cbase;
-            };
+            int64_t b_pos = 0, b_len = 0, b_carried = 0;
             for (int ch = 0; ch * kAsThreads < c && brk < 0 && stp < 0; ++ch) {
                 const int t = ch * kAsThreads + tid;
                 const bool have = t < c;
-                int64_t l = 0, e = -1;
+                int64_t l = 0, p = 0, e = -1, ce = 0, Sj = 0;
                 bool stop = false;
                 if (have) {
-                    const unsigned long long v = __hip_atomic_load(&ans[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long v = __hip_atomic_load(&ans[2 * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long v2 = __hip_atomic_load(&ans[2 * t + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     l = (int64_t)(int32_t)(uint32_t)(v >> 32);
-                    const int64_t j = i + t;
+                    p = (int64_t)(int32_t)(uint32_t)v;
+                    Sj = S + (int64_t)agp[t];
                     if (l < 0) stop = true;
-                    else {
-                        e = j + l;
-                        if (e > Mbase && e > cover) stop = true;
-                    }
-                    if (stop) e = -1;
+                    else { e = i + t + l; ce = Sj + (int64_t)v2; }         // cnt(base, e) = cnt(base, j) + cnt(j, e)
                 }
-                // inclusive prefix maximum of e over the chunk, carried in from Mrun
-                int64_t pm = as_wave_incl_max(e);
-                if (lane == kWave - 1) w_i64[wv] = pm;
+                // inclusive prefix maximum of e over the chunk, carrying cnt(base, .) of the end that holds it
+                int64_t pe = e, pc = ce;
+#pragma unroll
+                for (int o = 1; o < kWave; o <<= 1) {
+                    const int64_t te = __shfl_up(pe, o, kWave), tc = __shfl_up(pc, o, kWave);
+                    if (lane >= o && te > pe) { pe = te; pc = tc; }
+                }
+                if (lane == kWave - 1) { w_e[wv] = pe; w_c[wv] = pc; }
                 __syncthreads();
-                int64_t carry = Mrun;
-                for (int q = 0; q < wv; ++q) carry = w_i64[q] > carry ? w_i64[q] : carry;
-                int64_t chunk_max = Mrun;
-                for (int q = 0; q < kAsWaves; ++q) chunk_max = w_i64[q] > chunk_max ? w_i64[q] : chunk_max;
-                pm = pm > carry ? pm : carry;              // M_j
+                int64_t ce_in = Mrun, cc_in = Crun;        // what comes in from the left of this wave
+                for (int q = 0; q < wv; ++q) if (w_e[q] > ce_in) { ce_in = w_e[q]; cc_in = w_c[q]; }
+                int64_t ch_e = Mrun, ch_c = Crun;          // ... and what the whole chunk leaves
+                for (int q = 0; q < kAsWaves; ++q) if (w_e[q] > ch_e) { ch_e = w_e[q]; ch_c = w_c[q]; }
+                // exclusive values (what the positions BEFORE this one left), then this position's own
+                int64_t xe = __shfl_up(pe, 1, kWave), xc = __shfl_up(pc, 1, kWave);
+                if (lane == 0 || xe <= ce_in) { xe = ce_in; xc = cc_in; }
+                int64_t Mj = xe, Cj = xc;
+                if (e > Mj) { Mj = e; Cj = ce; }
                 bool brk_here = false;
+                int64_t carried = 0;
                 if (have && !stop) {
-                    const int64_t carried = C_of(pm) - (S + (int64_t)agp[t]);
+                    carried = Cj - Sj;
                     brk_here = (l == carried && l != 0) || l > carried + 8;
                 }
                 int32_t fb = brk_here ? t : 0x7fffffff, fs = (have && stop) ? t : 0x7fffffff;
@@ -246,71 +293,56 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 __syncthreads();
                 int32_t b = 0x7fffffff, s2 = 0x7fffffff;
                 for (int q = 0; q < kAsWaves; ++q) { b = w_brk[q] < b ? w_brk[q] : b; s2 = w_stp[q] < s2 ? w_stp[q] : s2; }
-                __syncthreads();                           // (w_* are reused by the next chunk)
                 if (b < s2) brk = b;
                 else if (s2 != 0x7fffffff) stp = s2;
-                if (brk < 0 && stp < 0) Mrun = chunk_max;
+                if (brk < 0 && stp < 0) { Mrun = ch_e; Crun = ch_c; }
                 else {
-                    // M after the positions BEFORE the break / stop point: the prefix maximum just in front of it
+                    // the thread that holds the break / stop point hands over what lay before it (and, for a break, its answer)
                     const int at = brk >= 0 ? brk : stp;
-                    const int owner = at - ch * kAsThreads;          // thread of this chunk that holds it
-                    // (its own e is not part of what lies before it: take the exclusive value)
-                    int64_t excl = as_wave_incl_max(e);
-                    excl = __shfl_up(excl, 1, kWave);
-                    if (lane == 0) excl = -1;
-                    excl = excl > carry ? excl : carry;
-                    if (tid == owner) s_pos = excl;
+                    if (t == at) { s_v[0] = xe; s_v[1] = xc; s_v[2] = (p << 32) | (l & 0xffffffffll); s_v[3] = carried; }
                     __syncthreads();
-                    Mrun = s_pos;
-                    __syncthreads();
+                    Mrun = s_v[0]; Crun = s_v[1];
+                    b_pos = s_v[2] >> 32; b_len = (int64_t)(int32_t)(uint32_t)s_v[2]; b_carried = s_v[3];
                 }
+                __syncthreads();                           // (w_* and s_v are reused)
             }
 
+            lap(t_eval);
             if (brk >= 0) {
-                const unsigned long long v = __hip_atomic_load(&ans[brk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int64_t l = (int64_t)(int32_t)(uint32_t)(v >> 32), p = (int64_t)(int32_t)(uint32_t)v;
                 const int64_t j = i + brk;
-                int64_t Mj = Mrun;
-                if (j + l > Mj) Mj = j + l;
-                carried_at = C_of(Mj) - (S + (int64_t)agp[brk]);
                 n_search += (unsigned long long)(j - base + 1);
-                cursor = j; hit_pos = p; hit_len = l;
+                cursor = j; hit_pos = b_pos; hit_len = b_len; carried_at = b_carried;
                 found = true;
                 break;
             }
             if (stp < 0) {                                 // the whole window went by
-                const unsigned long long v = __hip_atomic_load(&ans[c - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long v = __hip_atomic_load(&ans[2 * (c - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 last_len = (int64_t)(int32_t)(uint32_t)(v >> 32);
                 last_pos = (int64_t)(int32_t)(uint32_t)v;
                 any_search = true;
-                C = C_of(Mrun);
-                M = Mrun;
+                M = Mrun; C = Crun;
                 S += (int64_t)agp[c];
                 i += c;
-                lane_mode = true;                          // a long differing stretch: one position per lane from here on
+                // a long differing stretch: after kAsWaveWins windows of one position per wave, one per lane (an edit of a
+                // few hundred bytes is walked over by the cheaper wave windows; unrelated data by 8192 positions a step)
+                if (++passed >= kAsWaveWins) lane_mode = true;
             } else {
-                // ---- 3. the stop point, on its own: exact answer, a count over its whole match ----
+                // ---- 3. the stop point, on its own: searched again without the cap (by the first wave of every workgroup) ----
                 ++n_stop;
                 const int64_t j = i + stp;
-                const unsigned long long v = __hip_atomic_load(&ans[stp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int64_t l = (int64_t)(int32_t)(uint32_t)(v >> 32), p = (int64_t)(int32_t)(uint32_t)v;
-                if (l < 0) {
-                    if (wv == 0) {
-                        int64_t p2 = 0, l2 = 0;
-                        ms_search_wave<IdxT>(old, n, sa, nw, m, j, 0, ptab, pk, &p2, &l2);
-                        if (lane == 0) { s_pos = p2; s_len = l2; }
-                    }
-                    __syncthreads();
-                    p = s_pos; l = s_len;
-                    __syncthreads();
+                if (wv == 0) {
+                    int64_t p2 = 0, l2 = 0;
+                    ms_search_wave<IdxT>(old, n, sa, nw, m, j, 0, ptab, pk, &p2, &l2);
+                    const int64_t cw2 = wave_cw(j, p2, l2);
+                    if (lane == 0) { s_v[0] = p2; s_v[1] = l2; s_v[2] = cw2; }
                 }
-                C = C_of(Mrun);
-                M = Mrun;
-                if (j + l > M) {
-                    C += count_agree(M, j + l);
-                    M = j + l;
-                }
+                __syncthreads();
+                const int64_t p = s_v[0], l = s_v[1], cw = s_v[2];
+                __syncthreads();
+                lap(t_stop);
                 const int64_t Sj = S + (int64_t)agp[stp];
+                M = Mrun; C = Crun;
+                if (j + l > M) { M = j + l; C = Sj + cw; }
                 const int64_t carried = C - Sj;
                 any_search = true;
                 last_pos = p; last_len = l;
@@ -324,6 +356,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 S = Sj + (agree(j) ? 1 : 0);
                 i = j + 1;
                 lane_mode = false;
+                passed = 0;
             }
             if (M < i) {                                   // (M >= i - 1 always: the last position walked over ends at or behind itself)
                 C += agree(M) ? 1 : 0;
@@ -340,7 +373,11 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
             emit = false;                                  // the old alignment explains it: keep scanning behind it
         }
         if (emit) {
-            if (blockIdx.x == 0 && tid == 0) { rec[2 * nrec] = cursor; rec[2 * nrec + 1] = hit_pos; }
+            // (the host works on the pairs while the scan goes on: it polls the slots in order; position and match
+            // travel in ONE 64-bit store, which is also the slot's "filled" mark -- no pair of values is ever ~0)
+            if (blockIdx.x == 0 && tid == 0)
+                __hip_atomic_store(&rec[nrec], ((unsigned long long)cursor << 32) | (unsigned long long)(uint32_t)hit_pos,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             ++nrec;
             shift = hit_pos - cursor;
         }
@@ -350,6 +387,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
         ctl->cursor = cursor; ctl->hit_len = hit_len; ctl->hit_pos = hit_pos; ctl->shift = shift;
         ctl->done = (!failed && cursor >= m) ? 1 : 0;
         ctl->searches = n_search; ctl->windows = n_win; ctl->stops = n_stop;
+        ctl->t_search = t_search; ctl->t_wait = t_wait; ctl->t_eval = t_eval; ctl->t_stop = t_stop;
     }
 }
 

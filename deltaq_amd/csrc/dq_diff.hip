@@ -403,50 +403,76 @@ void diff_index_drop(DiffIndex *ix)
 // (cursor, hit_pos) pair of every control triple; steps 2 and 3 run here on those pairs.  The list has room for
 // kAnchorRecs pairs per launch -- a new file that needs more (text with a short match every few bytes) continues from
 // the state the kernel left.
-constexpr int64_t kAnchorRecs = 1 << 18;
-constexpr size_t kAnchorScratch = 256 + (size_t)kAsLaneWin * 8 + (size_t)kAnchorRecs * 16;
+constexpr int64_t kAnchorRecs = 1 << 16;
+constexpr size_t kAnchorScratch = 256 + (size_t)kAsMaxLaneWin * 32;
+constexpr unsigned long long kAnchorPending = ~0ull;
 
-int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch, const uint8_t *nw, int64_t m,
-                   bsdiff::RawStreams &raw)
+// ring: kAnchorRecs words of pinned host memory the kernel writes the pairs into (one 64-bit store each) and this
+// thread reads while the kernel runs -- steps 2 and 3 of a triple overlap the device's search for the next anchors
+int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch, unsigned long long *ring, const uint8_t *nw,
+                   int64_t m, bsdiff::RawStreams &raw, bool *retry_on_host)
 {
+    *retry_on_host = false;
     AnchorCtl *d_ctl = reinterpret_cast<AnchorCtl *>(scratch);
     unsigned long long *d_ans = reinterpret_cast<unsigned long long *>(scratch + 256);
-    int64_t *d_rec = reinterpret_cast<int64_t *>(scratch + 256 + (size_t)kAsLaneWin * 8);
     static_assert(sizeof(AnchorCtl) <= 256, "control block");
     bsdiff::TripleEmitter em(ix.old, ix.n, nw, m, raw);
     AnchorCtl st{};
-    std::vector<int64_t> pairs;
     std::lock_guard<std::mutex> lk(c.mu);                 // (the device context's stream and pinned areas)
     int rc = init_ctx(c, ix.dev);
     if (rc != DQ_OK) return rc;
     AnchorCtl *h_up = reinterpret_cast<AnchorCtl *>(c.pinned + 512), *h_back = reinterpret_cast<AnchorCtl *>(c.pinned);
+    const bool trace = env("DQ_TRACE") != nullptr;
+    const int groups = env("DQ_SCAN_GROUPS") ? std::max(8, std::min(kAsMaxGroups, atoi(env("DQ_SCAN_GROUPS")))) : kAsGroups;
     for (;;) {
         Launcher L{c, c.stream, g_prof_on.load()};
         *h_up = AnchorCtl{};
         h_up->cursor = st.cursor; h_up->hit_len = st.hit_len; h_up->hit_pos = st.hit_pos; h_up->shift = st.shift;
+        for (int64_t k = 0; k < kAnchorRecs; ++k) ring[k] = kAnchorPending;
+        std::atomic_thread_fence(std::memory_order_seq_cst);
         HIP_TRY(hipMemcpyAsync(d_ctl, h_up, sizeof(AnchorCtl), hipMemcpyHostToDevice, c.stream));
         auto launch = [&]() -> int {
             LAUNCH(L, DQ_K_MATCH_SEARCH, m, m * 2,
-                   hipLaunchKernelGGL(anchor_scan_kernel<int32_t>, dim3(kAsGroups), dim3(kAsThreads), 0, c.stream,
+                   hipLaunchKernelGGL(anchor_scan_kernel<int32_t>, dim3(groups), dim3(kAsThreads), 0, c.stream,
                                       (const uint8_t *)ix.d_old, ix.n, (const int32_t *)ix.d_sa, (const uint8_t *)d_new, m,
-                                      (const int32_t *)ix.d_tab, ix.pk, d_ans, d_rec, kAnchorRecs, d_ctl));
+                                      (const int32_t *)ix.d_tab, ix.pk, d_ans, ring, kAnchorRecs, d_ctl));
             return DQ_OK;
         };
         rc = launch();
         if (rc != DQ_OK) { drop_pending(c, c.stream); return rc; }
         HIP_TRY(hipMemcpyAsync(h_back, d_ctl, sizeof(AnchorCtl), hipMemcpyDeviceToHost, c.stream));
+        // ---- the pairs as they come: slot k is filled once it no longer reads "pending" ----
+        int64_t taken = 0;
+        auto take_filled = [&]() -> bool {
+            const unsigned long long v = __atomic_load_n(&ring[taken], __ATOMIC_ACQUIRE);
+            if (v == kAnchorPending) return false;
+            em.take((int64_t)(v >> 32), (int64_t)(uint32_t)v);
+            ++taken;
+            return true;
+        };
+        for (uint32_t idle = 0;;) {
+            if (taken < kAnchorRecs && take_filled()) { idle = 0; continue; }
+            if ((++idle & 63u) != 0) continue;             // (a stream query costs more than a look at the slot)
+            const hipError_t q = hipStreamQuery(c.stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { drop_pending(c, c.stream); return fail(DQ_ERR_HIP, "anchor scan: stream query failed", q); }
+        }
         HIP_TRY(hipStreamSynchronize(c.stream));
         rc = flush_profile(c);
         if (rc != DQ_OK) return rc;
         st = *h_back;
-        if (st.error) return fail(DQ_ERR_HIP, "anchor scan: grid barrier timed out");
+        // (a workgroup of the persistent grid did not get onto the device in time -- a device kept full by other work:
+        // the caller runs the host loop over windows instead; nothing of this attempt is kept)
+        if (st.error) { *retry_on_host = true; return fail(DQ_ERR_HIP, "anchor scan: grid barrier timed out"); }
         const int64_t got = (int64_t)st.nrec;
-        if (got < 0 || got > kAnchorRecs) return fail(DQ_ERR_HIP, "anchor scan: bad record count");
-        if (got > 0) {
-            pairs.resize((size_t)got * 2);
-            HIP_TRY(hipMemcpy(pairs.data(), d_rec, (size_t)got * 16, hipMemcpyDeviceToHost));
-            bsdiff::scan_from_anchors(em, pairs.data(), got);
+        if (got < taken || got > kAnchorRecs) return fail(DQ_ERR_HIP, "anchor scan: bad record count");
+        while (taken < got) {                              // what the kernel wrote after the last look
+            if (!take_filled()) return fail(DQ_ERR_HIP, "anchor scan: a record slot was left unfilled");
         }
+        if (trace)
+            fprintf(stderr, "[dq] anchor scan launch: %llu windows, %llu stop points, %lld pairs; workgroup 0: search %.2f ms, barrier wait "
+                    "%.2f ms, evaluation %.2f ms, stop points %.2f ms\n", st.windows, st.stops, (long long)got, st.t_search * 1e-5,
+                    st.t_wait * 1e-5, st.t_eval * 1e-5, st.t_stop * 1e-5);
         raw.searches += (int64_t)st.searches;
         raw.windows += (int64_t)st.windows;
         raw.exact += (int64_t)st.stops;
@@ -488,14 +514,17 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
     HIP_TRY(hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice));
     stamp("new on device");
     // the anchor search of the scan loop on the device (default), or the host loop over windows of device answers
-    const bool device_scan = env("DQ_SCAN_DEVICE") ? atoi(env("DQ_SCAN_DEVICE")) != 0 : false;
+    const bool device_scan = env("DQ_SCAN_DEVICE") ? atoi(env("DQ_SCAN_DEVICE")) != 0 : true;
     if (device_scan) {
-        rc = scan_on_device(ix, c, d_new, d_new + b_new + 256, nw, m, raw);
+        bool retry_on_host = false;
+        static_assert(kDiffPinnedBytes >= (size_t)kAnchorRecs * 8, "the pinned window area holds the anchor ring");
+        rc = scan_on_device(ix, c, d_new, d_new + b_new + 256, reinterpret_cast<unsigned long long *>(pinned), nw, m, raw, &retry_on_host);
         stamp("scan (device)");
         if (trace)
-            fprintf(stderr, "[dq] device scan: %lld searches, %lld windows, %lld stop points, %zu triples\n", (long long)raw.searches,
-                    (long long)raw.windows, (long long)raw.exact, raw.ctrl.size() / 24);
-        return rc;
+            fprintf(stderr, "[dq] device scan: %lld searches, %lld windows, %lld stop points, %zu triples%s\n", (long long)raw.searches,
+                    (long long)raw.windows, (long long)raw.exact, raw.ctrl.size() / 24, retry_on_host ? " -- given up, host loop instead" : "");
+        if (!retry_on_host) return rc;
+        raw = bsdiff::RawStreams{};
     }
     SearchWindows win{ix.d_old, ix.d_sa, d_new, ix.n, m, dev};
     win.d_ptab = ix.d_tab;

@@ -53,8 +53,26 @@ __device__ __forceinline__ int64_t ms_wave_lcp(const uint8_t *a, int64_t la, con
 {
     const int lane = lane_id();
     const int64_t lim = la < lb ? la : lb;
-    // 2 KiB per step (four independent 512-byte slices in flight: a long match is a chain of dependent steps, and the
-    // scan-loop driver waits for it) while 12 more bytes exist beyond every lane's 8
+    // 4 KiB per step (eight independent 512-byte slices in flight: a long match is a chain of dependent steps, and the
+    // scan loop waits for it), then 2 KiB, while 12 more bytes exist beyond every lane's 8
+    while (k + 8 * 64 * 8 + 4 <= lim) {
+        uint64_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t j = k + u * 512 + 8 * lane;
+            x[u] = ms_load8(a + j) ^ ms_load8(b + j);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint64_t bad = __ballot(x[u] != 0);
+            if (bad) {
+                const int f = __builtin_ctzll(bad);
+                const uint64_t xf = ms_readlane64(x[u], f);
+                return k + u * 512 + 8 * f + (__builtin_ctzll(xf) >> 3);
+            }
+        }
+        k += 8 * 64 * 8;
+    }
     while (k + 4 * 64 * 8 + 4 <= lim) {
         uint64_t x[4];
 #pragma unroll

@@ -6,11 +6,11 @@ The reference's loop keeps two running numbers while it walks from `base` (the e
 (k + shift < n and old[k + shift] == new[k]) and  M_j = max(base, max_{k <= j} (k + len_k))  they satisfy, at the break
 test of position j,
         carried_j = #{ k in [j, M_j) : agree(k) } = cnt(base, M_j) - cnt(base, j),
-so the tests of a whole window of positions can be evaluated from two running sums -- C = cnt(base, M) and
-S = cnt(base, j) -- and a prefix count of agree() over the bytes the window covers.  A position whose answer is not
-exact yet (the search hit its cap) or whose match reaches beyond the covered bytes is a STOP POINT: the window is
-evaluated up to it, then it is taken on its own (exact search, a count over its whole match), and a new window starts
-behind it.  test_models_cpu.py checks the anchors this gives against a literal transcription of the loop and the
+and every search also reports cw_j = cnt(j, j + len_j), so that cnt(base, j + len_j) = S_j + cw_j with S_j = cnt(base, j)
+-- a prefix count over the window's positions.  The tests of a whole window are then a prefix maximum of the match
+ends that carries cnt(base, end), minus S_j.  A position whose answer is not exact yet (the search hit its cap) is a
+STOP POINT: the window is evaluated up to it, then it is searched again exactly and taken on its own, and a new
+window starts behind it.  test_models_cpu.py checks the anchors this gives against a literal transcription of the loop and the
 streams the product's emitter makes of them against the oracle's."""
 import numpy as np
 
@@ -43,10 +43,11 @@ def literal_anchors(old, new, pos, ln):
     return out
 
 
-def windowed_anchors(old, new, pos, ln, capped, w_first=8, w_next=32, extra=16, rng=None):
+def windowed_anchors(old, new, pos, ln, capped, w_first=8, w_next=32, extra=0, rng=None):
     """The kernel's evaluation.  capped(j) -> True: the window's answer for position j comes back undecided (len < 0)
     unless it is the window's first position; the exact answer (pos[j], ln[j]) is fetched when the position is taken on
-    its own.  Window sizes / coverage are parameters so that small inputs exercise every branch."""
+    its own.  Every answer comes with cw = cnt(j, j + len), counted by the wave that searched (`extra` is unused: the
+    first form of the kernel covered a few bytes behind the window instead)."""
     n, m = len(old), len(new)
     cursor = hit_pos = hit_len = shift = 0
     out = []
@@ -65,40 +66,31 @@ def windowed_anchors(old, new, pos, ln, capped, w_first=8, w_next=32, extra=16, 
         found = False
         first_window = True
         streak = 0                                         # stop points in a row that did not break
-        last = None                                        # last position searched (exact answer)
+        last = None                                        # last position walked over (exact answer)
         while i < m and not found:
             W = w_first if first_window else w_next
             first_window = False
             c = min(W, m - i)
             stats["windows"] += 1
-            cover = i + c + extra                          # prefix counts exist for [i, cover]
             agp = [0]
-            for k in range(i, min(cover, m) + 1):
-                agp.append(agp[-1] + (agree(k) if k < m else 0))
-            # agp[x - i] = cnt(i, x) for x in [i, min(cover, m)]; positions >= m never agree and are never asked for
-            lens = []
+            for k in range(i, i + c):
+                agp.append(agp[-1] + agree(k))             # agp[x] = cnt(i, i + x)
+            lens, cws = [], []
             for j in range(i, i + c):
                 exact = (j == i) or streak >= 2 or not capped(j)
-                lens.append(int(ln[j]) if exact else -1)
-            # ---- stop point: first capped position, or first match that raises M beyond the covered bytes ----
-            s = None
-            for t, l in enumerate(lens):
-                j = i + t
-                if l < 0 or (j + l > M and j + l > cover):
-                    s = t
-                    break
+                l = int(ln[j]) if exact else -1
+                lens.append(l)
+                cws.append(cnt(j, j + l) if l >= 0 else 0)
+            s = next((t for t, l in enumerate(lens) if l < 0), None)          # stop point: first capped position
             upto = c if s is None else s
-            # ---- positions before it: prefix maximum of the match ends, the two running sums, the break test ----
             f = None
             Mj, Cj = M, C
-            for t in range(upto):
+            for t in range(upto):                          # prefix maximum of the ends, carrying cnt(base, end)
                 j = i + t
-                e = j + lens[t]
-                if e > Mj:                                 # (both inside the coverage, or the stop rule would have fired)
-                    assert M <= cover and e <= cover
-                    Cj = C + agp[e - i] - agp[M - i]
-                    Mj = e
                 Sj = S + agp[t]
+                e = j + lens[t]
+                if e > Mj:
+                    Mj, Cj = e, Sj + cws[t]
                 carried = Cj - Sj
                 if (lens[t] == carried and lens[t] != 0) or lens[t] > carried + 8:
                     f = t
@@ -107,6 +99,11 @@ def windowed_anchors(old, new, pos, ln, capped, w_first=8, w_next=32, extra=16, 
                 cursor, hit_pos, hit_len, carried_at = i + f, int(pos[i + f]), lens[f], carried
                 found = True
                 break
+            # (what the positions before the stop point / the whole window left)
+            Mj, Cj = M, C
+            for t in range(upto):
+                if i + t + lens[t] > Mj:
+                    Mj, Cj = i + t + lens[t], S + agp[t] + cws[t]
             if s is None:                                  # the whole window went by
                 last = i + c - 1
                 S += agp[c]
@@ -117,11 +114,10 @@ def windowed_anchors(old, new, pos, ln, capped, w_first=8, w_next=32, extra=16, 
                 j = i + s
                 l = int(ln[j])                             # exact now
                 last = j
-                C, M = Cj, Mj                              # what the positions before it left
-                if j + l > M:
-                    C += cnt(M, j + l)
-                    M = j + l
                 Sj = S + agp[s]
+                C, M = Cj, Mj
+                if j + l > M:
+                    M, C = j + l, Sj + cnt(j, j + l)
                 carried = C - Sj
                 if (l == carried and l != 0) or l > carried + 8:
                     cursor, hit_pos, hit_len, carried_at = j, int(pos[j]), l, carried

@@ -49,6 +49,12 @@ while time.time() < t_end:
         with open(os.environ["STRESS_LOG"], "w") as f:
             f.write(repr(dict(count=count, n=n, m=int(new.size), t=round(time.time() - (t_end - budget), 1))) + "\n")
         np.save(os.environ["STRESS_LOG"] + ".old.npy", old); np.save(os.environ["STRESS_LOG"] + ".new.npy", new)
+    # (the device's anchor search with grids of several sizes, and the host loop over windows it falls back to)
+    os.environ.pop("DQ_SCAN_DEVICE", None); os.environ.pop("DQ_SCAN_GROUPS", None)
+    mode = int(rng.integers(0, 6))
+    if mode == 0: os.environ["DQ_SCAN_DEVICE"] = "0"
+    elif mode == 1: os.environ["DQ_SCAN_GROUPS"] = "8"
+    elif mode == 2: os.environ["DQ_SCAN_GROUPS"] = "64"
     t0 = time.time(); ctrl, diff, extra, st = Diff.Scan(old, new); t1 = time.time()
     sa = oracle.divsufsort(old)
     wc, wd, we, ns = oracle.bsdiff_scan(old, sa, new); t2 = time.time()

@@ -58,8 +58,16 @@ def pairs(oracle_mod):
     return out
 
 
-def test_raw_streams_equal_the_reference_loop(backend_lib, oracle_mod):
+# the anchor search of the scan loop runs on the device by default (dq_anchor_scan.h: one persistent launch per new
+# file); the host loop over windows of device answers stays as the path a starved launch falls back to
+SCAN_PATHS = [{}, {"DQ_SCAN_DEVICE": "0"}, {"DQ_SCAN_GROUPS": "8"}, {"DQ_SCAN_GROUPS": "64"}]
+
+
+@pytest.mark.parametrize("env", SCAN_PATHS, ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "device-scan")
+def test_raw_streams_equal_the_reference_loop(backend_lib, oracle_mod, monkeypatch, env):
     from deltaq_amd import Diff
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     for old, new in pairs(oracle_mod):
         ctrl, diff, extra, stats = Diff.Scan(old, new)
         sa = oracle_mod.divsufsort(old)
