@@ -89,10 +89,15 @@ __device__ long long *g_bkt_ts = nullptr;            // [ntiles][16]
 #define DQ_BKT_PHASE(i) do { } while (0)
 #endif
 
-template <typename IdxT>
+// kExt: every word comes with one more byte of key (E[i] belongs to W[i]; radix_rank_kernel's kTextPackedExt / kKeysExt
+// passes carried it along): it is appended to the word's low key bits, so the tile sorts by 8 more bits and the tie bits
+// mean "equal in all of them".  The bytes of a tile are fetched when the tile starts (not a tile ahead like the words:
+// the register file has no room for them), behind the zeroing of the bin table.
+template <typename IdxT, bool kExt = false>
 __global__ __launch_bounds__(kBktThreads, 4) void bucket_sort_kernel(
     const uint64_t *__restrict__ W, int ib, int lowbits, const int64_t *__restrict__ bounds, int64_t ntiles,
-    IdxT *__restrict__ SA, uint32_t *__restrict__ ebits, BucketFlags *__restrict__ flags)
+    IdxT *__restrict__ SA, uint32_t *__restrict__ ebits, BucketFlags *__restrict__ flags,
+    const uint8_t *__restrict__ E = nullptr)
 {
     constexpr int kBinsPerThread = kBktNB / kBktThreads;   // 24 sixteen-bit counters = 12 LDS words
     constexpr int kWords = kBinsPerThread / 2;
@@ -139,6 +144,17 @@ __global__ __launch_bounds__(kBktThreads, 4) void bucket_sort_kernel(
         const int64_t lo = lo_n;
         const uint32_t M = M_n;
         DQ_BKT_PHASE(0);
+        uint32_t ex[kExt ? kBktItems : 1];
+        if (kExt) {
+            const uint8_t *En = E + (M ? lo : 0);
+            const uint32_t last_ = M > 0 ? M - 1 : 0;
+#pragma unroll
+            for (int k = 0; k < kBktItems; ++k) {
+                const uint32_t e_ = (uint32_t)(k * kBktThreads) + tid;
+                ex[k] = En[e_ < last_ ? e_ : last_];
+            }
+        }
+        const int lowbits_t = kExt ? lowbits + 8 : lowbits;             // low key bits of the tile's keys
         // ---- this tile's words leave the fetch registers: key (relative to the tile's first bucket) and suffix ----
         if (tid == 0) { s_edge[0] = wd[0]; s_overflow = 0; }
         if (tid == kBktThreads - 1) s_edge[1] = wd[kBktItems - 1];          // (clamped loads: element M-1)
@@ -146,7 +162,7 @@ __global__ __launch_bounds__(kBktThreads, 4) void bucket_sort_kernel(
         __syncthreads();
         DQ_BKT_PHASE(1);
         const uint64_t kfirst = s_edge[0] >> bshift, klast = s_edge[1] >> bshift;
-        const uint64_t range = (klast - kfirst + 1) << lowbits;            // tile keys are < range
+        const uint64_t range = (klast - kfirst + 1) << lowbits_t;          // tile keys are < range
         // range << 6 must fit 32 bits
         const bool bad = M != 0 && range > (1ull << (32 - kBktArrBits));
         // bin = key * mult >> 32 < bins: mult <= bins * 2^32 / range.  (A float reciprocal is within 2^-22 of the
@@ -160,6 +176,7 @@ __global__ __launch_bounds__(kBktThreads, 4) void bucket_sort_kernel(
 #pragma unroll
         for (int k = 0; k < kBktItems; ++k) {
             key[k] = (uint32_t)((wd[k] >> ib) - kbase);
+            if (kExt) key[k] = (key[k] << 8) | ex[k];
             sufs[k * kBktThreads + tid] = (uint32_t)wd[k] & imask;          // read back by this same thread
         }
         // ---- request the next tile ----

@@ -210,7 +210,11 @@ struct OnesweepCtl {
 //             pair inside one digit run of the tile (atomic OR of the few set bits), plus the
 //             first and last word of each of the tile's digit runs in seam_tab so that
 //             tie_seam_kernel (dq_ties.h) can decide the pairs that straddle two tiles
-enum OnesweepMode { kPairs = 0, kText = 1, kTextPacked = 2, kKeys = 3, kKeysLast = 4, kKeysLastTies = 5 };
+// kTextPackedExt / kKeysExt: packed words as above PLUS one more byte of key per element in a value array (ValT =
+//             uint8_t): at n >= 2^30 a 64-bit word has room for 33 key bits beside the suffix, which leaves 22 % of
+//             2^31 random suffixes tied; 8 more bits, carried through the digit passes and used by the bucket pass as
+//             low key bits, leave 0.1 %
+enum OnesweepMode { kPairs = 0, kText = 1, kTextPacked = 2, kKeys = 3, kKeysLast = 4, kKeysLastTies = 5, kTextPackedExt = 6, kKeysExt = 7 };
 constexpr uint64_t kSeamEmpty = ~0ull;          // seam_tab marker: the tile has no key with this digit
 
 // developer instrumentation (tools/kbench): per-tile phase timestamps from thread 0
@@ -223,23 +227,25 @@ __device__ long long *g_phase_ts = nullptr;          // [ntiles][8]
 
 template <typename IdxT, typename StatusT, int kItems, int kMode, int kMinWaves, int kThreads = kBlock,
           bool kEarlyVals = false, bool kLdsMatch = true, int kExchRounds = 1, bool kAtomicBase = false,
-          bool kCoded = false>
+          bool kCoded = false, typename ValT = IdxT>
 __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
-    const uint64_t *__restrict__ kin, const IdxT *__restrict__ vin,
-    uint64_t *__restrict__ kout, IdxT *__restrict__ vout, int64_t m, int shift, int keybits, int ib,
+    const uint64_t *__restrict__ kin, const ValT *__restrict__ vin,
+    uint64_t *__restrict__ kout, ValT *__restrict__ vout, int64_t m, int shift, int keybits, int ib,
     const int64_t *__restrict__ digit_offset /*[256] for this pass*/,
     StatusT *__restrict__ status /*[ntiles][256]*/, OnesweepCtl *__restrict__ ctl,
     int64_t *__restrict__ sticky_error, uint32_t *__restrict__ ebits = nullptr,
     uint64_t *__restrict__ seam_tab /*[ntiles][256][2]*/ = nullptr,
     const uint16_t *__restrict__ codetab /*[256], kCoded*/ = nullptr)
 {
-    constexpr bool kFromText = (kMode == kText || kMode == kTextPacked);
+    constexpr bool kFromText = (kMode == kText || kMode == kTextPacked || kMode == kTextPackedExt);
+    constexpr bool kPackedText = (kMode == kTextPacked || kMode == kTextPackedExt);
     static_assert(!kCoded || kMode == kText, "coded keys: first pass of the pair sort only");
     // arrival-order ranking (below) only where digits are near-uniform -- packed words are chosen for random-like
     // text; a skewed digit would put hundreds of same-address LDS atomics of a tile in a row
-    constexpr bool kAtomicRank = kAtomicBase && kMode == kTextPacked;
+    constexpr bool kAtomicRank = kAtomicBase && kPackedText;
     constexpr bool kTies = (kMode == kKeysLastTies);
-    constexpr bool kHasVals = (kMode == kPairs || kMode == kText);
+    constexpr bool kHasVals = (kMode == kPairs || kMode == kText || kMode == kTextPackedExt || kMode == kKeysExt);
+    static_assert((kMode != kTextPackedExt && kMode != kKeysExt) || sizeof(ValT) == 1, "the extra key bits travel as bytes");
     static_assert(!kFromText || (kItems % 4) == 0, "text mode packs 4 suffixes per lane");
     static_assert(kThreads % kRadixSize == 0, "threads 0..255 own one digit each");
     constexpr int kWavesB = kThreads / kWave;
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     };
 
     uint64_t key[kItems];
+    ValT val[kItems];
     if (kFromText) {
         const uint32_t *t32 = reinterpret_cast<const uint32_t *>(kin);
         const int kshift = 64 - keybits;                      // key = leading `keybits` bits of the suffix
@@ -326,18 +333,21 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
                 const uint32_t w0 = t32[qd], w1 = t32[qd + 1], w2 = t32[qd + 2];
                 const uint64_t x = __builtin_bswap64((uint64_t)w0 | ((uint64_t)w1 << 32));
                 const uint64_t y = (uint64_t)__builtin_bswap32(w2) << 32;
-                key[4 * j + 0] = x >> kshift;
-                key[4 * j + 1] = ((x << 8) | (y >> 56)) >> kshift;
-                key[4 * j + 2] = ((x << 16) | (y >> 48)) >> kshift;
-                key[4 * j + 3] = ((x << 24) | (y >> 40)) >> kshift;
-                if (kMode == kTextPacked) {
+                const uint64_t x4[4] = {x, (x << 8) | (y >> 56), (x << 16) | (y >> 48), (x << 24) | (y >> 40)};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    key[4 * j + c] = x4[c] >> kshift;
+                    // (the 8 key bits behind the word's: kshift >= 8 on this path -- the word leaves them no room)
+                    if (kMode == kTextPackedExt) val[4 * j + c] = (ValT)((x4[c] >> (kshift - 8)) & 0xffu);
+                }
+                if (kPackedText) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         key[4 * j + c] = (key[4 * j + c] << ib) | (uint64_t)(base + e0 + c);
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) key[4 * j + c] = ~0ull;
+                for (int c = 0; c < 4; ++c) { key[4 * j + c] = ~0ull; if (kMode == kTextPackedExt) val[4 * j + c] = (ValT)0; }
             }
         }
     } else if (valid == kTileN) {
@@ -353,13 +363,12 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
 
     // values (suffix indices): synthesised, or loaded -- early (more bytes in flight, more
     // registers) or after the ranking loop
-    IdxT val[kItems];
     auto load_vals = [&]() {
-        if (!kHasVals) {
-            // packed words carry their suffix index
+        if (!kHasVals || kMode == kTextPackedExt) {
+            // packed words carry their suffix index (and the extra key byte was made with the key)
         } else if (kMode == kText) {
 #pragma unroll
-            for (int k = 0; k < kItems; ++k) val[k] = (IdxT)(base + elem(k));
+            for (int k = 0; k < kItems; ++k) val[k] = (ValT)(base + elem(k));
         } else if (valid == kTileN) {
 #pragma unroll
             for (int k = 0; k < kItems; ++k) val[k] = vin[base + wbase + k * kWave];
@@ -367,12 +376,12 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
 #pragma unroll
             for (int k = 0; k < kItems; ++k) {
                 const int e = wbase + k * kWave;
-                val[k] = e < valid ? vin[base + e] : (IdxT)0;
+                val[k] = e < valid ? vin[base + e] : (ValT)0;
             }
         }
     };
     if (kEarlyVals) load_vals();
-    if (kMode == kPairs) { asm volatile("" :: "v"(key[kItems - 1])); }
+    if (kMode == kPairs || kMode == kKeysExt) { asm volatile("" :: "v"(key[kItems - 1])); }
     DQ_PHASE(1);
 
     // ---- rank inside the wave.  peers(d) = lanes of this wave holding digit d in this round:
@@ -518,12 +527,12 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
         for (int k = r * (kItems / kExchRounds); k < (r + 1) * (kItems / kExchRounds); ++k)
             skey[k] = exch[k * kThreads + tid - r * kExchN];
     }
-    IdxT sval[kItems];
+    ValT sval[kItems];
     if (kHasVals) {
-        constexpr int kValN = kExchN * (int)(sizeof(uint64_t) / sizeof(IdxT));    // values per round
+        constexpr int kValN = kExchN * (int)(sizeof(uint64_t) / sizeof(ValT));    // values per round
         constexpr int kValRounds = kTileN / kValN > 0 ? kTileN / kValN : 1;
         constexpr int kValCap = kTileN / kValRounds;
-        IdxT *exv = reinterpret_cast<IdxT *>(exch);
+        ValT *exv = reinterpret_cast<ValT *>(exch);
 #pragma unroll
         for (int r = 0; r < kValRounds; ++r) {
             __syncthreads();
@@ -641,7 +650,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
                     if (hasprev) run_last[dp] = prev;
                 }
                 if (q == valid - 1) run_last[d] = skey[k];
-                vout[o] = (IdxT)(skey[k] & smask);
+                vout[o] = (ValT)(skey[k] & smask);
             }
         }
         __syncthreads();
@@ -658,7 +667,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
             const IdxT o = gofs[digit_of(skey[k], shift)] + (IdxT)q;
             kout[o] = skey[k];
             if (kHasVals) vout[o] = sval[k];
-            if (kMode == kKeysLast) vout[o] = (IdxT)(skey[k] & ((1ull << ib) - 1));
+            if (kMode == kKeysLast) vout[o] = (ValT)(skey[k] & ((1ull << ib) - 1));
         }
     }
     }

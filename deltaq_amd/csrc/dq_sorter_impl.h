@@ -126,17 +126,18 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
 // ranking, exchange, look-back, stores: ~17-22 us for the big tiles whatever their number -- 64 KiB ... 1 MiB of
 // text spend half their sort in these passes): they take 2048-key tiles (256 threads x 8), several per CU at once.
 template <typename IdxT, int kMode, bool kSmall = false> struct RankCfg {
-    static constexpr bool kWords = (kMode == kTextPacked || kMode == kKeys || kMode == kKeysLast || kMode == kKeysLastTies);
+    static constexpr bool kExtra = (kMode == kTextPackedExt || kMode == kKeysExt);          // words + one more key byte each
+    static constexpr bool kWords = (kMode == kTextPacked || kMode == kKeys || kMode == kKeysLast || kMode == kKeysLastTies || kExtra);
     // (a 1024-thread tile for the tie-recording last pass, whose runs are 4-byte SA entries, measured +18 %)
     static constexpr int kThreads = kSmall ? 256 : 512;
-    static constexpr int kItems = kSmall ? 8 : kWords ? 24 : (sizeof(IdxT) == 4 ? 20 : 16);
+    static constexpr int kItems = kSmall ? 8 : kExtra ? 20 : kWords ? 24 : (sizeof(IdxT) == 4 ? 20 : 16);
     static constexpr int kMinWaves = 2;
     static constexpr int kRounds = 2;
     // LDS match tables beat 8 ballots on near-uniform digits (words: -6%), but equal digits in a wave are
     // same-address LDS atomics: pair passes run on text-like (skewed) data and keep the ballots
     static constexpr bool kLdsMatch = kWords;
     // the first pass of a sort has no earlier order to keep: atomic cursors instead of the look-back
-    static constexpr bool kAtomicBase = (kMode == kTextPacked || kMode == kText);
+    static constexpr bool kAtomicBase = (kMode == kTextPacked || kMode == kText || kMode == kTextPackedExt);
 };
 
 // Zero the look-back state (ticket + status words) of ALL digit passes of one sort with a single
@@ -184,6 +185,33 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
                               (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1,
                               ebits, seam_tab, (const uint16_t *)w.codetab));
     return DQ_OK;
+}
+
+// a digit pass over packed words that travel with one more byte of key each (kTextPackedExt: made from the text; kKeysExt)
+template <typename IdxT, int kMode>
+int rank_pass_ext(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const uint8_t *ein, uint64_t *kout, uint8_t *eout,
+                  int64_t m, int pass, int ib, int shift, int keybits)
+{
+    static_assert(kMode == kTextPackedExt || kMode == kKeysExt, "extra-byte modes");
+    using Cfg = RankCfg<IdxT, kMode>;
+    constexpr int kTileN = Cfg::kThreads * Cfg::kItems;
+    const int64_t ntiles = (m + kTileN - 1) / kTileN;
+    char *area = w.ctl_status + (size_t)pass * w.ctl_status_stride;
+    OnesweepCtl *ctl = reinterpret_cast<OnesweepCtl *>(area);
+    auto go = [&](auto status_tag) -> int {
+        using StatusT = decltype(status_tag);
+        StatusT *status = reinterpret_cast<StatusT *>(area + 256);
+        if (256 + (size_t)ntiles * kRadixSize * sizeof(StatusT) > w.ctl_status_stride)
+            return fail(DQ_ERR_HIP, "status buffer too small");
+        LAUNCH(L, DQ_K_RADIX_RANK, m, m * (kMode == kTextPackedExt ? 1 + 8 + 1 : 18),
+               hipLaunchKernelGGL((radix_rank_kernel<IdxT, StatusT, Cfg::kItems, kMode, Cfg::kMinWaves, Cfg::kThreads, false,
+                                                     Cfg::kLdsMatch, Cfg::kRounds, Cfg::kAtomicBase, false, uint8_t>),
+                                  dim3((unsigned)ntiles), dim3(Cfg::kThreads), 0, L.st, kin, ein, kout, eout, m, shift, keybits, ib,
+                                  (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1,
+                                  (uint32_t *)nullptr, (uint64_t *)nullptr, (const uint16_t *)w.codetab));
+        return DQ_OK;
+    };
+    return m < (1ll << 30) ? go(uint32_t{}) : go(uint64_t{});
 }
 
 template <typename IdxT, int kMode, bool kCoded = false>
@@ -734,7 +762,8 @@ struct SuffixSorter {
             cmax = std::max(cmax, c.pinned[b]);
             if (c.pinned[b] > 0) { const double p = (double)c.pinned[b] / (double)n; h0 -= p * std::log2(p); }
         }
-        const int keybits = std::min(64 - ib, 36);
+        int keybits = std::min(64 - ib, 36);
+        if (const char *v = env("DQ_BUCKET_KEYBITS")) keybits = std::max(17, std::min(keybits, atoi(v)));      // (tests: few key bits on small inputs)
         if (!packed) {
             // Words were not chosen because too many suffixes would stay tied for the tie-bit path of the plain
             // passes (2 GiB of random bytes: 33 key bits leave 1/4 of them tied).  Those ties are shallow, which the
@@ -765,6 +794,15 @@ struct SuffixSorter {
         const int64_t X = std::min<int64_t>(((int64_t)need + 255) / 256 * 256, 5120);
         const int64_t C = kBktCap - X;
         const int lowbits = keybits - 8 * bbytes;
+        // One more byte of key beside every word (kTextPackedExt / kKeysExt passes, bucket_sort_kernel<kExt>) where the
+        // word's own key bits would leave more than a few per cent of the suffixes tied: 2 GiB of random bytes have 33
+        // bits beside the 31-bit suffix -- 22 % tied, 19 ms of direct comparisons behind one 64-byte sector each --
+        // and 41 with the byte (0.1 %).  The bytes live in the idle index buffer Va (two arrays of n).
+        // DQ_BUCKET_EXT = 0 | 1 overrides (tests: small inputs).
+        bool ext = !coded && keybits + 8 <= 56 && lowbits + 8 <= 18 &&
+                   (double)n * std::exp2(-(double)keybits * h0 / 8.0) > 0.02 && (size_t)2 * align_up((size_t)n) <= (size_t)(n + 2) * sizeof(IdxT);
+        if (const char *v = env("DQ_BUCKET_EXT")) ext = atoi(v) != 0 && keybits + 8 <= 56 && (size_t)2 * align_up((size_t)n) <= (size_t)(n + 2) * sizeof(IdxT);
+        uint8_t *E[2] = {reinterpret_cast<uint8_t *>(w.Va), reinterpret_cast<uint8_t *>(w.Va) + align_up((size_t)n)};
         const int64_t ntiles = (n + C - 1) / C;
         uint32_t *ebits = reinterpret_cast<uint32_t *>(w.Vb);                  // zeroed by onesweep_sort_text_prepare
         TieCounters *ctr = reinterpret_cast<TieCounters *>(w.totals + 6);     // zero since run()
@@ -774,15 +812,18 @@ struct SuffixSorter {
         hipLaunchKernelGGL(text_digit_offsets_kernel, dim3(bbytes), dim3(kBlock), 0, st,
                            (const int64_t *)w.bytehist, (const uint8_t *)w.text, n, bbytes, w.digit_offset);
         HIP_TRY(hipGetLastError());
-        int rc = rank_pass<IdxT, kTextPacked>(L, w, text64, (const IdxT *)nullptr, K[1], (IdxT *)nullptr, n, 0, kb, ib,
-                                             nullptr, nullptr, ib + lowbits, keybits);
+        int rc = ext ? rank_pass_ext<IdxT, kTextPackedExt>(L, w, text64, (const uint8_t *)nullptr, K[1], E[1], n, 0, ib, ib + lowbits, keybits)
+                     : rank_pass<IdxT, kTextPacked>(L, w, text64, (const IdxT *)nullptr, K[1], (IdxT *)nullptr, n, 0, kb, ib,
+                                                    nullptr, nullptr, ib + lowbits, keybits);
         if (rc != DQ_OK) return rc;
         for (int p = 1; p < bbytes; ++p) {                   // pass p reads buffer p & 1 and writes the other
-            rc = rank_pass<IdxT, kKeys>(L, w, K[p & 1], (const IdxT *)nullptr, K[(p & 1) ^ 1], (IdxT *)nullptr, n, p, kb, ib,
-                                        nullptr, nullptr, ib + lowbits + 8 * p, keybits);
+            rc = ext ? rank_pass_ext<IdxT, kKeysExt>(L, w, K[p & 1], E[p & 1], K[(p & 1) ^ 1], E[(p & 1) ^ 1], n, p, ib, ib + lowbits + 8 * p, keybits)
+                     : rank_pass<IdxT, kKeys>(L, w, K[p & 1], (const IdxT *)nullptr, K[(p & 1) ^ 1], (IdxT *)nullptr, n, p, kb, ib,
+                                              nullptr, nullptr, ib + lowbits + 8 * p, keybits);
             if (rc != DQ_OK) return rc;
         }
         uint64_t *Ks = K[bbytes & 1], *Kfree = K[(bbytes & 1) ^ 1];           // sorted words / the other buffer
+        const uint8_t *Es = E[bbytes & 1];
         LAUNCH(L, DQ_K_BUCKET_SORT, ntiles, ntiles * 16 * 8,
                hipLaunchKernelGGL(bucket_bounds_kernel, dim3((unsigned)((ntiles + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                                   st, (const uint64_t *)Ks, n, ib + lowbits, C, X, ntiles, w.bkt_bounds, flags));
@@ -790,13 +831,21 @@ struct SuffixSorter {
             int v = 0;
             c.ncu = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c.dev) == hipSuccess && v > 0 ? v : 256;
         }
-        LAUNCH(L, DQ_K_BUCKET_SORT, n, n * (8 + wb) + n / 8,                  // persistent: one workgroup per CU
-               hipLaunchKernelGGL(bucket_sort_kernel<IdxT>, dim3((unsigned)std::min<int64_t>(ntiles, c.ncu)),
-                                  dim3(kBktThreads), 0, st, (const uint64_t *)Ks, ib, lowbits,
-                                  (const int64_t *)w.bkt_bounds, ntiles, d_sa, ebits, flags));
+        if (ext) {
+            LAUNCH(L, DQ_K_BUCKET_SORT, n, n * (9 + wb) + n / 8,              // persistent: one workgroup per CU
+                   hipLaunchKernelGGL((bucket_sort_kernel<IdxT, true>), dim3((unsigned)std::min<int64_t>(ntiles, c.ncu)),
+                                      dim3(kBktThreads), 0, st, (const uint64_t *)Ks, ib, lowbits,
+                                      (const int64_t *)w.bkt_bounds, ntiles, d_sa, ebits, flags, Es));
+        } else {
+            LAUNCH(L, DQ_K_BUCKET_SORT, n, n * (8 + wb) + n / 8,              // persistent: one workgroup per CU
+                   hipLaunchKernelGGL((bucket_sort_kernel<IdxT, false>), dim3((unsigned)std::min<int64_t>(ntiles, c.ncu)),
+                                      dim3(kBktThreads), 0, st, (const uint64_t *)Ks, ib, lowbits,
+                                      (const int64_t *)w.bkt_bounds, ntiles, d_sa, ebits, flags, (const uint8_t *)nullptr));
+        }
+        if (ext && env("DQ_TRACE")) fprintf(stderr, "[dq] bucketed round 0 with %d + 8 key bits per suffix (n=%lld)\n", keybits, (long long)n);
         bool overflow = false;
         fin_cap = n / 8;
-        const int64_t hb = keybits / 8;                  // whole bytes the members of a tie group share
+        const int64_t hb = (keybits + (ext ? 8 : 0)) / 8;    // whole bytes the members of a tie group share
         rc = collect_ties<IdxT>(L, c, w, n, kb, ib, ebits, nullptr, (const IdxT *)d_sa, Kfree, w.Va, &m, &overflow,
                                 fin_cap, Ks, w.Vb, &fin_left, /*seams=*/false, hb);
         if (rc != DQ_OK) return rc;

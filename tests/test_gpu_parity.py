@@ -310,6 +310,25 @@ def test_bucketed_round0(ldss, oracle_mod, backend_lib, monkeypatch):
     assert _abi.profile_snapshot()["bucket_sort_kernel"]["launches"] == 2
     assert _abi.last_sort_info()["initial_active"] < 40_000                # ... and it did not fall back: 36-bit keys leave few ties
     assert np.array_equal(sa, oracle_mod.divsufsort(T))
+    # one more byte of key beside every word (what n >= 2^30 takes, where a word has room for 33 key bits only): forced
+    # on 16 MB with 26-bit words, with and without the byte -- the byte cuts the ties 256-fold
+    monkeypatch.setenv("DQ_BUCKET", "1")
+    monkeypatch.setenv("DQ_BUCKET_KEYBITS", "26")
+    T = rnd(16_000_001, 79)
+    T[2_000_000:2_004_000] = T[11_000_000:11_004_000]
+    ref = oracle_mod.divsufsort(T)
+    tied = {}
+    for ext in ("0", "1"):
+        monkeypatch.setenv("DQ_BUCKET_EXT", ext)
+        backend_lib.dq_profile_reset()
+        backend_lib.dq_profile_enable(1)
+        sa = ldss.Sort(T)
+        backend_lib.dq_profile_enable(0)
+        assert _abi.profile_snapshot()["bucket_sort_kernel"]["launches"] == 2, ext
+        tied[ext] = _abi.last_sort_info()["initial_active"]
+        assert np.array_equal(sa, ref), ext
+        assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), ref.astype(np.int64)), ext
+    assert tied["1"] * 50 < tied["0"], tied
 
 
 def structured_text(rng, n):
