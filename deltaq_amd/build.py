@@ -58,16 +58,32 @@ def _obj_stale(src: str) -> bool:
     return any((not os.path.exists(p)) or os.path.getmtime(p) > t for p in deps + [os.path.join(CSRC, src)])
 
 
+MANIFEST = os.path.join(HERE, "libdq_sufsort_hip.manifest")
+
+
+def _source_digest() -> str:
+    """sha256 over every file the library is built from (names and contents)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "dq_sufsort.h"))
+    for p in files:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+    """The library is current iff the manifest written beside it at build time names the sources as they are now.
+    (By content, not by time stamps: the GPU box gets a copy of the tree whose file times say nothing.)"""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(MANIFEST):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    if os.path.isdir(OBJ) and all(os.path.exists(_obj(s)) for s in SOURCES):
-        return any(_obj_stale(s) or os.path.getmtime(_obj(s)) > t for s in SOURCES)
-    # a snapshot that carries the library but not the objects (the GPU box): compare with every source
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
-    srcs.append(os.path.join(os.path.dirname(HERE), "include", "dq_sufsort.h"))
-    return any(os.path.getmtime(p) > t for p in srcs)
+    try:
+        return open(MANIFEST).read().strip() != _source_digest()
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -101,6 +117,9 @@ def _build_locked(force: bool, verbose: bool) -> str:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(MANIFEST + ".tmp", "w") as f:
+        f.write(_source_digest() + "\n")
+    os.replace(MANIFEST + ".tmp", MANIFEST)
     return LIB_PATH
 
 

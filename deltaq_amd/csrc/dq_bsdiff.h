@@ -178,8 +178,19 @@ struct TripleEmitter {
 
         // ---- 3. one control triple ----
         const size_t d0 = out.diff.size();
-        out.diff.resize(d0 + (size_t)fwd);
-        for (int64_t i = 0; i < fwd; ++i) out.diff[d0 + (size_t)i] = (uint8_t)(nw[prev.at + i] - old[prev.in_old + i]);
+        out.diff.resize(d0 + (size_t)fwd);                   // (zeros)
+        {
+            // new - old, byte by byte -- but the forward extension is mostly equal bytes (that is what made it the
+            // extension): whole words of them are left as the zeros they already are
+            uint8_t *dst = out.diff.data() + d0;
+            const uint8_t *a = nw + prev.at, *b = old + prev.in_old;
+            int64_t i = 0;
+            for (; i + 8 <= fwd; i += 8) {
+                if (load_u64(a + i) == load_u64(b + i)) continue;
+                for (int q = 0; q < 8; ++q) dst[i + q] = (uint8_t)(a[i + q] - b[i + q]);
+            }
+            for (; i < fwd; ++i) dst[i] = (uint8_t)(a[i] - b[i]);
+        }
         const int64_t gap = (cursor - back) - (prev.at + fwd);
         if (gap > 0) out.extra.insert(out.extra.end(), nw + prev.at + fwd, nw + prev.at + fwd + gap);
         emit_packed(fwd);
