@@ -309,6 +309,13 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
 
     uint64_t key[kItems];
     ValT val[kItems];
+    // (kTextPackedExt: the extra key bytes of a lane's 4 consecutive suffixes wait packed in one register -- one
+    // register each cost the text pass its second workgroup per CU: 142 VGPRs)
+    uint32_t vpack[kMode == kTextPackedExt ? kItems / 4 : 1];
+    auto val_of = [&](int k) -> ValT {
+        if (kMode == kTextPackedExt) return (ValT)((vpack[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        return val[k];
+    };
     if (kFromText) {
         const uint32_t *t32 = reinterpret_cast<const uint32_t *>(kin);
         const int kshift = 64 - keybits;                      // key = leading `keybits` bits of the suffix
@@ -334,11 +341,12 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
                 const uint64_t x = __builtin_bswap64((uint64_t)w0 | ((uint64_t)w1 << 32));
                 const uint64_t y = (uint64_t)__builtin_bswap32(w2) << 32;
                 const uint64_t x4[4] = {x, (x << 8) | (y >> 56), (x << 16) | (y >> 48), (x << 24) | (y >> 40)};
+                if (kMode == kTextPackedExt) vpack[j] = 0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     key[4 * j + c] = x4[c] >> kshift;
                     // (the 8 key bits behind the word's: kshift >= 8 on this path -- the word leaves them no room)
-                    if (kMode == kTextPackedExt) val[4 * j + c] = (ValT)((x4[c] >> (kshift - 8)) & 0xffu);
+                    if (kMode == kTextPackedExt) vpack[j] |= (uint32_t)((x4[c] >> (kshift - 8)) & 0xffu) << (8 * c);
                 }
                 if (kPackedText) {
 #pragma unroll
@@ -347,7 +355,8 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { key[4 * j + c] = ~0ull; if (kMode == kTextPackedExt) val[4 * j + c] = (ValT)0; }
+                for (int c = 0; c < 4; ++c) key[4 * j + c] = ~0ull;
+                if (kMode == kTextPackedExt) vpack[j] = 0;
             }
         }
     } else if (valid == kTileN) {
@@ -539,7 +548,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
 #pragma unroll
             for (int k = 0; k < kItems; ++k) {
                 const uint32_t p = pos[k] - (uint32_t)(r * kValCap);
-                if (p < (uint32_t)kValCap) exv[p] = val[k];
+                if (p < (uint32_t)kValCap) exv[p] = val_of(k);
             }
             __syncthreads();
 #pragma unroll
