@@ -39,7 +39,8 @@ constexpr int64_t kAsCap = 64;                            // comparison cap of t
 constexpr int kAsWaveWins = 3;                            // wave windows walked over before the lane windows take over
 
 struct AnchorCtl {
-    unsigned long long arrive;                            // grid barrier: arrivals so far
+    unsigned long long arrive;                            // (unused since the per-workgroup arrival words)
+    unsigned long long reserved;
     unsigned long long nrec;                              // (cursor, hit_pos) pairs written
     long long cursor, hit_len, hit_pos, shift;            // the loop's state at an anchor boundary (in and out)
     long long done;                                       // 1: the end of new has been reached and reported
@@ -100,8 +101,11 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     const IdxT *__restrict__ ptab, int pk,
     unsigned long long *__restrict__ ans /* [2][lane window][2]: len << 32 | pos, then cnt(j, j + len) */,
     unsigned long long *__restrict__ rec /* [rec_cap] in PINNED HOST memory: cursor << 32 | hit_pos, one store each */,
-    int64_t rec_cap, AnchorCtl *__restrict__ ctl)
+    int64_t rec_cap, AnchorCtl *__restrict__ ctl,
+    unsigned long long *__restrict__ arrived /* [gridDim.x], zeroed: windows whose answers workgroup w has published;
+                                               [kAsMaxGroups + w]: windows workgroup w has finished evaluating */)
 {
+    unsigned long long *finished = arrived + kAsMaxGroups;
     __shared__ uint16_t agp[kAsMaxLaneWin + 2];           // agp[x] = cnt(i, i + x), x = 0 .. c
     const int64_t kAsWaveWin = (int64_t)gridDim.x * kAsWaves;      // positions of a one-wave-per-position window
     const int64_t kAsLaneWin = kAsWaveWin * kWave;                 // ... of a one-lane-per-position window
@@ -115,7 +119,6 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     const int lane = lane_id();
     const int wv = tid >> 6;
     const int gwave = blockIdx.x * kAsWaves + wv;         // this wave's place in the grid
-    unsigned long long bar_target = 0;
 
     // ---- uniform state (every thread of every workgroup carries the same values) ----
     int64_t cursor = ctl->cursor, hit_len = ctl->hit_len, hit_pos = ctl->hit_pos, shift = ctl->shift;
@@ -137,28 +140,53 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
         return as_wave_count_equal(old + shift, n - shift, nw, m, j, upto);
     };
 
-    // Grid barrier.  Everything the workgroups exchange goes through agent-scope relaxed atomics (answers: stores /
-    // loads that bypass the non-coherent cache levels; the arrival counter), as in radix_rank_kernel's status words:
-    // no fences, so the read-only data (old, new, suffix array, prefix table) stays cached from window to window.
-    // The answers of a wave are complete (s_waitcnt in __syncthreads) before its workgroup's arrival is counted.
-    auto grid_barrier = [&]() {
-        __syncthreads();
-        bar_target += gridDim.x;
-        if (tid == 0) {
-            __hip_atomic_fetch_add(&ctl->arrive, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t spins = 0, bad = 0;
-            while (__hip_atomic_load(&ctl->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bar_target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24) || ((spins & 1023u) == 0 && __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    bad = 1;
-                    break;
-                }
+    // No grid-wide barrier.  A workgroup publishes its window-W answers, then sets arrived[w] = W + 1; an evaluator
+    // waits only for the workgroups that own the positions it is about to look at, 64 positions at a time in order --
+    // the loop usually breaks near the front of a window, the slowest of its 256 searches rarely lies there.  Two
+    // answer buffers are taken in turn, so nobody may publish window W before EVERYBODY is through with window W - 2:
+    // finished[w] counts the evaluations workgroup w has completed (a lagging barrier: it holds only a workgroup that is two windows
+    // ahead; one word per workgroup).  Progress: the workgroups at the smallest window index never wait for anybody behind them.
+    // Everything exchanged goes through agent-scope relaxed atomics (answers: stores / loads that bypass the
+    // non-coherent cache levels), as radix_rank_kernel's status words do: no fences, so the read-only data (old, new,
+    // suffix array, prefix table) stays cached from window to window.  A wave's answers are complete (s_waitcnt in
+    // __syncthreads) before its workgroup's arrival is published.
+    auto spin_until = [&](unsigned long long *word, unsigned long long target) -> bool {      // (one lane's wait)
+        uint32_t spins = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24) || ((spins & 1023u) == 0 && __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
             }
-            s_err = bad;
         }
+        return true;
+    };
+    // wait for the workgroups [w0, w1) to have published window `win_no`; called by the whole workgroup
+    auto await_groups = [&](int w0, int w1, unsigned long long win_no) {
+        if (tid == 0) s_err = 0;
+        __syncthreads();
+        if (tid < w1 - w0 && !spin_until(&arrived[w0 + tid], win_no + 1)) s_err = 1;
         __syncthreads();
         if (s_err) failed = true;
+    };
+    auto publish_arrival = [&](unsigned long long win_no) {
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&arrived[blockIdx.x], win_no + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // (every workgroup on its own word -- a sum over the workgroups says nothing: half of them two windows ahead
+    // would make it look as if everybody had finished one)
+    auto await_lagging = [&](unsigned long long win_no) {             // before publishing window win_no
+        if (win_no < 2) return;
+        if (tid == 0) s_err = 0;
+        __syncthreads();
+        if (tid < (int)gridDim.x && !spin_until(&finished[tid], win_no - 1)) s_err = 1;
+        __syncthreads();
+        if (s_err) failed = true;
+    };
+    unsigned long long n_finished = 0;
+    auto window_done = [&]() {
+        ++n_finished;
+        if (tid == 0) __hip_atomic_store(&finished[blockIdx.x], n_finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // (two answer buffers, taken in turn by the windows: a workgroup that is through with window k publishes window
     // k + 1 while a slower one still reads window k; nobody reaches window k + 2 before everybody has left window k)
@@ -168,6 +196,11 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
         __hip_atomic_store(&ans[2 * slot], ((unsigned long long)(uint32_t)(int32_t)l << 32) | (uint32_t)(int32_t)p,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ans[2 * slot + 1], (unsigned long long)cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The arrival word that follows (another address, written by another wave of the workgroup behind a barrier) must
+        // not become visible before these two: the wave waits here until its own stores have been performed.  (A
+        // workgroup-scope barrier alone does not wait for global stores -- seen as evaluators reading the answers of
+        // two windows ago: diverging workgroups, a wait that never ended, one wrong patch in 4 000.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     while (cursor < m && !failed) {
@@ -184,9 +217,13 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
         while (i < m && !found && !failed) {
             const int64_t win = lane_mode ? kAsLaneWin : kAsWaveWin;
             const int64_t c = (m - i) < win ? (m - i) : win;
+            const unsigned long long win_no = n_win;        // windows are numbered from 0, the same everywhere
             ans_w = ans + (size_t)(n_win & 1ull) * (2 * (size_t)kAsMaxLaneWin);
             unsigned long long *ans = ans_w;              // (shadows the parameter: this window's buffer)
             ++n_win;
+            await_lagging(win_no);
+            lap(t_wait);
+            if (failed) break;
             // ---- 0. the window's answers (and each match's own agree count), one position per wave or per lane ----
             if (!lane_mode) {
                 if (gwave < c) {
@@ -214,10 +251,8 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                     }
                 }
             }
+            publish_arrival(win_no);
             lap(t_search);
-            grid_barrier();
-            lap(t_wait);
-            if (failed) break;
 
             // ---- 1. prefix counts of agree() over the window's positions ----
             {
@@ -249,9 +284,17 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
             int64_t Mrun = M, Crun = C;                    // (M, cnt(base, M)) after the positions walked over so far
             int brk = -1, stp = -1;                        // window index of the first break / stop point
             int64_t b_pos = 0, b_len = 0, b_carried = 0;
-            for (int ch = 0; ch * kAsThreads < c && brk < 0 && stp < 0; ++ch) {
-                const int t = ch * kAsThreads + tid;
-                const bool have = t < c;
+            // (one-wave-per-position windows: 64 positions a step, the answers of 16 workgroups; one-lane-per-position
+            // windows: 256 positions a step, the answers of one workgroup)
+            const int span = lane_mode ? kAsThreads : kWave;
+            for (int ch = 0; (int64_t)ch * span < c && brk < 0 && stp < 0; ++ch) {
+                lap(t_eval);
+                if (lane_mode) await_groups(ch, ch + 1, win_no);
+                else await_groups(ch * (kWave / kAsWaves), (ch + 1) * (kWave / kAsWaves) < (int)gridDim.x ? (ch + 1) * (kWave / kAsWaves) : (int)gridDim.x, win_no);
+                lap(t_wait);
+                if (failed) break;
+                const int t = ch * span + tid;
+                const bool have = tid < span && t < c;
                 int64_t l = 0, p = 0, e = -1, ce = 0, Sj = 0;
                 bool stop = false;
                 if (have) {
@@ -309,11 +352,13 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
             }
 
             lap(t_eval);
+            if (failed) break;
             if (brk >= 0) {
                 const int64_t j = i + brk;
                 n_search += (unsigned long long)(j - base + 1);
                 cursor = j; hit_pos = b_pos; hit_len = b_len; carried_at = b_carried;
                 found = true;
+                window_done();
                 break;
             }
             if (stp < 0) {                                 // the whole window went by
@@ -321,6 +366,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 last_len = (int64_t)(int32_t)(uint32_t)(v >> 32);
                 last_pos = (int64_t)(int32_t)(uint32_t)v;
                 any_search = true;
+                window_done();
                 M = Mrun; C = Crun;
                 S += (int64_t)agp[c];
                 i += c;
@@ -329,6 +375,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 if (++passed >= kAsWaveWins) lane_mode = true;
             } else {
                 // ---- 3. the stop point, on its own: searched again without the cap (by the first wave of every workgroup) ----
+                window_done();                             // (nothing below reads the window's answers)
                 ++n_stop;
                 const int64_t j = i + stp;
                 if (wv == 0) {

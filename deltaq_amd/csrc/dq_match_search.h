@@ -27,6 +27,7 @@ namespace dq {
 
 constexpr int kMsThreads = 256;
 constexpr int kMsLaneBytes = 256;        // a lane compares this far on its own (8 bytes a step) before the wave takes over
+constexpr int kMsWaveLaneBytes = 64;     // ... in the one-query-per-wave search, whose caller waits for the slowest wave
 
 __device__ __forceinline__ uint64_t ms_readlane64(uint64_t v, int lane)
 {
@@ -300,9 +301,27 @@ __device__ __forceinline__ void ms_search_wave(const uint8_t *__restrict__ old, 
         bool more = false;
         *over = false;
         if (want) {
-            const int64_t stop = j + kMsLaneBytes < lim ? j + kMsLaneBytes : lim;
+            // A lane compares kMsWaveLaneBytes on its own -- one step of 32 bytes in flight together, then 8 at a time --
+            // before the wave takes the comparison over (512 bytes a step and more): the window the scan loop waits for
+            // is as slow as its slowest search, and that is the one position whose match goes on for kilobytes; a lane
+            // walking 256 bytes of it in 32 dependent steps cost more than the rest of the search.  With a cap, never
+            // beyond the cap.
+            const int64_t budget = (cap > 0 && cap < kMsWaveLaneBytes) ? cap : (int64_t)kMsWaveLaneBytes;
+            const int64_t stop = j + budget < lim ? j + budget : lim;
             bool diff = false;
-            while (j + 8 <= stop && j + 12 <= la && j + 12 <= lq) {
+            if (j + 32 <= stop && j + 36 <= la && j + 36 <= lq) {
+                uint64_t x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = ms_load8(a + j + 8 * u) ^ ms_load8(q + j + 8 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!diff) {
+                        if (x[u]) { j += __builtin_ctzll(x[u]) >> 3; diff = true; }
+                        else j += 8;
+                    }
+                }
+            }
+            while (!diff && j + 8 <= stop && j + 12 <= la && j + 12 <= lq) {
                 const uint64_t x = ms_load8(a + j) ^ ms_load8(q + j);
                 if (x) { j += __builtin_ctzll(x) >> 3; diff = true; break; }
                 j += 8;
