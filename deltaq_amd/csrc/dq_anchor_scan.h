@@ -19,8 +19,8 @@
 // the window counts up to it, then it is searched again exactly and taken on its own.
 //
 // Grid: G = kAsGroups workgroups of 4 waves, all resident.  A window's searches are dealt out one position per wave
-// (4 G = 256 positions; 65-ary search, dq_match_search.h) or, while the loop walks through a long differing stretch, one
-// per lane (256 G = 16384); the answers meet in device memory behind ONE grid barrier per window, and every workgroup then evaluates
+// (4 G = 512 positions; 65-ary search, dq_match_search.h) or, while the loop walks through a long differing stretch, one
+// per lane (256 G = 32768); the answers meet in device memory behind ONE grid barrier per window, and every workgroup then evaluates
 // the window on its own -- the same integer decisions everywhere, so no second exchange is needed.  The barrier is an
 // agent-scope counter (bounded spin, error flag); answers are agent-scope atomic stores / loads (the L2s of the 8 XCDs
 // are not coherent with each other).
@@ -31,9 +31,10 @@ namespace dq {
 
 constexpr int kAsThreads = 256;
 constexpr int kAsWaves = kAsThreads / kWave;
-constexpr int kAsGroups = 64;                             // workgroups of the persistent grid (DQ_SCAN_GROUPS: 8 .. kAsMaxGroups;
-                                                          // measured on 16 MiB pairs with 2000 edits: 16 / 32 / 64 groups = 86 / 63 / 58 ms of kernel)
-constexpr int kAsMaxGroups = 64;
+constexpr int kAsGroups = 128;                            // workgroups of the persistent grid (DQ_SCAN_GROUPS: 8 .. kAsMaxGroups;
+                                                          // Diff.Create of 16 MiB random / text pairs with 2000 edits:
+                                                          // 64 groups 59 / 94 ms, 96: 57 / 92, 128: 55 / 92)
+constexpr int kAsMaxGroups = 128;
 constexpr int kAsMaxLaneWin = kAsMaxGroups * kAsWaves * kWave;   // positions of the largest one-lane-per-position window
 constexpr int64_t kAsCap = 64;                            // comparison cap of the speculative positions
 constexpr int kAsWaveWins = 3;                            // wave windows walked over before the lane windows take over

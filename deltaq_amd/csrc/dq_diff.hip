@@ -404,7 +404,7 @@ void diff_index_drop(DiffIndex *ix)
 // kAnchorRecs pairs per launch -- a new file that needs more (text with a short match every few bytes) continues from
 // the state the kernel left.
 constexpr int64_t kAnchorRecs = 1 << 16;
-constexpr size_t kAnchorScratch = 256 + 1024 + (size_t)kAsMaxLaneWin * 32;
+constexpr size_t kAnchorScratch = 256 + 2048 + (size_t)kAsMaxLaneWin * 32;
 constexpr unsigned long long kAnchorPending = ~0ull;
 
 // ring: kAnchorRecs words of pinned host memory the kernel writes the pairs into (one 64-bit store each) and this
@@ -415,8 +415,8 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
     *retry_on_host = false;
     AnchorCtl *d_ctl = reinterpret_cast<AnchorCtl *>(scratch);
     unsigned long long *d_arrived = reinterpret_cast<unsigned long long *>(scratch + 256);       // [kAsMaxGroups]
-    static_assert(2 * kAsMaxGroups * 8 <= 1024, "arrival + completion words");
-    unsigned long long *d_ans = reinterpret_cast<unsigned long long *>(scratch + 256 + 1024);
+    static_assert(2 * kAsMaxGroups * 8 <= 2048, "arrival + completion words");
+    unsigned long long *d_ans = reinterpret_cast<unsigned long long *>(scratch + 256 + 2048);
     static_assert(sizeof(AnchorCtl) <= 256, "control block");
     bsdiff::TripleEmitter em(ix.old, ix.n, nw, m, raw);
     AnchorCtl st{};
@@ -433,7 +433,7 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         for (int64_t k = 0; k < kAnchorRecs; ++k) ring[k] = kAnchorPending;
         std::atomic_thread_fence(std::memory_order_seq_cst);
         HIP_TRY(hipMemcpyAsync(d_ctl, h_up, sizeof(AnchorCtl), hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(hipMemsetAsync(d_arrived, 0, 1024, c.stream));
+        HIP_TRY(hipMemsetAsync(d_arrived, 0, 2048, c.stream));
         auto launch = [&]() -> int {
             LAUNCH(L, DQ_K_MATCH_SEARCH, m, m * 2,
                    hipLaunchKernelGGL(anchor_scan_kernel<int32_t>, dim3(groups), dim3(kAsThreads), 0, c.stream,

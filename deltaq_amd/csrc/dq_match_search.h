@@ -55,7 +55,8 @@ __device__ __forceinline__ int64_t ms_wave_lcp(const uint8_t *a, int64_t la, con
     const int lane = lane_id();
     const int64_t lim = la < lb ? la : lb;
     // 4 KiB per step (eight independent 512-byte slices in flight: a long match is a chain of dependent steps, and the
-    // scan loop waits for it), then 2 KiB, while 12 more bytes exist beyond every lane's 8
+    // scan loop waits for it), then 2 KiB, while 12 more bytes exist beyond every lane's 8.  (Sixteen slices were
+    // measured: the wave search spills, every window twice as slow.)
     while (k + 8 * 64 * 8 + 4 <= lim) {
         uint64_t x[8];
 #pragma unroll

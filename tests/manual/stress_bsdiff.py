@@ -54,7 +54,7 @@ while time.time() < t_end:
     mode = int(rng.integers(0, 6))
     if mode == 0: os.environ["DQ_SCAN_DEVICE"] = "0"
     elif mode == 1: os.environ["DQ_SCAN_GROUPS"] = "8"
-    elif mode == 2: os.environ["DQ_SCAN_GROUPS"] = "64"
+    elif mode == 2: os.environ["DQ_SCAN_GROUPS"] = "48"
     t0 = time.time(); ctrl, diff, extra, st = Diff.Scan(old, new); t1 = time.time()
     sa = oracle.divsufsort(old)
     wc, wd, we, ns = oracle.bsdiff_scan(old, sa, new); t2 = time.time()

@@ -60,7 +60,7 @@ def pairs(oracle_mod):
 
 # the anchor search of the scan loop runs on the device by default (dq_anchor_scan.h: one persistent launch per new
 # file); the host loop over windows of device answers stays as the path a starved launch falls back to
-SCAN_PATHS = [{}, {"DQ_SCAN_DEVICE": "0"}, {"DQ_SCAN_GROUPS": "8"}, {"DQ_SCAN_GROUPS": "64"}]
+SCAN_PATHS = [{}, {"DQ_SCAN_DEVICE": "0"}, {"DQ_SCAN_GROUPS": "8"}, {"DQ_SCAN_GROUPS": "48"}]
 
 
 @pytest.mark.parametrize("env", SCAN_PATHS, ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "device-scan")
