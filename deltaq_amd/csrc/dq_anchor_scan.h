@@ -20,10 +20,11 @@
 //
 // Grid: G = kAsGroups workgroups of 4 waves, all resident.  A window's searches are dealt out one position per wave
 // (4 G = 512 positions; 65-ary search, dq_match_search.h) or, while the loop walks through a long differing stretch, one
-// per lane (256 G = 32768); the answers meet in device memory behind ONE grid barrier per window, and every workgroup then evaluates
-// the window on its own -- the same integer decisions everywhere, so no second exchange is needed.  The barrier is an
-// agent-scope counter (bounded spin, error flag); answers are agent-scope atomic stores / loads (the L2s of the 8 XCDs
-// are not coherent with each other).
+// per lane (256 G = 32768).  The answers meet in device memory; every workgroup evaluates the window on its own -- the
+// same integer decisions everywhere, so nothing but the answers is exchanged -- 64 positions at a time, as the
+// workgroups that own them report their arrival (no grid-wide barrier; a lagging barrier of one window keeps the two
+// answer buffers apart).  Every exchanged word is an agent-scope atomic (the L2s of the 8 XCDs are not coherent with
+// each other); every spin is bounded and ends in an error flag, on which the host falls back to its own loop.
 #pragma once
 #include "dq_match_search.h"
 
@@ -40,15 +41,14 @@ constexpr int64_t kAsCap = 64;                            // comparison cap of t
 constexpr int kAsWaveWins = 3;                            // wave windows walked over before the lane windows take over
 
 struct AnchorCtl {
-    unsigned long long arrive;                            // (unused since the per-workgroup arrival words)
-    unsigned long long reserved;
     unsigned long long nrec;                              // (cursor, hit_pos) pairs written
     long long cursor, hit_len, hit_pos, shift;            // the loop's state at an anchor boundary (in and out)
     long long done;                                       // 1: the end of new has been reached and reported
     unsigned long long searches, windows, stops;          // Search calls the reference's loop makes; windows; stop points
     unsigned int error;                                   // 1: the barrier timed out
     unsigned int pad;
-    unsigned long long t_search, t_wait, t_eval, t_stop;  // workgroup 0's time per phase, in 100 MHz ticks (DQ_TRACE prints them)
+    unsigned long long t_search, t_wait, t_eval, t_stop;  // workgroup 0's time searching / waiting for answers / evaluating /
+                                                          // at stop points, in 100 MHz ticks (DQ_TRACE prints them)
 };
 
 template <typename T>

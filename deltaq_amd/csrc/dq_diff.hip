@@ -473,7 +473,7 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
             if (!take_filled()) return fail(DQ_ERR_HIP, "anchor scan: a record slot was left unfilled");
         }
         if (trace)
-            fprintf(stderr, "[dq] anchor scan launch: %llu windows, %llu stop points, %lld pairs; workgroup 0: search %.2f ms, barrier wait "
+            fprintf(stderr, "[dq] anchor scan launch: %llu windows, %llu stop points, %lld pairs; workgroup 0: search %.2f ms, waiting for answers "
                     "%.2f ms, evaluation %.2f ms, stop points %.2f ms\n", st.windows, st.stops, (long long)got, st.t_search * 1e-5,
                     st.t_wait * 1e-5, st.t_eval * 1e-5, st.t_stop * 1e-5);
         raw.searches += (int64_t)st.searches;
