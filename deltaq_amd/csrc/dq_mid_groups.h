@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
             bool keyed = false;
             if (RL) {
                 const uint32_t r = RL[s[k]];
-                if (run_order) { k2[k] = (int64_t)r >= h ? (ElemT)run_order_key(text, n, (int64_t)s[k], r) : (ElemT)0; keyed = true; }
+                if (run_order) { k2[k] = (int64_t)r >= h ? (ElemT)run_order_key(text, n, (int64_t)s[k], r, run_order) : (ElemT)0; keyed = true; }
                 else if ((int64_t)r > h) off = (int64_t)r;
             }
             if (!keyed) {

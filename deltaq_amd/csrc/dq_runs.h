@@ -31,11 +31,13 @@ constexpr int kRunThreads = 256;
 constexpr int kRunPer = kRunChunk / kRunThreads;     // 16 bytes per thread
 constexpr int kRunScanThreads = 1024;
 
-// key2 of the run-order round for a suffix s that starts with r >= h bytes c (r = RL[s])
-__device__ __forceinline__ uint32_t run_order_key(const uint8_t *__restrict__ text, int64_t n, int64_t s, uint32_t r)
+// key2 of the run-order round for a suffix s that starts with r >= h bytes c (r = RL[s]).  With a period p > 1 (the late
+// run rounds, see below) the "run" is a stretch that repeats itself every p bytes, r its length, and the byte that ends
+// it is compared with the byte the repetition would have put there: text[e - p] (p = 1: any byte of the run).
+__device__ __forceinline__ uint32_t run_order_key(const uint8_t *__restrict__ text, int64_t n, int64_t s, uint32_t r, int period = 1)
 {
     const int64_t e = s + (int64_t)r;
-    const bool down = e >= n || text[e] < text[s];            // the end of the text sorts before every byte
+    const bool down = e >= n || text[e] < text[e - period];   // the end of the text sorts before every byte
     return down ? r : (0x80000000u | (0x7fffffffu - r));
 }
 
@@ -59,10 +61,14 @@ __device__ __forceinline__ void affine_rscan(uint32_t *a, uint8_t *open, int t)
 // pass 1 (kFinal = false): per chunk, lead[c] = run length at the chunk's first byte counted inside the chunk,
 //         link[c] = the run reaches the chunk's end AND the text goes on with the same byte
 // pass 3 (kFinal = true):  RL[i] for every position, with carry[c + 1] = true run length at the first byte of the next chunk
+// period p (1 for runs of one byte): position x is LINKED to x + 1 iff text[x] == text[x + p] (and x + p < n); a run is a
+// maximal chain of links, its length in positions r, and what is stored is how far the text goes on repeating itself
+// from there: RL = min(r - 1 + p, n - position).  For p = 1 that is the number of equal bytes, as before.
 template <bool kFinal>
 __global__ __launch_bounds__(kRunThreads) void runlen_chunk_kernel(const uint8_t *__restrict__ text, int64_t n,
                                                                    uint32_t *__restrict__ lead, uint8_t *__restrict__ link,
-                                                                   const uint32_t *__restrict__ carry, uint32_t *__restrict__ RL)
+                                                                   const uint32_t *__restrict__ carry, uint32_t *__restrict__ RL,
+                                                                   int period = 1)
 {
     __shared__ uint32_t s_a[kRunThreads];
     __shared__ uint8_t s_open[kRunThreads];
@@ -70,23 +76,25 @@ __global__ __launch_bounds__(kRunThreads) void runlen_chunk_kernel(const uint8_t
     const int64_t c0 = (int64_t)blockIdx.x * kRunChunk;
     const int64_t end = c0 + kRunChunk < n ? c0 + kRunChunk : n;           // chunk = [c0, end)
     const int64_t p0 = c0 + (int64_t)t * kRunPer;
-    uint8_t b[kRunPer + 1];
+    auto linked = [&](int64_t x) -> bool { return x + period < n && text[x] == text[x + period]; };
+    bool e[kRunPer];                                                      // e[i]: position p0 + i is linked to the next one
 #pragma unroll
-    for (int i = 0; i <= kRunPer; ++i) b[i] = p0 + i < n ? text[p0 + i] : 0;  // (+1: the byte behind my segment)
+    for (int i = 0; i < kRunPer; ++i) e[i] = linked(p0 + i);
+    const bool end_linked = end < n && linked(end - 1);                    // the chunk's last position, to the next chunk
     // run lengths inside my segment, from the right; a position beyond `end` counts as a break
     uint32_t in[kRunPer];
     uint32_t run = 0;
 #pragma unroll
     for (int i = kRunPer - 1; i >= 0; --i) {
         const bool valid = p0 + i < end;
-        const bool cont = valid && i + 1 < kRunPer && p0 + i + 1 < end && b[i + 1] == b[i];
+        const bool cont = valid && i + 1 < kRunPer && p0 + i + 1 < end && e[i];
         run = valid ? (cont ? run + 1 : 1) : 0;
         in[i] = run;
     }
-    // my segment's map: its leading run, open iff that run covers the whole segment and the next segment (inside
-    // the chunk) starts with the same byte
+    // my segment's map: its leading run, open iff that run covers the whole segment and is linked to the next segment
+    // (inside the chunk)
     const int64_t seg_end = p0 + kRunPer;
-    const bool full = p0 < end && in[0] == (uint32_t)kRunPer && seg_end < end && b[kRunPer] == b[0];
+    const bool full = p0 < end && in[0] == (uint32_t)kRunPer && seg_end < end && e[kRunPer - 1];
     s_a[t] = p0 < end ? in[0] : 0;
     s_open[t] = full ? 1 : 0;
     __syncthreads();
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(kRunThreads) void runlen_chunk_kernel(const uint8_t
     if (!kFinal) {
         if (t == 0) {
             lead[blockIdx.x] = s_a[0];
-            link[blockIdx.x] = (c0 + (int64_t)s_a[0] == end && end < n && text[end] == b[0]) ? 1 : 0;
+            link[blockIdx.x] = (c0 + (int64_t)s_a[0] == end && end_linked) ? 1 : 0;
         }
         return;
     }
@@ -107,10 +115,11 @@ __global__ __launch_bounds__(kRunThreads) void runlen_chunk_kernel(const uint8_t
         if (p >= end) break;
         uint32_t r = in[i];
         // the run reaches my segment's end and goes on in the next segment (same chunk)?
-        if (i + (int)r == kRunPer && seg_end < end && b[kRunPer] == b[i]) r += next_seg;
+        if (i + (int)r == kRunPer && seg_end < end && e[kRunPer - 1]) r += next_seg;
         // ... reaches the chunk's end and goes on in the next chunk?
-        if (p + (int64_t)r == end && end < n && text[end] == b[i]) r += next_chunk;
-        RL[p] = r;
+        if (p + (int64_t)r == end && end_linked) r += next_chunk;
+        const int64_t far = (int64_t)r - 1 + period, left = n - p;
+        RL[p] = (uint32_t)(far < left ? far : left);
     }
 }
 

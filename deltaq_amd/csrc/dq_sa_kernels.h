@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kBlock) void gather_key2_kernel(uint64_t *__restric
             // a suffix that starts with a run of >= h equal bytes: the run's own order (run-order round), or the rank
             // behind the run (every later round); the text ending behind the run sorts first
             const uint32_t r = RL[s];
-            if (run_order) { k2 = (int64_t)r >= h ? (uint64_t)run_order_key(text, n, s, r) : 0ull; keyed = true; }
+            if (run_order) { k2 = (int64_t)r >= h ? (uint64_t)run_order_key(text, n, s, r, run_order) : 0ull; keyed = true; }
             else if ((int64_t)r > h) off = (int64_t)r;
         }
         if (!keyed) {

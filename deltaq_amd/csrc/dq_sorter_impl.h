@@ -568,7 +568,7 @@ struct SuffixSorter {
     // getting fewer -- a run of L bytes keeps ~L - h of its suffixes in one group for log2(L / h) rounds.  The run
     // lengths and the run-order round are then paid at that point, on the list as it is by then (libtorch_cpu.so:
     // one 5.5 MB run of 'X' among 128 MiB kept 16 rounds of 8 radix passes over ~6 M entries alive).
-    bool long_run_seen = false, runs_late_tried = false;
+    bool long_run_seen = false, late_runs_possible = false, runs_late_tried = false;
     int64_t last_large = -1, prev_large = -1;
     int run_order = 0;                  // 1 while the run-order round is being launched
     const uint32_t *rl() const { return runs_on ? w.RL : nullptr; }
@@ -893,7 +893,10 @@ struct SuffixSorter {
         // code repeated for several targets, not runs: 5-20 % slower with it.  1/16 of the text in 16-byte chunks of one value)
         runs_wanted = sizeof(IdxT) == 4 && c.pinned[256 + 8] != 0 && n >= (1 << 16) && c.pinned[256 + 9] * 16 * 16 >= n;
         long_run_seen = sizeof(IdxT) == 4 && c.pinned[256 + 8] != 0 && n >= (1 << 16);
-        if (const char *v = env("DQ_RUNS")) { runs_wanted = sizeof(IdxT) == 4 && atoi(v) != 0; long_run_seen = long_run_seen && atoi(v) != 0; }
+        // (the late rounds also take stretches that repeat with a period > 1, which the histogram pass does not see:
+        // large groups that stop shrinking are what calls them)
+        late_runs_possible = sizeof(IdxT) == 4 && n >= (1 << 16);
+        if (const char *v = env("DQ_RUNS")) { runs_wanted = sizeof(IdxT) == 4 && atoi(v) != 0; late_runs_possible = late_runs_possible && atoi(v) != 0; }
         if (const char *v = env("DQ_MID_GROUPS")) runs_wanted = runs_wanted && atoi(v) >= 256;   // (the LDS class carries the run offsets)
         V[kb & 1] = d_sa;
         V[(kb & 1) ^ 1] = w.Va;
@@ -1381,7 +1384,7 @@ struct SuffixSorter {
     }
 
     // RL[i] = number of equal bytes the text has from position i on (dq_runs.h): chunk pass, carry across chunks, final pass
-    int compute_run_lengths()
+    int compute_run_lengths(int period = 1)
     {
         if constexpr (sizeof(IdxT) != 4) {
             return fail(DQ_ERR_HIP, "run lengths: int32 indices only");
@@ -1389,12 +1392,12 @@ struct SuffixSorter {
             const int64_t nchunks = (n + kRunChunk - 1) / kRunChunk;
             LAUNCH(L, DQ_K_RUNS, n, 2 * n + 4 * n,
                    hipLaunchKernelGGL(runlen_chunk_kernel<false>, dim3((unsigned)nchunks), dim3(kRunThreads), 0, st,
-                                      (const uint8_t *)w.text, n, w.run_lead, w.run_link, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+                                      (const uint8_t *)w.text, n, w.run_lead, w.run_link, (const uint32_t *)nullptr, (uint32_t *)nullptr, period);
                    hipLaunchKernelGGL(runlen_carry_kernel, dim3(1), dim3(kRunScanThreads), 0, st, (const uint32_t *)w.run_lead,
                                       (const uint8_t *)w.run_link, nchunks, w.run_carry);
                    hipLaunchKernelGGL(runlen_chunk_kernel<true>, dim3((unsigned)nchunks), dim3(kRunThreads), 0, st,
                                       (const uint8_t *)w.text, n, (uint32_t *)nullptr, (uint8_t *)nullptr,
-                                      (const uint32_t *)w.run_carry, w.RL));
+                                      (const uint32_t *)w.run_carry, w.RL, period));
             return DQ_OK;
         }
     }
@@ -1469,19 +1472,25 @@ struct SuffixSorter {
             // runs seen late (see long_run_seen): the large groups have stopped shrinking -- run lengths now, one
             // run-order round at the current depth on the current list, the rank behind the run from then on
             const int64_t late_min = env("DQ_LATE_RUNS_MIN") ? std::max(1, atoi(env("DQ_LATE_RUNS_MIN"))) : (1 << 15);   // (tests: small inputs)
-            if (long_run_seen && !runs_on && !runs_late_tried && !run_order && last_large >= late_min && prev_large > 0 &&
+            if (late_runs_possible && !runs_on && !runs_late_tried && !run_order && last_large >= late_min && prev_large > 0 &&
                 last_large * 8 >= prev_large * 7 && h >= 32 && 32 + rbits <= 64 && uses_small_round(m) && !keys_ready &&
                 !list_ungrouped && !first_rank32 && mid_group_cap(m) > 0 && !env("DQ_NO_LATE_RUNS")) {
                 runs_late_tried = true;
-                rc = compute_run_lengths();
+                // the rules hold for stretches that repeat with any period P <= h (tests/test_models_cpu.py has the
+                // model): P = 64 (or the largest power of two <= h) takes runs of one byte and tables of 2-, 4-, ...
+                // 64-byte entries alike
+                int period = 1;
+                while (period * 2 <= 64 && period * 2 <= h) period *= 2;
+                if (const char *v = env("DQ_RUN_PERIOD")) period = std::max(1, std::min<int>((int)std::min<int64_t>(h, 1 << 20), atoi(v)));
+                rc = compute_run_lengths(period);
                 if (rc != DQ_OK) return rc;
                 runs_on = true;
-                run_order = 1;
+                run_order = period;                        // (the kernels take the period from here)
                 t_info[0] += 1;
                 t_info[2] += m;
                 if (env("DQ_TRACE"))
-                    fprintf(stderr, "[dq] late run-order round at h=%lld on %lld tied suffixes (%lld in large groups, %lld the round before)\n",
-                            (long long)h, (long long)m, (long long)last_large, (long long)prev_large);
+                    fprintf(stderr, "[dq] late run-order round (period %d) at h=%lld on %lld tied suffixes (%lld in large groups, %lld the round before)\n",
+                            period, (long long)h, (long long)m, (long long)last_large, (long long)prev_large);
                 rc = doubling_round_small(32);
                 run_order = 0;
                 if (rc != DQ_OK) return rc;

@@ -31,6 +31,8 @@ ENVS = [{}, {}, {}, {"DQ_SMALL_N": "0"}, {"DQ_NO_FUSED_TIES": "1"}, {"DQ_NO_SMAL
         {"DQ_MID_GROUPS": "1024", "DQ_SMALL_N": "0"}, {"DQ_MID_GROUPS": "256", "DQ_PAIR_CHAINS": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2"},
         {"DQ_MID_GROUPS": "1024", "DQ_PAIR_CHAINS": "0", "DQ_PACKED": "1", "DQ_KEY_BYTES": "2", "DQ_SMALL_N": "0"},
         {"DQ_LATE_RUNS_MIN": "1"}, {"DQ_LATE_RUNS_MIN": "1", "DQ_SMALL_N": "0"}, {"DQ_LATE_RUNS_MIN": "16", "DQ_MID_GROUPS": "256"},
+        {"DQ_LATE_RUNS_MIN": "1", "DQ_RUN_PERIOD": "1"}, {"DQ_LATE_RUNS_MIN": "1", "DQ_RUN_PERIOD": "3", "DQ_SMALL_N": "0"},
+        {"DQ_LATE_RUNS_MIN": "4", "DQ_RUN_PERIOD": "8", "DQ_PAIR_CHAINS": "0"},
         {"DQ_LATE_RUNS_MIN": "1", "DQ_UPD_BIN_MIN": "1", "DQ_PAIR_CHAINS": "2"}, {"DQ_NO_LATE_RUNS": "1"},
         {"DQ_UPD_BIN": "2", "DQ_UPD_BIN_MIN": "1"}, {"DQ_UPD_BIN": "1", "DQ_UPD_BIN_MIN": "1", "DQ_SMALL_N": "0"},
         {"DQ_UPD_BIN": "2", "DQ_UPD_BIN_MIN": "1", "DQ_RUNS": "1", "DQ_SMALL_N": "0"}, {"DQ_NO_UPD_WORDS": "1"},

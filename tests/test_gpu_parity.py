@@ -380,6 +380,7 @@ FUZZ_ENVS = [
     {"DQ_PAIR_CHAINS": "2", "DQ_NO_BINNED_ISA": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0"},
     {"DQ_LATE_RUNS_MIN": "1", "DQ_SMALL_N": "0"},          # run lengths + run-order round as soon as large groups stagnate
     {"DQ_LATE_RUNS_MIN": "1", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "256", "DQ_PAIR_CHAINS": "0"},
+    {"DQ_LATE_RUNS_MIN": "1", "DQ_SMALL_N": "0", "DQ_RUN_PERIOD": "4", "DQ_PAIR_CHAINS": "0"},   # ... with a fixed period of 4
     {"DQ_UPD_BIN": "2", "DQ_UPD_BIN_MIN": "1", "DQ_SMALL_N": "0"},   # rank updates binned by suffix (two passes) before they are applied
     {"DQ_UPD_BIN": "1", "DQ_UPD_BIN_MIN": "1", "DQ_SMALL_N": "0", "DQ_RUNS": "1"},   # ... one pass
     {"DQ_NO_UPD_WORDS": "1", "DQ_SMALL_N": "0"},           # rank updates as (rank, suffix) in two arrays
@@ -603,7 +604,9 @@ def run_heavy_texts(oracle_mod):
 @pytest.mark.parametrize("env", [{}, {"DQ_RUNS": "1"}, {"DQ_RUNS": "0"}, {"DQ_RUNS": "1", "DQ_NO_SMALL": "1"},
                                  {"DQ_RUNS": "1", "DQ_BINNED_ISA": "1"}, {"DQ_RUNS": "1", "DQ_BINNED_ISA": "1", "DQ_NO_FIRST_SMALL": "1"},
                                  {"DQ_RUNS": "1", "DQ_SPARSE": "1"}, {"DQ_RUNS": "1", "DQ_MID_GROUPS": "256", "DQ_NO_BINNED_ISA": "1"},
-                                 {"DQ_LATE_RUNS_MIN": "1"}, {"DQ_LATE_RUNS_MIN": "64", "DQ_UPD_BIN_MIN": "1"}, {"DQ_NO_LATE_RUNS": "1"}],
+                                 {"DQ_LATE_RUNS_MIN": "1"}, {"DQ_LATE_RUNS_MIN": "64", "DQ_UPD_BIN_MIN": "1"}, {"DQ_NO_LATE_RUNS": "1"},
+                                 {"DQ_LATE_RUNS_MIN": "1", "DQ_RUN_PERIOD": "1"}, {"DQ_LATE_RUNS_MIN": "1", "DQ_RUN_PERIOD": "2"},
+                                 {"DQ_LATE_RUNS_MIN": "16", "DQ_RUN_PERIOD": "24"}],
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
 def test_runs_of_one_byte(ldss, oracle_mod, monkeypatch, env):
     monkeypatch.setenv("DQ_SMALL_N", "0")

@@ -208,33 +208,36 @@ def test_pair_chains_decide_like_the_suffix_array(oracle_mod):
 # ---------------------------------------------------------------------------------------------------------------
 # dq_runs.h: runs of one byte decided by their own structure.  A numpy model of the doubling rounds with the run
 # lengths, the run-order round and the per-member offsets, validated against the oracle BEFORE any kernel runs.
-def run_lengths(T):
+def run_lengths(T, period=1):
+    """RL[i] = how far the text goes on from i repeating itself with the given period: the largest L <= n - i with
+    T[k] == T[k + period] for every k in [i, i + L - period).  period 1: the number of equal bytes from i on."""
     n = T.size
-    RL = np.ones(n, np.int64)
-    for i in range(n - 2, -1, -1):
-        if T[i] == T[i + 1]:
-            RL[i] = RL[i + 1] + 1
-    return RL
+    ones = np.zeros(n + 1, np.int64)                                   # consecutive k >= i with T[k] == T[k + period]
+    for i in range(n - period - 1, -1, -1):
+        if T[i] == T[i + period]:
+            ones[i] = ones[i + 1] + 1
+    return np.minimum(ones[:n] + period, n - np.arange(n))
 
 
-def doubling_with_runs(T, h0=2):
-    """Prefix doubling from depth h0 (ranks = group starts of the h0-byte keys), with the run rules of dq_runs.h."""
+def doubling_with_runs(T, h0=2, period=1):
+    """Prefix doubling from depth h0 (ranks = group starts of the h0-byte keys), with the run rules of dq_runs.h.
+    period > 1: the same rules for stretches that repeat with that period (h0 >= period)."""
+    assert h0 >= period
     n = T.size
-    P = np.concatenate([T, np.zeros(h0, np.uint8)]).astype(np.uint64)
-    key = np.zeros(n, np.uint64)
-    for b in range(h0):
-        key = (key << np.uint64(8)) | P[b:b + n]
+    P = np.concatenate([T, np.zeros(h0, np.uint8)])
+    cols = [P[b:b + n] for b in range(h0)]                             # the first h0 bytes of every suffix, zero padded
     # (zero padding can tie a suffix that ends with one that goes on with zero bytes: the valid length breaks it)
     ln = np.minimum(n - np.arange(n), h0)
-    order = np.lexsort((ln, key))
-    k = key[order]
-    l = ln[order]
+    order = np.lexsort([ln] + cols[::-1])
     head = np.ones(n, bool)
-    head[1:] = (k[1:] != k[:-1]) | (l[1:] != l[:-1])
+    diff = ln[order][1:] != ln[order][:-1]
+    for c in cols:
+        diff |= c[order][1:] != c[order][:-1]
+    head[1:] = diff
     rank_sorted = np.maximum.accumulate(np.where(head, np.arange(n), 0))
     ISA = np.empty(n, np.int64)
     ISA[order] = rank_sorted
-    RL = run_lengths(T)
+    RL = run_lengths(T, period)
     Tx = np.concatenate([T.astype(np.int64), [-1]])                    # the end of the text sorts before every byte
 
     def rebucket(r, k2):
@@ -249,7 +252,8 @@ def doubling_with_runs(T, h0=2):
         r = ISA[s]
         if special:                                                   # the run-order round: depth h stays
             e = s + RL[s]
-            down = Tx[np.minimum(e, n)] < Tx[s]
+            # the byte that ends the stretch against the byte the repetition would have put there (period 1: T[s])
+            down = Tx[np.minimum(e, n)] < Tx[np.maximum(np.minimum(e, n) - period, 0)]
             enc = np.where(down, RL[s], (1 << 31) | ((1 << 31) - 1 - RL[s]))
             k2 = np.where(RL[s] >= h, enc, 0)
         else:
@@ -301,6 +305,39 @@ def test_run_order_rule_and_offsets_give_the_suffix_array(oracle_mod):
     SA, rounds = doubling_with_runs(T, 2)
     assert np.array_equal(SA, oracle_mod.divsufsort(T).astype(np.int64))
     assert rounds <= 4, rounds
+
+
+def test_run_rules_hold_for_stretches_of_any_period(oracle_mod):
+    """The generalisation the late run rounds use (dq_runs.h with a period): a stretch that repeats itself with period p
+    is also one of period 2p, 4p ...; the rules with period P decide every stretch whose period divides P."""
+    rng = np.random.default_rng(16)
+    for trial in range(60):
+        parts = []
+        for _ in range(int(rng.integers(2, 12))):
+            u = rng.random()
+            if u < 0.55:                                               # a periodic stretch
+                p = int(rng.choice([1, 2, 2, 4, 8, 3]))
+                unit = rng.integers(0, 3, p, dtype=np.uint8)
+                parts.append(np.resize(unit, int(rng.integers(1, 150))))
+            elif u < 0.7 and parts:                                    # an earlier stretch again
+                src = np.concatenate(parts)
+                a = int(rng.integers(0, src.size))
+                parts.append(src[a:a + int(rng.integers(1, 90))].copy())
+            else:
+                parts.append(rng.integers(0, 3, int(rng.integers(1, 6)), dtype=np.uint8))
+        T = np.concatenate(parts).astype(np.uint8)
+        ref = oracle_mod.divsufsort(T).astype(np.int64)
+        for period, h0 in ((1, 1), (2, 2), (2, 4), (4, 4), (8, 8), (8, 16), (16, 16), (3, 4)):
+            SA, _ = doubling_with_runs(T, h0, period)
+            assert np.array_equal(SA, ref), (trial, T.size, period, h0)
+    # a long stretch of period 2 takes a constant number of rounds with period 2 (or 8), log2(length) with period 1
+    T = np.concatenate([np.resize(np.array([1, 2], np.uint8), 6001), [0], np.resize(np.array([1, 2], np.uint8), 3000), [3]]).astype(np.uint8)
+    ref = oracle_mod.divsufsort(T).astype(np.int64)
+    r = {}
+    for period in (1, 2, 8):
+        SA, r[period] = doubling_with_runs(T, 8, period)
+        assert np.array_equal(SA, ref)
+    assert r[2] <= 5 and r[8] <= 5 and r[1] > r[2] + 3, r
 
 
 def test_run_length_passes_model():
