@@ -23,6 +23,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <atomic>
 #include <cstring>
 #include <vector>
 
@@ -127,6 +128,9 @@ struct TripleEmitter {
     RawStreams &out;
     struct Anchor { int64_t at = 0, in_old = 0; };          // a matched position of new and where it lies in old
     Anchor prev;                                             // end of the last emitted forward extension
+    // if set: the lengths of out.diff / out.extra that are final, published after every triple for a thread that
+    // frames the streams while they grow (the vectors must have their full capacity reserved: they may not move)
+    std::atomic<size_t> *progress = nullptr;
 
     TripleEmitter(const uint8_t *old_, int64_t n_, const uint8_t *nw_, int64_t m_, RawStreams &out_)
         : old(old_), n(n_), nw(nw_), m(m_), out(out_) {}
@@ -209,6 +213,10 @@ struct TripleEmitter {
         emit_packed((hit_pos - back) - (prev.in_old + fwd));
         prev.at = cursor - back;
         prev.in_old = hit_pos - back;
+        if (progress) {
+            progress[0].store(out.diff.size(), std::memory_order_release);
+            progress[1].store(out.extra.size(), std::memory_order_release);
+        }
     }
 };
 

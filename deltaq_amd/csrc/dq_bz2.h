@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <thread>
 #include <vector>
@@ -571,11 +572,9 @@ inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32
     return 0;
 }
 
-// level 1..9: blocks of level * 100000 - 19 run-length coded bytes (libbz2's limit).
-// The run-length pre-pass (which fixes the block boundaries) runs over the whole input first; the blocks themselves --
-// Burrows-Wheeler transform through the sorter, MTF / Huffman -- are independent and go to up to 4 threads (the extra
-// stream of two unrelated 4 MiB files is five blocks of random bytes: 250 ms of move-to-front on one thread); their
-// bit strings are then appended in order.  The sorter must be callable from several threads at once.
+// The blocks of a stream -- Burrows-Wheeler transform through the sorter, MTF / Huffman -- are independent and go to up
+// to 4 threads (the extra stream of two unrelated 4 MiB files is five blocks of random bytes: 250 ms of move-to-front
+// on one thread); their bit strings are then appended in order.
 // Process-wide budget of extra framing threads (block encoders of all streams of all concurrent Diff.Create calls):
 // one per hardware thread.  acquire() grants 0 ... want of them without waiting.
 inline std::atomic<int> &framing_threads_in_use()
@@ -597,54 +596,128 @@ inline int framing_threads_acquire(int want)
 }
 inline void framing_threads_release(int n) { if (n > 0) framing_threads_in_use().fetch_sub(n); }
 
-inline int bz2_compress(const uint8_t *src, size_t n, std::vector<uint8_t> &out, const DoubledSorter &sorter, int level = 9)
-{
-    BitWriter bw(out);
-    bw.bits(8, 'B'); bw.bits(8, 'Z'); bw.bits(8, 'h'); bw.bits(8, (uint32_t)('0' + level));
-    const size_t block_max = (size_t)level * 100000 - 19;
+// One stream, encoded while its bytes are still being produced.  feed() follows the producer with the run-length
+// pre-pass and the block CRCs (which fix the block boundaries exactly as one sweep over the finished stream would: a
+// run is only taken once the 255 bytes it may cover are known); a block that fills up goes to an encoder thread of
+// its own, if the process-wide budget has one, while the pre-pass carries on; finish() encodes what is left -- on
+// up to 4 threads -- and appends the bit strings in order.  The diff stream of two similar 16 MiB files is
+// 16 MiB of mostly zeros: its pre-pass and CRC (3 + 2..8 ms) now run beside the device's anchor search instead of
+// behind it, and the 900 KB blocks of the extra stream of unrelated files are encoded while the search goes on.
+// One thread calls feed() / finish(); the sorter must be callable from several threads at once.
+class StreamEncoder {
+public:
+    explicit StreamEncoder(DoubledSorter sorter_, int level_ = 9)
+        : sorter(std::move(sorter_)), level(level_), block_max((size_t)level_ * 100000 - 19) {}
+    StreamEncoder(const StreamEncoder &) = delete;
+    StreamEncoder &operator=(const StreamEncoder &) = delete;
+    ~StreamEncoder() { join_all(); }
+
+    // src[0, upto) is final and will not move; `last`: the stream ends at upto.  (src and the earlier bytes are the
+    // same from call to call.)
+    void feed(const uint8_t *src, size_t upto, bool last)
+    {
+        // a run may reach 255 bytes ahead: positions whose run could still grow wait for the next call
+        const size_t stop = last ? upto : (upto > 255 ? upto - 255 : 0);
+        while (pos < stop) {
+            if (!open) {
+                blocks.emplace_back();
+                blocks.back().rle.reserve(std::min(block_max, (last ? upto - pos : block_max)) + 8);
+                open = true;
+                crc = 0xffffffffu;
+                crc_done = pos;
+            }
+            std::vector<uint8_t> &blk = blocks.back().rle;
+            size_t i = pos;
+            // run-length pre-pass: a run of 4..255 equal bytes becomes 4 bytes + (length - 4)
+            while (i < stop && blk.size() + 5 <= block_max) {
+                const uint8_t c = src[i];
+                size_t run = 1;
+                const size_t lim = upto - i < 255 ? upto - i : 255;
+                if (lim >= 16 && src[i + 1] == c) {
+                    // a run has begun: extend it 8 bytes at a time
+                    const uint64_t pat = 0x0101010101010101ull * c;
+                    while (run + 8 <= lim) {
+                        uint64_t v;
+                        memcpy(&v, src + i + run, 8);
+                        if (v != pat) break;
+                        run += 8;
+                    }
+                }
+                while (run < lim && src[i + run] == c) ++run;
+                if (run >= 4) {
+                    blk.insert(blk.end(), 4, c);
+                    blk.push_back((uint8_t)(run - 4));
+                } else {
+                    blk.insert(blk.end(), run, c);
+                }
+                i += run;
+            }
+            pos = i;
+            crc = crc_update_mt(crc, src + crc_done, pos - crc_done);    // of the block's input bytes (4 threads from 2 MiB a call)
+            crc_done = pos;
+            if (blk.size() + 5 > block_max) close_block(/*more_to_come=*/true);
+        }
+        if (last && open) close_block(false);
+    }
+
+    // after feed(.., last = true): the whole stream "BZh<level>" ... end magic, appended to out
+    int finish(std::vector<uint8_t> &out)
+    {
+        if (open) close_block(false);
+        // what no thread has claimed yet: the caller and up to kBlockThreads - 1 more threads take the blocks in turn
+        size_t pending = 0;
+        for (Block &b : blocks) pending += b.claimed.load() == 0;
+        if (pending >= 2) {
+            size_t extra = std::min<size_t>(pending, 4) - 1;
+            const int granted = framing_threads_acquire((int)extra);
+            std::vector<std::thread> ts;
+            for (int t = 0; t < granted; ++t) {
+                try { ts.emplace_back([this] { encode_pending(); }); } catch (...) { break; }
+            }
+            encode_pending();
+            for (std::thread &t : ts) t.join();
+            framing_threads_release(granted);
+        } else {
+            encode_pending();
+        }
+        join_all();
+        BitWriter bw(out);
+        bw.bits(8, 'B'); bw.bits(8, 'Z'); bw.bits(8, 'h'); bw.bits(8, (uint32_t)('0' + level));
+        uint32_t combined = 0;
+        for (Block &b : blocks) {
+            if (b.rc != 0) return b.rc;
+            size_t k = 0;
+            for (; (k + 1) * 8 <= b.nbits; ++k) bw.bits(8, b.bytes[k]);
+            const int rest = (int)(b.nbits - k * 8);
+            if (rest > 0) bw.bits(rest, (uint32_t)b.bytes[k] >> (8 - rest));
+            combined = ((combined << 1) | (combined >> 31)) ^ b.crc;
+        }
+        bw.bits(24, (uint32_t)(kEndMagic >> 24));
+        bw.bits(24, (uint32_t)(kEndMagic & 0xffffff));
+        bw.bits(32, combined);
+        bw.flush();
+        return 0;
+    }
+
+    size_t consumed() const { return pos; }
+
+private:
     struct Block {
         std::vector<uint8_t> rle;        // run-length coded input of the block
         uint32_t crc = 0;
         std::vector<uint8_t> bytes;      // its bit string ...
         uint64_t nbits = 0;              // ... and how many bits of it count
         int rc = 0;
+        std::atomic<int> claimed{0};     // an encoder has taken it
     };
-    std::vector<Block> blocks;
-    size_t i = 0;
-    while (i < n) {
-        blocks.emplace_back();
-        std::vector<uint8_t> &blk = blocks.back().rle;
-        blk.reserve(std::min(block_max, n - i) + 8);
-        const size_t i0 = i;
-        // run-length pre-pass: a run of 4..255 equal bytes becomes 4 bytes + (length - 4)
-        while (i < n && blk.size() + 5 <= block_max) {
-            const uint8_t c = src[i];
-            size_t run = 1;
-            const size_t lim = n - i < 255 ? n - i : 255;
-            if (lim >= 16 && src[i + 1] == c) {
-                // a run has begun: extend it 8 bytes at a time
-                const uint64_t pat = 0x0101010101010101ull * c;
-                while (run + 8 <= lim) {
-                    uint64_t v;
-                    memcpy(&v, src + i + run, 8);
-                    if (v != pat) break;
-                    run += 8;
-                }
-            }
-            while (run < lim && src[i + run] == c) ++run;
-            if (run >= 4) {
-                blk.insert(blk.end(), 4, c);
-                blk.push_back((uint8_t)(run - 4));
-            } else {
-                blk.insert(blk.end(), run, c);
-            }
-            i += run;
-        }
-        blocks.back().crc = ~crc_update_mt(0xffffffffu, src + i0, i - i0);   // of the block's input bytes, in one sweep (4 threads from 2 MiB)
-    }
+    struct Helper {
+        std::thread t;
+    };
+
     // (nothing may leave a worker thread as an exception -- that would be std::terminate, not an error code: an
     // allocation that fails inside a block's encoder becomes that block's rc)
-    auto encode = [&](Block &b) {
+    void encode(Block &b)
+    {
         try {
             BitWriter w(b.bytes);
             b.rc = compress_block(w, b.rle, b.crc, sorter);
@@ -654,42 +727,55 @@ inline int bz2_compress(const uint8_t *src, size_t n, std::vector<uint8_t> &out,
         } catch (...) {
             b.rc = -3;
         }
-    };
-    if (blocks.size() >= 2) {
-        std::atomic<size_t> next{0};
-        auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < blocks.size();) encode(blocks[k]); };
-        struct Joiner {                  // joins on every way out of this scope
-            std::vector<std::thread> ts;
-            ~Joiner() { for (std::thread &t : ts) if (t.joinable()) t.join(); }
-        } pool;
-        // at most kBlockThreads encoder threads per stream, and no more framing threads process-wide than the host
-        // has cores (several Diff.Create calls at once: 3 streams x 4 block threads each would oversubscribe it)
-        size_t extra = std::min<size_t>(blocks.size(), 4) - 1;
-        const int granted = framing_threads_acquire((int)extra);
-        extra = (size_t)granted;
-        for (size_t t = 0; t < extra; ++t) {
-            try { pool.ts.emplace_back(work); } catch (...) { break; }
+    }
+    void encode_pending()
+    {
+        for (Block &b : blocks) {
+            int expect = 0;
+            if (b.claimed.compare_exchange_strong(expect, 1)) encode(b);
         }
-        work();
-        for (std::thread &t : pool.ts) t.join();
-        framing_threads_release(granted);
-    } else {
-        for (Block &b : blocks) encode(b);
     }
-    uint32_t combined = 0;
-    for (Block &b : blocks) {
-        if (b.rc != 0) return b.rc;
-        size_t k = 0;
-        for (; (k + 1) * 8 <= b.nbits; ++k) bw.bits(8, b.bytes[k]);
-        const int rest = (int)(b.nbits - k * 8);
-        if (rest > 0) bw.bits(rest, (uint32_t)b.bytes[k] >> (8 - rest));
-        combined = ((combined << 1) | (combined >> 31)) ^ b.crc;
+    void close_block(bool more_to_come)
+    {
+        Block &b = blocks.back();
+        b.crc = ~crc;
+        open = false;
+        if (!more_to_come) return;       // (the last block is finish()'s: the caller is about to wait for it anyway)
+        // full while the stream is still growing: encode it beside the pre-pass if a framing thread is to be had
+        if (framing_threads_acquire(1) != 1) return;
+        int expect = 0;
+        if (!b.claimed.compare_exchange_strong(expect, 1)) { framing_threads_release(1); return; }
+        try {
+            helpers.emplace_back();
+            helpers.back().t = std::thread([this, &b] { encode(b); framing_threads_release(1); });
+        } catch (...) {
+            if (!helpers.empty() && !helpers.back().t.joinable()) helpers.pop_back();
+            b.claimed.store(0);
+            framing_threads_release(1);
+        }
     }
-    bw.bits(24, (uint32_t)(kEndMagic >> 24));
-    bw.bits(24, (uint32_t)(kEndMagic & 0xffffff));
-    bw.bits(32, combined);
-    bw.flush();
-    return 0;
+    void join_all()
+    {
+        for (Helper &h : helpers) if (h.t.joinable()) h.t.join();
+        helpers.clear();
+    }
+
+    DoubledSorter sorter;
+    int level;
+    size_t block_max;
+    std::deque<Block> blocks;            // (a deque: blocks stay where they are while their encoders run)
+    std::deque<Helper> helpers;
+    size_t pos = 0, crc_done = 0;
+    uint32_t crc = 0;
+    bool open = false;
+};
+
+// level 1..9: blocks of level * 100000 - 19 run-length coded bytes (libbz2's limit).
+inline int bz2_compress(const uint8_t *src, size_t n, std::vector<uint8_t> &out, const DoubledSorter &sorter, int level = 9)
+{
+    StreamEncoder enc(sorter, level);
+    enc.feed(src, n, true);
+    return enc.finish(out);
 }
 
 }  // namespace bz2

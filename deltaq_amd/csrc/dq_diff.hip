@@ -399,6 +399,115 @@ void diff_index_drop(DiffIndex *ix)
     ix->own = nullptr;
 }
 
+// The suffix sorter as bzip2's block transform calls it (several encoder threads at once, each call leasing its own
+// device context); the first error is kept for the thread that collects the stream.
+struct BlockSorter {
+    int dev = 0;
+    std::atomic<int> rc{DQ_OK};
+    std::mutex mu;
+    std::string err;
+    int sort(const uint8_t *t, int64_t n2, int32_t *sa)
+    {
+        const int r = sufsort_host<int32_t>(t, n2, sa, dev);
+        if (r == DQ_OK) return 0;
+        int expect = DQ_OK;
+        if (rc.compare_exchange_strong(expect, r)) {
+            std::lock_guard<std::mutex> lk(mu);
+            err = t_err;                                  // (thread-local on the worker: carried over)
+        }
+        return -2;
+    }
+    bz2::DoubledSorter fn() { return [this](const uint8_t *t, int64_t n2, int32_t *sa) { return sort(t, n2, sa); }; }
+};
+
+// Framing that follows the scan: while the device searches for anchors and the emitter appends to the diff and extra
+// streams, one thread per stream runs bzip2's run-length pre-pass and block CRCs over what is final and sends full
+// blocks to their encoders (bz2::StreamEncoder).  What is left behind the scan is the last block of each stream.
+// The emitter's thread calls start / complete / abandon; finish(k) may be called from any one thread per stream.
+struct PatchFramer {
+    explicit PatchFramer(int dev) { sorter.dev = dev; }
+    PatchFramer(const PatchFramer &) = delete;
+    PatchFramer &operator=(const PatchFramer &) = delete;
+    ~PatchFramer() { abandon(); }
+
+    // raw.diff / raw.extra get their final capacity here (both stay below m bytes), so that they never move
+    bool start(bsdiff::RawStreams &raw, int64_t m)
+    {
+        try {
+            raw.diff.reserve((size_t)m);
+            raw.extra.reserve((size_t)m);
+            base[0] = raw.diff.data();
+            base[1] = raw.extra.data();
+            for (int k = 0; k < 2; ++k) {
+                final_len[k].store(0);
+                failed[k] = false;
+                enc[k].reset(new bz2::StreamEncoder(sorter.fn()));
+            }
+            state.store(0);
+            for (int k = 0; k < 2; ++k) th[k] = std::thread([this, k] { follow(k); });
+        } catch (const std::exception &) {
+            abandon();
+            return false;
+        }
+        running = true;
+        return true;
+    }
+    void complete() { state.store(1, std::memory_order_release); }
+    void abandon()
+    {
+        state.store(2, std::memory_order_release);
+        for (std::thread &t : th) if (t.joinable()) t.join();
+        for (auto &e : enc) e.reset();
+        running = false;
+    }
+    bool ready() const { return running && state.load() == 1; }
+
+    // stream k (0 diff, 1 extra) as a bzip2 stream
+    int finish(int k, std::vector<uint8_t> &out)
+    {
+        if (th[k].joinable()) th[k].join();
+        if (failed[k]) return fail(DQ_ERR_OOM, "bsdiff: out of memory while framing a stream");
+        const int rc = enc[k]->finish(out);
+        if (rc == -2) {
+            std::lock_guard<std::mutex> lk(sorter.mu);
+            t_err = sorter.err;
+            return sorter.rc.load();
+        }
+        if (rc != 0) return fail(DQ_ERR_HIP, "bzip2 block transform failed");
+        return DQ_OK;
+    }
+
+    std::atomic<size_t> final_len[2];                     // what the emitter has finished of diff / extra
+
+private:
+    void follow(int k)
+    {
+        size_t seen = 0;
+        for (;;) {
+            const int s = state.load(std::memory_order_acquire);           // (before the length: complete() comes after the last one)
+            if (s == 2) return;
+            const size_t upto = final_len[k].load(std::memory_order_acquire);
+            try {
+                enc[k]->feed(base[k], upto, s == 1);
+            } catch (...) {
+                failed[k] = true;
+                return;
+            }
+            if (s == 1) return;
+            if (upto - seen < (64u << 10)) std::this_thread::sleep_for(std::chrono::microseconds(200));
+            seen = upto;
+        }
+    }
+
+    BlockSorter sorter;
+    std::unique_ptr<bz2::StreamEncoder> enc[2];
+    std::thread th[2];
+    const uint8_t *base[2] = {nullptr, nullptr};
+    std::atomic<int> state{0};                            // 0 the streams are growing, 1 complete, 2 given up
+    bool failed[2] = {false, false};
+    bool running = false;
+};
+
 // Step 1 of the scan loop on the device (dq_anchor_scan.h): one persistent launch walks the whole new file and leaves the
 // (cursor, hit_pos) pair of every control triple; steps 2 and 3 run here on those pairs.  The list has room for
 // kAnchorRecs pairs per launch -- a new file that needs more (text with a short match every few bytes) continues from
@@ -410,7 +519,7 @@ constexpr unsigned long long kAnchorPending = ~0ull;
 // ring: kAnchorRecs words of pinned host memory the kernel writes the pairs into (one 64-bit store each) and this
 // thread reads while the kernel runs -- steps 2 and 3 of a triple overlap the device's search for the next anchors
 int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch, unsigned long long *ring, const uint8_t *nw,
-                   int64_t m, bsdiff::RawStreams &raw, bool *retry_on_host)
+                   int64_t m, bsdiff::RawStreams &raw, bool *retry_on_host, PatchFramer *framer)
 {
     *retry_on_host = false;
     AnchorCtl *d_ctl = reinterpret_cast<AnchorCtl *>(scratch);
@@ -419,6 +528,9 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
     unsigned long long *d_ans = reinterpret_cast<unsigned long long *>(scratch + 256 + 2048);
     static_assert(sizeof(AnchorCtl) <= 256, "control block");
     bsdiff::TripleEmitter em(ix.old, ix.n, nw, m, raw);
+    // (short files: two more threads cost more than the framing they would hide)
+    const int64_t follow_min = env("DQ_FRAME_FOLLOW_MIN") ? atoll(env("DQ_FRAME_FOLLOW_MIN")) : (int64_t)256 << 10;
+    if (framer && m >= follow_min && framer->start(raw, m)) em.progress = framer->final_len;
     AnchorCtl st{};
     std::lock_guard<std::mutex> lk(c.mu);                 // (the device context's stream and pinned areas)
     int rc = init_ctx(c, ix.dev);
@@ -482,11 +594,12 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         if (st.done) break;
         if (got == 0) return fail(DQ_ERR_HIP, "anchor scan: no progress");
     }
+    if (em.progress) framer->complete();
     return DQ_OK;
 }
 
 // Diff.Create's data path up to the raw streams for one new file: upload it, run the scan loop over windows of answers
-int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::RawStreams &raw)
+int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::RawStreams &raw, PatchFramer *framer = nullptr)
 {
     if (m < 0 || (m > 0 && !nw)) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
     if (m > 0x7fffffffLL) return fail(DQ_ERR_TOO_LARGE, "the BSDIFF40 path takes files below 2 GiB (int indices, as the reference)");
@@ -521,12 +634,13 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
     if (device_scan) {
         bool retry_on_host = false;
         static_assert(kDiffPinnedBytes >= (size_t)kAnchorRecs * 8, "the pinned window area holds the anchor ring");
-        rc = scan_on_device(ix, c, d_new, d_new + b_new + 256, reinterpret_cast<unsigned long long *>(pinned), nw, m, raw, &retry_on_host);
+        rc = scan_on_device(ix, c, d_new, d_new + b_new + 256, reinterpret_cast<unsigned long long *>(pinned), nw, m, raw, &retry_on_host, framer);
         stamp("scan (device)");
         if (trace)
             fprintf(stderr, "[dq] device scan: %lld searches, %lld windows, %lld stop points, %zu triples%s\n", (long long)raw.searches,
                     (long long)raw.windows, (long long)raw.exact, raw.ctrl.size() / 24, retry_on_host ? " -- given up, host loop instead" : "");
         if (!retry_on_host) return rc;
+        if (framer) framer->abandon();                     // (before the streams it reads go away)
         raw = bsdiff::RawStreams{};
     }
     SearchWindows win{ix.d_old, ix.d_sa, d_new, ix.n, m, dev};
@@ -557,7 +671,8 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
 }
 
 // Diff.Create's data path up to the raw streams: sort old on the device, keep the SA there, run the scan loop
-int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, bsdiff::RawStreams &raw)
+int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, bsdiff::RawStreams &raw,
+               PatchFramer *framer = nullptr)
 {
     if (n < 0 || m < 0) return fail(DQ_ERR_BAD_ARGS, "negative length");
     if ((n > 0 && !old) || (m > 0 && !nw)) return fail(DQ_ERR_BAD_ARGS, "null buffer");
@@ -570,44 +685,39 @@ int bsdiff_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int3
     DiffIndex ix;
     rc = diff_index_build(old, n, dev, nullptr, nullptr, /*cached=*/true, &ix);
     if (rc != DQ_OK) return rc;
-    return diff_index_scan(ix, nw, m, raw);
+    return diff_index_scan(ix, nw, m, raw, framer);
 }
 
 // one bzip2 stream; the Burrows-Wheeler transform of each block through the suffix sorter (blocks of a long stream
 // are encoded on several threads: the sorter is called concurrently, each call leasing its own device context)
 int bz2_stream(const std::vector<uint8_t> &src, std::vector<uint8_t> &out, int dev)
 {
-    std::atomic<int> sort_rc{DQ_OK};
-    std::mutex err_mu;
-    std::string err;
-    const int rc = bz2::bz2_compress(src.data(), src.size(), out,
-                                     [&](const uint8_t *t, int64_t n2, int32_t *sa) -> int {
-                                         const int r = sufsort_host<int32_t>(t, n2, sa, dev);
-                                         if (r == DQ_OK) return 0;
-                                         int expect = DQ_OK;
-                                         if (sort_rc.compare_exchange_strong(expect, r)) {
-                                             std::lock_guard<std::mutex> lk(err_mu);
-                                             err = t_err;                      // (thread-local on the worker: carried over)
-                                         }
-                                         return -2;
-                                     });
-    if (rc == -2) { t_err = err; return sort_rc.load(); }
+    BlockSorter sorter;
+    sorter.dev = dev;
+    const int rc = bz2::bz2_compress(src.data(), src.size(), out, sorter.fn());
+    if (rc == -2) { t_err = sorter.err; return sorter.rc.load(); }
     if (rc != 0) return fail(DQ_ERR_HIP, "bzip2 block transform failed");
     return DQ_OK;
 }
 
 // header + the three streams (Diff.cs:54-70 / :196-252).  The streams are framed side by side on three host threads:
 // their run-length / MTF / Huffman work overlaps, the block sorts take turns on the device.
-int frame_patch(const bsdiff::RawStreams &raw, int64_t m, int dev, std::vector<uint8_t> &patch)
+int frame_patch(const bsdiff::RawStreams &raw, int64_t m, int dev, std::vector<uint8_t> &patch, PatchFramer *framer = nullptr)
 {
+    const bool trace = env("DQ_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const bool followed = framer && framer->ready();       // diff and extra were framed while they grew: their last blocks are left
     std::vector<uint8_t> z[3];
     const std::vector<uint8_t> *src[3] = {&raw.ctrl, &raw.diff, &raw.extra};
     int rcs[3] = {DQ_OK, DQ_OK, DQ_OK};
     std::string errs[3];
     auto work = [&](int k) {
         try {
-            rcs[k] = bz2_stream(*src[k], z[k], dev);
+            rcs[k] = followed && k > 0 ? framer->finish(k - 1, z[k]) : bz2_stream(*src[k], z[k], dev);
             if (rcs[k] != DQ_OK) errs[k] = t_err;
+            if (trace) fprintf(stderr, "[dq] bsdiff stream %d framed   at %8.3f ms (%zu -> %zu bytes%s)\n", k,
+                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(),
+                               src[k]->size(), z[k].size(), followed && k > 0 ? ", behind the scan" : "");
         } catch (const std::exception &e) {
             rcs[k] = DQ_ERR_OOM;
             errs[k] = std::string("bsdiff: ") + e.what();
@@ -638,13 +748,15 @@ int frame_patch(const bsdiff::RawStreams &raw, int64_t m, int dev, std::vector<u
 
 int bsdiff_create_host(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, std::vector<uint8_t> &patch)
 {
-    bsdiff::RawStreams raw;
-    int rc = bsdiff_raw(old, n, nw, m, device, raw);
-    if (rc != DQ_OK) return rc;
     int dev = 0;
-    rc = resolve_device(device, &dev);
+    int rc = resolve_device(device, &dev);
     if (rc != DQ_OK) return rc;
-    return frame_patch(raw, m, dev, patch);
+    bsdiff::RawStreams raw;
+    PatchFramer framer(dev);                              // (after raw: it reads the streams until it is gone)
+    const bool follow = !env("DQ_FRAME_AFTER");
+    rc = bsdiff_raw(old, n, nw, m, device, raw, follow ? &framer : nullptr);
+    if (rc != DQ_OK) return rc;
+    return frame_patch(raw, m, dev, patch, &framer);
 }
 
 // Patch.Apply (Patch.cs:52-168): host only (dq_bspatch.h)
@@ -714,12 +826,13 @@ int diff_index_diff(const void *index, const uint8_t *nw, int64_t m, std::vector
 {
     const DiffIndex *ix = static_cast<const DiffIndex *>(index);
     bsdiff::RawStreams raw;
+    PatchFramer framer(ix->dev);
     {
         std::lock_guard<std::mutex> one_diff(ctx0(ix->dev).diff_mu);      // scan loops take turns on a device
-        const int rc = diff_index_scan(*ix, nw, m, raw);
+        const int rc = diff_index_scan(*ix, nw, m, raw, env("DQ_FRAME_AFTER") ? nullptr : &framer);
         if (rc != DQ_OK) return rc;
     }
-    return frame_patch(raw, m, ix->dev, patch);                            // (framing overlaps the next caller's scan loop)
+    return frame_patch(raw, m, ix->dev, patch, &framer);                            // (framing overlaps the next caller's scan loop)
 }
 
 void diff_index_delete(void *index)

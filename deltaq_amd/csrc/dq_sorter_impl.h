@@ -1472,8 +1472,12 @@ struct SuffixSorter {
             // runs seen late (see long_run_seen): the large groups have stopped shrinking -- run lengths now, one
             // run-order round at the current depth on the current list, the rank behind the run from then on
             const int64_t late_min = env("DQ_LATE_RUNS_MIN") ? std::max(1, atoi(env("DQ_LATE_RUNS_MIN"))) : (1 << 15);   // (tests: small inputs)
+            // (the run lengths are a sweep over the whole text, what they save is a few passes over the large groups:
+            // librocsparse.so, 256 MiB, 0.32 M members of large groups -- 2.2 ms of run lengths for nothing)
+            const int64_t late_share = env("DQ_LATE_RUNS_SHARE") ? std::max(1, atoi(env("DQ_LATE_RUNS_SHARE")))
+                                       : env("DQ_LATE_RUNS_MIN") ? (int64_t)1 << 30 : 64;      // (the tests' knob lifts this bar too)
             if (late_runs_possible && !runs_on && !runs_late_tried && !run_order && last_large >= late_min && prev_large > 0 &&
-                last_large * 8 >= prev_large * 7 && h >= 32 && 32 + rbits <= 64 && uses_small_round(m) && !keys_ready &&
+                last_large * late_share >= n && last_large * 8 >= prev_large * 7 && h >= 32 && 32 + rbits <= 64 && uses_small_round(m) && !keys_ready &&
                 !list_ungrouped && !first_rank32 && mid_group_cap(m) > 0 && !env("DQ_NO_LATE_RUNS")) {
                 runs_late_tried = true;
                 // the rules hold for stretches that repeat with any period P <= h (tests/test_models_cpu.py has the

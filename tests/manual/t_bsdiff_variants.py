@@ -24,6 +24,7 @@ old = datagen.gen_uniform(16 << 20, 5); pairs.append(("random 16 MiB, 2000 edits
 old = datagen.gen_enwik_like(16 << 20, 3, 64 * 1024); pairs.append(("text 16 MiB, 2000 edits", old, edited(rng, old, 2000)))
 old = datagen.gen_uniform(16 << 20, 7); pairs.append(("random 16 MiB, 200 edits", old, edited(rng, old, 200)))
 old = datagen.gen_uniform(16 << 20, 8); pairs.append(("random 16 MiB, 20000 edits of <= 40 bytes", old, edited(rng, old, 20000, 40)))
+pairs.append(("random 16 MiB vs unrelated 4 MiB", datagen.gen_uniform(16 << 20, 5), datagen.gen_uniform(4 << 20, 6)))
 variants = sys.argv[1:] or [""]
 for name, old, new in pairs:
     first = None

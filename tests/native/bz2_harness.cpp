@@ -33,6 +33,27 @@ int64_t t_bz2_compress(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap,
     return (int64_t)v.size();
 }
 
+// the same stream fed piece by piece as a producer would hand it over (pieces of 0 .. max_step bytes, seeded): the
+// pre-pass follows the pieces, full blocks are encoded on threads of their own while it carries on
+int64_t t_bz2_compress_fed(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap, int32_t level, int64_t max_step, uint32_t seed)
+{
+    std::vector<uint8_t> v;
+    dq::bz2::StreamEncoder enc(naive_sorter, level);
+    uint64_t x = seed * 0x9e3779b97f4a7c15ull + 1;
+    int64_t upto = 0;
+    while (upto < n) {
+        x = x * 6364136223846793005ull + 1442695040888963407ull;
+        upto = std::min<int64_t>(n, upto + (int64_t)((x >> 33) % (uint64_t)(max_step + 1)));
+        enc.feed(src, (size_t)upto, false);
+    }
+    enc.feed(src, (size_t)n, true);
+    const int rc = enc.finish(v);
+    if (rc != 0) return rc;
+    if ((int64_t)v.size() > cap) return -100;
+    memcpy(out, v.data(), v.size());
+    return (int64_t)v.size();
+}
+
 // limit < 0: no bound on the decoded size
 int64_t t_bz2_decompress_limit(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap, int64_t limit, int32_t *code)
 {

@@ -57,6 +57,30 @@ def sample_inputs(oracle_mod):
     return cases
 
 
+def test_stream_fed_in_pieces_is_the_stream_fed_at_once(harness, oracle_mod):
+    """StreamEncoder.feed() behind a producer (Diff.Create frames the diff / extra streams while the scan still runs):
+    the same bytes as one sweep over the finished stream, wherever the pieces end -- inside runs, on block boundaries,
+    empty pieces -- and with full blocks encoded on their own threads meanwhile."""
+    L = ctypes.CDLL(os.path.join(NATIVE, "libbz2_harness.so"))
+    L.t_bz2_compress_fed.restype = ctypes.c_int64
+    L.t_bz2_compress_fed.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                     ctypes.c_int64, ctypes.c_uint32]
+    rng = np.random.default_rng(8)
+    runs = np.repeat(rng.integers(0, 4, 3000, dtype=np.uint8), rng.integers(1, 700, 3000)).tobytes()      # runs across pieces
+    cases = sample_inputs(oracle_mod) + [runs[:250_000], rng.integers(0, 256, 320_000, dtype=np.uint8).tobytes(),
+                                         b"\x00" * 99_981 + b"\x01" * 99_981, b"ab" * 49_990 + b"b"]
+    for k, c in enumerate(cases):
+        level = 1 if len(c) > 60_000 else 9                  # (several blocks without megabytes for the naive sorter)
+        want = harness.compress(c, level)
+        for step, seed in ((1, 1), (7, 2), (300, 3), (5000, 4), (200_000, 5)):
+            if step == 1 and len(c) > 5000:
+                continue
+            out = np.empty(len(c) * 2 + 1000, np.uint8)
+            r = L.t_bz2_compress_fed(c, len(c), out.ctypes.data, out.size, level, step, seed)
+            assert r >= 0 and out[:r].tobytes() == want, (k, len(c), step)
+        assert bz2.decompress(want) == c
+
+
 def test_crc_variants_agree_with_the_definition(harness, oracle_mod):
     so = os.path.join(NATIVE, "libbz2_harness.so")
     L = ctypes.CDLL(so)

@@ -102,6 +102,29 @@ def test_bzip2_blocks_through_the_device_sorter(backend_lib, oracle_mod):
     assert len(patch) < new.size // 2                                     # text compresses: the framing does its job
 
 
+def test_framing_behind_the_scan_writes_the_same_patch(backend_lib, oracle_mod, monkeypatch):
+    """The diff and extra streams are framed while the scan loop still appends to them (bz2::StreamEncoder behind the
+    emitter, full blocks encoded on their own threads): byte for byte the patch of framing the finished streams."""
+    from deltaq_amd import Diff, Patch
+    rng = np.random.default_rng(17)
+    big_old = oracle_mod.gen_enwik_like(4_000_000, 12, 16384)
+    cases = list(pairs(oracle_mod)) + [(oracle_mod.gen_uniform(1_000_000, 5), oracle_mod.gen_enwik_like(3_000_000, 6, 4096)),
+                                       (big_old, edited(rng, big_old, 300)), (big_old, big_old.copy())]
+    monkeypatch.setenv("DQ_FRAME_AFTER", "1")
+    want = [Diff.CreateBytes(o, x) for o, x in cases]
+    monkeypatch.delenv("DQ_FRAME_AFTER")
+    for follow_min in ("0", None):
+        if follow_min is None:
+            monkeypatch.delenv("DQ_FRAME_FOLLOW_MIN")
+        else:
+            monkeypatch.setenv("DQ_FRAME_FOLLOW_MIN", follow_min)
+        for (o, x), w in zip(cases, want):
+            p = Diff.CreateBytes(o, x)
+            assert p == w, (o.size, x.size, follow_min)
+    for (o, x), w in zip(cases, want):
+        assert Patch.Apply(o, w) == x.tobytes()
+
+
 def test_one_old_many_new_index(backend_lib, oracle_mod):
     """DiffIndex: the old file is sorted once; every Create returns the patch Diff.Create writes for that pair.
     Also built on device-resident (text, suffix array) tensors of the caller, as a broadcast receiver holds them."""
