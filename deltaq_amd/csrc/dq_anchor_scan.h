@@ -21,8 +21,9 @@
 // Grid: G = kAsGroups workgroups of 4 waves, all resident.  A window's searches are dealt out one position per wave
 // (4 G = 512 positions; 65-ary search, dq_match_search.h) or, while the loop walks through a long differing stretch, one
 // per lane (256 G = 32768).  The answers meet in device memory; every workgroup evaluates the window on its own -- the
-// same integer decisions everywhere, so nothing but the answers is exchanged -- 64 positions at a time, as the
-// workgroups that own them report their arrival (no grid-wide barrier; a lagging barrier of one window keeps the two
+// same integer decisions everywhere, so nothing but the answers is exchanged -- the first 64 positions, then 256 at a
+// time, as their answers turn up: every answer word carries a tag of its window, so an evaluator waits on the very words
+// it needs and on nothing else (no grid-wide barrier, no arrival flags; a lagging barrier of one window keeps the two
 // answer buffers apart).  Every exchanged word is an agent-scope atomic (the L2s of the 8 XCDs are not coherent with
 // each other); every spin is bounded and ends in an error flag, on which the host falls back to its own loop.
 #pragma once
@@ -39,6 +40,11 @@ constexpr int kAsMaxGroups = 128;
 constexpr int kAsMaxLaneWin = kAsMaxGroups * kAsWaves * kWave;   // positions of the largest one-lane-per-position window
 constexpr int64_t kAsCap = 64;                            // comparison cap of the speculative positions
 constexpr int kAsWaveWins = 3;                            // wave windows walked over before the lane windows take over
+// An answer is two words, each with the tag of its window in the top two bits: tag << 62 | len << 31 | pos, and
+// tag << 62 | cnt(j, j + len).  The windows take the two answer buffers in turn; the k-th use of a buffer has tag k % 3, the
+// host fills the buffers with ones (tag 3) before a launch: a word of another window never passes for this one's.
+constexpr unsigned long long kAsStopLen = 0x7fffffffull;  // len field of a stop point (texts stay below 2^31 - 1 bytes)
+constexpr int kAsFirstSpan = 64;                          // positions of a wave window evaluated in the first step
 
 struct AnchorCtl {
     unsigned long long nrec;                              // (cursor, hit_pos) pairs written
@@ -100,13 +106,11 @@ template <typename IdxT>
 __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa, const uint8_t *__restrict__ nw, int64_t m,
     const IdxT *__restrict__ ptab, int pk,
-    unsigned long long *__restrict__ ans /* [2][lane window][2]: len << 32 | pos, then cnt(j, j + len) */,
+    unsigned long long *__restrict__ ans /* [2][lane window][2]: tagged answers, all ones before the launch */,
     unsigned long long *__restrict__ rec /* [rec_cap] in PINNED HOST memory: cursor << 32 | hit_pos, one store each */,
     int64_t rec_cap, AnchorCtl *__restrict__ ctl,
-    unsigned long long *__restrict__ arrived /* [gridDim.x], zeroed: windows whose answers workgroup w has published;
-                                               [kAsMaxGroups + w]: windows workgroup w has finished evaluating */)
+    unsigned long long *__restrict__ finished /* [gridDim.x], zeroed: windows workgroup w has finished evaluating */)
 {
-    unsigned long long *finished = arrived + kAsMaxGroups;
     __shared__ uint16_t agp[kAsMaxLaneWin + 2];           // agp[x] = cnt(i, i + x), x = 0 .. c
     const int64_t kAsWaveWin = (int64_t)gridDim.x * kAsWaves;      // positions of a one-wave-per-position window
     const int64_t kAsLaneWin = kAsWaveWin * kWave;                 // ... of a one-lane-per-position window
@@ -141,46 +145,36 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
         return as_wave_count_equal(old + shift, n - shift, nw, m, j, upto);
     };
 
-    // No grid-wide barrier.  A workgroup publishes its window-W answers, then sets arrived[w] = W + 1; an evaluator
-    // waits only for the workgroups that own the positions it is about to look at, 64 positions at a time in order --
-    // the loop usually breaks near the front of a window, the slowest of its 256 searches rarely lies there.  Two
-    // answer buffers are taken in turn, so nobody may publish window W before EVERYBODY is through with window W - 2:
-    // finished[w] counts the evaluations workgroup w has completed (a lagging barrier: it holds only a workgroup that is two windows
-    // ahead; one word per workgroup).  Progress: the workgroups at the smallest window index never wait for anybody behind them.
-    // Everything exchanged goes through agent-scope relaxed atomics (answers: stores / loads that bypass the
-    // non-coherent cache levels), as radix_rank_kernel's status words do: no fences, so the read-only data (old, new,
-    // suffix array, prefix table) stays cached from window to window.  A wave's answers are complete (s_waitcnt in
-    // __syncthreads) before its workgroup's arrival is published.
-    auto spin_until = [&](unsigned long long *word, unsigned long long target) -> bool {      // (one lane's wait)
-        uint32_t spins = 0;
-        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24) || ((spins & 1023u) == 0 && __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-        return true;
+    // No grid-wide barrier.  An evaluator loads the answer words of the positions it is about to look at and spins on
+    // them until both carry this window's tag -- the loop usually breaks near the front of a window, the slowest of
+    // its 512 searches rarely lies there.  Two answer buffers are taken in turn, so nobody may publish window W before
+    // EVERYBODY is through with window W - 2: finished[w] counts the evaluations workgroup w has completed (a lagging
+    // barrier: it holds only a workgroup that is two windows ahead; one word per workgroup, loaded before the search
+    // and looked at after it).  Progress: the workgroups at the smallest window index never wait for anybody behind them.
+    // Everything exchanged goes through agent-scope relaxed atomics (stores / loads that bypass the non-coherent cache
+    // levels), as radix_rank_kernel's status words do: no fences, so the read-only data (old, new, suffix array,
+    // prefix table) stays cached from window to window; and no ordering between words is relied upon -- each one
+    // says itself which window it belongs to.
+    auto give_up = [&]() {
+        __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_err = 1;
     };
-    // wait for the workgroups [w0, w1) to have published window `win_no`; called by the whole workgroup
-    auto await_groups = [&](int w0, int w1, unsigned long long win_no) {
-        if (tid == 0) s_err = 0;
-        __syncthreads();
-        if (tid < w1 - w0 && !spin_until(&arrived[w0 + tid], win_no + 1)) s_err = 1;
-        __syncthreads();
-        if (s_err) failed = true;
-    };
-    auto publish_arrival = [&](unsigned long long win_no) {
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(&arrived[blockIdx.x], win_no + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
+    auto others_gave_up = [&]() -> bool { return __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; };
     // (every workgroup on its own word -- a sum over the workgroups says nothing: half of them two windows ahead
     // would make it look as if everybody had finished one)
-    auto await_lagging = [&](unsigned long long win_no) {             // before publishing window win_no
-        if (win_no < 2) return;
-        if (tid == 0) s_err = 0;
-        __syncthreads();
-        if (tid < (int)gridDim.x && !spin_until(&finished[tid], win_no - 1)) s_err = 1;
+    auto lagging_load = [&](unsigned long long win_no) -> unsigned long long {       // issued before the search ...
+        if (win_no < 2 || tid >= (int)gridDim.x) return ~0ull;
+        return __hip_atomic_load(&finished[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto await_lagging = [&](unsigned long long win_no, unsigned long long seen) {   // ... checked before publishing window win_no
+        if (win_no >= 2 && tid < (int)gridDim.x) {
+            uint32_t spins = 0;
+            while (seen < win_no - 1) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24) || ((spins & 1023u) == 0 && others_gave_up())) { give_up(); break; }
+                seen = __hip_atomic_load(&finished[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         __syncthreads();
         if (s_err) failed = true;
     };
@@ -192,17 +186,27 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     // (two answer buffers, taken in turn by the windows: a workgroup that is through with window k publishes window
     // k + 1 while a slower one still reads window k; nobody reaches window k + 2 before everybody has left window k)
     unsigned long long *ans_w = ans;
+    unsigned long long tag_w = 0;
     auto publish = [&](int64_t slot, int64_t p, int64_t l, int64_t cw) {
         unsigned long long *ans = ans_w;
-        __hip_atomic_store(&ans[2 * slot], ((unsigned long long)(uint32_t)(int32_t)l << 32) | (uint32_t)(int32_t)p,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ans[2 * slot + 1], (unsigned long long)cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // The arrival word that follows (another address, written by another wave of the workgroup behind a barrier) must
-        // not become visible before these two: the wave waits here until its own stores have been performed.  (A
-        // workgroup-scope barrier alone does not wait for global stores -- seen as evaluators reading the answers of
-        // two windows ago: diverging workgroups, a wait that never ended, one wrong patch in 4 000.)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long lf = l < 0 ? kAsStopLen : (unsigned long long)l, pf = l < 0 ? 0ull : (unsigned long long)p;
+        __hip_atomic_store(&ans[2 * slot], (tag_w << 62) | (lf << 31) | pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ans[2 * slot + 1], (tag_w << 62) | (unsigned long long)cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    // both words of position `slot` of this window, waited for
+    auto fetch = [&](int64_t slot, unsigned long long *v, unsigned long long *v2) {
+        unsigned long long *ans = ans_w;
+        uint32_t spins = 0;
+        for (;;) {
+            *v = __hip_atomic_load(&ans[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *v2 = __hip_atomic_load(&ans[2 * slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((*v >> 62) == tag_w && (*v2 >> 62) == tag_w) return;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24) || ((spins & 1023u) == 0 && others_gave_up())) { give_up(); *v = *v2 = 0; return; }
+        }
+    };
+    if (tid == 0) s_err = 0;                               // (sticky: once set, every loop below ends)
+    __syncthreads();
 
     while (cursor < m && !failed) {
         if (nrec >= rec_cap) break;                       // the host empties the list and launches again from this state
@@ -220,40 +224,41 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
             const int64_t c = (m - i) < win ? (m - i) : win;
             const unsigned long long win_no = n_win;        // windows are numbered from 0, the same everywhere
             ans_w = ans + (size_t)(n_win & 1ull) * (2 * (size_t)kAsMaxLaneWin);
-            unsigned long long *ans = ans_w;              // (shadows the parameter: this window's buffer)
+            tag_w = (n_win >> 1) % 3ull;
             ++n_win;
-            await_lagging(win_no);
-            lap(t_wait);
-            if (failed) break;
+            const unsigned long long lag_seen = lagging_load(win_no);
             // ---- 0. the window's answers (and each match's own agree count), one position per wave or per lane ----
-            if (!lane_mode) {
-                if (gwave < c) {
-                    const int64_t scan = i + gwave;
-                    const bool exact = gwave == 0 || streak >= 2;
-                    int64_t p = 0, l = 0;
-                    ms_search_wave<IdxT>(old, n, sa, nw, m, scan, exact ? (int64_t)0 : kAsCap, ptab, pk, &p, &l, nullptr, /*resume_first=*/true);
-                    const int64_t cw = wave_cw(scan, p, l);
-                    if (lane == 0) publish(gwave, p, l, cw);
-                }
-            } else {
-                const int64_t idx = (int64_t)gwave * kWave + lane;
-                if ((int64_t)gwave * kWave < c) {          // (whole waves)
-                    int64_t p = 0, l = 0;
-                    const bool live = idx < c;
-                    ms_search_one<IdxT>(old, n, sa, nw, m, live ? i + idx : 0, live, kAsCap, ptab, pk, &p, &l);
-                    if (live) {
-                        const int64_t j = i + idx;
-                        int64_t cw = 0;
-                        if (l > 0) {
-                            if (p - j == shift) cw = l;
-                            else for (int64_t k = j; k < j + l; ++k) cw += agree(k) ? 1 : 0;
+            {
+                int64_t p = 0, l = 0, cw = 0, slot = -1;
+                if (!lane_mode) {
+                    if (gwave < c) {
+                        const int64_t scan = i + gwave;
+                        const bool exact = gwave == 0 || streak >= 2;
+                        ms_search_wave<IdxT>(old, n, sa, nw, m, scan, exact ? (int64_t)0 : kAsCap, ptab, pk, &p, &l, nullptr, /*resume_first=*/true);
+                        cw = wave_cw(scan, p, l);
+                        if (lane == 0) slot = gwave;
+                    }
+                } else {
+                    const int64_t idx = (int64_t)gwave * kWave + lane;
+                    if ((int64_t)gwave * kWave < c) {      // (whole waves)
+                        const bool live = idx < c;
+                        ms_search_one<IdxT>(old, n, sa, nw, m, live ? i + idx : 0, live, kAsCap, ptab, pk, &p, &l);
+                        if (live) {
+                            const int64_t j = i + idx;
+                            if (l > 0) {
+                                if (p - j == shift) cw = l;
+                                else for (int64_t k = j; k < j + l; ++k) cw += agree(k) ? 1 : 0;
+                            }
+                            slot = idx;
                         }
-                        publish(idx, p, l, cw);
                     }
                 }
+                lap(t_search);
+                await_lagging(win_no, lag_seen);           // (window win_no - 2 has been read by everybody)
+                lap(t_wait);
+                if (failed) break;
+                if (slot >= 0) publish(slot, p, l, cw);
             }
-            publish_arrival(win_no);
-            lap(t_search);
 
             // ---- 1. prefix counts of agree() over the window's positions ----
             {
@@ -281,32 +286,30 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 __syncthreads();
             }
 
-            // ---- 2. the positions, 256 at a time: prefix maximum of the match ends (with cnt(base, end)), break test ----
+            // ---- 2. the positions, a step at a time: prefix maximum of the match ends (with cnt(base, end)), break test ----
             int64_t Mrun = M, Crun = C;                    // (M, cnt(base, M)) after the positions walked over so far
             int brk = -1, stp = -1;                        // window index of the first break / stop point
             int64_t b_pos = 0, b_len = 0, b_carried = 0;
-            // (one-wave-per-position windows: 64 positions a step, the answers of 16 workgroups; one-lane-per-position
-            // windows: 256 positions a step, the answers of one workgroup)
-            const int span = lane_mode ? kAsThreads : kWave;
-            for (int ch = 0; (int64_t)ch * span < c && brk < 0 && stp < 0; ++ch) {
+            // (one-wave-per-position windows: the first 64 positions on their own -- a deletion or a copied stretch breaks
+            // on the first few -- then 256 a step; one-lane-per-position windows: 256 positions a step, one workgroup's answers)
+            for (int off = 0; off < (int)c && brk < 0 && stp < 0;) {
+                const int span = (!lane_mode && off == 0) ? kAsFirstSpan : kAsThreads;
                 lap(t_eval);
-                if (lane_mode) await_groups(ch, ch + 1, win_no);
-                else await_groups(ch * (kWave / kAsWaves), (ch + 1) * (kWave / kAsWaves) < (int)gridDim.x ? (ch + 1) * (kWave / kAsWaves) : (int)gridDim.x, win_no);
-                lap(t_wait);
-                if (failed) break;
-                const int t = ch * span + tid;
+                const int t = off + tid;
                 const bool have = tid < span && t < c;
                 int64_t l = 0, p = 0, e = -1, ce = 0, Sj = 0;
                 bool stop = false;
                 if (have) {
-                    const unsigned long long v = __hip_atomic_load(&ans[2 * t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long v2 = __hip_atomic_load(&ans[2 * t + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    l = (int64_t)(int32_t)(uint32_t)(v >> 32);
-                    p = (int64_t)(int32_t)(uint32_t)v;
+                    unsigned long long v, v2;
+                    fetch(t, &v, &v2);
+                    const unsigned long long lf = (v >> 31) & 0x7fffffffull;
+                    p = (int64_t)(v & 0x7fffffffull);
                     Sj = S + (int64_t)agp[t];
-                    if (l < 0) stop = true;
-                    else { e = i + t + l; ce = Sj + (int64_t)v2; }         // cnt(base, e) = cnt(base, j) + cnt(j, e)
+                    if (lf == kAsStopLen) { stop = true; l = -1; }
+                    else { l = (int64_t)lf; e = i + t + l; ce = Sj + (int64_t)(v2 & 0x3fffffffffffffffull); }   // cnt(base, e) = cnt(base, j) + cnt(j, e)
                 }
+                off += span;
+                lap(t_wait);
                 // inclusive prefix maximum of e over the chunk, carrying cnt(base, .) of the end that holds it
                 int64_t pe = e, pc = ce;
 #pragma unroll
@@ -316,6 +319,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 }
                 if (lane == kWave - 1) { w_e[wv] = pe; w_c[wv] = pc; }
                 __syncthreads();
+                if (s_err) { failed = true; break; }       // (an answer never came: everybody leaves)
                 int64_t ce_in = Mrun, cc_in = Crun;        // what comes in from the left of this wave
                 for (int q = 0; q < wv; ++q) if (w_e[q] > ce_in) { ce_in = w_e[q]; cc_in = w_c[q]; }
                 int64_t ch_e = Mrun, ch_c = Crun;          // ... and what the whole chunk leaves
@@ -363,9 +367,10 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 break;
             }
             if (stp < 0) {                                 // the whole window went by
-                const unsigned long long v = __hip_atomic_load(&ans[2 * (c - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last_len = (int64_t)(int32_t)(uint32_t)(v >> 32);
-                last_pos = (int64_t)(int32_t)(uint32_t)v;
+                // (its last position was in the last step: the word is this window's; never a stop point here)
+                const unsigned long long v = __hip_atomic_load(&ans_w[2 * (c - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last_len = (int64_t)((v >> 31) & 0x7fffffffull);
+                last_pos = (int64_t)(v & 0x7fffffffull);
                 any_search = true;
                 window_done();
                 M = Mrun; C = Crun;

@@ -18,6 +18,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -415,6 +418,11 @@ using DoubledSorter = std::function<int(const uint8_t *text, int64_t n2, int32_t
 inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32_t crc, const DoubledSorter &sorter)
 {
     const int32_t nblock = (int32_t)blk.size();
+    const bool trace = getenv("DQ_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = now();
+    double t_ph[5] = {0, 0, 0, 0, 0};                       // sort, last column, MTF, tables, bits
+    auto lap = [&](int k) { const auto t = now(); t_ph[k] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
     // ---- Burrows-Wheeler transform through the suffix array of block+block ----
     std::vector<uint8_t> doubled((size_t)nblock * 2);
     memcpy(doubled.data(), blk.data(), (size_t)nblock);
@@ -422,6 +430,7 @@ inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32
     std::vector<int32_t> sa((size_t)nblock * 2);
     const int rc = sorter(doubled.data(), (int64_t)nblock * 2, sa.data());
     if (rc != 0) return rc;
+    lap(0);
     std::vector<uint8_t> last((size_t)nblock);
     int32_t orig_ptr = -1, row = 0;
     for (int32_t i = 0; i < 2 * nblock; ++i) {
@@ -431,6 +440,7 @@ inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32
         last[(size_t)row++] = blk[(size_t)(s == 0 ? nblock - 1 : s - 1)];
     }
     if (row != nblock || orig_ptr < 0) return -3;
+    lap(1);
     // ---- symbols in use, MTF, RUNA / RUNB ----
     bool in_use[256] = {false};
     for (int32_t i = 0; i < nblock; ++i) in_use[blk[(size_t)i]] = true;
@@ -442,7 +452,9 @@ inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32
     mtfv.reserve((size_t)nblock + 1);
     int32_t mtf_freq[kMaxAlpha] = {0};
     {
-        uint8_t yy[256];
+        // (the list is searched 8 entries a step and moved with one memmove: the byte-by-byte walk of the classic
+        // coder cost 33 ms for a 900 kB block of random bytes -- average depth 128 -- against 5 ms for its transform)
+        uint8_t yy[256 + 8] = {0};
         for (int i = 0; i < n_in_use; ++i) yy[i] = (uint8_t)i;
         int64_t zrun = 0;
         auto flush_zeros = [&]() {
@@ -462,9 +474,18 @@ inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32
             if (yy[0] == c) { ++zrun; continue; }
             flush_zeros();
             int j = 1;
-            uint8_t prev = yy[0];
-            while (yy[j] != c) { const uint8_t t = yy[j]; yy[j] = prev; prev = t; ++j; }
-            yy[j] = prev;
+            if (yy[1] != c) {
+                // c sits in the list (it is in use): the first zero byte of (entries ^ c), lowest address first
+                const uint64_t pat = 0x0101010101010101ull * c;
+                for (j = 0;; j += 8) {
+                    uint64_t v;
+                    memcpy(&v, yy + j, 8);
+                    v ^= pat;
+                    const uint64_t z = (v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull;
+                    if (z) { j += __builtin_ctzll(z) >> 3; break; }
+                }
+            }
+            memmove(yy + 1, yy, (size_t)j);
             yy[0] = c;
             mtfv.push_back((uint16_t)(j + 1));
             mtf_freq[j + 1]++;
@@ -474,6 +495,7 @@ inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32
         mtf_freq[eob]++;
     }
     const int32_t n_mtf = (int32_t)mtfv.size();
+    lap(2);
     // ---- coding tables: initial split by frequency, 4 refinement rounds over groups of 50 symbols ----
     const int n_groups = n_mtf < 200 ? 2 : n_mtf < 600 ? 3 : n_mtf < 1200 ? 4 : n_mtf < 2400 ? 5 : 6;
     uint8_t len[kMaxGroups][kMaxAlpha];
@@ -494,15 +516,24 @@ inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32
     const int32_t n_sel = (n_mtf + kGroupSize - 1) / kGroupSize;
     std::vector<uint8_t> selector((size_t)n_sel);
     std::vector<int32_t> rfreq((size_t)kMaxGroups * kMaxAlpha);
+    static_assert(kMaxGroups * 10 <= 64 && kGroupSize * 20 < 1024, "six 10-bit cost fields in one word");
+    std::vector<uint64_t> packed((size_t)alpha);
     for (int iter = 0; iter < 4; ++iter) {
         std::fill(rfreq.begin(), rfreq.end(), 0);
+        // (the cost of a group of 50 symbols under all tables at once: their code lengths side by side in one word)
+        for (int v = 0; v < alpha; ++v) {
+            uint64_t w = 0;
+            for (int t = 0; t < n_groups; ++t) w |= (uint64_t)len[t][v] << (10 * t);
+            packed[(size_t)v] = w;
+        }
         for (int32_t g = 0; g < n_sel; ++g) {
             const int32_t a = g * kGroupSize, b = std::min<int32_t>(a + kGroupSize, n_mtf);
             int32_t best_cost = 0x7fffffff;
             int best = 0;
+            uint64_t costs = 0;
+            for (int32_t i = a; i < b; ++i) costs += packed[mtfv[(size_t)i]];
             for (int t = 0; t < n_groups; ++t) {
-                int32_t cost = 0;
-                for (int32_t i = a; i < b; ++i) cost += len[t][mtfv[(size_t)i]];
+                const int32_t cost = (int32_t)((costs >> (10 * t)) & 1023u);
                 if (cost < best_cost) { best_cost = cost; best = t; }
             }
             selector[(size_t)g] = (uint8_t)best;
@@ -521,6 +552,7 @@ inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32
             c <<= 1;
         }
     }
+    lap(3);
     // ---- the block ----
     bw.bits(24, (uint32_t)(kBlockMagic >> 24));
     bw.bits(24, (uint32_t)(kBlockMagic & 0xffffff));
@@ -569,6 +601,10 @@ inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32
         const int32_t a = g * kGroupSize, b = std::min<int32_t>(a + kGroupSize, n_mtf);
         for (int32_t i = a; i < b; ++i) bw.bits(len[t][mtfv[(size_t)i]], code[t][mtfv[(size_t)i]]);
     }
+    lap(4);
+    if (trace)
+        fprintf(stderr, "[dq] bzip2 block of %d bytes (%d symbols): transform %.2f ms, last column %.2f, move to front %.2f, tables %.2f, bits %.2f\n",
+                nblock, n_mtf, t_ph[0], t_ph[1], t_ph[2], t_ph[3], t_ph[4]);
     return 0;
 }
 

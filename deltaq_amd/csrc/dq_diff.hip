@@ -408,7 +408,11 @@ struct BlockSorter {
     std::string err;
     int sort(const uint8_t *t, int64_t n2, int32_t *sa)
     {
-        const int r = sufsort_host<int32_t>(t, n2, sa, dev);
+        const auto t0 = std::chrono::steady_clock::now();
+        const int r = sufsort_host<int32_t>(t, n2, sa, dev, /*doubled=*/true);
+        if (env("DQ_TRACE"))
+            fprintf(stderr, "[dq] bzip2 block transform: suffix array of %lld bytes in %.3f ms\n", (long long)n2,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (r == DQ_OK) return 0;
         int expect = DQ_OK;
         if (rc.compare_exchange_strong(expect, r)) {
@@ -523,8 +527,8 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
 {
     *retry_on_host = false;
     AnchorCtl *d_ctl = reinterpret_cast<AnchorCtl *>(scratch);
-    unsigned long long *d_arrived = reinterpret_cast<unsigned long long *>(scratch + 256);       // [kAsMaxGroups]
-    static_assert(2 * kAsMaxGroups * 8 <= 2048, "arrival + completion words");
+    unsigned long long *d_finished = reinterpret_cast<unsigned long long *>(scratch + 256);      // [kAsMaxGroups]
+    static_assert(kAsMaxGroups * 8 <= 2048, "completion words");
     unsigned long long *d_ans = reinterpret_cast<unsigned long long *>(scratch + 256 + 2048);
     static_assert(sizeof(AnchorCtl) <= 256, "control block");
     bsdiff::TripleEmitter em(ix.old, ix.n, nw, m, raw);
@@ -545,12 +549,13 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         for (int64_t k = 0; k < kAnchorRecs; ++k) ring[k] = kAnchorPending;
         std::atomic_thread_fence(std::memory_order_seq_cst);
         HIP_TRY(hipMemcpyAsync(d_ctl, h_up, sizeof(AnchorCtl), hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(hipMemsetAsync(d_arrived, 0, 2048, c.stream));
+        HIP_TRY(hipMemsetAsync(d_finished, 0, 2048, c.stream));
+        HIP_TRY(hipMemsetAsync(d_ans, 0xff, (size_t)kAsMaxLaneWin * 32, c.stream));       // (no answer word carries a window's tag yet)
         auto launch = [&]() -> int {
             LAUNCH(L, DQ_K_MATCH_SEARCH, m, m * 2,
                    hipLaunchKernelGGL(anchor_scan_kernel<int32_t>, dim3(groups), dim3(kAsThreads), 0, c.stream,
                                       (const uint8_t *)ix.d_old, ix.n, (const int32_t *)ix.d_sa, (const uint8_t *)d_new, m,
-                                      (const int32_t *)ix.d_tab, ix.pk, d_ans, ring, kAnchorRecs, d_ctl, d_arrived));
+                                      (const int32_t *)ix.d_tab, ix.pk, d_ans, ring, kAnchorRecs, d_ctl, d_finished));
             return DQ_OK;
         };
         rc = launch();
@@ -630,7 +635,8 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
     HIP_TRY(hipMemcpy(d_new, nw, (size_t)m, hipMemcpyHostToDevice));
     stamp("new on device");
     // the anchor search of the scan loop on the device (default), or the host loop over windows of device answers
-    const bool device_scan = env("DQ_SCAN_DEVICE") ? atoi(env("DQ_SCAN_DEVICE")) != 0 : true;
+    // (its answer words have 31 bits for a length, all ones standing for "not exact": files of 2^31 - 1 bytes take the host loop)
+    const bool device_scan = (env("DQ_SCAN_DEVICE") ? atoi(env("DQ_SCAN_DEVICE")) != 0 : true) && ix.n < 0x7fffffffLL && m < 0x7fffffffLL;
     if (device_scan) {
         bool retry_on_host = false;
         static_assert(kDiffPinnedBytes >= (size_t)kAnchorRecs * 8, "the pinned window area holds the anchor ring");

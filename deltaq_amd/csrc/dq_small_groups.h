@@ -259,4 +259,96 @@ __global__ __launch_bounds__(kBlock) void isa_update_words_kernel(const uint64_t
     }
 }
 
+// A DOUBLED text (block + block, as bzip2's rotation sort asks for: dq_bz2.h) ties suffix i with suffix i + half for
+// half - i characters -- the shorter one is a prefix of the longer -- although their order is known from the start: the
+// shorter one first.  Prefix doubling would carry all these pairs to h > half (17 rounds over the whole list for a
+// 900 kB block of random bytes whose real ties end after the first).  So between the rounds every tie group that is
+// exactly such a pair is written down -- its two slots of the suffix array and its two final ranks (ranks finer than
+// the current depth asks for are always welcome) -- and leaves the list; the rounds go on with the real ties only.
+constexpr int kTwThreads = 256, kTwItems = 8;
+constexpr int kTwTile = kTwThreads * kTwItems;          // (= the tile the pair-chain counters are sized for)
+
+// list position j: 0 = stays (its group is not such a pair), 1 / 2 = first / second entry of a pair.  *head: first of its group.
+template <typename IdxT>
+__device__ __forceinline__ int twin_class(const uint64_t *__restrict__ rank, const uint32_t *__restrict__ rank32,
+                                          const IdxT *__restrict__ suf, int64_t m, int64_t half, int64_t j, bool *head)
+{
+    auto rk = [&](int64_t q) -> uint64_t { return rank32 ? (uint64_t)rank32[q] : rank[q]; };
+    const uint64_t r = rk(j);
+    *head = j == 0 || rk(j - 1) != r;
+    const int64_t g0 = *head ? j : j - 1;                // where the pair would begin
+    if (!*head && g0 > 0 && rk(g0 - 1) == r) return 0;   // third or later member
+    if (g0 + 1 >= m || rk(g0 + 1) != r) return 0;
+    if (g0 + 2 < m && rk(g0 + 2) == r) return 0;
+    const int64_t a = (int64_t)suf[g0], b = (int64_t)suf[g0 + 1];
+    if (a - b != half && b - a != half) return 0;
+    return *head ? 1 : 2;
+}
+
+// pass 1: write the pairs down; per tile, the groups and the entries that stay (tile_cnt[2t], [2t + 1])
+template <typename IdxT>
+__global__ __launch_bounds__(kTwThreads) void twin_mark_kernel(const uint64_t *__restrict__ rank, const uint32_t *__restrict__ rank32,
+                                                               const IdxT *__restrict__ suf, int64_t m, int64_t half,
+                                                               IdxT *__restrict__ SA, IdxT *__restrict__ ISA, uint32_t *__restrict__ tile_cnt)
+{
+    __shared__ uint32_t part[2][kTwThreads / kWave];
+    const int64_t j0 = (int64_t)blockIdx.x * kTwTile + (int64_t)threadIdx.x * kTwItems;
+    uint32_t kept = 0, groups = 0;
+    for (int k = 0; k < kTwItems; ++k) {
+        const int64_t j = j0 + k;
+        if (j >= m) break;
+        bool head;
+        const int cls = twin_class<IdxT>(rank, rank32, suf, m, half, j, &head);
+        if (cls == 0) { ++kept; groups += head ? 1u : 0u; }
+        else if (cls == 1) {
+            const uint64_t r = rank32 ? (uint64_t)rank32[j] : rank[j];
+            const IdxT a = suf[j], b = suf[j + 1];
+            const IdxT hi = a > b ? a : b, lo = a > b ? b : a;
+            SA[r] = hi; SA[r + 1] = lo;
+            ISA[hi] = (IdxT)r; ISA[lo] = (IdxT)(r + 1);
+        }
+    }
+    const uint32_t ik = wave_incl_sum(kept), ig = wave_incl_sum(groups);
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (lane == kWave - 1) { part[0][wv] = ig; part[1][wv] = ik; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t g = 0, kp = 0;
+        for (int i = 0; i < kTwThreads / kWave; ++i) { g += part[0][i]; kp += part[1][i]; }
+        tile_cnt[2 * blockIdx.x] = g;
+        tile_cnt[2 * blockIdx.x + 1] = kp;
+    }
+}
+
+// pass 2 (tile_cnt scanned by pair_scan_kernel): the entries that stay, in order
+template <typename IdxT>
+__global__ __launch_bounds__(kTwThreads) void twin_compact_kernel(const uint64_t *__restrict__ rank, const uint32_t *__restrict__ rank32,
+                                                                  const IdxT *__restrict__ suf, int64_t m, int64_t half,
+                                                                  const uint32_t *__restrict__ tile_cnt,
+                                                                  uint64_t *__restrict__ out_rank, IdxT *__restrict__ out_suf)
+{
+    __shared__ uint32_t part[kTwThreads / kWave];
+    const int64_t j0 = (int64_t)blockIdx.x * kTwTile + (int64_t)threadIdx.x * kTwItems;
+    uint32_t stays = 0, kept = 0;
+    for (int k = 0; k < kTwItems; ++k) {
+        const int64_t j = j0 + k;
+        if (j >= m) break;
+        bool head;
+        if (twin_class<IdxT>(rank, rank32, suf, m, half, j, &head) == 0) { stays |= 1u << k; ++kept; }
+    }
+    const uint32_t incl = wave_incl_sum(kept);
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (lane == kWave - 1) part[wv] = incl;
+    __syncthreads();
+    int64_t p = (int64_t)tile_cnt[2 * blockIdx.x + 1] + (incl - kept);
+    for (int i = 0; i < wv; ++i) p += part[i];
+    for (int k = 0; k < kTwItems; ++k) {
+        if (!((stays >> k) & 1u)) continue;
+        const int64_t j = j0 + k;
+        out_rank[p] = rank32 ? (uint64_t)rank32[j] : rank[j];
+        out_suf[p] = suf[j];
+        ++p;
+    }
+}
+
 }  // namespace dq

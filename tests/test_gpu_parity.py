@@ -617,6 +617,32 @@ def test_runs_of_one_byte(ldss, oracle_mod, monkeypatch, env):
         assert np.array_equal(ldss.Sort(T), oracle_mod.divsufsort(T)), (env, T.size)
 
 
+@pytest.mark.parametrize("env", [{}, {"DQ_MID_GROUPS": "0"}, {"DQ_SPARSE": "1"}, {"DQ_BINNED_ISA": "1"}, {"DQ_SPARSE": "0", "DQ_PAIR_CHAINS": "2"},
+                                 {"DQ_NO_TWINS": "1"}],
+                         ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
+def test_doubled_texts_finish_at_the_twin_pairs(ldss, oracle_mod, monkeypatch, env):
+    """block + block, as the bzip2 encoder hands its blocks to the sorter (dq_bz2.h): suffix i + n/2 is a prefix of
+    suffix i, the pair stays tied for n/2 - i characters; the sorter stops as soon as nothing but such pairs is left
+    (twin_pairs_kernel) -- the suffix array is the same, entry for entry."""
+    import torch
+    monkeypatch.setenv("DQ_ASSUME_DOUBLED", "1")
+    monkeypatch.setenv("DQ_SMALL_N", "0")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(31)
+    zero_runs = np.tile(np.array([0, 0, 0, 0, 251], np.uint8), 40_000)             # a diff stream after its run-length pass
+    zero_runs[rng.integers(0, zero_runs.size, 300)] = rng.integers(1, 256, 300).astype(np.uint8)
+    blocks = [oracle_mod.gen_uniform(450_000, 3), oracle_mod.gen_enwik_like(300_000, 5, 8192), zero_runs,
+              np.zeros(20_000, np.uint8), np.tile(np.frombuffer(b"ab", np.uint8), 9_000), np.tile(oracle_mod.gen_uniform(777, 2), 40),
+              oracle_mod.gen_uniform(5, 1), oracle_mod.gen_uniform(4097, 9), oracle_mod.gen_uniform(3, 4).repeat(2000),
+              rng.integers(0, 2, 100_000).astype(np.uint8), np.frombuffer(b"a", np.uint8)]
+    for B in blocks:
+        T = np.ascontiguousarray(np.concatenate([B, B]), dtype=np.uint8)
+        ref = oracle_mod.divsufsort(T)
+        assert np.array_equal(ldss.Sort(T), ref), (env, B.size, "host")
+        assert np.array_equal(ldss.Sort(torch.from_numpy(T).cuda()).cpu().numpy(), ref), (env, B.size, "device")
+
+
 def test_regression_inputs_found_by_the_stress_runs(ldss, oracle_mod, monkeypatch):
     """Inputs that tests/manual/stress.py caught a build on (tests/golden/regress/*.npy, each with the flags it ran under).
     stress_332_18050: suffix-binned first ISA on an input that leaves fewer than n/6 suffixes tied -- the finisher of the
