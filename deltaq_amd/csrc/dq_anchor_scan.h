@@ -52,7 +52,7 @@ struct AnchorCtl {
     long long done;                                       // 1: the end of new has been reached and reported
     unsigned long long searches, windows, stops;          // Search calls the reference's loop makes; windows; stop points
     unsigned int error;                                   // 1: the barrier timed out
-    unsigned int pad;
+    unsigned int pad;                                     // in: 1 = fill in the times below
     unsigned long long t_search, t_wait, t_eval, t_stop;  // workgroup 0's time searching / waiting for answers / evaluating /
                                                           // at stop points, in 100 MHz ticks (DQ_TRACE prints them)
 };
@@ -131,7 +131,14 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     unsigned long long n_search = 0, n_win = 0, n_stop = 0;
     bool failed = false;
     unsigned long long t_search = 0, t_wait = 0, t_eval = 0, t_stop = 0, t0 = __builtin_readcyclecounter();
-    auto lap = [&](unsigned long long &acc) { const unsigned long long t1 = wall_clock64(); acc += t1 - t0; t0 = t1; };
+    // (only when asked for -- ctl->pad, set under DQ_TRACE: reading the clock ~7 times a window is not free)
+    const bool timed = ctl->pad != 0;
+    auto lap = [&](unsigned long long &acc) {
+        if (!timed) return;
+        const unsigned long long t1 = wall_clock64();
+        acc += t1 - t0;
+        t0 = t1;
+    };
     t0 = wall_clock64();
 
     auto agree = [&](int64_t k) -> bool { return k + shift < n && old[k + shift] == nw[k]; };

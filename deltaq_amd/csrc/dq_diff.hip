@@ -409,7 +409,23 @@ struct BlockSorter {
     int sort(const uint8_t *t, int64_t n2, int32_t *sa)
     {
         const auto t0 = std::chrono::steady_clock::now();
-        const int r = sufsort_host<int32_t>(t, n2, sa, dev, /*doubled=*/true);
+        SortHints hints;
+        hints.doubled = true;
+        // bzip2's run-length pre-pass turns a long run into a stretch of period 5 (four bytes + a count of 251): the diff
+        // stream of two similar files is little else.  One look at the block: where 1/8 of it lies in such stretches, the
+        // sorter is told (they tie thousands of suffixes per phase until the doubling has walked through them).
+        {
+            const int64_t nb = n2 / 2;
+            int64_t words = 0;
+            for (int64_t i = 0; i + 13 <= nb; i += 8) {
+                uint64_t a, b;
+                memcpy(&a, t + i, 8);
+                memcpy(&b, t + i + 5, 8);
+                words += a == b;
+            }
+            if (words * 64 >= nb && nb >= (1 << 15)) hints.run_period = 5;
+        }
+        const int r = sufsort_host<int32_t>(t, n2, sa, dev, hints);
         if (env("DQ_TRACE"))
             fprintf(stderr, "[dq] bzip2 block transform: suffix array of %lld bytes in %.3f ms\n", (long long)n2,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -546,6 +562,7 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         Launcher L{c, c.stream, g_prof_on.load()};
         *h_up = AnchorCtl{};
         h_up->cursor = st.cursor; h_up->hit_len = st.hit_len; h_up->hit_pos = st.hit_pos; h_up->shift = st.shift;
+        h_up->pad = trace ? 1u : 0u;
         for (int64_t k = 0; k < kAnchorRecs; ++k) ring[k] = kAnchorPending;
         std::atomic_thread_fence(std::memory_order_seq_cst);
         HIP_TRY(hipMemcpyAsync(d_ctl, h_up, sizeof(AnchorCtl), hipMemcpyHostToDevice, c.stream));

@@ -292,12 +292,20 @@ struct JoinAll {                        // joins whatever was started, also when
 
 // ------------------------------------------------------------------ entry points across translation units
 // the suffix sorter (dq_sorter_impl.h; instantiated for int32_t in dq_sorter_i32.hip, int64_t in dq_sorter_i64.hip)
-// doubled: the caller vouches that text is some block twice (n even, text[i] == text[i + n / 2]): see twin_pairs_kernel
-template <typename IdxT> int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device, bool doubled = false);
+// What a caller inside the library knows about its text (bzip2's block transform, dq_bz2.h / dq_diff.hip):
+//   doubled     the text is some block twice (n even, text[i] == text[i + n / 2]): the pairs (i, i + n / 2) leave the
+//               list as soon as they are what is left of a tie group (twin_mark_kernel)
+//   run_period  a good part of the text lies in stretches that repeat with this period (<= 8): run lengths with that
+//               period and the run-order round up front (dq_runs.h), as for texts with long runs of one byte
+struct SortHints {
+    bool doubled = false;
+    int run_period = 0;
+};
+template <typename IdxT> int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device, SortHints hints = SortHints());
 template <typename IdxT> int sufsort_dev(const void *d_text, int64_t n, void *d_sa, int32_t device, void *stream);
 template <typename IdxT> int64_t sufsort_workspace_bytes(int64_t n);
-extern template int sufsort_host<int32_t>(const uint8_t *, int64_t, int32_t *, int32_t, bool);
-extern template int sufsort_host<int64_t>(const uint8_t *, int64_t, int64_t *, int32_t, bool);
+extern template int sufsort_host<int32_t>(const uint8_t *, int64_t, int32_t *, int32_t, SortHints);
+extern template int sufsort_host<int64_t>(const uint8_t *, int64_t, int64_t *, int32_t, SortHints);
 extern template int sufsort_dev<int32_t>(const void *, int64_t, void *, int32_t, void *);
 extern template int sufsort_dev<int64_t>(const void *, int64_t, void *, int32_t, void *);
 extern template int64_t sufsort_workspace_bytes<int32_t>(int64_t);

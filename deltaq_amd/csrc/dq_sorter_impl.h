@@ -896,6 +896,7 @@ struct SuffixSorter {
         // (the late rounds also take stretches that repeat with a period > 1, which the histogram pass does not see:
         // large groups that stop shrinking are what calls them)
         late_runs_possible = sizeof(IdxT) == 4 && n >= (1 << 16);
+        if (period_hint > 0 && sizeof(IdxT) == 4 && n >= (1 << 16)) runs_wanted = true;      // (the caller has seen the stretches)
         if (const char *v = env("DQ_RUNS")) { runs_wanted = sizeof(IdxT) == 4 && atoi(v) != 0; late_runs_possible = late_runs_possible && atoi(v) != 0; }
         if (const char *v = env("DQ_MID_GROUPS")) runs_wanted = runs_wanted && atoi(v) >= 256;   // (the LDS class carries the run offsets)
         V[kb & 1] = d_sa;
@@ -1405,6 +1406,7 @@ struct SuffixSorter {
     // ---- doubled text (dq_small_groups.h, twin_mark_kernel): the tie groups that are a pair (i, i + half) are written
     //      down and leave the list; *done: nothing is left.
     int64_t twin_half = 0;
+    int period_hint = 0;                // (SortHints::run_period)
     int twin_pairs_step(bool *done)
     {
         *done = false;
@@ -1460,13 +1462,19 @@ struct SuffixSorter {
         // Runs of one byte (dq_runs.h): run lengths of the text, then ONE round that orders the members of every
         // group inside a run by the run's own structure; from then on they gather the rank behind their run.
         if (runs_wanted && m > 0 && 32 + rbits <= 64 && ((uses_small_round(m) && !list_ungrouped) ? mid_group_cap(m) > 0 : true)) {
-            rc = compute_run_lengths();
+            // (a period other than 1 -- the caller's hint, or DQ_RUN_PERIOD in the tests -- must not exceed the depth the
+            // groups are tied to: the rules of dq_runs.h hold for P <= h)
+            int period = period_hint > 0 ? period_hint : 1;
+            if (const char *v = env("DQ_RUN_PERIOD")) period = std::max(1, atoi(v));
+            if (period > h || period > 64) period = 1;
+            rc = compute_run_lengths(period);
             if (rc != DQ_OK) return rc;
             runs_on = true;
-            run_order = 1;
+            run_order = period;
             t_info[0] += 1;
             t_info[2] += m;
-            if (env("DQ_TRACE")) fprintf(stderr, "[dq] run-order round at h=%lld on %lld tied suffixes\n", (long long)h, (long long)m);
+            if (env("DQ_TRACE"))
+                fprintf(stderr, "[dq] run-order round (period %d) at h=%lld on %lld tied suffixes\n", period, (long long)h, (long long)m);
             rc = (uses_small_round(m) && !list_ungrouped) ? doubling_round_small(32) : doubling_round_radix(32, 0);
             run_order = 0;
             if (rc != DQ_OK) return rc;
@@ -1582,11 +1590,12 @@ struct SuffixSorter {
 };
 
 template <typename IdxT>
-int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, IdxT *d_sa, bool doubled = false)
+int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, IdxT *d_sa, SortHints hints = SortHints())
 {
     SuffixSorter<IdxT> sorter(c, st, w, n, d_sa);
     // (DQ_ASSUME_DOUBLED: the tests vouch for their inputs through the public entry points)
-    if ((doubled || env("DQ_ASSUME_DOUBLED")) && n % 2 == 0 && !env("DQ_NO_TWINS")) sorter.twin_half = n / 2;
+    if ((hints.doubled || env("DQ_ASSUME_DOUBLED")) && n % 2 == 0 && !env("DQ_NO_TWINS")) sorter.twin_half = n / 2;
+    if (hints.run_period > 0 && !env("DQ_NO_PERIOD_HINT")) sorter.period_hint = hints.run_period;
     return sorter.run();
 }
 
@@ -1618,7 +1627,7 @@ int check_args(const void *text, int64_t n, const void *sa)
 
 // host buffers in / out  (ISuffixSort.Sort(text, suffixes))
 template <typename IdxT>
-int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device, bool doubled)
+int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device, SortHints hints)
 {
     int rc = check_args<IdxT>(text, n, sa);
     if (rc != DQ_OK) return rc;
@@ -1655,7 +1664,7 @@ int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device, bool 
     // at PCIe rate here (page-locking them per call with hipHostRegister measured no gain).
     HIP_TRY(hipMemcpyAsync(w.text, text, (size_t)n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(w.text + n, 0, 64, st));
-    rc = sufsort_device<IdxT>(c, st, w, n, w.SAbuf, doubled);
+    rc = sufsort_device<IdxT>(c, st, w, n, w.SAbuf, hints);
     if (rc != DQ_OK) { drop_pending(c, st); return rc; }
     HIP_TRY(hipMemcpyAsync(sa, w.SAbuf, (size_t)n * sizeof(IdxT), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

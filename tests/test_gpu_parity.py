@@ -606,7 +606,8 @@ def run_heavy_texts(oracle_mod):
                                  {"DQ_RUNS": "1", "DQ_SPARSE": "1"}, {"DQ_RUNS": "1", "DQ_MID_GROUPS": "256", "DQ_NO_BINNED_ISA": "1"},
                                  {"DQ_LATE_RUNS_MIN": "1"}, {"DQ_LATE_RUNS_MIN": "64", "DQ_UPD_BIN_MIN": "1"}, {"DQ_NO_LATE_RUNS": "1"},
                                  {"DQ_LATE_RUNS_MIN": "1", "DQ_RUN_PERIOD": "1"}, {"DQ_LATE_RUNS_MIN": "1", "DQ_RUN_PERIOD": "2"},
-                                 {"DQ_LATE_RUNS_MIN": "16", "DQ_RUN_PERIOD": "24"}],
+                                 {"DQ_LATE_RUNS_MIN": "16", "DQ_RUN_PERIOD": "24"},
+                                 {"DQ_RUNS": "1", "DQ_RUN_PERIOD": "5"}, {"DQ_RUNS": "1", "DQ_RUN_PERIOD": "3", "DQ_MID_GROUPS": "256"}],
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
 def test_runs_of_one_byte(ldss, oracle_mod, monkeypatch, env):
     monkeypatch.setenv("DQ_SMALL_N", "0")
@@ -618,7 +619,7 @@ def test_runs_of_one_byte(ldss, oracle_mod, monkeypatch, env):
 
 
 @pytest.mark.parametrize("env", [{}, {"DQ_MID_GROUPS": "0"}, {"DQ_SPARSE": "1"}, {"DQ_BINNED_ISA": "1"}, {"DQ_SPARSE": "0", "DQ_PAIR_CHAINS": "2"},
-                                 {"DQ_NO_TWINS": "1"}],
+                                 {"DQ_NO_TWINS": "1"}, {"DQ_RUNS": "1", "DQ_RUN_PERIOD": "5"}, {"DQ_RUNS": "1", "DQ_RUN_PERIOD": "5", "DQ_NO_TWINS": "1"}],
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "default")
 def test_doubled_texts_finish_at_the_twin_pairs(ldss, oracle_mod, monkeypatch, env):
     """block + block, as the bzip2 encoder hands its blocks to the sorter (dq_bz2.h): suffix i + n/2 is a prefix of
