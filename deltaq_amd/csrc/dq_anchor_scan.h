@@ -41,8 +41,12 @@ constexpr int kAsMaxLaneWin = kAsMaxGroups * kAsWaves * kWave;   // positions of
 constexpr int64_t kAsCap = 64;                            // comparison cap of the speculative positions
 constexpr int kAsWaveWins = 3;                            // wave windows walked over before the lane windows take over
 // An answer is two words, each with the tag of its window in the top two bits: tag << 62 | len << 31 | pos, and
-// tag << 62 | cnt(j, j + len).  The windows take the two answer buffers in turn; the k-th use of a buffer has tag k % 3, the
-// host fills the buffers with ones (tag 3) before a launch: a word of another window never passes for this one's.
+// tag << 62 | cnt(j, j + len).  The windows of a kind (one position per wave / per lane) take the two answer buffers of
+// their kind in turn; the k-th use of a buffer has tag k % 3, the host fills the buffers with ones (tag 3) before a
+// launch.  Every use of a buffer writes ALL the slots a later use can read (a window is shorter than its kind's size
+// only at the end of the file), so what a reader can find in a slot is this use's word or the use before's -- never a
+// word of three uses ago with the same tag.  (With one pair of buffers for both kinds, a slot beyond the 512 of a wave
+// window kept its word from the last lane window however long ago: tests/manual/stress_bsdiff.py seed 421.)
 constexpr unsigned long long kAsStopLen = 0x7fffffffull;  // len field of a stop point (texts stay below 2^31 - 1 bytes)
 constexpr int kAsFirstSpan = 64;                          // positions of a wave window evaluated in the first step
 
@@ -106,7 +110,7 @@ template <typename IdxT>
 __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa, const uint8_t *__restrict__ nw, int64_t m,
     const IdxT *__restrict__ ptab, int pk,
-    unsigned long long *__restrict__ ans /* [2][lane window][2]: tagged answers, all ones before the launch */,
+    unsigned long long *__restrict__ ans /* [2][lane window][2] then [2][wave window][2]: tagged answers, all ones before the launch */,
     unsigned long long *__restrict__ rec /* [rec_cap] in PINNED HOST memory: cursor << 32 | hit_pos, one store each */,
     int64_t rec_cap, AnchorCtl *__restrict__ ctl,
     unsigned long long *__restrict__ finished /* [gridDim.x], zeroed: windows workgroup w has finished evaluating */)
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     int64_t cursor = ctl->cursor, hit_len = ctl->hit_len, hit_pos = ctl->hit_pos, shift = ctl->shift;
     int64_t nrec = 0;
     unsigned long long n_search = 0, n_win = 0, n_stop = 0;
+    unsigned long long n_wave_win = 0, n_lane_win = 0;  // windows of either kind so far
     bool failed = false;
     unsigned long long t_search = 0, t_wait = 0, t_eval = 0, t_stop = 0, t0 = __builtin_readcyclecounter();
     // (only when asked for -- ctl->pad, set under DQ_TRACE: reading the clock ~7 times a window is not free)
@@ -230,8 +235,15 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
             const int64_t win = lane_mode ? kAsLaneWin : kAsWaveWin;
             const int64_t c = (m - i) < win ? (m - i) : win;
             const unsigned long long win_no = n_win;        // windows are numbered from 0, the same everywhere
-            ans_w = ans + (size_t)(n_win & 1ull) * (2 * (size_t)kAsMaxLaneWin);
-            tag_w = (n_win >> 1) % 3ull;
+            {
+                // (the buffers of this window's kind, by the count of windows of that kind)
+                unsigned long long &uses = lane_mode ? n_lane_win : n_wave_win;
+                unsigned long long *kind = lane_mode ? ans : ans + 4 * (size_t)kAsMaxLaneWin;
+                const size_t slots = lane_mode ? (size_t)kAsMaxLaneWin : (size_t)kAsMaxGroups * kAsWaves;
+                ans_w = kind + (size_t)(uses & 1ull) * (2 * slots);
+                tag_w = (uses >> 1) % 3ull;
+                ++uses;
+            }
             ++n_win;
             const unsigned long long lag_seen = lagging_load(win_no);
             // ---- 0. the window's answers (and each match's own agree count), one position per wave or per lane ----

@@ -533,7 +533,8 @@ private:
 // kAnchorRecs pairs per launch -- a new file that needs more (text with a short match every few bytes) continues from
 // the state the kernel left.
 constexpr int64_t kAnchorRecs = 1 << 16;
-constexpr size_t kAnchorScratch = 256 + 2048 + (size_t)kAsMaxLaneWin * 32;
+constexpr size_t kAnchorAnswers = ((size_t)kAsMaxLaneWin + (size_t)kAsMaxGroups * kAsWaves) * 32;    // two buffers of either kind, 16 B a slot
+constexpr size_t kAnchorScratch = 256 + 2048 + kAnchorAnswers;
 constexpr unsigned long long kAnchorPending = ~0ull;
 
 // ring: kAnchorRecs words of pinned host memory the kernel writes the pairs into (one 64-bit store each) and this
@@ -567,7 +568,7 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         std::atomic_thread_fence(std::memory_order_seq_cst);
         HIP_TRY(hipMemcpyAsync(d_ctl, h_up, sizeof(AnchorCtl), hipMemcpyHostToDevice, c.stream));
         HIP_TRY(hipMemsetAsync(d_finished, 0, 2048, c.stream));
-        HIP_TRY(hipMemsetAsync(d_ans, 0xff, (size_t)kAsMaxLaneWin * 32, c.stream));       // (no answer word carries a window's tag yet)
+        HIP_TRY(hipMemsetAsync(d_ans, 0xff, kAnchorAnswers, c.stream));                   // (no answer word carries a window's tag yet)
         auto launch = [&]() -> int {
             LAUNCH(L, DQ_K_MATCH_SEARCH, m, m * 2,
                    hipLaunchKernelGGL(anchor_scan_kernel<int32_t>, dim3(groups), dim3(kAsThreads), 0, c.stream,

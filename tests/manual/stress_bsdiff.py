@@ -63,9 +63,27 @@ while time.time() < t_end:
     ok = np.array_equal(ctrl, wc) and np.array_equal(diff, wd) and np.array_equal(extra, we)
     what = "raw streams"
     if ok and count % 4 == 0:
+        # framing: behind the running scan from the first byte / behind it by default (files >= 256 KiB) / after it;
+        # block transform with and without the shortcuts for doubled blocks and run-length coded diff streams
+        for k in ("DQ_FRAME_FOLLOW_MIN", "DQ_FRAME_AFTER", "DQ_NO_TWINS", "DQ_NO_PERIOD_HINT"): os.environ.pop(k, None)
+        fm = int(rng.integers(0, 4))
+        if fm == 0: os.environ["DQ_FRAME_FOLLOW_MIN"] = "0"
+        elif fm == 1: os.environ["DQ_FRAME_AFTER"] = "1"
+        elif fm == 2: os.environ["DQ_FRAME_FOLLOW_MIN"] = "0"; os.environ["DQ_NO_TWINS"] = "1"; os.environ["DQ_NO_PERIOD_HINT"] = "1"
         patch = Diff.CreateBytes(old, new)
         ok = Patch.Apply(old, patch) == new.tobytes()
         what = "round trip"
+        if ok:                                            # ... and libbz2 reads the three streams as the raw streams they are
+            import bz2, struct
+            def plong(b):
+                v = struct.unpack("<Q", b)[0]
+                return -(v & ~(1 << 63)) if v >> 63 else v
+            lc, ld = plong(patch[8:16]), plong(patch[16:24])
+            z = [patch[32:32 + lc], patch[32 + lc:32 + lc + ld], patch[32 + lc + ld:]]
+            got = [bz2.decompress(x) if len(x) else b"" for x in z]
+            ok = (got[1] == wd.tobytes() and got[2] == we.tobytes() and len(got[0]) == 8 * wc.size and
+                  [plong(got[0][i:i + 8]) for i in range(0, len(got[0]), 8)] == wc.ravel().tolist())
+            what = "streams as libbz2 reads them"
     if not ok:
         print("failed:", what, "stats", st, flush=True)
         for rep in range(3):                              # the same pair again, in this process

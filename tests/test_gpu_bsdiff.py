@@ -4,6 +4,7 @@ bit; the container read by a reference-style reader (header + libbz2 + the oracl
 product's own Patch.Apply; patches framed by libbz2 applied by the product."""
 import bz2
 import io
+import os
 
 import numpy as np
 import pytest
@@ -123,6 +124,29 @@ def test_framing_behind_the_scan_writes_the_same_patch(backend_lib, oracle_mod, 
             assert p == w, (o.size, x.size, follow_min)
     for (o, x), w in zip(cases, want):
         assert Patch.Apply(o, w) == x.tobytes()
+
+
+def test_regression_pairs_found_by_the_stress_runs(backend_lib, oracle_mod, monkeypatch):
+    """Pairs tests/manual/stress_bsdiff.py caught a build on (tests/golden/regress/bsdiff_*_{old,new}.npy).
+    bsdiff_1120044142_236: windows of one position per lane and of one per wave shared their two answer buffers -- a slot
+    beyond the 512 of a wave window kept the word of the last lane window, and its two-bit tag came round again after
+    three uses of the buffer (raw streams differed in two runs out of three)."""
+    import glob
+    from conftest import GOLDEN_DIR
+    from deltaq_amd import Diff
+    olds = sorted(glob.glob(os.path.join(GOLDEN_DIR, "regress", "bsdiff_*_old.npy")))
+    assert olds
+    for f in olds:
+        old, new = np.load(f), np.load(f.replace("_old.npy", "_new.npy"))
+        wc, wd, we, _ = oracle_mod.bsdiff_scan(old, oracle_mod.divsufsort(old), new)
+        for env in SCAN_PATHS:
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            for rep in range(6):
+                ctrl, diff, extra, _ = Diff.Scan(old, new)
+                assert np.array_equal(ctrl, wc) and np.array_equal(diff, wd) and np.array_equal(extra, we), (os.path.basename(f), env, rep)
+            for k in env:
+                monkeypatch.delenv(k)
 
 
 def test_one_old_many_new_index(backend_lib, oracle_mod):
