@@ -15,8 +15,9 @@
 // Every searching wave (lane) also counts cw_j = cnt(j, j + len_j) over its own match, so that
 // cnt(base, j + len_j) = S_j + cw_j with S_j = cnt(base, j) -- a prefix count over the window's POSITIONS only.  A
 // whole window is then tested at once: prefix maximum of the match ends j + len_j carrying cnt(base, .) of the end
-// that holds the maximum, minus S_j.  A position whose answer is not exact (its search hit the cap) is a STOP POINT:
-// the window counts up to it, then it is searched again exactly and taken on its own.
+// that holds the maximum, minus S_j.  A position whose answer is not exact (its search hit the cap; or the count of its
+// long match is an upper bound that does not settle its break test, see wave_cw) is a STOP POINT: the window counts up
+// to it, then it is searched again exactly and taken on its own.
 //
 // Grid: G = kAsGroups workgroups of 4 waves, all resident.  A window's searches are dealt out one position per wave
 // (4 G = 512 positions; 65-ary search, dq_match_search.h) or, while the loop walks through a long differing stretch, one
@@ -49,6 +50,8 @@ constexpr int kAsWaveWins = 3;                            // wave windows walked
 // window kept its word from the last lane window however long ago: tests/manual/stress_bsdiff.py seed 421.)
 constexpr unsigned long long kAsStopLen = 0x7fffffffull;  // len field of a stop point (texts stay below 2^31 - 1 bytes)
 constexpr int kAsFirstSpan = 64;                          // positions of a wave window evaluated in the first step
+constexpr int64_t kAsCountFront = 4096;                   // bytes of a long match under another alignment that are counted (one step)
+constexpr unsigned long long kAsBoundBit = 1ull << 61;    // second answer word: the count is an upper bound
 
 struct AnchorCtl {
     unsigned long long nrec;                              // (cursor, hit_pos) pairs written
@@ -149,11 +152,21 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     auto agree = [&](int64_t k) -> bool { return k + shift < n && old[k + shift] == nw[k]; };
     // cnt(j, j + l) for the match (p, l) found at position j, by one wave: a match under the previous alignment agrees
     // everywhere; otherwise the bytes are compared (the part of [j, j + l) that the shifted old file still covers)
-    auto wave_cw = [&](int64_t j, int64_t p, int64_t l) -> int64_t {
+    // A long match under another alignment is counted over its first kAsCountFront bytes only, the rest taken as agreeing:
+    // an UPPER BOUND (*bound = true).  The evaluation lets such a position break where its length beats even the bound --
+    // the usual case: a new alignment after an edit, the old one wrong nearly everywhere -- and makes it a stop point
+    // (searched and counted again, exactly) where the bound would have to be carried on (tests/anchor_model.py, `loose`).
+    // 80 kB between two edits: 20 dependent steps of 4 KiB less for the one wave the window waits for.
+    auto wave_cw = [&](int64_t j, int64_t p, int64_t l, bool *bound) -> int64_t {
+        if (bound) *bound = false;
         if (l <= 0) return 0;
         if (p - j == shift) return l;
         const int64_t upto = (j + l) < (n - shift) ? (j + l) : (n - shift);
         if (upto <= j) return 0;
+        if (bound && upto - j > kAsCountFront + 512) {
+            *bound = true;
+            return as_wave_count_equal(old + shift, n - shift, nw, m, j, j + kAsCountFront) + (upto - j - kAsCountFront);
+        }
         return as_wave_count_equal(old + shift, n - shift, nw, m, j, upto);
     };
 
@@ -199,11 +212,12 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     // k + 1 while a slower one still reads window k; nobody reaches window k + 2 before everybody has left window k)
     unsigned long long *ans_w = ans;
     unsigned long long tag_w = 0;
-    auto publish = [&](int64_t slot, int64_t p, int64_t l, int64_t cw) {
+    auto publish = [&](int64_t slot, int64_t p, int64_t l, int64_t cw, bool bound) {
         unsigned long long *ans = ans_w;
         const unsigned long long lf = l < 0 ? kAsStopLen : (unsigned long long)l, pf = l < 0 ? 0ull : (unsigned long long)p;
         __hip_atomic_store(&ans[2 * slot], (tag_w << 62) | (lf << 31) | pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ans[2 * slot + 1], (tag_w << 62) | (unsigned long long)cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ans[2 * slot + 1], (tag_w << 62) | (bound ? kAsBoundBit : 0ull) | (unsigned long long)cw, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     };
     // both words of position `slot` of this window, waited for
     auto fetch = [&](int64_t slot, unsigned long long *v, unsigned long long *v2) {
@@ -249,12 +263,13 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
             // ---- 0. the window's answers (and each match's own agree count), one position per wave or per lane ----
             {
                 int64_t p = 0, l = 0, cw = 0, slot = -1;
+                bool cw_bound = false;
                 if (!lane_mode) {
                     if (gwave < c) {
                         const int64_t scan = i + gwave;
                         const bool exact = gwave == 0 || streak >= 2;
                         ms_search_wave<IdxT>(old, n, sa, nw, m, scan, exact ? (int64_t)0 : kAsCap, ptab, pk, &p, &l, nullptr, /*resume_first=*/true);
-                        cw = wave_cw(scan, p, l);
+                        cw = wave_cw(scan, p, l, &cw_bound);
                         if (lane == 0) slot = gwave;
                     }
                 } else {
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 await_lagging(win_no, lag_seen);           // (window win_no - 2 has been read by everybody)
                 lap(t_wait);
                 if (failed) break;
-                if (slot >= 0) publish(slot, p, l, cw);
+                if (slot >= 0) publish(slot, p, l, cw, cw_bound);
             }
 
             // ---- 1. prefix counts of agree() over the window's positions ----
@@ -317,7 +332,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 const int t = off + tid;
                 const bool have = tid < span && t < c;
                 int64_t l = 0, p = 0, e = -1, ce = 0, Sj = 0;
-                bool stop = false;
+                bool stop = false, bound = false;
                 if (have) {
                     unsigned long long v, v2;
                     fetch(t, &v, &v2);
@@ -325,7 +340,11 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                     p = (int64_t)(v & 0x7fffffffull);
                     Sj = S + (int64_t)agp[t];
                     if (lf == kAsStopLen) { stop = true; l = -1; }
-                    else { l = (int64_t)lf; e = i + t + l; ce = Sj + (int64_t)(v2 & 0x3fffffffffffffffull); }   // cnt(base, e) = cnt(base, j) + cnt(j, e)
+                    else {
+                        l = (int64_t)lf; e = i + t + l;
+                        ce = Sj + (int64_t)(v2 & 0x7fffffffull);                  // cnt(base, e) = cnt(base, j) + cnt(j, e)
+                        bound = (v2 & kAsBoundBit) != 0;
+                    }
                 }
                 off += span;
                 lap(t_wait);
@@ -353,6 +372,9 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 if (have && !stop) {
                     carried = Cj - Sj;
                     brk_here = (l == carried && l != 0) || l > carried + 8;
+                    // its own end is the running maximum and its count a bound: carried is at most this -- a break
+                    // that needs no more is one; anything else is decided with the exact count, on its own
+                    if (bound && e > xe && !(l > carried + 8)) { brk_here = false; stop = true; }
                 }
                 int32_t fb = brk_here ? t : 0x7fffffff, fs = (have && stop) ? t : 0x7fffffff;
                 fb = as_wave_min(fb);
@@ -406,7 +428,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 if (wv == 0) {
                     int64_t p2 = 0, l2 = 0;
                     ms_search_wave<IdxT>(old, n, sa, nw, m, j, 0, ptab, pk, &p2, &l2);
-                    const int64_t cw2 = wave_cw(j, p2, l2);
+                    const int64_t cw2 = wave_cw(j, p2, l2, nullptr);       // (exactly)
                     if (lane == 0) { s_v[0] = p2; s_v[1] = l2; s_v[2] = cw2; }
                 }
                 __syncthreads();

@@ -43,11 +43,14 @@ def literal_anchors(old, new, pos, ln):
     return out
 
 
-def windowed_anchors(old, new, pos, ln, capped, w_first=8, w_next=32, extra=0, rng=None):
+def windowed_anchors(old, new, pos, ln, capped, w_first=8, w_next=32, extra=0, rng=None, loose=None):
     """The kernel's evaluation.  capped(j) -> True: the window's answer for position j comes back undecided (len < 0)
     unless it is the window's first position; the exact answer (pos[j], ln[j]) is fetched when the position is taken on
     its own.  Every answer comes with cw = cnt(j, j + len), counted by the wave that searched (`extra` is unused: the
-    first form of the kernel covered a few bytes behind the window instead)."""
+    first form of the kernel covered a few bytes behind the window instead).
+    loose(j) -> slack >= 0: the count of a match that lies under another alignment comes as an UPPER BOUND (the wave
+    counted the front of a long match and took the rest as agreeing): cw + slack, at most len.  Such a position breaks
+    for certain if its length beats even the bound; otherwise -- if the bound would be carried on -- it is a stop point."""
     n, m = len(old), len(new)
     cursor = hit_pos = hit_len = shift = 0
     out = []
@@ -75,12 +78,17 @@ def windowed_anchors(old, new, pos, ln, capped, w_first=8, w_next=32, extra=0, r
             agp = [0]
             for k in range(i, i + c):
                 agp.append(agp[-1] + agree(k))             # agp[x] = cnt(i, i + x)
-            lens, cws = [], []
+            lens, cws, bound = [], [], []
             for j in range(i, i + c):
                 exact = (j == i) or streak >= 2 or not capped(j)
                 l = int(ln[j]) if exact else -1
                 lens.append(l)
-                cws.append(cnt(j, j + l) if l >= 0 else 0)
+                cw = cnt(j, j + l) if l >= 0 else 0
+                slack = 0
+                if loose is not None and l > 0 and int(pos[j]) - j != shift:
+                    slack = min(int(loose(j)), l - cw)
+                cws.append(cw + slack)
+                bound.append(slack > 0)
             s = next((t for t, l in enumerate(lens) if l < 0), None)          # stop point: first capped position
             upto = c if s is None else s
             f = None
@@ -89,9 +97,16 @@ def windowed_anchors(old, new, pos, ln, capped, w_first=8, w_next=32, extra=0, r
                 j = i + t
                 Sj = S + agp[t]
                 e = j + lens[t]
+                rests_on_bound = bound[t] and e > Mj       # (an end behind the running maximum: its count is not used)
                 if e > Mj:
                     Mj, Cj = e, Sj + cws[t]
                 carried = Cj - Sj
+                if rests_on_bound:
+                    if lens[t] > carried + 8:              # carried <= this bound: it breaks whatever the true count is
+                        f = t
+                    else:                                  # undecided: this position is taken on its own, exactly
+                        s, upto = t, t
+                    break
                 if (lens[t] == carried and lens[t] != 0) or lens[t] > carried + 8:
                     f = t
                     break

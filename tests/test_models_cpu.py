@@ -511,7 +511,7 @@ def test_windowed_anchor_search_equals_the_loop(oracle_mod):
     L.t_scan_from_anchors.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                       ctypes.c_int64] + [ctypes.c_void_p] * 6
     rng = np.random.default_rng(2024)
-    stops = windows = 0
+    stops = windows = bound_stops = 0
     for trial, old, new in _edited_pairs(oracle_mod, rng, 120):
         sa = oracle_mod.divsufsort(old)
         pos, ln = oracle_mod.bsdiff_search(old, sa, new) if new.size else (np.zeros(0, np.int32), np.zeros(0, np.int32))
@@ -524,6 +524,11 @@ def test_windowed_anchor_search_equals_the_loop(oracle_mod):
             got, st = anchor_model.windowed_anchors(O, N, pos, ln, capped, w1, w2, ex)
             assert got == want, (trial, w1, w2, ex, cap)
             stops += st["stops"]; windows += st["windows"]
+            # counts of matches under another alignment as upper bounds (the kernel counts the front of a long match only)
+            slack = rng.integers(0, 40, new.size + 1) * (rng.integers(0, 3, new.size + 1) > 0)
+            got, st = anchor_model.windowed_anchors(O, N, pos, ln, capped, w1, w2, ex, loose=lambda j: slack[j])
+            assert got == want, (trial, w1, w2, ex, cap, "bounds")
+            bound_stops += st["stops"]
         # the product's emitter on those anchors = the oracle's streams
         pairs = np.array(want, dtype=np.int64).reshape(-1)
         m = new.size
@@ -540,3 +545,4 @@ def test_windowed_anchor_search_equals_the_loop(oracle_mod):
         assert np.array_equal(trip, wc), trial
         assert np.array_equal(diff[:lens[1]], wd) and np.array_equal(extra[:lens[2]], we), trial
     assert stops > 100 and windows > 1000            # the stop-point path was exercised
+    assert bound_stops > stops                       # ... and so were the bounds that could not decide
