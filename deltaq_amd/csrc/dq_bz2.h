@@ -59,22 +59,9 @@ struct CrcTable {
 inline constexpr CrcTable kCrcTable{};
 inline const uint32_t *crc_table() { return kCrcTable.v[0]; }
 
-inline uint32_t crc_update(uint32_t crc, const uint8_t *p, size_t n)
-{
-    const auto &T = kCrcTable.v;
-    size_t i = 0;
-    for (; i + 8 <= n; i += 8) {
-        const uint32_t a = crc ^ (((uint32_t)p[i] << 24) | ((uint32_t)p[i + 1] << 16) | ((uint32_t)p[i + 2] << 8) | p[i + 3]);
-        crc = T[7][a >> 24] ^ T[6][(a >> 16) & 255] ^ T[5][(a >> 8) & 255] ^ T[4][a & 255] ^
-              T[3][p[i + 4]] ^ T[2][p[i + 5]] ^ T[1][p[i + 6]] ^ T[0][p[i + 7]];
-    }
-    for (; i < n; ++i) crc = (crc << 8) ^ T[0][(crc >> 24) ^ p[i]];
-    return crc;
-}
-
-// ---- the same CRC over a long buffer on several threads.  The register update is linear over GF(2): the state after
-// A || B from state s is  Z^{len(B)}(state after A from s)  xor  (state after B from 0), Z = "one zero byte" as a 32 x 32
-// bit matrix (the construction of zlib's crc32_combine, for this polynomial and bit order).
+// ---- the register update is linear over GF(2): the state after A || B from state s is
+// Z^{len(B)}(state after A from s)  xor  (state after B from 0), Z = "one zero byte" as a 32 x 32 bit matrix (the
+// construction of zlib's crc32_combine, for this polynomial and bit order).
 inline uint32_t gf2_times(const uint32_t *mat, uint32_t vec)
 {
     uint32_t sum = 0;
@@ -83,22 +70,61 @@ inline uint32_t gf2_times(const uint32_t *mat, uint32_t vec)
     return sum;
 }
 
+// Z^(2^k) for k = 0 .. 47, built once
+struct ZeroBytePowers {
+    uint32_t m[48][32];
+    ZeroBytePowers()
+    {
+        for (int i = 0; i < 32; ++i) {                       // column i: what one zero byte makes of the state 1 << i
+            const uint32_t c = 1u << i;
+            m[0][i] = (c << 8) ^ kCrcTable.v[0][c >> 24];
+        }
+        for (int k = 1; k < 48; ++k)
+            for (int i = 0; i < 32; ++i) m[k][i] = gf2_times(m[k - 1], m[k - 1][i]);
+    }
+};
+
 // state after nbytes zero bytes, from `state`
 inline uint32_t crc_shift(uint32_t state, uint64_t nbytes)
 {
-    uint32_t op[32], sq[32];
-    for (int i = 0; i < 32; ++i) {                       // column i: what one zero byte makes of the state 1 << i
-        const uint32_t c = 1u << i;
-        op[i] = (c << 8) ^ kCrcTable.v[0][c >> 24];
-    }
-    for (; nbytes; nbytes >>= 1) {
-        if (nbytes & 1u) state = gf2_times(op, state);
-        for (int i = 0; i < 32; ++i) sq[i] = gf2_times(op, op[i]);
-        memcpy(op, sq, sizeof op);
-    }
+    static const ZeroBytePowers zp;
+    for (int k = 0; nbytes && k < 48; nbytes >>= 1, ++k)
+        if (nbytes & 1u) state = gf2_times(zp.m[k], state);
     return state;
 }
 
+// (a stretch of >= 64 zero bytes -- the diff stream of two similar files is little else -- is stepped over with
+// crc_shift: a few dozen table-free operations instead of one table lookup per byte)
+inline uint32_t crc_update(uint32_t crc, const uint8_t *p, size_t n)
+{
+    const auto &T = kCrcTable.v;
+    size_t i = 0;
+    while (i + 8 <= n) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        if (w == 0) {
+            size_t j = i + 8;
+            while (j + 8 <= n) {
+                memcpy(&w, p + j, 8);
+                if (w) break;
+                j += 8;
+            }
+            if (j - i >= 64) {
+                crc = crc_shift(crc, j - i);
+                i = j;
+                continue;
+            }
+        }
+        const uint32_t a = crc ^ (((uint32_t)p[i] << 24) | ((uint32_t)p[i + 1] << 16) | ((uint32_t)p[i + 2] << 8) | p[i + 3]);
+        crc = T[7][a >> 24] ^ T[6][(a >> 16) & 255] ^ T[5][(a >> 8) & 255] ^ T[4][a & 255] ^
+              T[3][p[i + 4]] ^ T[2][p[i + 5]] ^ T[1][p[i + 6]] ^ T[0][p[i + 7]];
+        i += 8;
+    }
+    for (; i < n; ++i) crc = (crc << 8) ^ T[0][(crc >> 24) ^ p[i]];
+    return crc;
+}
+
+// ---- the same CRC over a long buffer on several threads
 inline uint32_t crc_update_mt(uint32_t crc, const uint8_t *p, size_t n)
 {
     constexpr size_t kMinPart = (size_t)1 << 20;
@@ -687,6 +713,28 @@ public:
                     blk.insert(blk.end(), run, c);
                 }
                 i += run;
+                if (run == 255) {
+                    // a long stretch of one byte: the runs of 255 that follow are counted 8 bytes a step and written
+                    // as the five bytes each of them becomes, while they start in front of `stop` and fit the block
+                    const uint64_t pat = 0x0101010101010101ull * c;
+                    size_t z = 0;                              // further bytes equal to c from i on
+                    while (i + z + 8 <= upto) {
+                        uint64_t v;
+                        memcpy(&v, src + i + z, 8);
+                        if (v != pat) break;
+                        z += 8;
+                    }
+                    size_t more = z / 255;
+                    if (i < stop) more = std::min(more, (stop - i + 254) / 255); else more = 0;
+                    more = std::min(more, (block_max - blk.size()) / 5);
+                    if (more > 0) {
+                        const size_t at = blk.size();
+                        blk.resize(at + 5 * more);
+                        uint8_t *o = blk.data() + at;
+                        for (size_t k = 0; k < more; ++k, o += 5) { o[0] = o[1] = o[2] = o[3] = c; o[4] = 251; }
+                        i += 255 * more;
+                    }
+                }
             }
             pos = i;
             crc = crc_update_mt(crc, src + crc_done, pos - crc_done);    // of the block's input bytes (4 threads from 2 MiB a call)
@@ -737,6 +785,19 @@ public:
 
     size_t consumed() const { return pos; }
 
+    // (tests: the run-length coded blocks and their CRCs as the pre-pass cut them, before anything is encoded --
+    // constructed with hold = true, so that no block leaves for an encoder thread)
+    void hold_blocks() { hold = true; }
+    void copy_blocks(std::vector<uint8_t> &rle, std::vector<uint32_t> &lens, std::vector<uint32_t> &crcs)
+    {
+        if (open) close_block(false);
+        for (Block &b : blocks) {
+            rle.insert(rle.end(), b.rle.begin(), b.rle.end());
+            lens.push_back((uint32_t)b.rle.size());
+            crcs.push_back(b.crc);
+        }
+    }
+
 private:
     struct Block {
         std::vector<uint8_t> rle;        // run-length coded input of the block
@@ -776,7 +837,7 @@ private:
         Block &b = blocks.back();
         b.crc = ~crc;
         open = false;
-        if (!more_to_come) return;       // (the last block is finish()'s: the caller is about to wait for it anyway)
+        if (!more_to_come || hold) return;   // (the last block is finish()'s: the caller is about to wait for it anyway)
         // full while the stream is still growing: encode it beside the pre-pass if a framing thread is to be had
         if (framing_threads_acquire(1) != 1) return;
         int expect = 0;
@@ -804,6 +865,7 @@ private:
     size_t pos = 0, crc_done = 0;
     uint32_t crc = 0;
     bool open = false;
+    bool hold = false;
 };
 
 // level 1..9: blocks of level * 100000 - 19 run-length coded bytes (libbz2's limit).

@@ -507,12 +507,14 @@ private:
             const int s = state.load(std::memory_order_acquire);           // (before the length: complete() comes after the last one)
             if (s == 2) return;
             const size_t upto = final_len[k].load(std::memory_order_acquire);
+            const auto t0 = std::chrono::steady_clock::now();
             try {
                 enc[k]->feed(base[k], upto, s == 1);
             } catch (...) {
                 failed[k] = true;
                 return;
             }
+            busy_ms[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (s == 1) return;
             if (upto - seen < (64u << 10)) std::this_thread::sleep_for(std::chrono::microseconds(200));
             seen = upto;
@@ -526,6 +528,8 @@ private:
     std::atomic<int> state{0};                            // 0 the streams are growing, 1 complete, 2 given up
     bool failed[2] = {false, false};
     bool running = false;
+public:
+    double busy_ms[2] = {0, 0};                           // time inside feed() (DQ_TRACE prints it)
 };
 
 // Step 1 of the scan loop on the device (dq_anchor_scan.h): one persistent launch walks the whole new file and leaves the
@@ -559,6 +563,7 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
     AnchorCtl *h_up = reinterpret_cast<AnchorCtl *>(c.pinned + 512), *h_back = reinterpret_cast<AnchorCtl *>(c.pinned);
     const bool trace = env("DQ_TRACE") != nullptr;
     const int groups = env("DQ_SCAN_GROUPS") ? std::max(8, std::min(kAsMaxGroups, atoi(env("DQ_SCAN_GROUPS")))) : kAsGroups;
+    double emit_ms = 0;                                   // (DQ_TRACE: time inside the emitter)
     for (;;) {
         Launcher L{c, c.stream, g_prof_on.load()};
         *h_up = AnchorCtl{};
@@ -584,7 +589,13 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         auto take_filled = [&]() -> bool {
             const unsigned long long v = __atomic_load_n(&ring[taken], __ATOMIC_ACQUIRE);
             if (v == kAnchorPending) return false;
-            em.take((int64_t)(v >> 32), (int64_t)(uint32_t)v);
+            if (trace) {
+                const auto t0 = std::chrono::steady_clock::now();
+                em.take((int64_t)(v >> 32), (int64_t)(uint32_t)v);
+                emit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            } else {
+                em.take((int64_t)(v >> 32), (int64_t)(uint32_t)v);
+            }
             ++taken;
             return true;
         };
@@ -618,6 +629,7 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         if (got == 0) return fail(DQ_ERR_HIP, "anchor scan: no progress");
     }
     if (em.progress) framer->complete();
+    if (trace) fprintf(stderr, "[dq] emitter (steps 2 and 3 on the host, beside the kernel): %.2f ms\n", emit_ms);
     return DQ_OK;
 }
 
@@ -739,6 +751,8 @@ int frame_patch(const bsdiff::RawStreams &raw, int64_t m, int dev, std::vector<u
         try {
             rcs[k] = followed && k > 0 ? framer->finish(k - 1, z[k]) : bz2_stream(*src[k], z[k], dev);
             if (rcs[k] != DQ_OK) errs[k] = t_err;
+            if (trace && followed && k > 0)
+                fprintf(stderr, "[dq] bsdiff stream %d: %.2f ms of run-length pre-pass and CRC behind the scan\n", k, framer->busy_ms[k - 1]);
             if (trace) fprintf(stderr, "[dq] bsdiff stream %d framed   at %8.3f ms (%zu -> %zu bytes%s)\n", k,
                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(),
                                src[k]->size(), z[k].size(), followed && k > 0 ? ", behind the scan" : "");

@@ -54,6 +54,30 @@ int64_t t_bz2_compress_fed(const uint8_t *src, int64_t n, uint8_t *out, int64_t 
     return (int64_t)v.size();
 }
 
+// the pre-pass alone, fed in pieces: run-length coded blocks back to back in `rle` (capacity cap), their lengths and
+// CRCs in lens / crcs (capacity max_blocks); returns the number of blocks, or a negative code
+int64_t t_bz2_prepass(const uint8_t *src, int64_t n, int32_t level, int64_t max_step, uint32_t seed, uint8_t *rle, int64_t cap,
+                      uint32_t *lens, uint32_t *crcs, int64_t max_blocks)
+{
+    dq::bz2::StreamEncoder enc(naive_sorter, level);
+    enc.hold_blocks();
+    uint64_t x = seed * 0x9e3779b97f4a7c15ull + 1;
+    int64_t upto = 0;
+    while (upto < n) {
+        x = x * 6364136223846793005ull + 1442695040888963407ull;
+        upto = std::min<int64_t>(n, upto + (int64_t)((x >> 33) % (uint64_t)(max_step + 1)));
+        enc.feed(src, (size_t)upto, false);
+    }
+    enc.feed(src, (size_t)n, true);
+    std::vector<uint8_t> r;
+    std::vector<uint32_t> l, c;
+    enc.copy_blocks(r, l, c);
+    if ((int64_t)r.size() > cap || (int64_t)l.size() > max_blocks) return -100;
+    if (!r.empty()) memcpy(rle, r.data(), r.size());
+    for (size_t k = 0; k < l.size(); ++k) { lens[k] = l[k]; crcs[k] = c[k]; }
+    return (int64_t)l.size();
+}
+
 // limit < 0: no bound on the decoded size
 int64_t t_bz2_decompress_limit(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap, int64_t limit, int32_t *code)
 {

@@ -81,6 +81,77 @@ def test_stream_fed_in_pieces_is_the_stream_fed_at_once(harness, oracle_mod):
         assert bz2.decompress(want) == c
 
 
+_REV8 = bytes(int(f"{i:08b}"[::-1], 2) for i in range(256))
+
+
+def crc32_bzip2(data):
+    """bzip2's CRC (polynomial 0x04c11db7, most significant bit first) is zlib's with every byte and the result mirrored."""
+    import zlib
+    return int(f"{zlib.crc32(bytes(data).translate(_REV8)) & 0xffffffff:032b}"[::-1], 2)
+
+
+def rle1_blocks(data, level):
+    """bzip2's first run-length pass and its block cut, written out plainly: runs of 4..255 equal bytes become four bytes
+    and a count; a block closes when fewer than 5 bytes of room are left in its level * 100000 - 19."""
+    a = np.frombuffer(data, np.uint8)
+    block_max = level * 100000 - 19
+    starts = np.flatnonzero(np.concatenate([[True], a[1:] != a[:-1]])) if a.size else np.zeros(0, np.int64)
+    ends = np.concatenate([starts[1:], [a.size]]) if a.size else starts
+    blocks, spans, cur, cur_start, pos = [], [], bytearray(), 0, 0
+    for s0, e0 in zip(starts.tolist(), ends.tolist()):
+        c, left = int(a[s0]), e0 - s0
+        while left > 0:
+            if len(cur) + 5 > block_max:
+                blocks.append(bytes(cur)); spans.append((cur_start, pos)); cur, cur_start = bytearray(), pos
+            run = min(left, 255)
+            cur += bytes([c]) * 4 + bytes([run - 4]) if run >= 4 else bytes([c]) * run
+            left -= run; pos += run
+    if a.size:
+        blocks.append(bytes(cur)); spans.append((cur_start, pos))
+    return blocks, spans
+
+
+def test_prepass_cuts_the_blocks_of_the_definition(harness, oracle_mod):
+    """Long stretches of one byte take a short cut through the pre-pass (runs of 255 counted 8 bytes a step, written as
+    their five bytes) and through the CRC (zero bytes stepped over with the zero-byte operator): the blocks, their
+    boundaries and their CRCs are those of the plain definition -- around multiples of 255, across block boundaries
+    (level 1: a block is 99 981 coded bytes = 5 MB of zeros), wherever the pieces fed end."""
+    L = ctypes.CDLL(os.path.join(NATIVE, "libbz2_harness.so"))
+    L.t_bz2_prepass.restype = ctypes.c_int64
+    L.t_bz2_prepass.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_void_p,
+                                ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    L.t_crc_bitwise.restype = ctypes.c_uint32
+    L.t_crc_bitwise.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    L.t_crc_sliced.restype = ctypes.c_uint32
+    L.t_crc_sliced.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+    rng = np.random.default_rng(12)
+    cases = [b"\x00" * k for k in (254, 255, 256, 509, 510, 511, 764, 765, 766, 1020, 255 * 40, 255 * 40 + 3)]
+    cases += [b"\x07" * 5_200_000 + b"xyz" + b"\x00" * 6_000_000,                  # block boundaries inside the stretches
+              b"\x00" * 5_099_031 + b"ab" + b"\x00" * 300, b"\x00" * 5_099_030 + b"ab", b"\x00" * 5_098_776 + b"\x01" * 600]
+    mixed = bytearray()
+    for _ in range(300):                                    # stretches of every length between noise
+        mixed += bytes([int(rng.integers(0, 3))]) * int(rng.integers(1, 3000)) + rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8).tobytes()
+    cases.append(bytes(mixed))
+    for k, c in enumerate(cases):
+        want, spans = rle1_blocks(c, 1)
+        for step, seed in ((10_000_000, 1), (1000, 2), (257, 3), (70_000, 4)):
+            rle = np.empty(len(c) + 64, np.uint8); lens = np.zeros(4096, np.uint32); crcs = np.zeros(4096, np.uint32)
+            nb = L.t_bz2_prepass(c, len(c), 1, step, seed, rle.ctypes.data, rle.size, lens.ctypes.data, crcs.ctypes.data, 4096)
+            assert nb == len(want), (k, step, nb, len(want))
+            off = 0
+            for b in range(nb):
+                assert rle[off:off + lens[b]].tobytes() == want[b], (k, step, b)
+                off += int(lens[b])
+                piece = c[spans[b][0]:spans[b][1]]
+                assert int(crcs[b]) == crc32_bzip2(piece), (k, step, b)
+    assert crc32_bzip2(b"123456789") == 0xfc891918 == L.t_crc_bitwise(b"123456789", 9)      # (the catalogue's check value)
+    # the stepped-over zero bytes against the bit-by-bit definition
+    for n in (63, 64, 65, 71, 72, 1000, 4096 + 3, 100_000):
+        for lead in (b"", b"\x01", b"abc", b"\x00\x00\x05"):
+            buf = lead + b"\x00" * n + b"\x09" + b"\x00" * (n // 2)
+            assert L.t_crc_sliced(buf, len(buf)) == L.t_crc_bitwise(buf, len(buf)), (n, lead)
+
+
 def test_crc_variants_agree_with_the_definition(harness, oracle_mod):
     so = os.path.join(NATIVE, "libbz2_harness.so")
     L = ctypes.CDLL(so)
