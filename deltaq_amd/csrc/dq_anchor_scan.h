@@ -348,13 +348,20 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 }
                 off += span;
                 lap(t_wait);
-                // inclusive prefix maximum of e over the chunk, carrying cnt(base, .) of the end that holds it
-                int64_t pe = e, pc = ce;
+                // inclusive prefix maximum of e over the chunk, carrying cnt(base, .) of the end that holds it: both in ONE
+                // word per lane (end relative to the window + 1 above, the count's complement below -- equal ends carry
+                // the same count, cnt(base, e) is a function of e, unless one of them is an upper bound: then the
+                // smaller count is the exact one and the complement makes the maximum pick it), one shuffle a round
+                const uint64_t key = e < 0 ? 0ull : (((uint64_t)(uint32_t)(e - i + 1)) << 32) | (uint64_t)(0xffffffffu - (uint32_t)ce);
+                uint64_t pk = key;
 #pragma unroll
                 for (int o = 1; o < kWave; o <<= 1) {
-                    const int64_t te = __shfl_up(pe, o, kWave), tc = __shfl_up(pc, o, kWave);
-                    if (lane >= o && te > pe) { pe = te; pc = tc; }
+                    const uint64_t tk = __shfl_up(pk, o, kWave);
+                    if (lane >= o && tk > pk) pk = tk;
                 }
+                auto end_of = [&](uint64_t k) -> int64_t { return k ? (int64_t)(k >> 32) - 1 + i : (int64_t)-1; };
+                auto cnt_of = [&](uint64_t k) -> int64_t { return k ? (int64_t)(0xffffffffu - (uint32_t)k) : (int64_t)0; };
+                const int64_t pe = end_of(pk), pc = cnt_of(pk);
                 if (lane == kWave - 1) { w_e[wv] = pe; w_c[wv] = pc; }
                 __syncthreads();
                 if (s_err) { failed = true; break; }       // (an answer never came: everybody leaves)
@@ -363,7 +370,8 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 int64_t ch_e = Mrun, ch_c = Crun;          // ... and what the whole chunk leaves
                 for (int q = 0; q < kAsWaves; ++q) if (w_e[q] > ch_e) { ch_e = w_e[q]; ch_c = w_c[q]; }
                 // exclusive values (what the positions BEFORE this one left), then this position's own
-                int64_t xe = __shfl_up(pe, 1, kWave), xc = __shfl_up(pc, 1, kWave);
+                const uint64_t xk = __shfl_up(pk, 1, kWave);
+                int64_t xe = end_of(xk), xc = cnt_of(xk);
                 if (lane == 0 || xe <= ce_in) { xe = ce_in; xc = cc_in; }
                 int64_t Mj = xe, Cj = xc;
                 if (e > Mj) { Mj = e; Cj = ce; }
@@ -376,9 +384,10 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                     // that needs no more is one; anything else is decided with the exact count, on its own
                     if (bound && e > xe && !(l > carried + 8)) { brk_here = false; stop = true; }
                 }
-                int32_t fb = brk_here ? t : 0x7fffffff, fs = (have && stop) ? t : 0x7fffffff;
-                fb = as_wave_min(fb);
-                fs = as_wave_min(fs);
+                // (the lanes of a wave hold consecutive positions: the first lane that says so is the first position)
+                const uint64_t mb = __ballot(brk_here), ms = __ballot(have && stop);
+                const int32_t t0w = off - span + (wv << 6);                       // position of this wave's lane 0
+                const int32_t fb = mb ? t0w + __builtin_ctzll(mb) : 0x7fffffff, fs = ms ? t0w + __builtin_ctzll(ms) : 0x7fffffff;
                 if (lane == 0) { w_brk[wv] = fb; w_stp[wv] = fs; }
                 __syncthreads();
                 int32_t b = 0x7fffffff, s2 = 0x7fffffff;
