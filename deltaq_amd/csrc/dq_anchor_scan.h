@@ -59,7 +59,7 @@ struct AnchorCtl {
     long long done;                                       // 1: the end of new has been reached and reported
     unsigned long long searches, windows, stops;          // Search calls the reference's loop makes; windows; stop points
     unsigned int error;                                   // 1: the barrier timed out
-    unsigned int pad;                                     // in: 1 = fill in the times below
+    unsigned int pad;                                     // in: bit 0 = fill in the times below; bits 8..13 = s_sleep of a poller
     unsigned long long t_search, t_wait, t_eval, t_stop;  // workgroup 0's time searching / waiting for answers / evaluating /
                                                           // at stop points, in 100 MHz ticks (DQ_TRACE prints them)
 };
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     bool failed = false;
     unsigned long long t_search = 0, t_wait = 0, t_eval = 0, t_stop = 0, t0 = __builtin_readcyclecounter();
     // (only when asked for -- ctl->pad, set under DQ_TRACE: reading the clock ~7 times a window is not free)
-    const bool timed = ctl->pad != 0;
+    const bool timed = (ctl->pad & 1u) != 0;
+    const int poll_sleep = (int)((ctl->pad >> 8) & 63u);  // (from the host: DQ_SCAN_POLL_SLEEP, 16 by default)
     auto lap = [&](unsigned long long &acc) {
         if (!timed) return;
         const unsigned long long t1 = wall_clock64();
@@ -227,7 +228,15 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
             *v = __hip_atomic_load(&ans[2 * slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *v2 = __hip_atomic_load(&ans[2 * slot + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((*v >> 62) == tag_w && (*v2 >> 62) == tag_w) return;
-            __builtin_amdgcn_s_sleep(1);
+            // (thousands of lanes poll while the slowest searches still run, and uncached polls are fabric traffic: how
+            // long a poller sleeps is what it costs the searches.  s_sleep 1 / 4 / 16 / 32: Diff.Create of the 16 MiB pairs
+            // with 2000 and 20 000 edits 44.6 / 42.6 / 42.5 / 42.5 ms and 277 / 271 / 268 / 270 ms; the host sends 16)
+            if (poll_sleep <= 1) __builtin_amdgcn_s_sleep(1);
+            else if (poll_sleep == 2) __builtin_amdgcn_s_sleep(2);
+            else if (poll_sleep <= 4) __builtin_amdgcn_s_sleep(4);
+            else if (poll_sleep <= 8) __builtin_amdgcn_s_sleep(8);
+            else if (poll_sleep <= 16) __builtin_amdgcn_s_sleep(16);
+            else __builtin_amdgcn_s_sleep(32);
             if (++spins > (1u << 24) || ((spins & 1023u) == 0 && others_gave_up())) { give_up(); *v = *v2 = 0; return; }
         }
     };

@@ -568,7 +568,7 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         Launcher L{c, c.stream, g_prof_on.load()};
         *h_up = AnchorCtl{};
         h_up->cursor = st.cursor; h_up->hit_len = st.hit_len; h_up->hit_pos = st.hit_pos; h_up->shift = st.shift;
-        h_up->pad = trace ? 1u : 0u;
+        h_up->pad = (trace ? 1u : 0u) | ((unsigned)(env("DQ_SCAN_POLL_SLEEP") ? std::max(1, std::min(32, atoi(env("DQ_SCAN_POLL_SLEEP")))) : 16) << 8);
         for (int64_t k = 0; k < kAnchorRecs; ++k) ring[k] = kAnchorPending;
         std::atomic_thread_fence(std::memory_order_seq_cst);
         HIP_TRY(hipMemcpyAsync(d_ctl, h_up, sizeof(AnchorCtl), hipMemcpyHostToDevice, c.stream));
