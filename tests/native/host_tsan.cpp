@@ -3,6 +3,7 @@
 // re-entrant entry points, and these pieces run on the callers' threads (three framing threads per Diff.Create,
 // Patch.Apply on whatever thread calls it, the codeword table of a coded round 0 on the sorting thread).
 //   g++ -O1 -g -std=c++17 -fsanitize=thread tests/native/host_tsan.cpp -o host_tsan -pthread
+#include <atomic>
 #include <cstdio>
 #include <numeric>
 #include <thread>
@@ -76,10 +77,51 @@ static void worker(int id)
     }
 }
 
+// The hand-over of dq_diff.hip's PatchFramer, on its own: a producer appends to a stream whose capacity is reserved and
+// publishes the length that is final (release); a follower reads the state, then the length (acquire), and feeds the
+// encoder, whose full blocks go to encoder threads of their own; the result must be the stream framed at once.
+static void follow_a_growing_stream(int id)
+{
+    uint64_t x = 77 + (uint64_t)id;
+    auto rnd = [&]() { x += 0x9E3779B97F4A7C15ull; uint64_t z = x; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                       z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    const size_t total = 260000 + 5000 * (size_t)id;          // level 1: three blocks of 99 981 coded bytes
+    std::vector<uint8_t> stream;
+    stream.reserve(total);
+    const uint8_t *base = stream.data();
+    std::atomic<size_t> final_len{0};
+    std::atomic<int> state{0};
+    bz2::StreamEncoder enc(doubling_sorter, 1);
+    std::thread follower([&] {
+        for (;;) {
+            const int s = state.load(std::memory_order_acquire);
+            const size_t upto = final_len.load(std::memory_order_acquire);
+            enc.feed(base, upto, s == 1);
+            if (s == 1) return;
+            std::this_thread::yield();
+        }
+    });
+    while (stream.size() < total) {                              // pieces of text, runs and noise
+        const size_t piece = std::min<size_t>(total - stream.size(), 1 + rnd() % 3000);
+        const int kind = (int)(rnd() % 3);
+        const uint8_t c = (uint8_t)(rnd() % 4);
+        for (size_t k = 0; k < piece; ++k)
+            stream.push_back(kind == 0 ? c : kind == 1 ? (uint8_t)("etaoin shrdlu"[rnd() % 13]) : (uint8_t)rnd());
+        final_len.store(stream.size(), std::memory_order_release);
+    }
+    state.store(1, std::memory_order_release);
+    follower.join();
+    std::vector<uint8_t> fed, once, back;
+    if (enc.finish(fed) != 0 || bz2::bz2_compress(stream.data(), stream.size(), once, doubling_sorter, 1) != 0 || fed != once ||
+        bz2::bz2_decompress(fed.data(), fed.size(), back) != 0 || back != stream)
+        __atomic_fetch_add(&g_bad, 1, __ATOMIC_RELAXED);
+}
+
 int main()
 {
     std::vector<std::thread> ts;
     for (int i = 0; i < 6; ++i) ts.emplace_back(worker, i);
+    for (int i = 0; i < 2; ++i) ts.emplace_back(follow_a_growing_stream, i);
     for (auto &t : ts) t.join();
     if (g_bad) { fprintf(stderr, "%d wrong results\n", g_bad); return 1; }
     printf("ok\n");

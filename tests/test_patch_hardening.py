@@ -32,7 +32,9 @@ def test_hostile_patches_under_asan_ubsan():
 def test_host_pieces_from_six_threads_under_tsan():
     """dq_bz2.h / dq_bspatch.h / dq_alpha_code.h run on the callers' threads (three framing threads per Diff.Create):
     six threads at once under ThreadSanitizer -- no shared mutable state (the CRC table is a compile-time constant,
-    the codeword tables are per call)."""
+    the codeword tables are per call).  Two more threads each run the hand-over Diff.Create frames its growing streams
+    with (producer appends and publishes a length, a follower feeds bz2::StreamEncoder, full blocks are encoded on
+    threads of their own) and compare the result with the stream framed at once."""
     exe = os.path.join(NATIVE, "host_tsan")
     src = os.path.join(NATIVE, "host_tsan.cpp")
     deps = [src] + [os.path.join(CSRC, h) for h in ("dq_bspatch.h", "dq_bsdiff.h", "dq_bz2.h", "dq_alpha_code.h")]
