@@ -51,6 +51,7 @@ constexpr int kAsWaveWins = 3;                            // wave windows walked
 constexpr unsigned long long kAsStopLen = 0x7fffffffull;  // len field of a stop point (texts stay below 2^31 - 1 bytes)
 constexpr int kAsFirstSpan = 64;                          // positions of a wave window evaluated in the first step
 constexpr int64_t kAsCountFront = 4096;                   // bytes of a long match under another alignment that are counted (one step)
+constexpr int64_t kAsFront = 512;                         // bytes behind every window position fetched ahead of its search
 constexpr unsigned long long kAsBoundBit = 1ull << 61;    // second answer word: the count is an upper bound
 
 struct AnchorCtl {
@@ -277,8 +278,29 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                     if (gwave < c) {
                         const int64_t scan = i + gwave;
                         const bool exact = gwave == 0 || streak >= 2;
+                        // The first 512 bytes behind the position under the CURRENT alignment, 8 per lane, asked for before
+                        // the search (the addresses are known: their latency hides behind the first probes): the agree
+                        // count of a match that ends inside them is read off the lanes' words, and for a longer one they
+                        // are the counted front of the upper bound -- no dependent step of its own in either case.
+                        int64_t front = n - shift - scan < m - scan ? n - shift - scan : m - scan;       // bytes both texts have
+                        front = front - 4 < kAsFront ? ((front - 4) & ~(int64_t)7) : kAsFront;           // (ms_load8 touches whole dwords)
+                        uint64_t fx = ~0ull;
+                        if (8 * lane + 8 <= front) fx = ms_load8(old + shift + scan + 8 * lane) ^ ms_load8(nw + scan + 8 * lane);
                         ms_search_wave<IdxT>(old, n, sa, nw, m, scan, exact ? (int64_t)0 : kAsCap, ptab, pk, &p, &l, nullptr, /*resume_first=*/true);
-                        cw = wave_cw(scan, p, l, &cw_bound);
+                        const int64_t len_here = (scan + l < n - shift ? scan + l : n - shift) - scan;   // bytes of the match agree() can hold for
+                        if (l > 0 && p - scan != shift && len_here > 0 && front >= 64 && (len_here <= front || len_here > kAsFront + 64)) {
+                            const int64_t take = len_here < front ? len_here : front;                    // counted bytes: [0, take)
+                            const int64_t mine = take - 8 * lane;                                        // ... of this lane's 8
+                            constexpr uint64_t k7f = 0x7f7f7f7f7f7f7f7full;
+                            uint64_t eq = ~(((fx & k7f) + k7f) | fx | k7f);                              // 0x80 in every byte the two texts agree in
+                            if (mine <= 0) eq = 0;
+                            else if (mine < 8) eq &= (1ull << (8 * mine)) - 1;
+                            const uint32_t c = (uint32_t)__popcll(eq);
+                            cw = (int64_t)__shfl(wave_incl_sum(c), kWave - 1, kWave) + (len_here - take);  // (+ the bytes behind the front, taken as agreeing)
+                            cw_bound = len_here > take;
+                        } else {
+                            cw = wave_cw(scan, p, l, &cw_bound);
+                        }
                         if (lane == 0) slot = gwave;
                     }
                 } else {
