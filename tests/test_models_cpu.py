@@ -340,6 +340,89 @@ def test_run_rules_hold_for_stretches_of_any_period(oracle_mod):
     assert r[2] <= 5 and r[8] <= 5 and r[1] > r[2] + 3, r
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# dq_small_groups.h, twin_mark_kernel / twin_compact_kernel: doubled texts (bzip2's block + block).  Suffix i + half is a
+# proper prefix of suffix i, so the pair stays tied for half - i characters although its order is known: the shorter one
+# first.  Between the rounds every tie group that is exactly such a pair gets its two final ranks and leaves the list.
+def doubling_without_twins(T2, h0=2):
+    n = T2.size
+    half = n // 2
+    P = np.concatenate([T2, np.zeros(h0, np.uint8)])
+    cols = [P[b:b + n] for b in range(h0)]
+    ln = np.minimum(n - np.arange(n), h0)
+    order = np.lexsort([ln] + cols[::-1])
+    head = np.ones(n, bool)
+    diff = ln[order][1:] != ln[order][:-1]
+    for c in cols:
+        diff |= c[order][1:] != c[order][:-1]
+    head[1:] = diff
+    ISA = np.empty(n, np.int64)
+    ISA[order] = np.maximum.accumulate(np.where(head, np.arange(n), 0))
+    h, rounds, written = h0, 0, 0
+    while True:
+        # the list: members of groups of more than one, in rank order
+        cnt = np.bincount(ISA, minlength=n)
+        s = np.flatnonzero(cnt[ISA] > 1)
+        if s.size == 0:
+            break
+        s = s[np.argsort(ISA[s], kind="stable")]
+        r = ISA[s]
+        # ---- the twin step: groups of exactly two members that lie `half` apart are written down
+        gsize = cnt[r]
+        first = np.ones(s.size, bool)
+        first[1:] = r[1:] != r[:-1]
+        pair_head = np.flatnonzero(first & (gsize == 2))
+        a, b = s[pair_head], s[pair_head + 1]
+        twin = np.abs(a - b) == half
+        hi, lo = np.maximum(a, b)[twin], np.minimum(a, b)[twin]
+        ISA[hi] = r[pair_head][twin]                                   # the shorter suffix first
+        ISA[lo] = r[pair_head][twin] + 1
+        written += int(twin.sum())
+        keep = np.ones(s.size, bool)
+        keep[pair_head[twin]] = False
+        keep[pair_head[twin] + 1] = False
+        s, r = s[keep], r[keep]
+        if s.size == 0:
+            break
+        # ---- one plain doubling round on what is left (ranks finer than depth h are welcome as keys)
+        q = s + h
+        k2 = np.where(q < n, ISA[np.minimum(q, n - 1)] + h, n - 1 - s)
+        o = np.lexsort((k2, r))
+        ss, rs, ks = s[o], r[o], k2[o]
+        m = ss.size
+        newhead = np.ones(m, bool)
+        newhead[1:] = (rs[1:] != rs[:-1]) | (ks[1:] != ks[:-1])
+        ghead = np.ones(m, bool)
+        ghead[1:] = rs[1:] != rs[:-1]
+        j = np.arange(m)
+        ISA[ss] = rs + (np.maximum.accumulate(np.where(newhead, j, -1)) - np.maximum.accumulate(np.where(ghead, j, -1)))
+        h *= 2
+        rounds += 1
+        assert h < 4 * n + 8, "no progress"
+    SA = np.empty(n, np.int64)
+    SA[ISA] = np.arange(n)
+    return SA, rounds, written
+
+
+def test_twin_pairs_of_a_doubled_text_leave_the_list_early(oracle_mod):
+    rng = np.random.default_rng(23)
+    blocks = [rng.integers(0, 256, 3000, dtype=np.uint8), rng.integers(0, 2, 700, dtype=np.uint8), np.zeros(64, np.uint8),
+              np.resize(np.array([0, 0, 0, 0, 251], np.uint8), 1200), np.resize(np.array([7, 9], np.uint8), 300),
+              np.frombuffer(b"abracadabra" * 30 + b"x", np.uint8), np.array([5], np.uint8), np.array([1, 1], np.uint8)]
+    for _ in range(25):
+        parts = [np.resize(rng.integers(0, 3, int(rng.integers(1, 6)), dtype=np.uint8), int(rng.integers(1, 200))) for _ in range(int(rng.integers(1, 9)))]
+        blocks.append(np.concatenate(parts).astype(np.uint8))
+    for B in blocks:
+        T2 = np.concatenate([B, B]).astype(np.uint8)
+        ref = oracle_mod.divsufsort(T2).astype(np.int64)
+        for h0 in (1, 2, 8):
+            SA, rounds, written = doubling_without_twins(T2, h0)
+            assert np.array_equal(SA, ref), (B.size, h0)
+    # a block of random bytes: its real ties end with the first round or two, its 3000 pairs would have lasted eleven
+    SA, rounds, written = doubling_without_twins(np.concatenate([blocks[0], blocks[0]]), 2)
+    assert rounds <= 2 and written >= 2800, (rounds, written)
+
+
 def test_run_length_passes_model():
     """The three-pass run-length computation of dq_runs.h (segments of 16, chunks of 4096, carry across chunks) in numpy."""
     rng = np.random.default_rng(9)
