@@ -1526,8 +1526,11 @@ struct SuffixSorter {
             // librocsparse.so, 256 MiB, 0.32 M members of large groups -- 2.2 ms of run lengths for nothing)
             const int64_t late_share = env("DQ_LATE_RUNS_SHARE") ? std::max(1, atoi(env("DQ_LATE_RUNS_SHARE")))
                                        : env("DQ_LATE_RUNS_MIN") ? (int64_t)1 << 30 : 64;      // (the tests' knob lifts this bar too)
+            // (stagnation: the large groups kept at least late_ratio / 8 of their members over the last round.  Measured with
+            // 5 / 8 and 4 / 8, which call the round one doubling earlier on libtorch_cpu.so: 25.3 / 25.5 ms against 24.8)
+            const int64_t late_ratio = env("DQ_LATE_RUNS_RATIO") ? std::max(1, std::min(8, atoi(env("DQ_LATE_RUNS_RATIO")))) : 7;
             if (late_runs_possible && !runs_on && !runs_late_tried && !run_order && last_large >= late_min && prev_large > 0 &&
-                last_large * late_share >= n && last_large * 8 >= prev_large * 7 && h >= 32 && 32 + rbits <= 64 && uses_small_round(m) && !keys_ready &&
+                last_large * late_share >= n && last_large * 8 >= prev_large * late_ratio && h >= 32 && 32 + rbits <= 64 && uses_small_round(m) && !keys_ready &&
                 !list_ungrouped && !first_rank32 && mid_group_cap(m) > 0 && !env("DQ_NO_LATE_RUNS")) {
                 runs_late_tried = true;
                 // the rules hold for stretches that repeat with any period P <= h (tests/test_models_cpu.py has the
