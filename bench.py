@@ -65,10 +65,20 @@ def main() -> int:
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as fresh child
+        # processes, before this process has loaded the library or touched the GPU; relay their output (rank 0
+        # prints the line) and leave with their status.  One rank can never stand in for N.
+        return launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree", file=sys.stderr)
+        return 2
 
     # Native builds first, before anything initialises the GPU runtime (compilers are child processes;
     # under rocprofv3 the GPU is already up, so a stale library there is an error, not a rebuild).
@@ -97,11 +107,20 @@ def main() -> int:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    devices_seen = [torch.cuda.current_device()]
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        # every rank names the device it runs on: one GPU per rank, unless the plumbing test shares cuda:0 on purpose
+        seen = [None] * world
+        dist.all_gather_object(seen, (int(torch.cuda.current_device()), os.environ.get("HIP_VISIBLE_DEVICES"),
+                                      os.environ.get("ROCR_VISIBLE_DEVICES")))
+        devices_seen = [x[0] for x in seen]
+        if not args.share_gpu and len(set(seen)) != world:
+            raise SystemExit(f"bench.py: {world} ranks but devices {seen}: two ranks share a GPU")
 
     n = args.size_mib << 20
     if args.workload == "uniform":
@@ -187,6 +206,7 @@ def main() -> int:
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_of_6p3": round(achieved / HBM_COPY_GBS, 4),      # against the measured copy ceiling
                 "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_stale": bool(traffic is None and traffic_src is not None and traffic_src.startswith("stale")),
                 "launches": rs["launches"],
                 "avg_launch_us": round(rs["ms"] / rs["launches"] * 1e3, 2),
                 "alg_bytes_per_launch": rs["alg_bytes"] // rs["launches"],
@@ -195,7 +215,8 @@ def main() -> int:
         out = {
             "metric": "MB of text suffix-sorted per second (bit-exact SA)",
             "value": round(value, 2), "unit": "MB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "gpus_flag": args.gpus, "devices_per_rank": devices_seen,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 text / u64 keys / int32 SA", "data": "synthetic",
@@ -222,6 +243,30 @@ def main() -> int:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child process (nothing in
+    this process has initialised the GPU yet), pass its output through and return its exit status."""
+    import socket
+    import subprocess
+    if not os.environ.get("DQ_BENCH_ALLOW_OVERSUBSCRIBE") and "--share-gpu" not in sys.argv:
+        try:
+            import torch
+            have = torch.cuda.device_count()            # (counts devices without initialising the runtime on this image)
+        except Exception:                               # noqa: BLE001
+            have = None
+        if have is not None and have < n:
+            print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print("bench.py: no launcher around --gpus %d, starting the ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, cwd=ROOT)
 
 
 def managed_reference_probe():
@@ -281,16 +326,22 @@ def profiled_kernels(sorter, host, dev, steps=2):
 def pmc_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this same command
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, tools/profile_gpu.sh):
-    2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md."""
+    2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md.
+    The file names the library it was taken from (deltaq_amd.build._source_digest() at profiling time): counters of
+    another build are not reported -- (None, "stale: ...") instead."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath):
         return None, None
     try:
+        from deltaq_amd import build as dq_build
         tj = json.load(open(tpath))
         if tj.get("workload") != f"{args.workload}-{args.size_mib}MiB":
             return None, None
+        have, want = tj.get("library_source_digest"), dq_build._source_digest()
+        if have != want:
+            return None, f"stale: profiles/traffic.json was taken from library sources {str(have)[:12]}, this is {want[:12]}"
         return int(tj[kernel]["hbm_bytes_per_launch"]), \
-            "profiles/traffic.json (rocprofv3 PMC, 2*FETCH_SIZE+WRITE_SIZE per launch)"
+            "profiles/traffic.json (rocprofv3 PMC, 2*FETCH_SIZE+WRITE_SIZE per launch; library sources %s)" % want[:12]
     except Exception:
         return None, None
 
@@ -348,7 +399,75 @@ def other_configs(sorter, dev):
     recs.append(match_search_record(sorter, dev))
     recs.append(reference_benchmark_shape(sorter))
     recs.append(bsdiff_create_record(dev))
+    recs.append(config3_record(sorter, dev))         # last: it leaves > 100 GiB of cached workspace, released at its end
     return recs
+
+
+SEED_CONFIG3 = 0x5EED0004      # 2 GiB uniform, int64 SA
+
+
+def config3_record(sorter, dev, reps=3):
+    """BASELINE configs[3]: 2 GiB uniform-random bytes, 64-bit suffix array (dq_sufsort_hip_dev_i64), text and SA
+    resident in HBM.  The suffix array of the timed sorts is checked on the host by LDSSChecker.Check (the oracle's
+    threaded evaluation) and 10^5 sampled strict pairs.  Skipped, with the reason, where the device or the host is
+    too small for it (text + 16 GiB of SA + ~112 GiB of workspace in HBM; text + SA + the checker's arrays in RAM)."""
+    import numpy as np
+    import torch
+    import oracle
+    from deltaq_amd import _abi
+    from tools import datagen
+    name = "configs[3]: 2 GiB uniform random, int64 SA"
+    n = 1 << 31
+    L = _abi.load()
+    try:
+        free_hbm, _total = torch.cuda.mem_get_info(dev)
+        need_hbm = n + 8 * n + int(L.dq_sufsort_hip_workspace_bytes(n, 8)) + (1 << 30)
+        ram = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_AVPHYS_PAGES")
+        need_ram = n + 8 * n + 8 * n + (4 << 30)           # text, SA, the checker's inverse, slack
+        L.dq_sufsort_hip_release()                         # the earlier records' cached workspaces go first
+        torch.cuda.empty_cache()
+        free_hbm, _total = torch.cuda.mem_get_info(dev)
+        if free_hbm < need_hbm:
+            return {"config": name, "skipped": f"free HBM {free_hbm >> 30} GiB < {need_hbm >> 30} GiB needed"}
+        if ram < need_ram:
+            return {"config": name, "skipped": f"free host RAM {ram >> 30} GiB < {need_ram >> 30} GiB needed for the check"}
+        host = datagen.gen_uniform(n, SEED_CONFIG3)
+        text = torch.from_numpy(host).to(dev)
+        sa = torch.empty(n, dtype=torch.int64, device=dev)
+        sorter.Sort(text, sa)                              # first call grows the workspace
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            sorter.Sort(text, sa)
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        info = _abi.last_sort_info()
+        ms = min(ts) * 1e3
+        rec = {"config": name, "device_resident_ms": round(ms, 3), "device_resident_ms_all": [round(x * 1e3, 2) for x in ts],
+               "device_resident_MBps": round(n / 1e3 / ms, 1), "rounds": info["rounds"], "index_bytes": 8}
+        L.dq_profile_reset()
+        L.dq_profile_enable(1)
+        sorter.Sort(text, sa)
+        torch.cuda.synchronize(dev)
+        L.dq_profile_enable(0)
+        rec["kernels"] = kernel_table(_abi.profile_snapshot(), 1)
+        got = np.empty(n, dtype=np.int64)
+        step = 1 << 28
+        for a in range(0, n, step):                        # in pieces: no pinned 16 GiB staging buffer
+            got[a:a + step] = sa[a:a + step].cpu().numpy()
+        del sa, text
+        t0 = time.perf_counter()
+        rec["sufcheck_mt"] = int(oracle.sufcheck_mt(host, got))
+        rec["sampled_strict_pairs_1e5_first_bad"] = int(oracle.verify_sampled(host, got, 100_000, 11))
+        rec["check_s"] = round(time.perf_counter() - t0, 1)
+        rec["checked_ok"] = bool(rec["sufcheck_mt"] == oracle.CHECK_DONE and rec["sampled_strict_pairs_1e5_first_bad"] == -1)
+        return rec
+    except Exception as e:                                  # noqa: BLE001 -- report, do not lose the bench line
+        return {"config": name, "error": repr(e)[:300]}
+    finally:
+        L.dq_sufsort_hip_release()
+        torch.cuda.empty_cache()
 
 
 def real_binary_record(sorter, dev, mib=128):

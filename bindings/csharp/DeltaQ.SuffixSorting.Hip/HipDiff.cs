@@ -46,6 +46,9 @@ internal static unsafe class Native
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
     internal static extern void dq_bsdiff_index_free(IntPtr index);
 
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+    internal static extern int dq_last_diff_info(long* info, int count);
+
     internal static string LastError() => Marshal.PtrToStringAnsi(dq_last_error()) ?? string.Empty;
 
     internal static void Check(int rc, string what)
@@ -83,6 +86,22 @@ public static class HipDiff
 
         byte[] patch = CreateBytes(oldData, newData, device, out long length);
         output.Write(patch, 0, checked((int)length));
+    }
+
+    /// <summary>
+    /// Shape of the last Create / HipDiffIndex.Create on this thread (dq_last_diff_info): Search calls of the loop
+    /// (Diff.cs:106), windows, positions asked again exactly, device scans given back to the host loop, workgroups.
+    /// A non-zero fourth entry means the call was correct but slow: the device was kept full by other work.
+    /// </summary>
+    public static unsafe long[] LastDiffInfo()
+    {
+        var info = new long[5];
+        fixed (long* p = info)
+        {
+            Native.Check(Native.dq_last_diff_info(p, info.Length), nameof(Native.dq_last_diff_info));
+        }
+
+        return info;
     }
 
     public static unsafe byte[] CreateBytes(ReadOnlySpan<byte> oldData, ReadOnlySpan<byte> newData, int device, out long length)

@@ -32,7 +32,7 @@ EXPORTS = (
     "dq_sufsort_hip_workspace_bytes", "dq_sufsort_hip_release",
     "dq_profile_enable", "dq_profile_reset", "dq_profile_get", "dq_profile_kernel_name",
     "dq_profile_category_count",
-    "dq_last_sort_info",
+    "dq_last_sort_info", "dq_last_diff_info",
 )
 
 
@@ -135,6 +135,8 @@ def load() -> ctypes.CDLL:
     L.dq_profile_category_count.argtypes = []
     L.dq_last_sort_info.restype = i32
     L.dq_last_sort_info.argtypes = [ctypes.POINTER(i64)] * 3
+    L.dq_last_diff_info.restype = i32
+    L.dq_last_diff_info.argtypes = [ctypes.POINTER(i64), i32]
     _lib = L
     return L
 
@@ -173,6 +175,14 @@ def category_of(kernel_name: str) -> int:
         if L.dq_profile_kernel_name(cat).decode() == kernel_name:
             return cat
     raise KeyError(kernel_name)
+
+
+def last_diff_info() -> dict:
+    """Shape of the last Diff.Create / index diff on this thread (dq_last_diff_info)."""
+    L = load()
+    v = (ctypes.c_int64 * 5)()
+    L.dq_last_diff_info(v, 5)
+    return {"searches": v[0], "windows": v[1], "exact": v[2], "host_loop_fallbacks": v[3], "scan_groups": v[4]}
 
 
 def last_sort_info() -> dict:

@@ -67,7 +67,8 @@ class Diff:
         _abi.check(L.dq_bsdiff_scan_i32(p(O), O.size, p(N), m, ctrl.ctypes.data, m + 1, ctypes.byref(nc), diff.ctypes.data,
                                         ctypes.byref(nd), extra.ctypes.data, ctypes.byref(ne), stats, device))
         return (ctrl[:3 * nc.value].reshape(-1, 3).copy(), diff[:nd.value].copy(), extra[:ne.value].copy(),
-                {"searches": stats[0], "windows": stats[1], "exact": stats[2]})
+                {"searches": stats[0], "windows": stats[1], "exact": stats[2],
+                 "host_loop_fallbacks": _abi.last_diff_info()["host_loop_fallbacks"]})
 
 
 class DiffIndex:

@@ -44,18 +44,49 @@ def _deps(src: str) -> list[str]:
     if not os.path.exists(dep):
         return []
     text = open(dep).read().replace("\\\n", " ")
-    return [p for p in text.split(":", 1)[-1].split() if p.startswith(CSRC) or p.startswith(os.path.dirname(HERE))]
+    root = os.path.dirname(HERE)
+    out = []
+    for p in text.split(":", 1)[-1].split():
+        # the list holds absolute paths of the tree the object was compiled in; the tree may have been copied since
+        # (the GPU box gets a snapshot under another path): re-root what belongs to the repository, drop system headers
+        for mark, base in (("/deltaq_amd/csrc/", CSRC), ("/include/", os.path.join(root, "include"))):
+            k = p.rfind(mark)
+            if k >= 0 and not p.startswith("/opt/") and not p.startswith("/usr/"):
+                out.append(os.path.join(base, p[k + len(mark):]))
+                break
+    return out
+
+
+def _obj_digest(src: str) -> str | None:
+    """sha256 over the contents of every file the object was compiled from (the compiler's own list, -MD) and the flags;
+    None when that list is missing or names a file that is gone."""
+    import hashlib
+    deps = _deps(src)
+    if not deps:
+        return None
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for p in sorted(set(deps + [os.path.join(CSRC, src)])):
+        if not os.path.exists(p):
+            return None
+        h.update(os.path.relpath(p, os.path.dirname(HERE)).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def _obj_stale(src: str) -> bool:
+    """By content, like the library itself: the object is current iff the digest stamped beside it when it was compiled
+    names its sources as they are now.  (File times order nothing in a copied tree: an object that travelled to the
+    GPU box with an edited header would be relinked as it is and the manifest stamped over it.)"""
     obj = _obj(src)
-    if not os.path.exists(obj):
+    stamp = obj[:-2] + ".digest"
+    if not os.path.exists(obj) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(obj)
-    deps = _deps(src)
-    if not deps:
+    d = _obj_digest(src)
+    try:
+        return d is None or open(stamp).read().strip() != d
+    except OSError:
         return True
-    return any((not os.path.exists(p)) or os.path.getmtime(p) > t for p in deps + [os.path.join(CSRC, src)])
 
 
 MANIFEST = os.path.join(HERE, "libdq_sufsort_hip.manifest")
@@ -104,7 +135,15 @@ def _compile(src: str, verbose: bool) -> None:
     cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-MD", "-MF", obj[:-2] + ".d", "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
+    stamp = obj[:-2] + ".digest"
+    if os.path.exists(stamp):
+        os.remove(stamp)                    # (an interrupted compile leaves no stamp behind)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    d = _obj_digest(src)
+    if d is not None:
+        with open(stamp + ".tmp", "w") as f:
+            f.write(d + "\n")
+        os.replace(stamp + ".tmp", stamp)
 
 
 def _build_locked(force: bool, verbose: bool) -> str:

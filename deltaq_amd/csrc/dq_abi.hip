@@ -52,8 +52,8 @@ int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *con
             }
             bc.bslot_cap = 0;
             for (int k = 0; k < kBatchSlots; ++k)
-                ok = ok && hipMalloc((void **)&bc.bslot_text[k], (size_t)cap + 64) == hipSuccess &&
-                     hipMalloc((void **)&bc.bslot_sa[k], (size_t)cap * sizeof(int32_t)) == hipSuccess;
+                ok = ok && dq_malloc((void **)&bc.bslot_text[k], (size_t)cap + 64) == hipSuccess &&
+                     dq_malloc((void **)&bc.bslot_sa[k], (size_t)cap * sizeof(int32_t)) == hipSuccess;
             if (ok) bc.bslot_cap = (size_t)cap;
         }
         if (!ok) { *err = "batch slot allocation failed"; return DQ_ERR_OOM; }
@@ -478,6 +478,13 @@ int32_t dq_last_sort_info(int64_t *rounds, int64_t *initial_active, int64_t *sum
     if (rounds) *rounds = t_info[0];
     if (initial_active) *initial_active = t_info[1];
     if (sum_active) *sum_active = t_info[2];
+    return DQ_OK;
+}
+
+int32_t dq_last_diff_info(int64_t *info, int32_t count)
+{
+    if (!info || count < 0) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
+    for (int32_t k = 0; k < count; ++k) info[k] = k < 5 ? t_diff_info[k] : 0;
     return DQ_OK;
 }
 

@@ -60,7 +60,9 @@ struct AnchorCtl {
     long long done;                                       // 1: the end of new has been reached and reported
     unsigned long long searches, windows, stops;          // Search calls the reference's loop makes; windows; stop points
     unsigned int error;                                   // 1: the barrier timed out
-    unsigned int pad;                                     // in: bit 0 = fill in the times below; bits 8..13 = s_sleep of a poller
+    unsigned int pad;                                     // in: bit 0 = fill in the times below; bits 8..13 = s_sleep of a poller;
+                                                          // bits 16..20 = log2 of the spin bound (0: 24); bits 24..31: test knob,
+                                                          // workgroup (k - 1) sleeps before it publishes a window's answers
     unsigned long long t_search, t_wait, t_eval, t_stop;  // workgroup 0's time searching / waiting for answers / evaluating /
                                                           // at stop points, in 100 MHz ticks (DQ_TRACE prints them)
 };
@@ -143,6 +145,11 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     // (only when asked for -- ctl->pad, set under DQ_TRACE: reading the clock ~7 times a window is not free)
     const bool timed = (ctl->pad & 1u) != 0;
     const int poll_sleep = (int)((ctl->pad >> 8) & 63u);  // (from the host: DQ_SCAN_POLL_SLEEP, 16 by default)
+    // every spin is bounded: 2^24 polls (seconds) in production; the fault-injection tests send a bound of a few polls
+    // (DQ_FAULT=spin), under which the launch reports its error and the host loop takes the file
+    const uint32_t spin_bound = 1u << (((ctl->pad >> 16) & 31u) ? ((ctl->pad >> 16) & 31u) : 24u);
+    // (DQ_SCAN_SLOW_GROUP=k: workgroup k - 1 is the straggler of every window -- the adversarial schedule of the tests)
+    const bool slow_me = ((ctl->pad >> 24) & 255u) == (unsigned)blockIdx.x + 1u;
     auto lap = [&](unsigned long long &acc) {
         if (!timed) return;
         const unsigned long long t1 = wall_clock64();
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
             uint32_t spins = 0;
             while (seen < win_no - 1) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24) || ((spins & 1023u) == 0 && others_gave_up())) { give_up(); break; }
+                if (++spins > spin_bound || ((spins & 1023u) == 0 && others_gave_up())) { give_up(); break; }
                 seen = __hip_atomic_load(&finished[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
             else if (poll_sleep <= 8) __builtin_amdgcn_s_sleep(8);
             else if (poll_sleep <= 16) __builtin_amdgcn_s_sleep(16);
             else __builtin_amdgcn_s_sleep(32);
-            if (++spins > (1u << 24) || ((spins & 1023u) == 0 && others_gave_up())) { give_up(); *v = *v2 = 0; return; }
+            if (++spins > spin_bound || ((spins & 1023u) == 0 && others_gave_up())) { give_up(); *v = *v2 = 0; return; }
         }
     };
     if (tid == 0) s_err = 0;                               // (sticky: once set, every loop below ends)
@@ -322,6 +329,9 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 await_lagging(win_no, lag_seen);           // (window win_no - 2 has been read by everybody)
                 lap(t_wait);
                 if (failed) break;
+                if (slow_me) {                             // (test knob: ~50 us behind everybody else, every window)
+                    for (int z = 0; z < 64; ++z) __builtin_amdgcn_s_sleep(127);
+                }
                 if (slot >= 0) publish(slot, p, l, cw, cw_bound);
             }
 

@@ -44,7 +44,7 @@ int match_search_dev(const void *d_old, int64_t n, const void *d_sa, const void 
     if (!d_ptab && env("DQ_SEARCH_PTAB") && n > 0) {
         pk = atoi(env("DQ_SEARCH_PTAB")) >= 3 ? 3 : 2;
         const int64_t total = (1ll << (8 * pk)) + 1;
-        HIP_TRY(hipMalloc(&tmp_tab.p, (size_t)total * sizeof(IdxT)));
+        HIP_TRY(dq_malloc(&tmp_tab.p, (size_t)total * sizeof(IdxT)));
         hipLaunchKernelGGL(prefix_bounds_kernel<IdxT>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                            (const uint8_t *)d_old, n, (const IdxT *)d_sa, pk, (IdxT *)tmp_tab.p);
         HIP_TRY(hipGetLastError());
@@ -93,7 +93,7 @@ int match_search_host(const uint8_t *old, int64_t n, const IdxT *sa, const uint8
     char *base = nullptr;
     const size_t b_old = align_up((size_t)n + 16), b_sa = align_up((size_t)n * sizeof(IdxT) + 16), b_new = align_up((size_t)m + 16);
     const size_t b_sc = scans ? align_up((size_t)count * 8) : 0, b_out = align_up((size_t)count * sizeof(IdxT));
-    hipError_t e = hipMalloc((void **)&base, b_old + b_sa + b_new + b_sc + 2 * b_out);
+    hipError_t e = dq_malloc((void **)&base, b_old + b_sa + b_new + b_sc + 2 * b_out);
     if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(match search buffers)", e);
     char *d_old = base, *d_sa = d_old + b_old, *d_new = d_sa + b_sa, *d_sc = d_new + b_new, *d_pos = d_sc + b_sc,
          *d_len = d_pos + b_out;
@@ -335,7 +335,7 @@ int grow_cached(char **buf, size_t *have, size_t want, const char *what)
 {
     if (*have >= want) return DQ_OK;
     if (*buf) { (void)hipFree(*buf); *buf = nullptr; *have = 0; }
-    hipError_t e = hipMalloc((void **)buf, want);
+    hipError_t e = dq_malloc((void **)buf, want);
     if (e != hipSuccess) return fail(DQ_ERR_OOM, what, e);
     *have = want;
     return DQ_OK;
@@ -366,7 +366,7 @@ int diff_index_build(const uint8_t *old, int64_t n, int32_t device, const void *
             ix->own = c.diff_idx;
             ix->own_cached = true;
         } else {
-            hipError_t e = hipMalloc((void **)&ix->own, total);
+            hipError_t e = dq_malloc((void **)&ix->own, total);
             if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(bsdiff index)", e);
         }
     }
@@ -562,13 +562,55 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
     if (rc != DQ_OK) return rc;
     AnchorCtl *h_up = reinterpret_cast<AnchorCtl *>(c.pinned + 512), *h_back = reinterpret_cast<AnchorCtl *>(c.pinned);
     const bool trace = env("DQ_TRACE") != nullptr;
-    const int groups = env("DQ_SCAN_GROUPS") ? std::max(8, std::min(kAsMaxGroups, atoi(env("DQ_SCAN_GROUPS")))) : kAsGroups;
+    int groups = env("DQ_SCAN_GROUPS") ? std::max(8, std::min(kAsMaxGroups, atoi(env("DQ_SCAN_GROUPS")))) : kAsGroups;
+    // The grid is persistent and its workgroups wait for each other's answers: all of them must be on the device at
+    // once.  What the device holds (occupancy of this kernel x compute units; a partitioned or smaller part holds
+    // fewer than 128) bounds the grid; below 8 workgroups, or for a while after a launch whose workgroups waited in
+    // vain (a device kept full by other streams or processes -- every such launch costs its spin bound), the host
+    // loop over windows takes the file instead.
+    if (c.scan_groups_cap < 0) {
+        int per_cu = 0, ncu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, anchor_scan_kernel<int32_t>, kAsThreads, 0) != hipSuccess) per_cu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ix.dev) != hipSuccess) ncu = 0;
+        c.scan_groups_cap = per_cu > 0 && ncu > 0 ? per_cu * ncu : kAsGroups;       // (unknown: as before)
+        if (trace) fprintf(stderr, "[dq] anchor scan: %d workgroups per compute unit x %d compute units resident\n", per_cu, ncu);
+    }
+    if (const char *v = env("DQ_SCAN_GROUPS_CAP")) groups = std::min(groups, std::max(0, atoi(v)));      // (tests: a small device)
+    groups = std::min(groups, c.scan_groups_cap);
+    t_diff_info[4] = groups;
+    if (groups < 8 || c.scan_skip > 0) {
+        if (c.scan_skip > 0) --c.scan_skip;
+        *retry_on_host = true;
+        return fail(DQ_ERR_HIP, groups < 8 ? "anchor scan: the device holds fewer than 8 of its workgroups" : "anchor scan: skipped after a starved launch");
+    }
     double emit_ms = 0;                                   // (DQ_TRACE: time inside the emitter)
+    // Whatever way this function is left once a launch is out -- a failed copy, an exception out of the emitter -- the
+    // kernel must be off the stream before anybody refills the ring or the answer buffers: it is told to stop (the
+    // error word every spin looks at), the stream drains, the timing events go back to their pool.
+    struct LaunchGuard {
+        DeviceCtx &c; AnchorCtl *d_ctl; bool armed = false;
+        ~LaunchGuard()
+        {
+            if (!armed) return;
+            hipStream_t side = nullptr;
+            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess) {
+                static const unsigned int one = 1;
+                (void)hipMemcpyAsync(&d_ctl->error, &one, sizeof(one), hipMemcpyHostToDevice, side);
+                (void)hipStreamSynchronize(side);
+                (void)hipStreamDestroy(side);
+            }
+            drop_pending(c, c.stream);                    // (synchronises c.stream first)
+        }
+    } guard{c, d_ctl};
     for (;;) {
         Launcher L{c, c.stream, g_prof_on.load()};
         *h_up = AnchorCtl{};
         h_up->cursor = st.cursor; h_up->hit_len = st.hit_len; h_up->hit_pos = st.hit_pos; h_up->shift = st.shift;
         h_up->pad = (trace ? 1u : 0u) | ((unsigned)(env("DQ_SCAN_POLL_SLEEP") ? std::max(1, std::min(32, atoi(env("DQ_SCAN_POLL_SLEEP")))) : 16) << 8);
+        // (the tests: a spin bound of 2^k polls -- DQ_FAULT=spin: 2 --, and workgroup k - 1 as the straggler of every window)
+        if (t_fault.spin) h_up->pad |= 1u << 16;
+        else if (const char *v = env("DQ_SCAN_SPIN_LOG2")) h_up->pad |= (unsigned)std::max(1, std::min(24, atoi(v))) << 16;
+        if (const char *v = env("DQ_SCAN_SLOW_GROUP")) h_up->pad |= (unsigned)std::max(0, std::min(255, atoi(v))) << 24;
         for (int64_t k = 0; k < kAnchorRecs; ++k) ring[k] = kAnchorPending;
         std::atomic_thread_fence(std::memory_order_seq_cst);
         HIP_TRY(hipMemcpyAsync(d_ctl, h_up, sizeof(AnchorCtl), hipMemcpyHostToDevice, c.stream));
@@ -583,6 +625,7 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         };
         rc = launch();
         if (rc != DQ_OK) { drop_pending(c, c.stream); return rc; }
+        guard.armed = true;
         HIP_TRY(hipMemcpyAsync(h_back, d_ctl, sizeof(AnchorCtl), hipMemcpyDeviceToHost, c.stream));
         // ---- the pairs as they come: slot k is filled once it no longer reads "pending" ----
         int64_t taken = 0;
@@ -601,18 +644,27 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         };
         for (uint32_t idle = 0;;) {
             if (taken < kAnchorRecs && take_filled()) { idle = 0; continue; }
-            if ((++idle & 63u) != 0) continue;             // (a stream query costs more than a look at the slot)
+            if ((++idle & 63u) != 0) { if ((idle & 7u) == 0) __builtin_ia32_pause(); continue; }   // (a stream query costs more than a look at the slot)
             const hipError_t q = hipStreamQuery(c.stream);
             if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) { drop_pending(c, c.stream); return fail(DQ_ERR_HIP, "anchor scan: stream query failed", q); }
+            if (q != hipErrorNotReady) return fail(DQ_ERR_HIP, "anchor scan: stream query failed", q);
+            // (nothing new for thousands of looks: the kernel is inside a long search -- leave the core to the framing
+            // and encoder threads of this and other callers for a moment)
+            if (idle >= (1u << 14)) std::this_thread::yield();
         }
         HIP_TRY(hipStreamSynchronize(c.stream));
+        guard.armed = false;                              // (the kernel has left the stream)
         rc = flush_profile(c);
         if (rc != DQ_OK) return rc;
         st = *h_back;
         // (a workgroup of the persistent grid did not get onto the device in time -- a device kept full by other work:
-        // the caller runs the host loop over windows instead; nothing of this attempt is kept)
-        if (st.error) { *retry_on_host = true; return fail(DQ_ERR_HIP, "anchor scan: grid barrier timed out"); }
+        // the caller runs the host loop over windows instead; nothing of this attempt is kept; the next 16 diffs on this
+        // device do not try again)
+        if (st.error) {
+            if (!t_fault.spin && !env("DQ_SCAN_SPIN_LOG2")) c.scan_skip = 16;     // (not under the tests' own bound)
+            *retry_on_host = true;
+            return fail(DQ_ERR_HIP, "anchor scan: grid barrier timed out");
+        }
         const int64_t got = (int64_t)st.nrec;
         if (got < taken || got > kAnchorRecs) return fail(DQ_ERR_HIP, "anchor scan: bad record count");
         while (taken < got) {                              // what the kernel wrote after the last look
@@ -638,6 +690,7 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
 {
     if (m < 0 || (m > 0 && !nw)) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
     if (m > 0x7fffffffLL) return fail(DQ_ERR_TOO_LARGE, "the BSDIFF40 path takes files below 2 GiB (int indices, as the reference)");
+    for (int64_t &x : t_diff_info) x = 0;
     if (m == 0) return DQ_OK;
     const int dev = ix.dev;
     HIP_TRY(hipSetDevice(dev));
@@ -653,7 +706,7 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
     int rc = grow_cached(&c.diff_dev, &c.diff_dev_bytes, b_new + 256 + kAnchorScratch, "hipMalloc(bsdiff buffers)");
     if (rc != DQ_OK) return rc;
     if (!c.diff_pinned) {
-        hipError_t e = hipHostMalloc((void **)&c.diff_pinned, kDiffPinnedBytes, hipHostMallocCoherent);   // (windows + the packed answers the loop polls)
+        hipError_t e = dq_host_malloc((void **)&c.diff_pinned, kDiffPinnedBytes, hipHostMallocCoherent);   // (windows + the packed answers the loop polls)
         if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipHostMalloc(search windows)", e);
     }
     char *pinned = c.diff_pinned;
@@ -675,7 +728,11 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
         if (trace)
             fprintf(stderr, "[dq] device scan: %lld searches, %lld windows, %lld stop points, %zu triples%s\n", (long long)raw.searches,
                     (long long)raw.windows, (long long)raw.exact, raw.ctrl.size() / 24, retry_on_host ? " -- given up, host loop instead" : "");
-        if (!retry_on_host) return rc;
+        if (!retry_on_host) {
+            t_diff_info[0] = raw.searches; t_diff_info[1] = raw.windows; t_diff_info[2] = raw.exact;
+            return rc;
+        }
+        t_diff_info[3] += 1;                               // (not silently: dq_last_diff_info says the host loop took this file)
         if (framer) framer->abandon();                     // (before the streams it reads go away)
         raw = bsdiff::RawStreams{};
     }
@@ -703,6 +760,7 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
     // (the loop polled the kernels' own completion counts: drain the stream before the buffers are reused)
     const hipError_t drained = hipStreamSynchronize(c.stream);
     if (rc == DQ_OK && drained != hipSuccess) return fail(DQ_ERR_HIP, "scan loop: stream did not drain", drained);
+    t_diff_info[0] = raw.searches; t_diff_info[1] = raw.windows; t_diff_info[2] = raw.exact;
     return rc;
 }
 

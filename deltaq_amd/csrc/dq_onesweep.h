@@ -26,7 +26,6 @@ constexpr int kHistBlocks = 512;
 constexpr int kHistThreads = 1024;   // 16 waves share one set of sub-histograms: 512 workgroups fill the 256 CUs
 constexpr int kMaxPasses = 8;
 
-constexpr uint32_t kSpinLimit = 1u << 24;
 
 // ---------------------------------------------------------------------------------
 // radix_hist_kernel: partial[g][p][d] = #keys in workgroup g's share whose digit p is d,
@@ -601,7 +600,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
                 t -= used;
                 if (!done && used == 0) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > kSpinLimit) { atomicExch(&ctl->error, 1u); *sticky_error = 1; break; }
+                    if (++spins > g_spin_limit) { atomicExch(&ctl->error, 1u); *sticky_error = 1; break; }
                 }
             }
             status_store<StatusT>(mine, SB::kPrefix | (StatusT)(excl + tot));

@@ -30,6 +30,9 @@ constexpr int kSmallMaxN = 8192;          // largest text the single-workgroup s
 // ------------------------------------------------------------------ errors
 inline thread_local std::string t_err;
 inline thread_local int64_t t_info[3] = {0, 0, 0};
+// the last Diff.Create / index diff on this thread (dq_last_diff_info): Search calls of the loop, windows, positions
+// asked again exactly, launches of the device's anchor scan that were given back to the host loop, workgroups of its grid
+inline thread_local int64_t t_diff_info[5] = {0, 0, 0, 0, 0};
 
 inline int fail(int code, const char *what, hipError_t e = hipSuccess)
 {
@@ -42,8 +45,35 @@ inline int fail(int code, const char *what, hipError_t e = hipSuccess)
     return code;
 }
 
+// ------------------------------------------------------------------ fault injection (tests of the error paths)
+// DQ_FAULT = alloc:K | hip:K | spin, read once per outermost call on this thread (EnvScope) and, like every DQ_* flag but
+// DQ_TRACE, only under DQ_DEBUG_FLAGS=1:
+//   alloc:K   the K-th device / pinned allocation of the call fails as if the device were out of memory   -> DQ_ERR_OOM
+//   hip:K     the K-th checked HIP call of the call (copies, memsets, launches, event work) fails          -> DQ_ERR_HIP
+//   spin      every bounded device spin gives up at its first empty poll: the look-back of radix_rank_kernel /
+//             seg_fused_kernel (-> DQ_ERR_HIP) and the answer exchange of anchor_scan_kernel (-> the host loop)
+// What the tests then check: the error code and message, nothing written to the caller's output, the next call on the
+// same thread correct, dq_sufsort_hip_release leaving no allocation behind (failure detection).
+struct FaultPlan {
+    int alloc_at = 0, hip_at = 0;       // 0: off
+    int alloc_seen = 0, hip_seen = 0;
+    bool spin = false;
+};
+inline thread_local FaultPlan t_fault;
+inline bool fault_alloc() { return t_fault.alloc_at > 0 && ++t_fault.alloc_seen == t_fault.alloc_at; }
+inline bool fault_hip() { return t_fault.hip_at > 0 && ++t_fault.hip_seen == t_fault.hip_at; }
+
+// every device / pinned allocation of the library goes through these two (DQ_FAULT=alloc:K counts them)
+inline hipError_t dq_malloc(void **p, size_t bytes) { return fault_alloc() ? hipErrorOutOfMemory : hipMalloc(p, bytes); }
+inline hipError_t dq_host_malloc(void **p, size_t bytes, unsigned flags)
+{
+    return fault_alloc() ? hipErrorOutOfMemory : hipHostMalloc(p, bytes, flags);
+}
+
 #define HIP_TRY(expr)                                                                   \
     do {                                                                                \
+        if (t_fault.hip_at && fault_hip())                                              \
+            return fail(DQ_ERR_HIP, "injected fault (DQ_FAULT=hip) instead of " #expr); \
         hipError_t e_ = (expr);                                                         \
         if (e_ != hipSuccess)                                                           \
             return fail(e_ == hipErrorOutOfMemory ? DQ_ERR_OOM : DQ_ERR_HIP, #expr, e_); \
@@ -59,8 +89,17 @@ struct EnvCache {
     static constexpr int kMax = 64;
     Entry e[kMax];
     int count = 0, depth = 0;
+    bool debug_flags = false;           // DQ_DEBUG_FLAGS as the outermost call on this thread found it
 };
 inline thread_local EnvCache t_env;
+
+// The adaptive choices are compiled in; the DQ_* overrides (forced paths of the tests, experiment knobs, fault
+// injection) are honoured only in a process that sets DQ_DEBUG_FLAGS=1 -- a stray DQ_PACKED in a production environment
+// changes nothing.  Exempt: DQ_TRACE (prints, decides nothing) and DQ_HIP_DEVICE (which device "-1" means).
+inline bool env_gated(const char *name)
+{
+    return strcmp(name, "DQ_TRACE") != 0 && strcmp(name, "DQ_HIP_DEVICE") != 0 && strcmp(name, "DQ_DEBUG_FLAGS") != 0;
+}
 
 inline const char *env(const char *name)
 {
@@ -68,6 +107,10 @@ inline const char *env(const char *name)
     for (int i = 0; i < c.count; ++i)
         if (c.e[i].name == name || strcmp(c.e[i].name, name) == 0) return c.e[i].set ? c.e[i].val.c_str() : nullptr;
     const char *v = getenv(name);
+    if (v && env_gated(name)) {
+        const char *g = c.depth > 0 ? (c.debug_flags ? "1" : nullptr) : getenv("DQ_DEBUG_FLAGS");
+        if (!g || atoi(g) == 0) v = nullptr;
+    }
     if (c.depth == 0 || c.count == EnvCache::kMax) return v;          // outside an entry point: nothing is kept
     EnvCache::Entry &x = c.e[c.count++];
     x.name = name; x.set = v != nullptr; x.val = v ? v : "";
@@ -75,8 +118,20 @@ inline const char *env(const char *name)
 }
 
 struct EnvScope {
-    EnvScope() { if (t_env.depth++ == 0) t_env.count = 0; }
-    ~EnvScope() { --t_env.depth; }
+    EnvScope()
+    {
+        if (t_env.depth++ != 0) return;
+        t_env.count = 0;
+        const char *g = getenv("DQ_DEBUG_FLAGS");
+        t_env.debug_flags = g && atoi(g) != 0;
+        t_fault = FaultPlan{};
+        if (const char *f = env("DQ_FAULT")) {
+            if (strncmp(f, "alloc:", 6) == 0) t_fault.alloc_at = std::max(1, atoi(f + 6));
+            else if (strncmp(f, "hip:", 4) == 0) t_fault.hip_at = std::max(1, atoi(f + 4));
+            else if (strcmp(f, "spin") == 0) t_fault.spin = true;
+        }
+    }
+    ~EnvScope() { if (--t_env.depth == 0) t_fault = FaultPlan{}; }
 };
 
 // ------------------------------------------------------------------ profiling
@@ -122,6 +177,11 @@ struct DeviceCtx {
     char *diff_idx = nullptr;           // index buffers of the one-shot form
     size_t diff_idx_bytes = 0;
     char *diff_pinned = nullptr;        // fixed size (SearchWindows)
+    // the persistent grid of the device's anchor scan (dq_anchor_scan.h) must be resident as a whole: workgroups the
+    // device holds at once (occupancy x compute units; -1: not asked yet), and how many diffs still skip the device
+    // scan after a launch whose workgroups waited in vain for each other (a device kept full by other work)
+    int scan_groups_cap = -1;
+    int scan_skip = 0;
 };
 constexpr int kMaxDevices = 64;
 // A device has several contexts ("slots": stream + workspace + pinned areas each).  Texts of up to kSlotSmallN bytes
@@ -166,8 +226,8 @@ inline int init_ctx(DeviceCtx &c, int dev)
     // c.dev is published only once every resource exists: a failure half way (e.g. pinned memory
     // exhausted) frees what was made and leaves the context unbuilt, so the next call retries
     hipError_t e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c.pinned, 8192, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c.pinned_io, kSmallIoBytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = dq_host_malloc((void **)&c.pinned, 8192, hipHostMallocDefault);
+    if (e == hipSuccess) e = dq_host_malloc((void **)&c.pinned_io, kSmallIoBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c.readback, hipEventDisableTiming);
     if (e != hipSuccess) {
         if (c.readback) (void)hipEventDestroy(c.readback);
@@ -197,7 +257,7 @@ inline int ensure_ws(DeviceCtx &c, size_t bytes)
 {
     if (c.ws_bytes >= bytes) return DQ_OK;
     if (c.ws) { (void)hipFree(c.ws); c.ws = nullptr; c.ws_bytes = 0; }
-    hipError_t e = hipMalloc((void **)&c.ws, bytes);
+    hipError_t e = dq_malloc((void **)&c.ws, bytes);
     if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(workspace)", e);
     c.ws_bytes = bytes;
     return DQ_OK;

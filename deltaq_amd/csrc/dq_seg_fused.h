@@ -60,7 +60,7 @@ __device__ __forceinline__ uint64_t seg_lookback(uint64_t *st, int64_t tile, Seg
         const uint64_t below = p >= kWave ? ~0ull : ((1ull << p) - 1);
         if (notready & below) {                                         // a nearer tile has not published yet
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) { atomicExch(&ctl->error, 1u); *sticky_error = 1; return acc; }
+            if (++spins > g_spin_limit) { atomicExch(&ctl->error, 1u); *sticky_error = 1; return acc; }
             continue;
         }
         if (lane > p) v = 0;

@@ -56,6 +56,8 @@ struct Workspace {
     uint8_t *text;
     uint64_t *K0, *K1;
     IdxT *Va, *Vb, *ISA, *SAbuf;
+    uint64_t *X;                // third list buffer (keys / update words) of a doubling round over more than n/2 tied suffixes
+    IdxT *Xs;                   // ... and its suffixes
     int64_t *bkt_bounds;        // tile bounds of the bucketed round 0 (dq_bucket_sort.h)
     int64_t *totals;            // [0] active count, [1] sticky look-back timeout flag
     SmallGroupCounters *sg_ctr; // one per chained small-group round
@@ -90,6 +92,13 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.Vb = (IdxT *)take((un + 2) * sizeof(IdxT));
     w.ISA = (IdxT *)take(un * sizeof(IdxT));
     w.SAbuf = with_sa ? (IdxT *)take(un * sizeof(IdxT)) : nullptr;
+    // (n > 2^32 is refused before anything is allocated; texts of more than n/2 tied suffixes after round 0 -- real
+    // binaries -- take their first doubling rounds through the LDS class too, whose three output lists then need a
+    // buffer of their own: +12 n / +16 n bytes of a 288 GB device)
+    if (un < (1ull << 32)) {            // (exactly 2^32 bytes: no small-group rounds, uses_small_round())
+        w.X = (uint64_t *)take((un + 2) * 8);
+        w.Xs = (IdxT *)take((un + 2) * sizeof(IdxT));
+    }
     w.bkt_bounds = (int64_t *)take((un / 4096 + 4) * 8);
     w.totals = (int64_t *)take(64);
     w.sg_ctr = (SmallGroupCounters *)take(kSgChain * sizeof(SmallGroupCounters));
@@ -666,9 +675,12 @@ struct SuffixSorter {
     // ---- dense inputs: first ISA + first key2 gather through suffix-binned words (dq_isa_pairs.h).
     //      keys = the sorted round-0 keys (buffer P1), P0 = the other key buffer (free).  On return the
     //      tied list is (P1, Va) and m its length.
+    // (wide: a list of more than n/2 entries -- the output lists of its round do not fit beside each other in the
+    // partner buffers, see round_layout(); DQ_NO_WIDE_SMALL=1: such lists take the radix path as before round 5)
+    bool wide_list(int64_t mm) const { return mm * 2 > n; }
     bool uses_small_round(int64_t mm) const
     {
-        return !env("DQ_NO_SMALL") && mm * 2 <= n && n < (1ll << 32);
+        return !env("DQ_NO_SMALL") && n < (1ll << 32) && (!wide_list(mm) || !env("DQ_NO_WIDE_SMALL"));
     }
 
     int build_isa_binned(uint64_t *keys, uint64_t *P0, int kb, int kshift0)
@@ -1081,6 +1093,26 @@ struct SuffixSorter {
     int64_t sg_half() const { return (n / 2 + 1) & ~(int64_t)1; }
     int64_t sg_top() const { return n + 2; }
 
+    // Where a round over the list (A, As)[0, mm) puts what it produces.  T (still tied, next list) always grows from the
+    // start of the partner pair (B, Bs).  A list of at most n/2 entries leaves room there for L (members of large
+    // groups, from n/2) and U (rank updates, downward from n + 2); the radix sort of L ping-pongs with the idle second
+    // half of A.  A longer list (real binaries after raw 8-byte keys: 2/3 of the suffixes tied) would run T into L, so L
+    // and U go to the third buffer (w.X, w.Xs): an entry goes to L or is flagged for T / U, never both, so L (upward) and
+    // U (downward) share it; L's sort ping-pongs with A itself, which is dead once the round's updates are applied, and
+    // so never ends in B, where its survivors are appended behind T.
+    struct RoundLayout {
+        uint64_t *t_rank; IdxT *t_suf;
+        uint64_t *l_key; IdxT *l_suf;
+        uint64_t *u_end; IdxT *u_suf_end;
+        uint64_t *l_partner; IdxT *l_partner_suf;
+    };
+    RoundLayout round_layout(int64_t mm, uint64_t *A, IdxT *As, uint64_t *B, IdxT *Bs) const
+    {
+        const int64_t half = sg_half(), top = sg_top();
+        if (!wide_list(mm)) return {B, Bs, B + half, Bs + half, B + top, Bs + top, A + half, As + half};
+        return {B, Bs, w.X, w.Xs, w.X + top, w.Xs + top, A, As};
+    }
+
     // update entries of the LDS-class rounds as single words (rank << ib | suffix) where two indices fit one
     int upd_ib() const
     {
@@ -1095,27 +1127,27 @@ struct SuffixSorter {
     // 75 M updates: 2.75 ms as random writes; one pass 0.35 + 1.7 ms; two passes (16 bits, DQ_UPD_BIN=2) 0.75 + 1.07 ms
     // -- the passes eat most of what the writes gain, and lists of a few million entries gain nothing.
     static constexpr int64_t kUpdBinMin = 1ll << 24;
-    int apply_rank_updates(uint64_t *A, IdxT *As, uint64_t *B, IdxT *Bs, int64_t mU, int u_ib)
+    int apply_rank_updates(uint64_t *A, IdxT *As, uint64_t *u_end, IdxT *u_suf_end, int64_t mU, int u_ib)
     {
-        const int64_t top = sg_top();
+        // (the entries lie downward from u_end / u_suf_end: B + top of the round's partner pair, or the third buffer's)
         int passes = env("DQ_UPD_BIN") ? std::max(0, std::min(2, atoi(env("DQ_UPD_BIN")))) : 1;
         const int64_t min_len = env("DQ_UPD_BIN_MIN") ? std::max(1, atoi(env("DQ_UPD_BIN_MIN"))) : kUpdBinMin;
         if (u_ib < 16 || mU < min_len || (size_t)(mU + 1) * 8 > (size_t)(n + 2) * sizeof(IdxT)) passes = 0;
         if (passes == 0) {
             LAUNCH(L, DQ_K_ISA_UPDATE, mU, mU * (u_ib ? 8 + wb : 8 + wb + wb),
                    hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(mU)), dim3(kBlock), 0, st,
-                                      (const uint64_t *)(B + top), (const IdxT *)(Bs + top), mU, w.ISA,
+                                      (const uint64_t *)u_end, (const IdxT *)u_suf_end, mU, w.ISA,
                                       (const SmallGroupCounters *)nullptr, u_ib));
             return DQ_OK;
         }
-        // the word list starts on an even entry (16-byte key loads of the histogram kernel): one filler word in
+        // the word list starts on a 16-byte boundary (key loads of the histogram kernel): one filler word in
         // front of it if need be -- all ones: a suffix field >= n, skipped by the update kernel
-        int64_t first = top - mU, cnt = mU;
-        if (first & 1) {
-            --first; ++cnt;
-            HIP_TRY(hipMemsetAsync(B + first, 0xff, 8, st));
+        uint64_t *U = u_end - mU;
+        int64_t cnt = mU;
+        if (reinterpret_cast<uintptr_t>(U) & 8) {
+            --U; ++cnt;
+            HIP_TRY(hipMemsetAsync(U, 0xff, 8, st));
         }
-        const uint64_t *U = B + first;
         const int sh0 = passes == 2 ? u_ib - 16 : u_ib - 8;
         const int blocks = (int)std::min<int64_t>(kHistBlocks, ((cnt >> 1) + kHistThreads - 1) / kHistThreads + 1);
         int rc = L.begin(DQ_K_RADIX_HIST, cnt, cnt * 8);
@@ -1147,7 +1179,7 @@ struct SuffixSorter {
     {
         uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
         IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
-        const int64_t half = sg_half(), top = sg_top();
+        const RoundLayout lay = round_layout(m, A, As, B, Bs);
         SmallGroupCounters *ctr = reinterpret_cast<SmallGroupCounters *>(w.totals + 4);
         HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(SmallGroupCounters), st));
         const bool cap32 = m < kSgShortList;           // (cap 32 on long lists measured: radix -2.4 ms, this kernel +2.8 ms)
@@ -1157,7 +1189,7 @@ struct SuffixSorter {
         const int mid_g = mid_group_cap(m);
         const bool use_mid = mid_g > 0;
         if (use_mid) {
-            int rc = launch_mid_round(mid_g, m, A, As, B, Bs, h, kbits, ctr, nullptr, m * (8 + wb + wb + wb + 8 + wb));
+            int rc = launch_mid_round(mid_g, m, A, As, lay, h, kbits, ctr, nullptr, m * (8 + wb + wb + wb + 8 + wb));
             if (rc != DQ_OK) return rc;
             first_rank32 = nullptr;
         } else if (cap32) {
@@ -1165,32 +1197,32 @@ struct SuffixSorter {
             LAUNCH(L, DQ_K_SMALL_ROUND, m, m * (8 + wb + wb + wb + 8 + wb),
                    hipLaunchKernelGGL((small_group_round_kernel<IdxT, kSgMaxGShort>), dim3((unsigned)((m + kTile - 1) / kTile)),
                                       dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
-                                      (const IdxT *)w.ISA, m, n, h, kbits, d_sa, B, Bs, B + half, Bs + half, B + top,
-                                      Bs + top, ctr, (const SmallGroupCounters *)nullptr));
+                                      (const IdxT *)w.ISA, m, n, h, kbits, d_sa, lay.t_rank, lay.t_suf, lay.l_key, lay.l_suf, lay.u_end,
+                                      lay.u_suf_end, ctr, (const SmallGroupCounters *)nullptr));
         } else {
             constexpr int kTile = sg_tile<kSgMaxG>();
             LAUNCH(L, DQ_K_SMALL_ROUND, m, m * (8 + wb + wb + wb + 8 + wb),
                    hipLaunchKernelGGL((small_group_round_kernel<IdxT, kSgMaxG>), dim3((unsigned)((m + kTile - 1) / kTile)),
                                       dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
-                                      (const IdxT *)w.ISA, m, n, h, kbits, d_sa, B, Bs, B + half, Bs + half, B + top,
-                                      Bs + top, ctr, (const SmallGroupCounters *)nullptr));
+                                      (const IdxT *)w.ISA, m, n, h, kbits, d_sa, lay.t_rank, lay.t_suf, lay.l_key, lay.l_suf, lay.u_end,
+                                      lay.u_suf_end, ctr, (const SmallGroupCounters *)nullptr));
         }
         HIP_TRY(hipMemcpyAsync(c.pinned, ctr, sizeof(SmallGroupCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const int64_t m1 = c.pinned[0] & 0xffffffffll, mU = (int64_t)((uint64_t)c.pinned[0] >> 32), mL = c.pinned[1];
         if (env("DQ_TRACE"))
-            fprintf(stderr, "[dq] %s round h=%lld m=%lld -> tied %lld, to radix %lld, moved %lld\n",
+            fprintf(stderr, "[dq] %s round h=%lld m=%lld%s -> tied %lld, to radix %lld, moved %lld\n",
                     use_mid ? "mid-group" : "small", (long long)h,
-                    (long long)m, (long long)m1, (long long)mL, (long long)mU);
+                    (long long)m, wide_list(m) ? " (wide)" : "", (long long)m1, (long long)mL, (long long)mU);
         if (mU > 0) {
-            const int rc = apply_rank_updates(A, As, B, Bs, mU, use_mid ? upd_ib() : 0);
+            const int rc = apply_rank_updates(A, As, lay.u_end, lay.u_suf_end, mU, use_mid ? upd_ib() : 0);
             if (rc != DQ_OK) return rc;
         }
         int64_t mLs = 0;
         if (mL > 0) {
-            // radix ping-pong partner: the unused second half of X's own buffers
-            uint64_t *Kx[2] = {B + half, A + half};
-            IdxT *Vx[2] = {Bs + half, As + half};
+            // radix ping-pong partner: the unused second half of X's own buffers (a wide list: all of them, see round_layout)
+            uint64_t *Kx[2] = {lay.l_key, lay.l_partner};
+            IdxT *Vx[2] = {lay.l_suf, lay.l_partner_suf};
             int xcur = 0;
             int rc = onesweep_sort_pairs<IdxT>(L, w, Kx, Vx, mL, kbits + rbits, xcur);
             if (rc != DQ_OK) return rc;
@@ -1217,16 +1249,15 @@ struct SuffixSorter {
     }
 
     // one round of mid_group_round_kernel<kG> on the list (A, As)[0, mm); prev: the previous chained round's counters
-    int launch_mid_round(int g, int64_t mm, const uint64_t *A, const IdxT *As, uint64_t *B, IdxT *Bs, int64_t hh, int kbits,
+    int launch_mid_round(int g, int64_t mm, const uint64_t *A, const IdxT *As, const RoundLayout &lay, int64_t hh, int kbits,
                          SmallGroupCounters *ctr, const SmallGroupCounters *prev, int64_t alg_bytes)
     {
-        const int64_t half = sg_half(), top = sg_top();
         const int64_t tile = g == 256 ? mg_tile<256>() : g == 512 ? mg_tile<512>() : mg_tile<1024>();
         const dim3 grid((unsigned)((mm + tile - 1) / tile));
         auto go = [&](auto kern) -> int {
             LAUNCH(L, DQ_K_MID_ROUND, mm, alg_bytes,
-                   hipLaunchKernelGGL(kern, grid, dim3(kMgThreads), 0, st, A, As, (const IdxT *)w.ISA, mm, n, hh, kbits, d_sa, B, Bs,
-                                      B + half, Bs + half, B + top, Bs + top, ctr, prev, rl(), (const uint8_t *)w.text, run_order,
+                   hipLaunchKernelGGL(kern, grid, dim3(kMgThreads), 0, st, A, As, (const IdxT *)w.ISA, mm, n, hh, kbits, d_sa, lay.t_rank, lay.t_suf,
+                                      lay.l_key, lay.l_suf, lay.u_end, lay.u_suf_end, ctr, prev, rl(), (const uint8_t *)w.text, run_order,
                                       first_rank32, upd_ib()));
             return DQ_OK;
         };
@@ -1237,16 +1268,17 @@ struct SuffixSorter {
     template <int kCap>
     int small_chain()
     {
-        const int64_t half = sg_half(), top = sg_top();
         const int64_t m_in = m;
         HIP_TRY(hipMemsetAsync(w.sg_ctr, 0, kSgChain * sizeof(SmallGroupCounters), st));
         int64_t hr = h;
         for (int r = 0; r < kSgChain; ++r) {
             uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
             IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
+            // (every round of the chain is laid out for the list length the chain starts with: an upper bound of the others')
+            const RoundLayout lay = round_layout(m_in, A, As, B, Bs);
             const int kbits = std::min(bit_length((uint64_t)(n - 1) + (uint64_t)hr), 64 - rbits);   // (no radix keys are made)
             if constexpr (kCap == 0) {                                       // (every group has <= small_cap members here)
-                const int rc = launch_mid_round(small_cap, m_in, A, As, B, Bs, hr, kbits, w.sg_ctr + r,
+                const int rc = launch_mid_round(small_cap, m_in, A, As, lay, hr, kbits, w.sg_ctr + r,
                                                 r == 0 ? (const SmallGroupCounters *)nullptr : w.sg_ctr + r - 1, 0);
                 if (rc != DQ_OK) return rc;
             } else {
@@ -1254,12 +1286,12 @@ struct SuffixSorter {
                 LAUNCH(L, DQ_K_SMALL_ROUND, m_in, 0,
                        hipLaunchKernelGGL((small_group_round_kernel<IdxT, kCap>), dim3((unsigned)((m_in + kTile - 1) / kTile)),
                                           dim3(kSgThreads), 0, st, (const uint64_t *)A, (const IdxT *)As,
-                                          (const IdxT *)w.ISA, m_in, n, hr, kbits, d_sa, B, Bs, B + half, Bs + half, B + top,
-                                          Bs + top, w.sg_ctr + r, r == 0 ? (const SmallGroupCounters *)nullptr : w.sg_ctr + r - 1));
+                                          (const IdxT *)w.ISA, m_in, n, hr, kbits, d_sa, lay.t_rank, lay.t_suf, lay.l_key, lay.l_suf, lay.u_end,
+                                          lay.u_suf_end, w.sg_ctr + r, r == 0 ? (const SmallGroupCounters *)nullptr : w.sg_ctr + r - 1));
             }
             LAUNCH(L, DQ_K_ISA_UPDATE, m_in, 0,
                    hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(m_in)), dim3(kBlock), 0, st,
-                                      (const uint64_t *)(B + top), (const IdxT *)(Bs + top), (int64_t)0, w.ISA,
+                                      (const uint64_t *)lay.u_end, (const IdxT *)lay.u_suf_end, (int64_t)0, w.ISA,
                                       (const SmallGroupCounters *)(w.sg_ctr + r), kCap == 0 ? upd_ib() : 0));
             rcur ^= 1;
             hr *= 2;
@@ -1592,9 +1624,26 @@ struct SuffixSorter {
     }
 };
 
+// DQ_FAULT=spin (dq_runtime.h): the look-back spins of this translation unit's kernels give up at their first empty poll
+// while a call asks for it; the production bound comes back with the next call that does not.
+template <typename IdxT>
+int set_spin_fault(int dev)
+{
+    static std::mutex mu;
+    static std::atomic<bool> lowered[kMaxDevices];
+    if (!t_fault.spin && !lowered[dev].load(std::memory_order_acquire)) return DQ_OK;
+    std::lock_guard<std::mutex> lk(mu);
+    const uint32_t want = t_fault.spin ? 0u : kSpinLimit;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_spin_limit), &want, sizeof(want)));
+    lowered[dev].store(t_fault.spin, std::memory_order_release);
+    return DQ_OK;
+}
+
 template <typename IdxT>
 int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, IdxT *d_sa, SortHints hints = SortHints())
 {
+    const int frc = set_spin_fault<IdxT>(c.dev);
+    if (frc != DQ_OK) return frc;
     SuffixSorter<IdxT> sorter(c, st, w, n, d_sa);
     // (DQ_ASSUME_DOUBLED: the tests vouch for their inputs through the public entry points)
     if ((hints.doubled || env("DQ_ASSUME_DOUBLED")) && n % 2 == 0 && !env("DQ_NO_TWINS")) sorter.twin_half = n / 2;
@@ -1669,8 +1718,13 @@ int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device, SortH
     HIP_TRY(hipMemsetAsync(w.text + n, 0, 64, st));
     rc = sufsort_device<IdxT>(c, st, w, n, w.SAbuf, hints);
     if (rc != DQ_OK) { drop_pending(c, st); return rc; }
-    HIP_TRY(hipMemcpyAsync(sa, w.SAbuf, (size_t)n * sizeof(IdxT), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // (one checked step: a failure must not leave a copy into the caller's array in flight behind the return)
+    auto copy_out = [&]() -> hipError_t {
+        const hipError_t e = hipMemcpyAsync(sa, w.SAbuf, (size_t)n * sizeof(IdxT), hipMemcpyDeviceToHost, st);
+        const hipError_t e2 = hipStreamSynchronize(st);
+        return e != hipSuccess ? e : e2;
+    };
+    HIP_TRY(copy_out());
     return DQ_OK;
 }
 

@@ -189,6 +189,13 @@ int32_t dq_profile_category_count(void);   /* DQ_K_COUNT of the loaded library *
  * over all rounds. */
 int32_t dq_last_sort_info(int64_t *rounds, int64_t *initial_active, int64_t *sum_active);
 
+/* Shape of the last dq_bsdiff_create / dq_bsdiff_scan_i32 / dq_bsdiff_index_diff on this thread, `count` entries (5 are
+ * defined, further ones read 0): Search calls the reference's loop makes (Diff.cs:106), windows of scan positions,
+ * positions asked again exactly, launches of the device's anchor scan that were given back to the host loop (its
+ * persistent grid waited in vain: a device kept full by other work -- the patch is the same, the call slower),
+ * workgroups of that grid. */
+int32_t dq_last_diff_info(int64_t *info, int32_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
 ROOT='/root/repo'
 sys.path.insert(0, ROOT)

@@ -4,6 +4,7 @@
 Structured random inputs of 1 B .. 24 MB (tests/test_gpu_parity.py::structured_text), random forced-path
 environments, int32 / int64, host and device entry points; every SA is bit-compared with the oracle."""
 import os, sys, time
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -5,6 +5,7 @@ STRESS_LOG=<file> keeps the pair being worked on, for the post-mortem of a crash
 Random old files of 0 .. 3 MB (uniform, few symbols, text-like, periodic), new = old with random edits / an unrelated
 file / a prefix; raw streams compared with the oracle's scan loop, patches applied back."""
 import os, sys, time
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

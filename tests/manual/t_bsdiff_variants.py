@@ -2,6 +2,7 @@
 """Diff.Create natively under forced settings (window sizes of the scan-loop driver ...): time per pair, windows.
 usage: t_bsdiff_variants.py "" "DQ_WIN_MIN=512,DQ_WIN_SECOND=512" ..."""
 import os, sys, time
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -2,6 +2,7 @@
 """Bucketed round 0 (dq_bucket_sort.h) on a GPU box: parity on uniform / forced / fallback inputs, then timing
 against the plain digit passes.   python tests/manual/t_bucket.py [quick]"""
 import os, sys, time
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -3,6 +3,7 @@
 every variant's suffix array is compared with the first one's (which is checked by sufcheck + sampled strict pairs).
 usage: t_case.py <enwik256|enwik64|textk1024|libtorch128|rocsparse256|rocsparse64> "" "DQ_X=1,DQ_Y=2" ...   (T_TRACE=1: per-round trace)"""
 import glob, os, sys, time
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -3,6 +3,7 @@
 every variant's suffix array is compared with the first one's on the device, the first one checked by sufcheck.
 usage: t_enwik_variants.py "DQ_MID_GROUPS=0" "DQ_MID_GROUPS=256" ...   ("" = defaults; several settings: "A=1,B=2")"""
 import os, sys, time
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -3,6 +3,7 @@
 per-kernel profile -- run once per library variant (tools/exp/build_variant.sh; DQ_SUFSORT_LIB selects it):
     DQ_SUFSORT_LIB=tools/exp/libdq_nowalk.so python tests/manual/t_exp_round1.py enwik256"""
 import os, sys
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "manual"))
 os.environ["DQ_EXP_STOP_ROUNDS"] = os.environ.get("DQ_EXP_STOP_ROUNDS", "1")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where the time of "one old file, many new files" goes: index build, per-file diffs, teardown, against per-pair Diff.Create."""
 import os, sys, time
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

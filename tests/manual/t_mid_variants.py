@@ -2,6 +2,7 @@
 """Mid-size text-like inputs under forced settings: wall clock per sort (device-resident), launches, rounds.
 usage: t_mid_variants.py "" "DQ_MID_SHORT=1" ..."""
 import os, sys, time
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

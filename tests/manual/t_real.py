@@ -3,6 +3,7 @@
 Python sources (text), a tar-like mix.  Each: device-resident sort time, the path taken (DQ_TRACE), sufcheck +
 sampled strict order; smaller prefixes are bit-compared with the oracle."""
 import glob, os, sys, time
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel profile of one real-data sort (a 64 MiB slice of a shared library of the image)."""
 import glob, os, sys, time
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

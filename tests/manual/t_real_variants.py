@@ -2,6 +2,7 @@
 """Real data from the image under forced settings: device-resident time, rounds; every variant's SA equals the first's.
 usage: t_real_variants.py "" "DQ_RUNS=0" ..."""
 import glob, os, sys, time
+os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -303,3 +303,55 @@ def test_bench_line_of_two_ranks_sharing_the_gpu():
     assert "error" not in ssg and ssg["sufcheck"] is True and ssg["buffers"] == 4, ssg
     many = b["one_old_many_new"]
     assert "error" not in many and many["patches_apply"] is True and many["new_files"] == 8, many
+
+
+def _bench_env():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in [k for k in env if k.startswith("DQ_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")]:
+        env.pop(k)
+    return env
+
+
+def test_bench_refuses_a_launcher_that_disagrees_with_gpus_flag():
+    """`--gpus N` is not decoration: a world size that differs from it is an error, not a 1-GPU number (round-4 verdict:
+    the flag was parsed and never read, so `bench.py --gpus 8` without a launcher measured one GPU with rc 0)."""
+    import subprocess
+    env = dict(_bench_env(), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env,
+                       timeout=300, cwd=ROOT)
+    assert p.returncode == 2 and "disagree" in p.stderr, (p.returncode, p.stderr[-500:])
+    assert '"metric"' not in p.stdout
+
+
+def test_bench_without_a_launcher_starts_its_own_ranks():
+    """No GPU here: what can be checked is that `python bench.py --gpus 2` becomes a torch.distributed.run of two ranks
+    (each of which then refuses to run without a GPU) and that the failure comes back as the exit status -- never a
+    line with n_gpus 1."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: test_bench_without_a_launcher_runs_two_ranks covers it")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True,
+                       env=_bench_env(), timeout=600, cwd=ROOT)
+    assert p.returncode != 0
+    assert "starting the ranks" in p.stderr and "--nproc-per-node 2" in p.stderr, p.stderr[-1500:]
+    assert p.stderr.count("bench.py needs a GPU") >= 1, p.stderr[-1500:]
+    assert '"metric"' not in p.stdout
+
+
+@pytest.mark.gpu
+def test_bench_without_a_launcher_runs_two_ranks():
+    """`python bench.py --gpus 2 --share-gpu --backend gloo` with NO launcher around it: bench.py starts the two ranks
+    itself and the line says n_gpus 2, with configs[4] dealt 64 / 64."""
+    import json
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--share-gpu", "--backend", "gloo", "--no-cpu-baseline"], capture_output=True, text=True,
+                       env=_bench_env(), timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["gpus_flag"] == 2 and rec["devices_per_rank"] == [0, 0]
+    assert rec["batch"]["sharding"]["buffers_per_rank"] == [64, 64]

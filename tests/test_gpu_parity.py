@@ -385,6 +385,11 @@ FUZZ_ENVS = [
     {"DQ_UPD_BIN": "1", "DQ_UPD_BIN_MIN": "1", "DQ_SMALL_N": "0", "DQ_RUNS": "1"},   # ... one pass
     {"DQ_NO_UPD_WORDS": "1", "DQ_SMALL_N": "0"},           # rank updates as (rank, suffix) in two arrays
     {"DQ_SPARSE": "1", "DQ_BINNED_ISA": "1", "DQ_SMALL_N": "0"},     # suffix-binned inverse suffix array at the sparse-to-dense switch
+    # lists of more than n/2 tied suffixes through the LDS class (third list buffer, round 5): 2-byte keys tie nearly everybody
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_SMALL_N": "0"},
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_BINNED_ISA": "1", "DQ_UPD_BIN_MIN": "1"},
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "0", "DQ_NO_CHAIN": "1"},
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_NO_WIDE_SMALL": "1"},   # ... and as before: the radix path
 ]
 
 
@@ -534,6 +539,10 @@ FORCED_PATHS = [
     {"DQ_PAIR_CHAINS": "2"},                                     # pair chains (dq_pair_chains.h) before / after every round
     {"DQ_PAIR_CHAINS": "2", "DQ_NO_BINNED_ISA": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
     {"DQ_PAIR_CHAINS": "1", "DQ_PACKED": "1", "DQ_KEY_BYTES": "2"},
+    {"DQ_NO_WIDE_SMALL": "1"},                                   # lists of more than n/2 entries through the radix rounds (the default before round 5)
+    {"DQ_NO_WIDE_SMALL": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_BINNED_ISA": "1", "DQ_UPD_BIN_MIN": "1"},   # wide lists, binned first ISA, binned updates
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_RUNS": "1", "DQ_NO_UPD_WORDS": "1"},        # wide lists, run-order round, two-array updates
 ]
 
 
