@@ -44,6 +44,9 @@ internal static unsafe class Native
     internal static extern int dq_bsdiff_index_diff(IntPtr index, byte* newData, long m, byte* patch, long cap, long* patchLen);
 
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+    internal static extern int dq_bsdiff_index_clone(IntPtr index, int device, IntPtr* indexOut);
+
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
     internal static extern void dq_bsdiff_index_free(IntPtr index);
 
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
@@ -209,6 +212,31 @@ public sealed unsafe class HipDiffIndex : IDisposable
         }
 
         _index = ix;
+    }
+
+    private HipDiffIndex(byte[] oldData, IntPtr index)
+    {
+        _old = oldData;
+        _pin = GCHandle.Alloc(_old, GCHandleType.Pinned);      // (a second pin of the same array: each copy frees its own)
+        _index = index;
+    }
+
+    /// <summary>
+    /// One more copy of this index on <paramref name="device"/> (dq_bsdiff_index_clone): the suffix array travels device
+    /// to device over xGMI instead of being sorted again -- the exchange step of the many-files path, without a
+    /// collective library in the process.  Clone to each device of the node from a thread of its own: xGMI is point to
+    /// point, so the copies use different links.
+    /// </summary>
+    public HipDiffIndex Clone(int device)
+    {
+        if (_index == IntPtr.Zero)
+        {
+            throw new ObjectDisposedException(nameof(HipDiffIndex));
+        }
+
+        IntPtr ix;
+        Native.Check(Native.dq_bsdiff_index_clone(_index, device, &ix), nameof(Native.dq_bsdiff_index_clone));
+        return new HipDiffIndex(_old, ix);
     }
 
     /// <summary>The patch <c>Diff.Create(oldData, newData, ...)</c> writes.</summary>

@@ -28,7 +28,7 @@ EXPORTS = (
     "dq_sufsort_hip_batch_i32",
     "dq_bsdiff_search_dev_i32", "dq_bsdiff_search_dev_i64", "dq_bsdiff_search_i32", "dq_bsdiff_search_i64",
     "dq_bsdiff_create", "dq_bsdiff_patch_bound", "dq_bsdiff_scan_i32", "dq_bspatch_apply",
-    "dq_bsdiff_index_create", "dq_bsdiff_index_buffers", "dq_bsdiff_index_diff", "dq_bsdiff_index_free",
+    "dq_bsdiff_index_create", "dq_bsdiff_index_clone", "dq_bsdiff_index_buffers", "dq_bsdiff_index_diff", "dq_bsdiff_index_free",
     "dq_sufsort_hip_workspace_bytes", "dq_sufsort_hip_release",
     "dq_profile_enable", "dq_profile_reset", "dq_profile_get", "dq_profile_kernel_name",
     "dq_profile_category_count",
@@ -110,6 +110,8 @@ def load() -> ctypes.CDLL:
                                      ctypes.POINTER(i64), vp, i32]
     L.dq_bsdiff_index_create.restype = i32
     L.dq_bsdiff_index_create.argtypes = [vp, i64, vp, vp, i32, ctypes.POINTER(vp)]
+    L.dq_bsdiff_index_clone.restype = i32
+    L.dq_bsdiff_index_clone.argtypes = [vp, i32, ctypes.POINTER(vp)]
     L.dq_bsdiff_index_buffers.restype = i32
     L.dq_bsdiff_index_buffers.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(i64)]
     L.dq_bsdiff_index_diff.restype = i32

@@ -95,6 +95,16 @@ class DiffIndex:
         _abi.check(L.dq_bsdiff_index_create(p, self._old.size, d_old, d_sa, device, ctypes.byref(h)))
         self._h = h
 
+    def clone(self, device: int = -1) -> "DiffIndex":
+        """One more copy of this index on ``device`` (dq_bsdiff_index_clone): device-to-device copies -- xGMI between the
+        devices of a node -- instead of a second sort.  The copy shares this index's host text and is closed on its own."""
+        other = object.__new__(DiffIndex)
+        other._lib, other._old, other._keep = self._lib, self._old, ()
+        h = ctypes.c_void_p()
+        _abi.check(self._lib.dq_bsdiff_index_clone(self._h, device, ctypes.byref(h)))
+        other._h = h
+        return other
+
     def buffers(self):
         """(device pointer of the text, device pointer of the suffix array, n)"""
         a, b, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64()

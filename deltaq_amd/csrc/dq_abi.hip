@@ -333,6 +333,20 @@ int32_t dq_bsdiff_index_create(const uint8_t *old_data, int64_t n, const void *d
     }
 }
 
+int32_t dq_bsdiff_index_clone(const void *index, int32_t device, void **index_out)
+{
+    EnvScope flags;
+    if (!index || !index_out) return fail(DQ_ERR_BAD_ARGS, "null index");
+    *index_out = nullptr;
+    try {
+        return diff_index_clone(index, device, index_out);
+    } catch (const std::bad_alloc &) {
+        return fail(DQ_ERR_OOM, "bsdiff: host allocation failed");
+    } catch (const std::exception &e) {
+        return fail(DQ_ERR_HIP, e.what());
+    }
+}
+
 int32_t dq_bsdiff_index_buffers(const void *index, const void **d_old, const void **d_sa, int64_t *n)
 {
     if (!index) return fail(DQ_ERR_BAD_ARGS, "null index");

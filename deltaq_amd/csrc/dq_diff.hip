@@ -393,6 +393,47 @@ int diff_index_build(const uint8_t *old, int64_t n, int32_t device, const void *
     return DQ_OK;
 }
 
+// One more copy of an index on `device` (the same device or another one of the node): text, suffix array and prefix
+// table are copied device to device -- over xGMI when the devices differ -- instead of being computed again.  This is
+// the exchange step of the many-files path for a host that has no collective library in its process (the C# shim):
+// xGMI is point to point, so the copies to 7 other devices of a node, issued from 7 threads, travel over 7 different
+// links at once -- what a broadcast over those links does, without a communicator.
+int diff_index_copy(const DiffIndex &src, int32_t device, DiffIndex *ix)
+{
+    int dev = 0;
+    int rc = resolve_device(device, &dev);
+    if (rc != DQ_OK) return rc;
+    HIP_TRY(hipSetDevice(dev));
+    ix->dev = dev; ix->n = src.n; ix->old = src.old; ix->pk = src.pk;
+    int pk = 0;
+    const size_t b_tab = diff_tab_bytes(src.n, &pk);
+    const size_t b_old = align_up((size_t)src.n + 16), b_sa = align_up((size_t)src.n * 4 + 16);
+    if (pk != src.pk) return fail(DQ_ERR_BAD_ARGS, "index to copy is inconsistent");
+    const hipError_t e = dq_malloc((void **)&ix->own, b_old + b_sa + b_tab);
+    if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipMalloc(bsdiff index copy)", e);
+    ix->d_old = ix->own;
+    ix->d_sa = ix->own + b_old;
+    ix->d_tab = pk ? ix->own + b_old + b_sa : nullptr;
+    if (dev != src.dev) {
+        // direct peer access where the platform has it (xGMI inside a node); hipMemcpyPeer stages through the host without
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dev, src.dev) == hipSuccess && can) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(src.dev, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        }
+    }
+    auto copy = [&](const char *to, const char *from, size_t bytes) -> hipError_t {
+        if (bytes == 0) return hipSuccess;
+        return dev == src.dev ? hipMemcpy(const_cast<char *>(to), from, bytes, hipMemcpyDeviceToDevice)
+                              : hipMemcpyPeer(const_cast<char *>(to), dev, from, src.dev, bytes);
+    };
+    HIP_TRY(copy(ix->d_old, src.d_old, (size_t)src.n));
+    HIP_TRY(copy(ix->d_sa, src.d_sa, (size_t)src.n * 4));
+    if (pk) HIP_TRY(copy(ix->d_tab, src.d_tab, (((size_t)1 << (8 * pk)) + 1) * 4));
+    HIP_TRY(hipDeviceSynchronize());
+    return DQ_OK;
+}
+
 void diff_index_drop(DiffIndex *ix)
 {
     if (ix->own && !ix->own_cached) { (void)hipSetDevice(ix->dev); (void)hipFree(ix->own); }
@@ -904,6 +945,16 @@ int diff_index_new(const uint8_t *old, int64_t n, int32_t device, const void *d_
 {
     DiffIndex *ix = new DiffIndex();
     const int rc = diff_index_build(old, n, device, d_old, d_sa, /*cached=*/false, ix);
+    if (rc != DQ_OK) { diff_index_drop(ix); delete ix; return rc; }
+    *index_out = ix;
+    return DQ_OK;
+}
+
+int diff_index_clone(const void *index, int32_t device, void **index_out)
+{
+    const DiffIndex *src = static_cast<const DiffIndex *>(index);
+    DiffIndex *ix = new DiffIndex();
+    const int rc = diff_index_copy(*src, device, ix);
     if (rc != DQ_OK) { diff_index_drop(ix); delete ix; return rc; }
     *index_out = ix;
     return DQ_OK;

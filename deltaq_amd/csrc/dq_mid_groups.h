@@ -169,11 +169,7 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
             }
             if (!keyed) {
                 const int64_t q = (int64_t)s[k] + off;
-#ifdef DQ_EXPERIMENT_MG_NOGATHER        /* timing experiment only: no random read of the inverse suffix array */
-                k2[k] = (ElemT)(((uint64_t)q * 0x9E3779B97F4A7C15ull) >> 40);
-#else
                 k2[k] = q < n ? (ElemT)((int64_t)ISA[q] + h) : (off > h ? (ElemT)0 : (ElemT)(n - 1 - (int64_t)s[k]));   // as gather_key2_kernel
-#endif
             }
         }
     }
@@ -194,11 +190,7 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
         if (own[k]) {
             int less = 0, eq = 0, eq_before = 0;
             const int g0 = ghead[k], me = e - g0;
-#ifdef DQ_EXPERIMENT_MG_NOWALK          /* timing experiment only (tools/exp): what the kernel costs without the walk */
-            for (int i = 0; i < (gsize[k] > 2 ? 2 : gsize[k]); ++i) {
-#else
             for (int i = 0; i < gsize[k]; ++i) {
-#endif
                 const ElemT o = s_key2[g0 + i];
                 less += o < k2[k];
                 eq += o == k2[k];

@@ -191,12 +191,6 @@ struct OnesweepCtl {
 //                     respect to the text order because members of a tie group are re-ranked
 //                     by the doubling rounds anyway.
 // ---------------------------------------------------------------------------------
-#ifndef DQ_LOOK_WIN
-#define DQ_LOOK_WIN 8
-#endif
-#ifndef DQ_LOOK_WIN2
-#define DQ_LOOK_WIN2 8
-#endif
 // kPairs      (key, suffix) pairs in two arrays
 // kText       round 0, first pass: keys built from the text, suffix index synthesised
 // kTextPacked same, but the suffix index is packed into the low `ib` bits of the key word
@@ -216,11 +210,8 @@ struct OnesweepCtl {
 enum OnesweepMode { kPairs = 0, kText = 1, kTextPacked = 2, kKeys = 3, kKeysLast = 4, kKeysLastTies = 5, kTextPackedExt = 6, kKeysExt = 7 };
 constexpr uint64_t kSeamEmpty = ~0ull;          // seam_tab marker: the tile has no key with this digit
 
-// developer instrumentation (tools/kbench): per-tile phase timestamps from thread 0
-#ifdef DQ_KERNEL_PHASE_TIMING
-__device__ long long *g_phase_ts = nullptr;          // [ntiles][8]
-#define DQ_PHASE(i) do { if (threadIdx.x == 0 && g_phase_ts) g_phase_ts[(long long)s_tile * 8 + (i)] = clock64(); } while (0)
-#else
+// (tools/kbench/kbench.hip defines DQ_PHASE before it includes this header to stamp a tile's phases; the library does not)
+#ifndef DQ_PHASE
 #define DQ_PHASE(i) do { } while (0)
 #endif
 
@@ -234,7 +225,8 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     StatusT *__restrict__ status /*[ntiles][256]*/, OnesweepCtl *__restrict__ ctl,
     int64_t *__restrict__ sticky_error, uint32_t *__restrict__ ebits = nullptr,
     uint64_t *__restrict__ seam_tab /*[ntiles][256][2]*/ = nullptr,
-    const uint16_t *__restrict__ codetab /*[256], kCoded*/ = nullptr)
+    const uint16_t *__restrict__ codetab /*[256], kCoded*/ = nullptr,
+    int xcd_group = 0 /* kAtomicBase: tiles per XCD and group of the XCD-aware tile order, 0 = blockIdx order */)
 {
     constexpr bool kFromText = (kMode == kText || kMode == kTextPacked || kMode == kTextPackedExt);
     constexpr bool kPackedText = (kMode == kTextPacked || kMode == kTextPackedExt);
@@ -274,18 +266,29 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     // 64-bit words of `status`, zeroed like the status words) instead of the decoupled look-back -- no
     // dependence on other tiles at all, so no ticket either.  Tiles land in whatever order the adds arrive.
     if (kAtomicBase) {
-        if (tid == 0) s_tile = blockIdx.x;
+        // No tile depends on another here, so the tile a workgroup takes is a pure placement choice: workgroup b runs
+        // on XCD b % 8 (observed, MI355X_MICROARCH.md; nothing breaks if not), and with blockIdx order the 8 tiles
+        // whose digit runs are neighbours in every output region are written through 8 different L2s -- partial lines
+        // all round.  Inside every group of 8 G workgroups XCD x takes tiles x G ... x G + G - 1 instead: the runs of G
+        // consecutive tiles meet in one L2 and leave it as whole lines (tools/kbench/scatter.hip: 64 Mi words in
+        // 384-byte runs to 256 regions 184 -> 155 us).
+        if (tid == 0) {
+            uint32_t t = blockIdx.x;
+            if (xcd_group > 0) {
+                const uint32_t grp = 8u * (uint32_t)xcd_group, g = t / grp, r = t % grp;
+                if ((g + 1) * grp <= gridDim.x) t = g * grp + (r & 7u) * (uint32_t)xcd_group + (r >> 3);
+            }
+            s_tile = t;
+        }
     } else if (tid == 0) {
         // Tiles are handed out by an atomic ticket, so a tile's predecessors are always running.
-        // (Experiment kept behind DQ_XCD_REMAP: permuting ticket -> tile inside groups of 64 so that
-        // the workgroups of one XCD get 8 consecutive tiles and adjacent digit runs meet in one
-        // L2.  It lengthened the look-back waits more than it saved on partial-line writes.)
-        const uint32_t g = atomicAdd(&ctl->ticket, 1u);
-        uint32_t t = g;
-#ifdef DQ_XCD_REMAP   /* measured: -4% on pairs passes, +2% on the text pass; off */
-        const uint32_t ntiles = (uint32_t)((m + kTileN - 1) / kTileN);
-        if ((g | 63u) < ntiles) t = (g & ~63u) | ((g & 7u) << 3) | ((g >> 3) & 7u);
-#endif
+        // (Measured and dropped: XCD-aware orders under the look-back.  Round 1: ticket -> tile permuted inside groups of
+        // 64 (-4 % pairs, +2 % text pass).  Round 5: per-XCD tile queues keyed by HW_REG_XCC_ID, G = 4 / 8 / 16 tiles per
+        // die and group -- the write pattern that gains 16 % in tools/kbench/scatter.hip -- made every look-back pass
+        // SLOWER: 256 MiB of text 30.35 -> 31.4 ms, libtorch_cpu.so 23.3 -> 24.1 ms; a tile waits longer for
+        // predecessors that another die's queue hands out later than a single ticket would.  Only the first pass of a
+        // sort, which has no look-back, takes the XCD-aware order -- above.)
+        const uint32_t t = atomicAdd(&ctl->ticket, 1u);
         s_tile = t;
     }
     for (int i = tid; i < kWavesB * kRadixSize; i += kThreads) (&whist[0][0])[i] = 0;
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     //      start fetching the predecessors' status words; the look-back is RESOLVED LATE, after
     //      the LDS exchanges, so its cross-XCD round trips and any straggling predecessor
     //      overlap this tile's own exchange work instead of stalling the workgroup ----
-    constexpr int kLookWin = DQ_LOOK_WIN;
+    constexpr int kLookWin = 8;            // status words fetched at publish time (16 / 32 measured: no gain)
     uint32_t tot = 0, incl = 0;
     StatusT sw[kLookWin];
     unsigned long long abase = 0;
@@ -560,13 +563,9 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     // ---- resolve the look-back: sum aggregates until an inclusive prefix shows up ----
     if (tid < kRadixSize) {
         StatusT excl = 0;
-#ifdef DQ_EXPERIMENT_SKIP_LOOKBACK
-        if (false) {
-#else
         if (kAtomicBase) {
             excl = (StatusT)abase;
         } else if (tile > 0) {
-#endif
             int64_t t = tile - 1;
             uint32_t spins = 0;
             bool done = false;
@@ -583,7 +582,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
                 t -= used;
             }
             // ... then kLookWin2 status words per round trip until an inclusive prefix shows up
-            constexpr int kLookWin2 = DQ_LOOK_WIN2;
+            constexpr int kLookWin2 = 8;
             while (!done) {
                 StatusT s2[kLookWin2];
 #pragma unroll
@@ -605,9 +604,6 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
             }
             status_store<StatusT>(mine, SB::kPrefix | (StatusT)(excl + tot));
         }
-#ifdef DQ_EXPERIMENT_SKIP_LOOKBACK
-        excl = (StatusT)tile * (StatusT)tot;     // timing experiment only: plausible, dependency-free offsets
-#endif
         gofs[tid] = (IdxT)(digit_offset[tid] + (int64_t)excl) - (IdxT)excl_tile;
     }
     __syncthreads();

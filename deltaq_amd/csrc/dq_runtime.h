@@ -385,6 +385,7 @@ int bsdiff_scan_raw(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m,
 int bsdiff_create_host(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, int32_t device, std::vector<uint8_t> &patch);
 int bspatch_apply_host(const uint8_t *old, int64_t n, const uint8_t *patch, int64_t plen, uint8_t *out, int64_t cap, int64_t *out_len);
 int diff_index_new(const uint8_t *old, int64_t n, int32_t device, const void *d_old, const void *d_sa, void **index_out);
+int diff_index_clone(const void *index, int32_t device, void **index_out);
 int diff_index_buffers(const void *index, const void **d_old, const void **d_sa, int64_t *n);
 int diff_index_diff(const void *index, const uint8_t *nw, int64_t m, std::vector<uint8_t> &patch);
 void diff_index_delete(void *index);

@@ -162,6 +162,14 @@ int prepare_status(Launcher &L, Workspace<IdxT> &w, int64_t m, int passes, int f
     return DQ_OK;
 }
 
+// XCD-aware tile order of the first digit pass of a sort (radix_rank_kernel, kAtomicBase): tiles per XCD and group.
+// DQ_XCD_GROUP = 0 (blockIdx order) | 1 .. 64.
+inline int xcd_tile_group()
+{
+    if (const char *v = env("DQ_XCD_GROUP")) return std::max(0, std::min(64, atoi(v)));
+    return 8;
+}
+
 template <typename IdxT, typename StatusT, int kMode, bool kCoded = false, bool kSmall = false>
 int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *vin,
                      uint64_t *kout, IdxT *vout, int64_t m, int pass, int kb, int ib,
@@ -192,7 +200,7 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
                               shift_override >= 0 ? shift_override : pass * kRadixBits + ib,
                               keybits > 0 ? keybits : 8 * kb, ib,
                               (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1,
-                              ebits, seam_tab, (const uint16_t *)w.codetab));
+                              ebits, seam_tab, (const uint16_t *)w.codetab, xcd_tile_group()));
     return DQ_OK;
 }
 
@@ -217,7 +225,7 @@ int rank_pass_ext(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const ui
                                                      Cfg::kLdsMatch, Cfg::kRounds, Cfg::kAtomicBase, false, uint8_t>),
                                   dim3((unsigned)ntiles), dim3(Cfg::kThreads), 0, L.st, kin, ein, kout, eout, m, shift, keybits, ib,
                                   (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1,
-                                  (uint32_t *)nullptr, (uint64_t *)nullptr, (const uint16_t *)w.codetab));
+                                  (uint32_t *)nullptr, (uint64_t *)nullptr, (const uint16_t *)w.codetab, xcd_tile_group()));
         return DQ_OK;
     };
     return m < (1ll << 30) ? go(uint32_t{}) : go(uint64_t{});
@@ -1461,6 +1469,8 @@ struct SuffixSorter {
             fprintf(stderr, "[dq] doubled text at h=%lld: %lld of %lld tied suffixes in pairs (i, i + n/2), %lld other groups\n", (long long)h,
                     (long long)(m - kept), (long long)m, (long long)groups);
         if (kept == 0) { *done = true; return DQ_OK; }
+        // (a look that takes nothing costs a launch and a host round trip per round; it is not given up after idle
+        // looks -- the pairs only become "all that is left of their group" as the rounds split the groups around them)
         if (kept == m) return DQ_OK;
         LAUNCH(L, DQ_K_SMALL_ROUND, m, m * (8 + wb) + kept * (8 + wb),
                hipLaunchKernelGGL(twin_compact_kernel<IdxT>, dim3((unsigned)ntiles), dim3(kTwThreads), 0, st, (const uint64_t *)Kr[rcur],
@@ -1517,10 +1527,7 @@ struct SuffixSorter {
         bool pair_paid = true;            // the last pair-chain phase finished at least half of its list
         int64_t pair_h = 0;               // h of the last phase
         int64_t abort_h = 0, abort_m = 0; // h and list length when a phase last gave up after its count
-        // (DQ_EXP_STOP_ROUNDS=k: timing experiments only -- leave after k doubling rounds with an unfinished suffix array)
-        const int64_t stop_rounds = env("DQ_EXP_STOP_ROUNDS") ? atoi(env("DQ_EXP_STOP_ROUNDS")) : -1;
         while (m > 0) {
-            if (stop_rounds >= 0 && t_info[0] >= stop_rounds) break;
             if (twin_half > 0 && !keys_ready && !list_ungrouped && !run_order) {
                 bool done = false;
                 rc = twin_pairs_step(&done);

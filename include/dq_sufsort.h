@@ -125,12 +125,18 @@ int64_t dq_bsdiff_patch_bound(int64_t n, int64_t m);
  *                            (n int32) -- e.g. received by RCCL broadcast from the rank that sorted -- and must stay
  *                            valid until dq_bsdiff_index_free.  old_data (host) is read by every diff (the scan loop
  *                            walks it, Diff.cs:129-191) and must stay valid as long as the index.
+ *   dq_bsdiff_index_clone    one more copy of an index on `device` (the same device or another one of the node): text,
+ *                            suffix array and prefix table travel device to device -- over xGMI between devices --
+ *                            instead of being computed again.  For a host without a collective library in its process
+ *                            (the C# shim): clones to the other devices of a node, made from one thread each, use one
+ *                            point-to-point link each.  Shares the source's host copy of old_data; freed on its own.
  *   dq_bsdiff_index_buffers  the device pointers (for a broadcast / gather by the caller) and n.
  *   dq_bsdiff_index_diff     = Diff.Create(oldData, newData, ...) without its suffix sort.  Thread-safe: scan loops of
  *                            concurrent callers take turns on the device, their bzip2 framing overlaps.
  *   dq_bsdiff_index_free     releases the index (not the caller's buffers). */
 int32_t dq_bsdiff_index_create(const uint8_t *old_data, int64_t n, const void *d_old, const void *d_sa, int32_t device,
                                void **index_out);
+int32_t dq_bsdiff_index_clone(const void *index, int32_t device, void **index_out);
 int32_t dq_bsdiff_index_buffers(const void *index, const void **d_old, const void **d_sa, int64_t *n);
 int32_t dq_bsdiff_index_diff(const void *index, const uint8_t *new_data, int64_t m, uint8_t *patch, int64_t cap,
                              int64_t *patch_len);

@@ -11,10 +11,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import oracle
 from deltaq_amd import HipSuffixSort
-src = open(os.path.join(ROOT, "tests", "test_gpu_parity.py")).read()
-ns = {}
-exec(src[src.index("def structured_text"):src.index("FUZZ_ENVS = [")], {"np": np}, ns)
-structured_text = ns["structured_text"]
+from structured_inputs import structured_text
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
@@ -37,7 +34,13 @@ ENVS = [{}, {}, {}, {"DQ_SMALL_N": "0"}, {"DQ_NO_FUSED_TIES": "1"}, {"DQ_NO_SMAL
         {"DQ_LATE_RUNS_MIN": "1", "DQ_UPD_BIN_MIN": "1", "DQ_PAIR_CHAINS": "2"}, {"DQ_NO_LATE_RUNS": "1"},
         {"DQ_UPD_BIN": "2", "DQ_UPD_BIN_MIN": "1"}, {"DQ_UPD_BIN": "1", "DQ_UPD_BIN_MIN": "1", "DQ_SMALL_N": "0"},
         {"DQ_UPD_BIN": "2", "DQ_UPD_BIN_MIN": "1", "DQ_RUNS": "1", "DQ_SMALL_N": "0"}, {"DQ_NO_UPD_WORDS": "1"},
-        {"DQ_SPARSE": "1", "DQ_BINNED_ISA": "1"}, {"DQ_SPARSE": "1", "DQ_BINNED_ISA": "1", "DQ_SMALL_N": "0", "DQ_LATE_RUNS_MIN": "1"}]
+        {"DQ_SPARSE": "1", "DQ_BINNED_ISA": "1"}, {"DQ_SPARSE": "1", "DQ_BINNED_ISA": "1", "DQ_SMALL_N": "0", "DQ_LATE_RUNS_MIN": "1"},
+        # round 5: lists of more than n/2 tied suffixes through the LDS class (third list buffer), the XCD-aware first pass
+        {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"}, {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0"},
+        {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_BINNED_ISA": "1", "DQ_UPD_BIN_MIN": "1", "DQ_SMALL_N": "0"},
+        {"DQ_PACKED": "0", "DQ_KEY_BYTES": "3", "DQ_SPARSE": "0", "DQ_RUNS": "1", "DQ_NO_UPD_WORDS": "1"},
+        {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_MID_GROUPS": "0"}, {"DQ_NO_WIDE_SMALL": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
+        {"DQ_XCD_GROUP": "0"}, {"DQ_XCD_GROUP": "3", "DQ_SMALL_N": "0"}, {"DQ_XCD_GROUP": "64", "DQ_BUCKET": "1"}]
 KEYS = sorted({k for e in ENVS for k in e})
 s = HipSuffixSort(0)
 t_end = time.time() + budget

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One named input under several forced settings: device-resident time, per-kernel profile, DQ_TRACE of the rounds;
 every variant's suffix array is compared with the first one's (which is checked by sufcheck + sampled strict pairs).
-usage: t_case.py <enwik256|enwik64|textk1024|libtorch128|rocsparse256|rocsparse64> "" "DQ_X=1,DQ_Y=2" ...   (T_TRACE=1: per-round trace)"""
+usage: t_case.py <uniform256|enwik256|enwik64|textk1024|libtorch128|rocsparse256|rocsparse64> "" "DQ_X=1,DQ_Y=2" ...   (T_TRACE=1: per-round trace)"""
 import glob, os, sys, time
 os.environ.setdefault("DQ_DEBUG_FLAGS", "1")      # the library honours its DQ_* overrides only under this gate
 import numpy as np
@@ -16,6 +16,8 @@ from tools import datagen
 def load_case(name):
     if name.startswith("textk"):                          # text of <k> KiB (the reference benchmark's size range)
         return datagen.gen_enwik_like(int(name[5:]) << 10, 0xD17A0, 64 * 1024)
+    if name.startswith("uniform"):                        # the north-star buffer (256) and its smaller siblings
+        return datagen.gen_uniform(int(name[7:]) << 20, 0x5EED0003)
     if name.startswith("enwik"):
         return datagen.gen_enwik_like(int(name[5:]) << 20, 0xD17A0)
     if name.startswith("libtorch"):

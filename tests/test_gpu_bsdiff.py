@@ -172,6 +172,53 @@ def test_one_old_many_new_index(backend_lib, oracle_mod):
                 assert [ix.Create(x) for x in news] == want
 
 
+def test_index_clone_gives_the_same_patches(backend_lib, oracle_mod):
+    """dq_bsdiff_index_clone: one more copy of an index -- on the same device and, where the node has more, on every other
+    one -- by device-to-device copies of text, suffix array and prefix table.  Every clone must return the patches
+    dq_bsdiff_create returns, go on working after the source is gone, and be freed on its own."""
+    import threading
+    import torch
+    from deltaq_amd import Diff, DiffIndex, HipSuffixSort, Patch
+    rng = np.random.default_rng(8)
+    ndev = backend_lib.dq_device_count()
+    for old in (oracle_mod.gen_enwik_like(5_000_000, 6, 16384),        # 3-byte prefix table
+                oracle_mod.gen_uniform(300_000, 22),                   # 2-byte
+                oracle_mod.net_random_bytes(4096)):                    # none
+        news = [edited(rng, old, k) for k in (2, 30)] + [oracle_mod.gen_uniform(40_000, 5), np.zeros(0, np.uint8)]
+        want = [Diff.CreateBytes(old, x) for x in news]
+        src = DiffIndex(old, 0)
+        clones = [src.clone(d) for d in range(ndev)] + [src.clone(0)]
+        assert [src.Create(x) for x in news] == want
+        src.close()                                                    # the copies own what they hold
+        got = [None] * len(clones)
+
+        def work(k):
+            got[k] = [clones[k].Create(x) for x in news]
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(len(clones))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for k, g in enumerate(got):
+            assert g == want, f"clone {k} of {len(clones)} (devices: {ndev})"
+        assert Patch.Apply(old, got[0][0]) == news[0].tobytes()
+        for c in clones:
+            c.close()
+    # a clone of an index that sits on the caller's buffers (a broadcast receiver's) owns copies of them
+    old = oracle_mod.gen_uniform(200_000, 23)
+    dT = torch.from_numpy(old).cuda()
+    dSA = HipSuffixSort(0).Sort(dT)
+    with DiffIndex(old, 0, device_text=dT, device_sa=dSA) as ix:
+        c = ix.clone(0)
+    del dT, dSA
+    torch.cuda.empty_cache()
+    x = edited(rng, old, 10)
+    assert c.Create(x) == Diff.CreateBytes(old, x)
+    c.close()
+    with pytest.raises(Exception):
+        DiffIndex(old, 0).clone(ndev + 3)                              # no such device
+
+
 def test_concurrent_callers_on_one_device(backend_lib, oracle_mod):
     """Four threads on one device at once: dq_bsdiff_create, diffs against a shared index, batched match searches
     and plain sorts -- the scan-loop windows (polled pinned answers, second-stage mailbox, cached buffers) are one

@@ -19,7 +19,7 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-BUDGET_S = int(os.environ.get("DQ_STRESS_SECONDS", "80"))
+BUDGET_S = int(os.environ.get("DQ_STRESS_SECONDS", "150"))
 
 
 def tree_seed() -> int:

@@ -7,7 +7,9 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
-#define DQ_KERNEL_PHASE_TIMING 1
+// per-tile phase timestamps from thread 0 of radix_rank_kernel (the library's DQ_PHASE is empty)
+__device__ long long *g_phase_ts = nullptr;          // [ntiles][8]
+#define DQ_PHASE(i) do { if (threadIdx.x == 0 && g_phase_ts) g_phase_ts[(long long)s_tile * 8 + (i)] = clock64(); } while (0)
 #include "../../deltaq_amd/csrc/dq_onesweep.h"
 
 using namespace dq;

@@ -4,10 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle
 from deltaq_amd import HipSuffixSort, _abi
-src = open(os.path.join(ROOT, "tests", "test_gpu_parity.py")).read()
-ns = {}
-exec(src[src.index("def structured_text"):src.index("FUZZ_ENVS = [")], {"np": np}, ns)
-structured_text = ns["structured_text"]
+from structured_inputs import structured_text
 env_len, target = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(0xD17A + env_len)
 sizes = [int(x) for x in rng.integers(1, 2000, 120)] + [int(x) for x in rng.integers(2000, 20000, 120)] + \
