@@ -48,7 +48,8 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
     const uint32_t *__restrict__ RL = nullptr /* run lengths of the text (dq_runs.h), or none */,
     const uint8_t *__restrict__ text = nullptr, int run_order = 0 /* 1: this is the run-order round */,
     const uint32_t *__restrict__ rank32 = nullptr /* the ranks as 32-bit values instead of `rank` (first round) */,
-    int u_ib = 0 /* > 0: update entries as single words (rank << u_ib | suffix) in u_rank_end, u_suf_end unused */)
+    int u_ib = 0 /* > 0: update entries as single words (rank << u_ib | suffix) in u_rank_end, u_suf_end unused */,
+    int l_shift = 0 /* > 0: the radix list's keys carry rank >> l_shift as their sort field, the low rank bits as payload */)
 {
     // chained rounds (no host round trip in between): the list length is what the previous round appended to T
     if (prev) {
@@ -262,7 +263,12 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
         }
         if (own_large[k]) {
             const int64_t p = (int64_t)base[1] + wave_cnt[1][k][wv] + mask_rank_lt(bl[k]);
-            l_key[p] = ((uint64_t)r[k] << kbits) | (uint64_t)k2[k];
+            // Every group on the radix list has more than kG members, so the ranks of two of them differ by more than
+            // kG >= 2^l_shift: rank >> l_shift still tells them apart, in order.  The sort field shrinks by l_shift bits
+            // (one or two digit passes fewer); the low rank bits travel below it, where no pass looks.
+            const uint64_t rr = (uint64_t)r[k];
+            l_key[p] = l_shift > 0 ? (((rr >> l_shift) << (kbits + l_shift)) | ((uint64_t)k2[k] << l_shift) | (rr & ((1ull << l_shift) - 1)))
+                                   : ((rr << kbits) | (uint64_t)k2[k]);
             l_suf[p] = s[k];
         }
         if (f[k] & 4) {

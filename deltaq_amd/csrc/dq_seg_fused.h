@@ -89,7 +89,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
     IdxT *__restrict__ SA, IdxT *__restrict__ ISA, uint64_t *__restrict__ act_rank,
     IdxT *__restrict__ act_suf, uint64_t *__restrict__ status /*[3][ntiles]*/, int64_t ntiles,
     SegCtl *__restrict__ ctl, int64_t *__restrict__ totals, int64_t *__restrict__ sticky_error,
-    int rank_from_isa = 0, uint32_t *__restrict__ list_rank = nullptr)
+    int rank_from_isa = 0, uint32_t *__restrict__ list_rank = nullptr,
+    int rank_lo = 0 /* > 0: the rank field holds rank >> rank_lo, the low rank_lo bits of a key (below kshift) the rest */)
 {
     __shared__ int64_t w_nh[kSegWaves], w_gh[kSegWaves], w_cnt[kSegWaves];
     __shared__ uint64_t s_prefix[3];
@@ -241,7 +242,9 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
                 const IdxT rg = gm ? wb_i + (IdxT)(k * kWave + 63 - __builtin_clzll(gm)) : cg;
                 // rank_from_isa: the composite key carries rank >> 1 (n close to 2^32, dq_sorter_impl.h::run);
                 // a tied suffix's own ISA entry is its parent rank
-                const IdxT rank = kInitial ? (IdxT)0 : (kWriteISA && rank_from_isa) ? ISA[suf[k]] : (IdxT)(ck[k] >> kbits);
+                IdxT rank = kInitial ? (IdxT)0 : (kWriteISA && rank_from_isa) ? ISA[suf[k]] : (IdxT)(ck[k] >> kbits);
+                // (the radix list of an LDS-class round: rank >> rank_lo above the key, the low bits as payload below it)
+                if (!kInitial && rank_lo > 0) rank = (IdxT)(((uint64_t)rank << rank_lo) | (kp[e] & ((1ull << rank_lo) - 1)));
                 const IdxT nr = rank + (rn - rg);
                 if (kEmitPairs) {
                     // (tied?, rank, suffix) in list order, coalesced: the inverse suffix array is built from

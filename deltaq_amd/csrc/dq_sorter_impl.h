@@ -255,21 +255,21 @@ void launch_hist(hipStream_t st, int blocks, const uint64_t *keys, int64_t m, ui
 // generic pairs: all digit histograms in one read, then one radix_rank_kernel per digit
 template <typename IdxT>
 int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V[2], int64_t m,
-                        int total_bits, int &cur)
+                        int total_bits, int &cur, int shift0 = 0 /* the sort field starts at this bit */)
 {
     const int passes = (total_bits + kRadixBits - 1) / kRadixBits;
     const int blocks = (int)std::min<int64_t>(kHistBlocks, ((m >> 1) + kHistThreads - 1) / kHistThreads + 1);
     int rc = L.begin(DQ_K_RADIX_HIST, m, m * 8);
     if (rc != DQ_OK) return rc;
     switch (passes) {
-        case 1: launch_hist<1>(L.st, blocks, K[cur], m, w.hist_partial); break;
-        case 2: launch_hist<2>(L.st, blocks, K[cur], m, w.hist_partial); break;
-        case 3: launch_hist<3>(L.st, blocks, K[cur], m, w.hist_partial); break;
-        case 4: launch_hist<4>(L.st, blocks, K[cur], m, w.hist_partial); break;
-        case 5: launch_hist<5>(L.st, blocks, K[cur], m, w.hist_partial); break;
-        case 6: launch_hist<6>(L.st, blocks, K[cur], m, w.hist_partial); break;
-        case 7: launch_hist<7>(L.st, blocks, K[cur], m, w.hist_partial); break;
-        default: launch_hist<8>(L.st, blocks, K[cur], m, w.hist_partial); break;
+        case 1: launch_hist<1>(L.st, blocks, K[cur], m, w.hist_partial, shift0); break;
+        case 2: launch_hist<2>(L.st, blocks, K[cur], m, w.hist_partial, shift0); break;
+        case 3: launch_hist<3>(L.st, blocks, K[cur], m, w.hist_partial, shift0); break;
+        case 4: launch_hist<4>(L.st, blocks, K[cur], m, w.hist_partial, shift0); break;
+        case 5: launch_hist<5>(L.st, blocks, K[cur], m, w.hist_partial, shift0); break;
+        case 6: launch_hist<6>(L.st, blocks, K[cur], m, w.hist_partial, shift0); break;
+        case 7: launch_hist<7>(L.st, blocks, K[cur], m, w.hist_partial, shift0); break;
+        default: launch_hist<8>(L.st, blocks, K[cur], m, w.hist_partial, shift0); break;
     }
     hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(passes), dim3(kHistScanThreads), 0, L.st,
                        (const uint32_t *)w.hist_partial, blocks, w.digit_offset);
@@ -279,7 +279,8 @@ int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V
     rc = prepare_status<IdxT>(L, w, m, passes);
     if (rc != DQ_OK) return rc;
     for (int p = 0; p < passes; ++p) {
-        rc = rank_pass<IdxT, kPairs>(L, w, K[cur], V[cur], K[cur ^ 1], V[cur ^ 1], m, p, 8);
+        rc = rank_pass<IdxT, kPairs>(L, w, K[cur], V[cur], K[cur ^ 1], V[cur ^ 1], m, p, 8, 0, nullptr, nullptr,
+                                     shift0 > 0 ? shift0 + p * kRadixBits : -1);
         if (rc != DQ_OK) return rc;
         cur ^= 1;
     }
@@ -526,7 +527,7 @@ int collect_ties(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int k
 template <typename IdxT, bool kInitial, bool kWriteSA, bool kWriteISA>
 int rebucket(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *keys, const IdxT *vals,
              int64_t m, int kbits, int kshift, IdxT *SA, uint64_t *act_rank, IdxT *act_suf,
-             int64_t *active_out, int rank_from_isa = 0)
+             int64_t *active_out, int rank_from_isa = 0, int rank_lo = 0)
 {
     const int64_t wb = (int64_t)sizeof(IdxT);
     const int64_t ntiles = (m + kSegFusedTile - 1) / kSegFusedTile;
@@ -537,7 +538,8 @@ int rebucket(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *keys
            hipLaunchKernelGGL((seg_fused_kernel<IdxT, kInitial, kWriteSA, kWriteISA>),
                               dim3((unsigned)ntiles), dim3(kSegThreads), 0, L.st, keys, vals, m, kbits, kshift, SA, w.ISA, act_rank,
                               act_suf, reinterpret_cast<uint64_t *>(w.seg_status + 256), ntiles,
-                              reinterpret_cast<SegCtl *>(w.seg_status), w.totals, w.totals + 1, rank_from_isa));
+                              reinterpret_cast<SegCtl *>(w.seg_status), w.totals, w.totals + 1, rank_from_isa,
+                              (uint32_t *)nullptr, rank_lo));
     HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, L.st));
     HIP_TRY(hipStreamSynchronize(L.st));
     *active_out = c.pinned[0];
@@ -1196,8 +1198,11 @@ struct SuffixSorter {
         // <= 32 on short lists, in small_group_round_kernel; everything else through the radix passes).
         const int mid_g = mid_group_cap(m);
         const bool use_mid = mid_g > 0;
+        // the radix list's composite keys with rank >> log2(mid_g) as the rank field (dq_mid_groups.h): 57 -> 48 bits for
+        // 256 MiB of text, 8 -> 6 digit passes per large-group sort.  DQ_NO_L_SHIFT=1: the full rank, as before round 5.
+        const int l_shift = (use_mid && !env("DQ_NO_L_SHIFT")) ? (mid_g >= 1024 ? 10 : mid_g >= 512 ? 9 : 8) : 0;
         if (use_mid) {
-            int rc = launch_mid_round(mid_g, m, A, As, lay, h, kbits, ctr, nullptr, m * (8 + wb + wb + wb + 8 + wb));
+            int rc = launch_mid_round(mid_g, m, A, As, lay, h, kbits, ctr, nullptr, m * (8 + wb + wb + wb + 8 + wb), l_shift);
             if (rc != DQ_OK) return rc;
             first_rank32 = nullptr;
         } else if (cap32) {
@@ -1232,10 +1237,10 @@ struct SuffixSorter {
             uint64_t *Kx[2] = {lay.l_key, lay.l_partner};
             IdxT *Vx[2] = {lay.l_suf, lay.l_partner_suf};
             int xcur = 0;
-            int rc = onesweep_sort_pairs<IdxT>(L, w, Kx, Vx, mL, kbits + rbits, xcur);
+            int rc = onesweep_sort_pairs<IdxT>(L, w, Kx, Vx, mL, std::max(1, kbits + rbits - l_shift), xcur, l_shift);
             if (rc != DQ_OK) return rc;
-            rc = rebucket<IdxT, false, true, true>(L, c, w, Kx[xcur], (const IdxT *)Vx[xcur], mL, kbits, 0, d_sa,
-                                                   B + m1, Bs + m1, &mLs);
+            rc = rebucket<IdxT, false, true, true>(L, c, w, Kx[xcur], (const IdxT *)Vx[xcur], mL, kbits, l_shift, d_sa,
+                                                   B + m1, Bs + m1, &mLs, 0, l_shift);
             if (rc != DQ_OK) return rc;
         }
         rcur ^= 1;
@@ -1258,7 +1263,7 @@ struct SuffixSorter {
 
     // one round of mid_group_round_kernel<kG> on the list (A, As)[0, mm); prev: the previous chained round's counters
     int launch_mid_round(int g, int64_t mm, const uint64_t *A, const IdxT *As, const RoundLayout &lay, int64_t hh, int kbits,
-                         SmallGroupCounters *ctr, const SmallGroupCounters *prev, int64_t alg_bytes)
+                         SmallGroupCounters *ctr, const SmallGroupCounters *prev, int64_t alg_bytes, int l_shift = 0)
     {
         const int64_t tile = g == 256 ? mg_tile<256>() : g == 512 ? mg_tile<512>() : mg_tile<1024>();
         const dim3 grid((unsigned)((mm + tile - 1) / tile));
@@ -1266,7 +1271,7 @@ struct SuffixSorter {
             LAUNCH(L, DQ_K_MID_ROUND, mm, alg_bytes,
                    hipLaunchKernelGGL(kern, grid, dim3(kMgThreads), 0, st, A, As, (const IdxT *)w.ISA, mm, n, hh, kbits, d_sa, lay.t_rank, lay.t_suf,
                                       lay.l_key, lay.l_suf, lay.u_end, lay.u_suf_end, ctr, prev, rl(), (const uint8_t *)w.text, run_order,
-                                      first_rank32, upd_ib()));
+                                      first_rank32, upd_ib(), l_shift));
             return DQ_OK;
         };
         return g == 256 ? go(mid_group_round_kernel<IdxT, 256>) : g == 512 ? go(mid_group_round_kernel<IdxT, 512>)
