@@ -48,6 +48,51 @@ __global__ __launch_bounds__(kPairThreads) void isa_from_pairs_kernel(const uint
         if (base + i < n) ISA[base + i] = (IdxT)image[i];
 }
 
+// Rank updates of a doubling round, applied window by window (round 5).  `words` = (rank << ib | suffix), sorted by the
+// top 16 bits of the suffix (two word passes of the radix sorter), so the updates of one span of kSpan consecutive
+// suffixes are consecutive; bounds[v] = index of the first word of span v (window_bounds_kernel).  A workgroup loads its
+// span of the inverse suffix array into LDS, applies the span's updates there and writes the span back in full lines --
+// 8 bytes of array traffic per suffix of a touched span instead of one read-modify-write of a 64-byte sector per update
+// (isa_update_words_kernel on words binned by 8 bits: 8x write amplification, rocprof WRITE_SIZE, round 4).  Pays while
+// at least ~1/16 of the array is updated.  A word whose suffix field is >= n is an alignment filler and is skipped.
+template <typename IdxT, int kSpan>
+__global__ __launch_bounds__(kPairThreads) void isa_update_window_kernel(const uint64_t *__restrict__ words, const int64_t *__restrict__ bounds,
+                                                                       int64_t n, int ib, IdxT *__restrict__ ISA)
+{
+    __shared__ uint32_t image[kSpan];
+    const int64_t lo = bounds[blockIdx.x], hi = bounds[blockIdx.x + 1];
+    if (lo >= hi) return;                                 // nothing moved in this span
+    const uint64_t mask = (1ull << ib) - 1;
+    const int64_t base = (int64_t)blockIdx.x * kSpan;
+    for (int i = threadIdx.x; i < kSpan; i += kPairThreads)
+        if (base + i < n) image[i] = (uint32_t)ISA[base + i];
+    __syncthreads();
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kPairThreads) {
+        const uint64_t w = words[i];
+        const int64_t sfx = (int64_t)(w & mask);
+        if (sfx < n) image[sfx - base] = (uint32_t)(w >> ib);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSpan; i += kPairThreads)
+        if (base + i < n) ISA[base + i] = (IdxT)image[i];
+}
+
+// bounds[v] = first index whose word lies in span >= v (v = 0 .. nspans), by binary search over the sorted words
+static __global__ __launch_bounds__(kBlock) void window_bounds_kernel(const uint64_t *__restrict__ words, int64_t count, int ib,
+                                                               int span_log2, int64_t nspans, int64_t *__restrict__ bounds)
+{
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (v > nspans) return;
+    const uint64_t mask = (1ull << ib) - 1;
+    int64_t lo = 0, hi = count;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)((words[mid] & mask) >> span_log2) < v) lo = mid + 1;
+        else hi = mid;
+    }
+    bounds[v] = lo;
+}
+
 // *count must be zero on entry; it ends as the number of tied suffixes appended
 template <typename IdxT>
 __global__ __launch_bounds__(kPairThreads) void key2_from_pairs_kernel(

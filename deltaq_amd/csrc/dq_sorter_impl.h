@@ -1142,7 +1142,17 @@ struct SuffixSorter {
         // (the entries lie downward from u_end / u_suf_end: B + top of the round's partner pair, or the third buffer's)
         int passes = env("DQ_UPD_BIN") ? std::max(0, std::min(2, atoi(env("DQ_UPD_BIN")))) : 1;
         const int64_t min_len = env("DQ_UPD_BIN_MIN") ? std::max(1, atoi(env("DQ_UPD_BIN_MIN"))) : kUpdBinMin;
-        if (u_ib < 16 || mU < min_len || (size_t)(mU + 1) * 8 > (size_t)(n + 2) * sizeof(IdxT)) passes = 0;
+        // (the second pass writes into the dead suffix buffer of the round's input list, as 64-bit words)
+        const bool second_fits = (size_t)(mU + 1) * 8 <= (size_t)(n + 2) * sizeof(IdxT);
+        // Dense updates (at least 1/4 of the array moves: the first round of a text-like input or a binary) are binned by
+        // the top 16 bits of the suffix and applied span by span inside LDS (isa_update_window_kernel): 256 MiB of text,
+        // 75 M updates: 0.4 + 1.45 ms -> 0.7 + 0.55 ms (the sort 29.87 -> 29.44 ms).  The window kernel moves the whole
+        // array once whatever the number of updates, and the second pass costs what it costs: at 1/6 of the array
+        // (second round of libtorch_cpu.so, 20.7 M of 134 M) the one-pass form is ahead again.  DQ_UPD_WINDOW = 0 | 1 overrides.
+        bool window = u_ib >= 16 && 2 * u_ib <= 63 && second_fits && mU >= min_len && mU * 4 >= n && !env("DQ_UPD_BIN");
+        if (const char *v = env("DQ_UPD_WINDOW")) window = atoi(v) != 0 && u_ib >= 16 && 2 * u_ib <= 63 && second_fits;
+        if (window) passes = 2;
+        if (u_ib < 16 || mU < min_len || (passes == 2 && !second_fits)) passes = window ? 2 : 0;
         if (passes == 0) {
             LAUNCH(L, DQ_K_ISA_UPDATE, mU, mU * (u_ib ? 8 + wb : 8 + wb + wb),
                    hipLaunchKernelGGL(isa_update_kernel<IdxT>, dim3(grid_for(mU)), dim3(kBlock), 0, st,
@@ -1151,7 +1161,7 @@ struct SuffixSorter {
             return DQ_OK;
         }
         // the word list starts on a 16-byte boundary (key loads of the histogram kernel): one filler word in
-        // front of it if need be -- all ones: a suffix field >= n, skipped by the update kernel
+        // front of it if need be -- all ones: a suffix field >= n, skipped by the update kernels
         uint64_t *U = u_end - mU;
         int64_t cnt = mU;
         if (reinterpret_cast<uintptr_t>(U) & 8) {
@@ -1179,6 +1189,22 @@ struct SuffixSorter {
             rc = rank_pass<IdxT, kKeys>(L, w, W1, (const IdxT *)nullptr, W2, (IdxT *)nullptr, cnt, 1, 8, u_ib, nullptr, nullptr, sh0 + 8);
             if (rc != DQ_OK) return rc;
             binned = W2;
+        }
+        if (window) {
+            // spans of 4096 suffixes (32768 where a bin of the 16-bit binning is wider than that), as isa_from_pairs_kernel
+            const int span_log2 = u_ib - 16 <= 12 ? 12 : 15;
+            const int64_t nspans = (n + ((int64_t)1 << span_log2) - 1) >> span_log2;
+            if ((size_t)(nspans + 1) * 8 > (size_t)((size_t)n / 4096 + 4) * 8) return fail(DQ_ERR_HIP, "window bounds do not fit");
+            LAUNCH(L, DQ_K_ISA_UPDATE, cnt, cnt * 8 + 2 * n * wb,
+                   hipLaunchKernelGGL(window_bounds_kernel, dim3((unsigned)((nspans + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, binned, cnt,
+                                      u_ib, span_log2, nspans, w.bkt_bounds);
+                   if (span_log2 == 12)
+                       hipLaunchKernelGGL((isa_update_window_kernel<IdxT, 4096>), dim3((unsigned)nspans), dim3(kPairThreads), 0, st, binned,
+                                          (const int64_t *)w.bkt_bounds, n, u_ib, w.ISA);
+                   else
+                       hipLaunchKernelGGL((isa_update_window_kernel<IdxT, 32768>), dim3((unsigned)nspans), dim3(kPairThreads), 0, st, binned,
+                                          (const int64_t *)w.bkt_bounds, n, u_ib, w.ISA));
+            return DQ_OK;
         }
         LAUNCH(L, DQ_K_ISA_UPDATE, cnt, cnt * (8 + wb),
                hipLaunchKernelGGL(isa_update_words_kernel<IdxT>, dim3(grid_for(cnt)), dim3(kBlock), 0, st, binned, cnt, u_ib, n, w.ISA));

@@ -42,6 +42,8 @@ ENVS = [{}, {}, {}, {"DQ_SMALL_N": "0"}, {"DQ_NO_FUSED_TIES": "1"}, {"DQ_NO_SMAL
         {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_MID_GROUPS": "0"}, {"DQ_NO_WIDE_SMALL": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
         {"DQ_NO_L_SHIFT": "1"}, {"DQ_NO_L_SHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_MID_GROUPS": "256"},
         {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_MID_GROUPS": "256", "DQ_PAIR_CHAINS": "0", "DQ_SMALL_N": "0"},
+        {"DQ_UPD_WINDOW": "1"}, {"DQ_UPD_WINDOW": "1", "DQ_SMALL_N": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
+        {"DQ_UPD_WINDOW": "1", "DQ_RUNS": "1", "DQ_LATE_RUNS_MIN": "1"}, {"DQ_UPD_WINDOW": "0"},
         {"DQ_XCD_GROUP": "0"}, {"DQ_XCD_GROUP": "3", "DQ_SMALL_N": "0"}, {"DQ_XCD_GROUP": "64", "DQ_BUCKET": "1"}]
 KEYS = sorted({k for e in ENVS for k in e})
 s = HipSuffixSort(0)

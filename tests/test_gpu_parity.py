@@ -365,6 +365,9 @@ FUZZ_ENVS = [
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "0", "DQ_NO_CHAIN": "1"},
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_NO_WIDE_SMALL": "1"},   # ... and as before: the radix path
     {"DQ_NO_L_SHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "256"},   # radix-list keys with the full rank
+    {"DQ_UPD_WINDOW": "1", "DQ_SMALL_N": "0"},             # rank updates applied span by span inside LDS (isa_update_window_kernel)
+    {"DQ_UPD_WINDOW": "1", "DQ_SMALL_N": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_RUNS": "1"},
+    {"DQ_UPD_WINDOW": "0", "DQ_SMALL_N": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "256", "DQ_PAIR_CHAINS": "0"},  # ... many large groups, rank >> 8
 ]
 
@@ -517,6 +520,9 @@ FORCED_PATHS = [
     {"DQ_PAIR_CHAINS": "1", "DQ_PACKED": "1", "DQ_KEY_BYTES": "2"},
     {"DQ_NO_WIDE_SMALL": "1"},                                   # lists of more than n/2 entries through the radix rounds (the default before round 5)
     {"DQ_NO_L_SHIFT": "1"},                                      # radix-list keys of the LDS-class rounds with the full rank (before round 5)
+    {"DQ_UPD_WINDOW": "1"},                                      # rank updates span by span in LDS, forced on every list
+    {"DQ_UPD_WINDOW": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_BINNED_ISA": "1"},
+    {"DQ_UPD_WINDOW": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
     {"DQ_NO_L_SHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_MID_GROUPS": "256"},
     {"DQ_NO_WIDE_SMALL": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_BINNED_ISA": "1", "DQ_UPD_BIN_MIN": "1"},   # wide lists, binned first ISA, binned updates
