@@ -1,0 +1,53 @@
+"""deltaq_amd/build.py decides by CONTENT what is stale (round-4 advisor): the library by the manifest, every object by a
+digest of the files its compiler-written dependency list names -- a tree copied to the GPU box carries objects and
+headers whose file times order nothing."""
+import os
+import time
+
+from conftest import ROOT
+
+
+def test_dependency_lists_are_rerooted_into_this_tree(tmp_path, monkeypatch):
+    from deltaq_amd import build as b
+    obj = tmp_path / "obj"
+    obj.mkdir()
+    monkeypatch.setattr(b, "OBJ", str(obj))
+    # a list written where the tree lay under another path, with a system header in it
+    (obj / "dq_abi.d").write_text(
+        "/somewhere/else/repo/deltaq_amd/csrc/obj/dq_abi.o: /somewhere/else/repo/deltaq_amd/csrc/dq_abi.hip \\\n"
+        "  /somewhere/else/repo/deltaq_amd/csrc/dq_runtime.h /opt/rocm/include/hip/hip_runtime.h \\\n"
+        "  /somewhere/else/repo/deltaq_amd/csrc/../../include/dq_sufsort.h\n")
+    deps = b._deps("dq_abi.hip")
+    assert os.path.join(b.CSRC, "dq_abi.hip") in deps and os.path.join(b.CSRC, "dq_runtime.h") in deps
+    assert os.path.join(ROOT, "include", "dq_sufsort.h") in [os.path.normpath(p) for p in deps]
+    assert not any(p.startswith("/opt/") for p in deps)
+    assert all(os.path.exists(p) for p in deps)
+
+
+def test_object_freshness_follows_content_not_time(tmp_path, monkeypatch):
+    from deltaq_amd import build as b
+    src_dir, obj = tmp_path / "csrc", tmp_path / "csrc" / "obj"
+    obj.mkdir(parents=True)
+    monkeypatch.setattr(b, "CSRC", str(src_dir))
+    monkeypatch.setattr(b, "OBJ", str(obj))
+    (src_dir / "unit.hip").write_text("int f() { return 1; }\n")
+    (src_dir / "dep.h").write_text("#define K 1\n")
+    (obj / "unit.d").write_text(f"x.o: /old/place/deltaq_amd/csrc/unit.hip /old/place/deltaq_amd/csrc/dep.h\n")
+    assert b._obj_stale("unit.hip")                       # no object, no stamp
+    (obj / "unit.o").write_bytes(b"\x7fELF")
+    assert b._obj_stale("unit.hip")                       # an object without a stamp says nothing
+    (obj / "unit.digest").write_text(b._obj_digest("unit.hip") + "\n")
+    assert not b._obj_stale("unit.hip")
+    # the header is OLDER than the object by its file time and still makes it stale once its content differs
+    (src_dir / "dep.h").write_text("#define K 2\n")
+    past = time.time() - 10_000
+    os.utime(src_dir / "dep.h", (past, past))
+    assert b._obj_stale("unit.hip")
+    # ... and a newer file time alone does not
+    (src_dir / "dep.h").write_text("#define K 1\n")
+    future = time.time() + 10_000
+    os.utime(src_dir / "dep.h", (future, future))
+    assert not b._obj_stale("unit.hip")
+    # other flags, other object
+    monkeypatch.setattr(b, "FLAGS", b.FLAGS + ["-DX"])
+    assert b._obj_stale("unit.hip")

@@ -11,5 +11,8 @@ for TAG in "$@"; do
   cp "$SRC/traffic.json" "$ROOT/profiles/$ROUND/${TAG}_traffic.json"
   STATS=$(find "$SRC/stats" -name '*kernel_stats.csv' | head -1)
   [ -n "$STATS" ] && cp "$STATS" "$ROOT/profiles/$ROUND/${TAG}_kernel_stats.csv"
-  grep '^{' "$SRC/stats.log" | tail -1 > "$ROOT/profiles/$ROUND/${TAG}_bench_line_under_rocprof.json" || true
+  # (the line printed under rocprof, when the profiled command was bench.py: no empty file otherwise)
+  if grep -q '^{' "$SRC/stats.log" 2>/dev/null; then
+    grep '^{' "$SRC/stats.log" | tail -1 > "$ROOT/profiles/$ROUND/${TAG}_bench_line_under_rocprof.json"
+  fi
 done

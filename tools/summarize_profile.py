@@ -69,6 +69,14 @@ def main():
                 v["hbm_bytes_per_launch"] = (2 * v["FETCH_SIZE_KiB_per_launch"] + v["WRITE_SIZE_KiB_per_launch"]) * 1024
         if len(sys.argv) > 2:
             traffic["workload"] = sys.argv[2]            # bench.py reports traffic only for the workload it was measured on
+        # ... and only for the library the counters were taken from: the digest of its sources at profiling time
+        try:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from deltaq_amd import build as dq_build
+            traffic["library_source_digest"] = dq_build._source_digest()
+        except Exception as e:                            # noqa: BLE001
+            traffic["library_source_digest"] = None
+            print("no source digest:", e)
         json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1, sort_keys=True)
 
 
