@@ -32,6 +32,7 @@
 #include "dq_isa_pairs.h"
 #include "dq_bucket_sort.h"
 #include "dq_pair_chains.h"
+#include "dq_tail.h"
 
 namespace dq {
 namespace {
@@ -101,7 +102,7 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     }
     w.bkt_bounds = (int64_t *)take((un / 4096 + 4) * 8);
     w.totals = (int64_t *)take(64);
-    w.sg_ctr = (SmallGroupCounters *)take(kSgChain * sizeof(SmallGroupCounters));
+    w.sg_ctr = (SmallGroupCounters *)take((kSgChain + 2) * sizeof(SmallGroupCounters));     // (+ the tail kernel's result, dq_tail.h)
     w.hist_partial = (uint32_t *)take((size_t)kHistBlocks * kMaxPasses * kRadixSize * 4);
     w.digit_offset = (int64_t *)take((size_t)kMaxPasses * kRadixSize * 8);
     w.codetab = (uint16_t *)take(512);
@@ -1282,6 +1283,10 @@ struct SuffixSorter {
     // ---- kSgChain small-group rounds back to back, lengths handed over on the device.  Only valid once
     //      every group has <= small_cap members (nothing goes to the radix list any more); the grids are sized for
     //      the current m, which is an upper bound for all later rounds.
+    // (a list within reach of the tail kernel -- dq_tail.h: the rest of the sort in one launch once <= tail_max suffixes
+    // are tied -- runs two rounds per host round trip instead of eight, so that the hand-over is not slept through)
+    int chain_len = kSgChain;
+    bool tail_behind_chain = false;
     int doubling_rounds_small_chain()
     {
         return small_cap > kSgMaxGShort ? small_chain<0>() : small_cap == kSgMaxGShort ? small_chain<kSgMaxGShort>() : small_chain<kSgMaxG>();
@@ -1308,9 +1313,9 @@ struct SuffixSorter {
     int small_chain()
     {
         const int64_t m_in = m;
-        HIP_TRY(hipMemsetAsync(w.sg_ctr, 0, kSgChain * sizeof(SmallGroupCounters), st));
+        HIP_TRY(hipMemsetAsync(w.sg_ctr, 0, (kSgChain + 2) * sizeof(SmallGroupCounters), st));
         int64_t hr = h;
-        for (int r = 0; r < kSgChain; ++r) {
+        for (int r = 0; r < chain_len; ++r) {
             uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
             IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
             // (every round of the chain is laid out for the list length the chain starts with: an upper bound of the others')
@@ -1335,16 +1340,39 @@ struct SuffixSorter {
             rcur ^= 1;
             hr *= 2;
         }
-        HIP_TRY(hipMemcpyAsync(c.pinned, w.sg_ctr, kSgChain * sizeof(SmallGroupCounters), hipMemcpyDeviceToHost, st));
+        // A list within reach of the tail kernel: it is launched right behind the chain, on the list and at the depth the
+        // chain leaves, and reads the list's length on the device -- if that is <= kTailMax the sort ends in this same
+        // host round trip, otherwise the kernel does nothing (no host round trip spent on finding out).
+        TailResult *res = reinterpret_cast<TailResult *>(w.sg_ctr + kSgChain);
+        const bool spec_tail = tail_behind_chain;
+        if (spec_tail) {
+            LAUNCH(L, DQ_K_SMALL_ROUND, m_in, 0,
+                   hipLaunchKernelGGL(tail_rounds_kernel<IdxT>, dim3(1), dim3(kTailThreads), 0, st, (const uint64_t *)Kr[rcur],
+                                      (const IdxT *)Vr[rcur], (int)0, n, hr, w.ISA, d_sa, rl(), res,
+                                      (const unsigned long long *)&w.sg_ctr[chain_len - 1].tied_moved));
+        }
+        HIP_TRY(hipMemcpyAsync(c.pinned, w.sg_ctr, (kSgChain + 2) * sizeof(SmallGroupCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         int64_t cur_m = m_in;
-        for (int r = 0; r < kSgChain; ++r) {
+        for (int r = 0; r < chain_len; ++r) {
             if (c.pinned[2 * r + 1] != 0) return fail(DQ_ERR_HIP, "chained small-group round met a large group");
             if (cur_m > 0) { t_info[0] += 1; t_info[2] += cur_m; }
             cur_m = c.pinned[2 * r] & 0xffffffffll;
         }
         m = cur_m;
         h = hr;
+        if (spec_tail && cur_m > 0) {
+            const int64_t rounds = c.pinned[2 * kSgChain], entries = c.pinned[2 * kSgChain + 1], left = c.pinned[2 * kSgChain + 2];
+            if (cur_m <= kTailMax) {                       // the kernel took the list
+                if (env("DQ_TRACE"))
+                    fprintf(stderr, "[dq] tail behind a chain of %d: %lld tied suffixes from h=%lld on, %lld rounds (%lld list entries in all)\n",
+                            chain_len, (long long)cur_m, (long long)hr, (long long)rounds, (long long)entries);
+                if (left != 0) return fail(DQ_ERR_HIP, "tail rounds did not finish (round bound hit)");
+                t_info[0] += rounds;
+                t_info[2] += entries;
+                m = 0;
+            }
+        }
         return DQ_OK;
     }
 
@@ -1455,6 +1483,28 @@ struct SuffixSorter {
         return DQ_OK;
     }
 
+    // ---- the last rounds in one launch (dq_tail.h): at most kTailMax tied suffixes, one workgroup, the list in LDS
+    int tail_rounds()
+    {
+        TailResult *res = reinterpret_cast<TailResult *>(w.sg_ctr + kSgChain);
+        static_assert(sizeof(TailResult) <= 2 * sizeof(SmallGroupCounters), "the result sits behind the chain counters");
+        HIP_TRY(hipMemsetAsync(res, 0, sizeof(TailResult), st));
+        LAUNCH(L, DQ_K_SMALL_ROUND, m, m * (8 + wb + wb + 64),
+               hipLaunchKernelGGL(tail_rounds_kernel<IdxT>, dim3(1), dim3(kTailThreads), 0, st, (const uint64_t *)Kr[rcur],
+                                  (const IdxT *)Vr[rcur], (int)m, n, h, w.ISA, d_sa, rl(), res));
+        HIP_TRY(hipMemcpyAsync(c.pinned, res, sizeof(TailResult), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const int64_t rounds = c.pinned[0], entries = c.pinned[1], left = c.pinned[2];
+        if (env("DQ_TRACE"))
+            fprintf(stderr, "[dq] tail: %lld tied suffixes from h=%lld on, %lld rounds in one launch (%lld list entries in all)\n",
+                    (long long)m, (long long)h, (long long)rounds, (long long)entries);
+        if (left != 0) return fail(DQ_ERR_HIP, "tail rounds did not finish (round bound hit)");
+        t_info[0] += rounds;
+        t_info[2] += entries;
+        m = 0;
+        return DQ_OK;
+    }
+
     // RL[i] = number of equal bytes the text has from position i on (dq_runs.h): chunk pass, carry across chunks, final pass
     int compute_run_lengths(int period = 1)
     {
@@ -1558,7 +1608,14 @@ struct SuffixSorter {
         bool pair_paid = true;            // the last pair-chain phase finished at least half of its list
         int64_t pair_h = 0;               // h of the last phase
         int64_t abort_h = 0, abort_m = 0; // h and list length when a phase last gave up after its count
+        // (DQ_TAIL_MAX = 0 ... 4096: the list length from which the rest of the sort is one launch; 0 = never)
+        const int64_t tail_max = env("DQ_TAIL_MAX") ? std::max(0, std::min(kTailMax, atoi(env("DQ_TAIL_MAX")))) : kTailMax;
         while (m > 0) {
+            if (m <= tail_max && n < (1ll << 32) && !keys_ready && !list_ungrouped && !first_rank32 && !run_order) {
+                rc = tail_rounds();
+                if (rc != DQ_OK) return rc;
+                break;
+            }
             if (twin_half > 0 && !keys_ready && !list_ungrouped && !run_order) {
                 bool done = false;
                 rc = twin_pairs_step(&done);
@@ -1628,6 +1685,8 @@ struct SuffixSorter {
             // (doubled text: a look at the pairs after every round while the list is long)
             if (only_small_groups && uses_small_round(m) && !keys_ready && !list_ungrouped && (twin_half == 0 || m < (1 << 16)) &&
                 !env("DQ_NO_CHAIN")) {
+                tail_behind_chain = tail_max >= kTailMax && m <= 4 * tail_max && n < (1ll << 32);      // (the kernel's own bound is kTailMax)
+                chain_len = tail_behind_chain ? 2 : kSgChain;
                 rc = doubling_rounds_small_chain();           // several rounds, one host round trip; updates h
                 if (rc != DQ_OK) return rc;
                 continue;

@@ -44,6 +44,10 @@ ENVS = [{}, {}, {}, {"DQ_SMALL_N": "0"}, {"DQ_NO_FUSED_TIES": "1"}, {"DQ_NO_SMAL
         {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_MID_GROUPS": "256", "DQ_PAIR_CHAINS": "0", "DQ_SMALL_N": "0"},
         {"DQ_UPD_WINDOW": "1"}, {"DQ_UPD_WINDOW": "1", "DQ_SMALL_N": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
         {"DQ_UPD_WINDOW": "1", "DQ_RUNS": "1", "DQ_LATE_RUNS_MIN": "1"}, {"DQ_UPD_WINDOW": "0"},
+        {"DQ_TAIL_MAX": "0"}, {"DQ_TAIL_MAX": "0", "DQ_SMALL_N": "0"}, {"DQ_TAIL_MAX": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
+        {"DQ_TAIL_MAX": "0", "DQ_RUNS": "1"}, {"DQ_TAIL_MAX": "0", "DQ_MID_GROUPS": "0"}, {"DQ_TAIL_MAX": "0", "DQ_PAIR_CHAINS": "2"},
+        {"DQ_TAIL_MAX": "77", "DQ_SMALL_N": "0"}, {"DQ_TAIL_MAX": "4096", "DQ_RUNS": "1", "DQ_SMALL_N": "0"},
+        {"DQ_TAIL_MAX": "2000", "DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0"},
         {"DQ_XCD_GROUP": "0"}, {"DQ_XCD_GROUP": "3", "DQ_SMALL_N": "0"}, {"DQ_XCD_GROUP": "64", "DQ_BUCKET": "1"}]
 KEYS = sorted({k for e in ENVS for k in e})
 s = HipSuffixSort(0)

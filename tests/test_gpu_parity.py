@@ -338,37 +338,42 @@ FUZZ_ENVS = [
     {},
     {"DQ_BINNED_ISA": "1", "DQ_SMALL_N": "0"},             # suffix-binned first inverse suffix array on every dense input
     {"DQ_SMALL_N": "0"},                                   # everything through the device-wide pipeline
-    {"DQ_NO_FUSED_TIES": "1", "DQ_NO_SMALL": "1"},         # general rebucket pass, radix-only doubling rounds
+    {"DQ_NO_FUSED_TIES": "1", "DQ_NO_SMALL": "1", "DQ_TAIL_MAX": "0"},         # general rebucket pass, radix-only doubling rounds
     {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2", "DQ_SMALL_N": "0"},   # tie bits with most suffixes tied
     {"DQ_SPARSE": "1", "DQ_SMALL_N": "0"},                 # finisher + key extension + fallback on dense inputs
-    {"DQ_NO_BINNED_ISA": "1", "DQ_NO_CHAIN": "1"},         # first ISA by scatter, one host round trip per small-group round
+    {"DQ_NO_BINNED_ISA": "1", "DQ_NO_CHAIN": "1", "DQ_TAIL_MAX": "0"},         # first ISA by scatter, one host round trip per small-group round
     {"DQ_FORCE_RSHIFT": "1", "DQ_SMALL_N": "0"},           # composite keys carry rank >> 1, true rank read from the ISA (n near 2^32)
     {"DQ_BUCKET": "1", "DQ_SMALL_N": "0"},                 # bucketed round 0 wherever packed words are chosen (+ its fallbacks)
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SMALL_N": "0"},   # round-0 keys from alphabetic codewords
-    {"DQ_MID_GROUPS": "0", "DQ_SMALL_N": "0"},             # doubling rounds with the small-group kernel + radix passes only
+    {"DQ_MID_GROUPS": "0", "DQ_SMALL_N": "0", "DQ_TAIL_MAX": "0"},             # doubling rounds with the small-group kernel + radix passes only
     {"DQ_MID_GROUPS": "256", "DQ_SMALL_N": "0"},           # doubling rounds through the LDS class for groups of up to 256 ...
-    {"DQ_MID_GROUPS": "1024", "DQ_SMALL_N": "0", "DQ_PAIR_CHAINS": "0", "DQ_NO_BINNED_ISA": "1"},   # ... 1024 members
-    {"DQ_RUNS": "1", "DQ_SMALL_N": "0"},                   # run lengths + run-order round on every input
-    {"DQ_RUNS": "1", "DQ_SMALL_N": "0", "DQ_NO_SMALL": "1", "DQ_NO_BINNED_ISA": "1"},
+    {"DQ_MID_GROUPS": "1024", "DQ_SMALL_N": "0", "DQ_PAIR_CHAINS": "0", "DQ_NO_BINNED_ISA": "1", "DQ_TAIL_MAX": "0"},   # ... 1024 members
+    {"DQ_RUNS": "1", "DQ_SMALL_N": "0", "DQ_TAIL_MAX": "0"},                   # run lengths + run-order round on every input
+    {"DQ_RUNS": "1", "DQ_SMALL_N": "0", "DQ_NO_SMALL": "1", "DQ_NO_BINNED_ISA": "1", "DQ_TAIL_MAX": "0"},
     {"DQ_PAIR_CHAINS": "2", "DQ_SMALL_N": "0"},            # tied pairs decided chain by chain as early and as often as allowed
-    {"DQ_PAIR_CHAINS": "2", "DQ_NO_BINNED_ISA": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0"},
-    {"DQ_LATE_RUNS_MIN": "1", "DQ_SMALL_N": "0"},          # run lengths + run-order round as soon as large groups stagnate
-    {"DQ_LATE_RUNS_MIN": "1", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "256", "DQ_PAIR_CHAINS": "0"},
+    {"DQ_PAIR_CHAINS": "2", "DQ_NO_BINNED_ISA": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_TAIL_MAX": "0"},
+    {"DQ_LATE_RUNS_MIN": "1", "DQ_SMALL_N": "0", "DQ_TAIL_MAX": "0"},          # run lengths + run-order round as soon as large groups stagnate
+    {"DQ_LATE_RUNS_MIN": "1", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "256", "DQ_PAIR_CHAINS": "0", "DQ_TAIL_MAX": "0"},
     {"DQ_LATE_RUNS_MIN": "1", "DQ_SMALL_N": "0", "DQ_RUN_PERIOD": "4", "DQ_PAIR_CHAINS": "0"},   # ... with a fixed period of 4
-    {"DQ_UPD_BIN": "2", "DQ_UPD_BIN_MIN": "1", "DQ_SMALL_N": "0"},   # rank updates binned by suffix (two passes) before they are applied
-    {"DQ_UPD_BIN": "1", "DQ_UPD_BIN_MIN": "1", "DQ_SMALL_N": "0", "DQ_RUNS": "1"},   # ... one pass
+    {"DQ_UPD_BIN": "2", "DQ_UPD_BIN_MIN": "1", "DQ_SMALL_N": "0", "DQ_TAIL_MAX": "0"},   # rank updates binned by suffix (two passes) before they are applied
+    {"DQ_UPD_BIN": "1", "DQ_UPD_BIN_MIN": "1", "DQ_SMALL_N": "0", "DQ_RUNS": "1", "DQ_TAIL_MAX": "0"},   # ... one pass
     {"DQ_NO_UPD_WORDS": "1", "DQ_SMALL_N": "0"},           # rank updates as (rank, suffix) in two arrays
     {"DQ_SPARSE": "1", "DQ_BINNED_ISA": "1", "DQ_SMALL_N": "0"},     # suffix-binned inverse suffix array at the sparse-to-dense switch
     # lists of more than n/2 tied suffixes through the LDS class (third list buffer, round 5): 2-byte keys tie nearly everybody
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_SMALL_N": "0"},
-    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_BINNED_ISA": "1", "DQ_UPD_BIN_MIN": "1"},
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_BINNED_ISA": "1", "DQ_UPD_BIN_MIN": "1", "DQ_TAIL_MAX": "0"},
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "0", "DQ_NO_CHAIN": "1"},
-    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_NO_WIDE_SMALL": "1"},   # ... and as before: the radix path
-    {"DQ_NO_L_SHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "256"},   # radix-list keys with the full rank
-    {"DQ_UPD_WINDOW": "1", "DQ_SMALL_N": "0"},             # rank updates applied span by span inside LDS (isa_update_window_kernel)
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_NO_WIDE_SMALL": "1", "DQ_TAIL_MAX": "0"},   # ... and as before: the radix path
+    {"DQ_NO_L_SHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "256", "DQ_TAIL_MAX": "0"},   # radix-list keys with the full rank
+    {"DQ_UPD_WINDOW": "1", "DQ_SMALL_N": "0", "DQ_TAIL_MAX": "0"},             # rank updates applied span by span inside LDS (isa_update_window_kernel)
     {"DQ_UPD_WINDOW": "1", "DQ_SMALL_N": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_RUNS": "1"},
-    {"DQ_UPD_WINDOW": "0", "DQ_SMALL_N": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
-    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "256", "DQ_PAIR_CHAINS": "0"},  # ... many large groups, rank >> 8
+    {"DQ_UPD_WINDOW": "0", "DQ_SMALL_N": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_TAIL_MAX": "0"},
+    # the last rounds of a sort in one launch (dq_tail.h, round 5; default from 4096 tied suffixes down): other switch points, off
+    {"DQ_TAIL_MAX": "64", "DQ_SMALL_N": "0"},
+    {"DQ_TAIL_MAX": "1000", "DQ_SMALL_N": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
+    {"DQ_TAIL_MAX": "4096", "DQ_SMALL_N": "0", "DQ_RUNS": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0"},
+    {"DQ_TAIL_MAX": "0", "DQ_SMALL_N": "0"},
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "256", "DQ_PAIR_CHAINS": "0", "DQ_TAIL_MAX": "0"},  # ... many large groups, rank >> 8
 ]
 
 
@@ -497,35 +502,38 @@ FORCED_PATHS = [
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "3", "DQ_SPARSE": "1"},   # pairs, sparse + fallback to dense
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "0"},   # pairs, 8-byte keys, dense doubling
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "1"},
-    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "4", "DQ_SPARSE": "0", "DQ_NO_SMALL": "1"},   # doubling without the small-group rounds
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "4", "DQ_SPARSE": "0", "DQ_NO_SMALL": "1", "DQ_TAIL_MAX": "0"},   # doubling without the small-group rounds
     {"DQ_NO_FUSED_TIES": "1"},                                   # packed sort + general rebucket pass instead of tie bits
     {"DQ_PACKED": "1", "DQ_KEY_BYTES": "2"},                     # tie bits with MANY ties (dense doubling after them)
     {"DQ_FORCE_RSHIFT": "1"},                                    # doubling rounds with rank >> 1 in the composite key
     {"DQ_FORCE_RSHIFT": "1", "DQ_SPARSE": "1"},
-    {"DQ_FORCE_RSHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "0", "DQ_NO_FIRST_SMALL": "1", "DQ_NO_SMALL": "1", "DQ_BINNED_ISA": "1"},   # ... on a list that came keyed from the binned first ISA
+    {"DQ_FORCE_RSHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "0", "DQ_NO_FIRST_SMALL": "1", "DQ_NO_SMALL": "1", "DQ_BINNED_ISA": "1", "DQ_TAIL_MAX": "0"},   # ... on a list that came keyed from the binned first ISA
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8"},    # coded round-0 keys (dq_alpha_code.h), dense doubling
     {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_SPARSE": "1"},
-    {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_NO_BINNED_ISA": "1", "DQ_NO_SMALL": "1"},
+    {"DQ_CODED": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_NO_BINNED_ISA": "1", "DQ_NO_SMALL": "1", "DQ_TAIL_MAX": "0"},
     {"DQ_MID_GROUPS": "0"},                                      # the two-class rounds: small_group_round_kernel (<= 8 / 32) + radix passes
-    {"DQ_MID_GROUPS": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_NO_CHAIN": "1"},
-    {"DQ_MID_GROUPS": "256"},                                    # tie groups of up to 256 / 512 / 1024 members finished in LDS (dq_mid_groups.h; 1024 is the default)
-    {"DQ_MID_GROUPS": "1024", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
+    {"DQ_MID_GROUPS": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_NO_CHAIN": "1", "DQ_TAIL_MAX": "0"},
+    {"DQ_MID_GROUPS": "256", "DQ_TAIL_MAX": "0"},                                    # tie groups of up to 256 / 512 / 1024 members finished in LDS (dq_mid_groups.h; 1024 is the default)
+    {"DQ_MID_GROUPS": "1024", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_TAIL_MAX": "0"},
     {"DQ_MID_GROUPS": "512", "DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_NO_CHAIN": "1"},
-    {"DQ_RUNS": "1"},                                            # runs of one byte ordered by their own structure (dq_runs.h), forced on
-    {"DQ_RUNS": "1", "DQ_NO_SMALL": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},   # ... through the radix rounds
-    {"DQ_RUNS": "1", "DQ_MID_GROUPS": "256", "DQ_NO_CHAIN": "1", "DQ_PAIR_CHAINS": "0"},
+    {"DQ_RUNS": "1", "DQ_TAIL_MAX": "0"},                                            # runs of one byte ordered by their own structure (dq_runs.h), forced on
+    {"DQ_RUNS": "1", "DQ_NO_SMALL": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_TAIL_MAX": "0"},   # ... through the radix rounds
+    {"DQ_RUNS": "1", "DQ_MID_GROUPS": "256", "DQ_NO_CHAIN": "1", "DQ_PAIR_CHAINS": "0", "DQ_TAIL_MAX": "0"},
     {"DQ_RUNS": "0"},
-    {"DQ_PAIR_CHAINS": "2"},                                     # pair chains (dq_pair_chains.h) before / after every round
-    {"DQ_PAIR_CHAINS": "2", "DQ_NO_BINNED_ISA": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
-    {"DQ_PAIR_CHAINS": "1", "DQ_PACKED": "1", "DQ_KEY_BYTES": "2"},
+    {"DQ_PAIR_CHAINS": "2", "DQ_TAIL_MAX": "0"},                                     # pair chains (dq_pair_chains.h) before / after every round
+    {"DQ_PAIR_CHAINS": "2", "DQ_NO_BINNED_ISA": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_TAIL_MAX": "0"},
+    {"DQ_PAIR_CHAINS": "1", "DQ_PACKED": "1", "DQ_KEY_BYTES": "2", "DQ_TAIL_MAX": "0"},
     {"DQ_NO_WIDE_SMALL": "1"},                                   # lists of more than n/2 entries through the radix rounds (the default before round 5)
-    {"DQ_NO_L_SHIFT": "1"},                                      # radix-list keys of the LDS-class rounds with the full rank (before round 5)
-    {"DQ_UPD_WINDOW": "1"},                                      # rank updates span by span in LDS, forced on every list
-    {"DQ_UPD_WINDOW": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_BINNED_ISA": "1"},
+    {"DQ_NO_L_SHIFT": "1", "DQ_TAIL_MAX": "0"},                                      # radix-list keys of the LDS-class rounds with the full rank (before round 5)
+    {"DQ_UPD_WINDOW": "1", "DQ_TAIL_MAX": "0"},                                      # rank updates span by span in LDS, forced on every list
+    {"DQ_UPD_WINDOW": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_BINNED_ISA": "1", "DQ_TAIL_MAX": "0"},
     {"DQ_UPD_WINDOW": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
-    {"DQ_NO_L_SHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_MID_GROUPS": "256"},
-    {"DQ_NO_WIDE_SMALL": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
-    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_BINNED_ISA": "1", "DQ_UPD_BIN_MIN": "1"},   # wide lists, binned first ISA, binned updates
+    {"DQ_TAIL_MAX": "0"},                                        # no tail kernel: the device-wide rounds to the end (before round 5)
+    {"DQ_TAIL_MAX": "100"},
+    {"DQ_TAIL_MAX": "4096", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_RUNS": "1"},
+    {"DQ_NO_L_SHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_MID_GROUPS": "256", "DQ_TAIL_MAX": "0"},
+    {"DQ_NO_WIDE_SMALL": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_TAIL_MAX": "0"},
+    {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_BINNED_ISA": "1", "DQ_UPD_BIN_MIN": "1", "DQ_TAIL_MAX": "0"},   # wide lists, binned first ISA, binned updates
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_RUNS": "1", "DQ_NO_UPD_WORDS": "1"},        # wide lists, run-order round, two-array updates
 ]
 
