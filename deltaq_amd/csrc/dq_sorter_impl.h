@@ -1287,6 +1287,7 @@ struct SuffixSorter {
     // are tied -- runs two rounds per host round trip instead of eight, so that the hand-over is not slept through)
     int chain_len = kSgChain;
     bool tail_behind_chain = false;
+    int spec_misses = 0;                 // chains that had the tail kernel behind them so far
     int doubling_rounds_small_chain()
     {
         return small_cap > kSgMaxGShort ? small_chain<0>() : small_cap == kSgMaxGShort ? small_chain<kSgMaxGShort>() : small_chain<kSgMaxG>();
@@ -1686,7 +1687,10 @@ struct SuffixSorter {
             if (only_small_groups && uses_small_round(m) && !keys_ready && !list_ungrouped && (twin_half == 0 || m < (1 << 16)) &&
                 !env("DQ_NO_CHAIN")) {
                 tail_behind_chain = tail_max >= kTailMax && m <= 4 * tail_max && n < (1ll << 32);      // (the kernel's own bound is kTailMax)
-                chain_len = tail_behind_chain ? 2 : kSgChain;
+                // (two rounds, then four, then eight per host round trip: a list that hovers just above the tail
+                // kernel's reach -- a long repeat among a few thousand suffixes -- must not pay a round trip every two rounds)
+                chain_len = tail_behind_chain ? std::min(kSgChain, 2 << std::min(spec_misses, 2)) : kSgChain;
+                if (tail_behind_chain) ++spec_misses;
                 rc = doubling_rounds_small_chain();           // several rounds, one host round trip; updates h
                 if (rc != DQ_OK) return rc;
                 continue;
