@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # The library honours its DQ_* overrides (forced code paths, fault injection) only under DQ_DEBUG_FLAGS=1
 # (dq_runtime.h: env()); the tests force paths all the time.  (bench.py runs without it: production behaviour.)
-os.environ.setdefault("DQ_DEBUG_FLAGS", "1")
+os.environ["DQ_DEBUG_FLAGS"] = "1"
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 ASSET_DIR = os.path.join(GOLDEN_DIR, "assets")
