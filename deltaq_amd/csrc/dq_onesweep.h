@@ -35,7 +35,7 @@ constexpr int kMaxPasses = 8;
 // ---------------------------------------------------------------------------------
 template <int kPasses>
 __global__ __launch_bounds__(kHistThreads) void radix_hist_kernel(const uint64_t *__restrict__ keys,
-                                                            int64_t m, uint32_t *__restrict__ partial,
+                                                            int64_t m, unsigned long long *__restrict__ acc /*[kMaxPasses][256], zeroed*/,
                                                             int shift0 = 0 /* digit p sits at bit shift0 + 8 p */)
 {
     __shared__ uint32_t hist[kPasses][kRadixSize * 4];     // kPasses * 4 KiB
@@ -76,9 +76,12 @@ __global__ __launch_bounds__(kHistThreads) void radix_hist_kernel(const uint64_t
         for (int p = 0; p < kPasses; ++p) atomicAdd(&hist[p][digit_of(k, shift0 + p * kRadixBits) << 2], 1u);
     }
     __syncthreads();
+    // (round 5: one global add per workgroup and counter -- 512 adds per address, ~6 us of them spread over the kernel's
+    // life -- instead of per-workgroup partial histograms that a second kernel summed in 38 us for 512 workgroups)
     for (int i = tid; i < kPasses * kRadixSize; i += kHistThreads) {
         const uint32_t *h4 = &(&hist[0][0])[i * 4];
-        partial[(int64_t)blockIdx.x * (kMaxPasses * kRadixSize) + i] = h4[0] + h4[1] + h4[2] + h4[3];
+        const uint32_t c = h4[0] + h4[1] + h4[2] + h4[3];
+        if (c) atomicAdd(&acc[i], (unsigned long long)c);
     }
 }
 
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(kHistThreads) void radix_hist_kernel(const uint64_t
 // builds the keys of 4 consecutive suffixes from 20 text bytes, as the first digit pass will.
 static __global__ __launch_bounds__(kHistThreads) void text_coded_hist_kernel(const uint32_t *__restrict__ t32, int64_t n,
                                                                        const uint16_t *__restrict__ codetab,
-                                                                       uint32_t *__restrict__ partial)
+                                                                       unsigned long long *__restrict__ acc /*[kMaxPasses][256], zeroed*/)
 {
     __shared__ uint32_t hist[kMaxPasses][kRadixSize * 4];
     __shared__ uint16_t ctab[256];
@@ -115,42 +118,20 @@ static __global__ __launch_bounds__(kHistThreads) void text_coded_hist_kernel(co
     __syncthreads();
     for (int i = tid; i < kMaxPasses * kRadixSize; i += kHistThreads) {
         const uint32_t *h4 = &(&hist[0][0])[i * 4];
-        partial[(int64_t)blockIdx.x * (kMaxPasses * kRadixSize) + i] = h4[0] + h4[1] + h4[2] + h4[3];
+        const uint32_t c = h4[0] + h4[1] + h4[2] + h4[3];
+        if (c) atomicAdd(&acc[i], (unsigned long long)c);
     }
 }
 
-// digit_offset[p][d] = number of keys whose digit p is < d   (one workgroup per digit place).
-// The partial sums are a latency chain (nblocks dependent-free but serial loads per digit), so
-// 4 slices of the workgroups are summed side by side and combined through LDS.
-constexpr int kHistScanThreads = 1024;
-static __global__ __launch_bounds__(kHistScanThreads) void radix_hist_scan_kernel(const uint32_t *__restrict__ partial,
-                                                                           int nblocks,
+// digit_offset[p][d] = number of keys whose digit p is < d   (one workgroup of 256 threads per digit place)
+constexpr int kHistScanThreads = kRadixSize;
+static __global__ __launch_bounds__(kHistScanThreads) void radix_hist_scan_kernel(const unsigned long long *__restrict__ acc,
                                                                            int64_t *__restrict__ digit_offset)
 {
-    __shared__ int64_t slice[kHistScanThreads / kRadixSize][kRadixSize];
-    __shared__ int64_t tmp[kWavesPerBlock];
-    const int p = blockIdx.x;
-    const int d = threadIdx.x & (kRadixSize - 1);
-    const int q = threadIdx.x / kRadixSize;
-    int64_t sum = 0;
-#pragma unroll 16
-    for (int g = q; g < nblocks; g += kHistScanThreads / kRadixSize)
-        sum += partial[(int64_t)g * (kMaxPasses * kRadixSize) + p * kRadixSize + d];
-    slice[q][d] = sum;
-    __syncthreads();
-    const int w = threadIdx.x >> 6;
-    int64_t incl = 0;
-    if (threadIdx.x < kRadixSize) {
-        sum = slice[0][d] + slice[1][d] + slice[2][d] + slice[3][d];
-        incl = wave_incl_sum(sum);
-        if (lane_id() == kWave - 1) tmp[w] = incl;
-    }
-    __syncthreads();
-    if (threadIdx.x < kRadixSize) {
-        int64_t off = 0;
-        for (int i = 0; i < w; ++i) off += tmp[i];
-        digit_offset[p * kRadixSize + d] = off + incl - sum;
-    }
+    __shared__ int64_t tmp[kHistScanThreads / kWave];
+    const int p = blockIdx.x, d = threadIdx.x;
+    int64_t total;
+    digit_offset[p * kRadixSize + d] = block_excl_sum((int64_t)acc[p * kRadixSize + d], tmp, &total);
 }
 
 // ---------------------------------------------------------------------------------

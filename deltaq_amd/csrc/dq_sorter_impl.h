@@ -62,7 +62,7 @@ struct Workspace {
     int64_t *bkt_bounds;        // tile bounds of the bucketed round 0 (dq_bucket_sort.h)
     int64_t *totals;            // [0] active count, [1] sticky look-back timeout flag
     SmallGroupCounters *sg_ctr; // one per chained small-group round
-    uint32_t *hist_partial;     // [kHistBlocks][8][256]
+    uint32_t *hist_partial;     // scratch: [8][256] 64-bit digit counters of the histogram kernels in front, pair-chain tables
     uint16_t *codetab;          // [256] codewords of the coded round 0 (dq_alpha_code.h)
     uint32_t *pc_tiles;         // per-tile counts / prefix sums of the pair-chain phase (dq_pair_chains.h)
     uint32_t *RL;               // run lengths of the text (dq_runs.h; int32 indices only)
@@ -248,9 +248,12 @@ int rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const IdxT *
 }
 
 template <int kPasses>
-void launch_hist(hipStream_t st, int blocks, const uint64_t *keys, int64_t m, uint32_t *partial, int shift0 = 0)
+void launch_hist(hipStream_t st, int blocks, const uint64_t *keys, int64_t m, uint32_t *acc_area, int shift0 = 0)
 {
-    hipLaunchKernelGGL(radix_hist_kernel<kPasses>, dim3(blocks), dim3(kHistThreads), 0, st, keys, m, partial, shift0);
+    // (the counters the workgroups add into: the first 16 KB of the histogram scratch area, zeroed here)
+    (void)hipMemsetAsync(acc_area, 0, (size_t)kMaxPasses * kRadixSize * 8, st);
+    hipLaunchKernelGGL(radix_hist_kernel<kPasses>, dim3(blocks), dim3(kHistThreads), 0, st, keys, m,
+                       reinterpret_cast<unsigned long long *>(acc_area), shift0);
 }
 
 // generic pairs: all digit histograms in one read, then one radix_rank_kernel per digit
@@ -273,7 +276,7 @@ int onesweep_sort_pairs(Launcher &L, Workspace<IdxT> &w, uint64_t *K[2], IdxT *V
         default: launch_hist<8>(L.st, blocks, K[cur], m, w.hist_partial, shift0); break;
     }
     hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(passes), dim3(kHistScanThreads), 0, L.st,
-                       (const uint32_t *)w.hist_partial, blocks, w.digit_offset);
+                       (const unsigned long long *)w.hist_partial, w.digit_offset);
     HIP_TRY(hipGetLastError());
     rc = L.end();
     if (rc != DQ_OK) return rc;
@@ -399,10 +402,12 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
             const int hblocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 2) + kHistThreads - 1) / kHistThreads + 1);
             int rc2 = L.begin(DQ_K_RADIX_HIST, n, n);
             if (rc2 != DQ_OK) return rc2;
+            HIP_TRY(hipMemsetAsync(w.hist_partial, 0, (size_t)kMaxPasses * kRadixSize * 8, L.st));
             hipLaunchKernelGGL(text_coded_hist_kernel, dim3(hblocks), dim3(kHistThreads), 0, L.st,
-                               reinterpret_cast<const uint32_t *>(w.text), n, (const uint16_t *)w.codetab, w.hist_partial);
+                               reinterpret_cast<const uint32_t *>(w.text), n, (const uint16_t *)w.codetab,
+                               reinterpret_cast<unsigned long long *>(w.hist_partial));
             hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(kMaxPasses), dim3(kHistScanThreads), 0, L.st,
-                               (const uint32_t *)w.hist_partial, hblocks, w.digit_offset);
+                               (const unsigned long long *)w.hist_partial, w.digit_offset);
             HIP_TRY(hipGetLastError());
             rc2 = L.end();
             if (rc2 != DQ_OK) return rc2;
@@ -1176,7 +1181,7 @@ struct SuffixSorter {
         if (passes == 2) launch_hist<2>(st, blocks, U, cnt, w.hist_partial, sh0);
         else launch_hist<1>(st, blocks, U, cnt, w.hist_partial, sh0);
         hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(passes), dim3(kHistScanThreads), 0, st,
-                           (const uint32_t *)w.hist_partial, blocks, w.digit_offset);
+                           (const unsigned long long *)w.hist_partial, w.digit_offset);
         HIP_TRY(hipGetLastError());
         rc = L.end();
         if (rc != DQ_OK) return rc;

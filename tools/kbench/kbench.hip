@@ -112,8 +112,9 @@ int main(int argc, char **argv)
 
     const int shift = 8;
     // ---- global histograms
-    float t_h = time_it([&]() { hipLaunchKernelGGL(radix_hist_kernel<8>, dim3(kHistBlocks), dim3(kHistThreads), 0, 0, B.k0, m, B.partial); });
-    float t_hs = time_it([&]() { hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(8), dim3(kHistScanThreads), 0, 0, B.partial, kHistBlocks, B.digit_offset); });
+    float t_h = time_it([&]() { CK(hipMemsetAsync(B.partial, 0, 8 * 256 * 8));
+                                hipLaunchKernelGGL(radix_hist_kernel<8>, dim3(kHistBlocks), dim3(kHistThreads), 0, 0, B.k0, m, reinterpret_cast<unsigned long long *>(B.partial), 0); });
+    float t_hs = time_it([&]() { hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(8), dim3(kHistScanThreads), 0, 0, reinterpret_cast<const unsigned long long *>(B.partial), B.digit_offset); });
     printf("hist (8 digits, one read) %8.1f us (%.1f GB/s)   hist_scan %6.1f us\n", t_h * 1e3, (double)m * 8 / (t_h * 1e-3) / 1e9, t_hs * 1e3);
 
     if (argc > 4) {     // profiling target: one variant only
