@@ -344,16 +344,17 @@ void choose_key_bytes(const int64_t *bytehist, const int64_t *kgram_coll, int64_
 // round 0, step 1: byte histogram of the text -> key width kb -> per-digit offsets
 template <typename IdxT>
 int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int *kb_out,
-                               bool *packed_out, bool *coded_out)
+                               bool *packed_out, bool *coded_out, const uint8_t *text_src = nullptr)
 {
     *coded_out = false;
     const int blocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 4) + kBlock - 1) / kBlock + 1);
     HIP_TRY(hipMemsetAsync(w.bytehist, 0, (256 + 10) * 8, L.st));
     // (+1 workgroup: the k-gram sample, whose 8 counters sit right behind the byte histogram: one readback)
     LAUNCH(L, DQ_K_TEXT_HIST, n, n,
+           // (text_src: the caller's device buffer, not copied yet -- this pass reads it and fills w.text, see the kernel)
            hipLaunchKernelGGL(text_hist_kernel, dim3(blocks + 1), dim3(kBlock), 0, L.st,
-                              (const uint8_t *)w.text, n, reinterpret_cast<unsigned long long *>(w.bytehist),
-                              reinterpret_cast<unsigned long long *>(w.bytehist + 256)));
+                              text_src ? text_src : (const uint8_t *)w.text, n, reinterpret_cast<unsigned long long *>(w.bytehist),
+                              reinterpret_cast<unsigned long long *>(w.bytehist + 256), text_src ? w.text : (uint8_t *)nullptr));
     int kb = 8;
     bool packed = false;
     HIP_TRY(hipMemcpyAsync(c.pinned, w.bytehist, (256 + 10) * 8, hipMemcpyDeviceToHost, L.st));
@@ -913,7 +914,7 @@ struct SuffixSorter {
         bool packed = false, coded = false;
         // pass p writes buffer (p+1)&1, so the last pass (kb-1) writes buffer kb&1: that one
         // must be the caller's SA, which is why the key width is chosen first
-        rc = onesweep_sort_text_prepare<IdxT>(L, c, w, n, &kb, &packed, &coded);
+        rc = onesweep_sort_text_prepare<IdxT>(L, c, w, n, &kb, &packed, &coded, text_src);
         if (rc != DQ_OK) return rc;
         // (c.pinned still holds the byte histogram, the k-gram sample and the long-run flag of text_hist_kernel)
         // (run lengths + the run-order round cost about one doubling round: worth it where a good part of the text lies
@@ -1537,6 +1538,7 @@ struct SuffixSorter {
     // ---- doubled text (dq_small_groups.h, twin_mark_kernel): the tie groups that are a pair (i, i + half) are written
     //      down and leave the list; *done: nothing is left.
     int64_t twin_half = 0;
+    const uint8_t *text_src = nullptr;   // the caller's device-resident text when w.text is still to be filled from it
     int period_hint = 0;                // (SortHints::run_period)
     int twin_pairs_step(bool *done)
     {
@@ -1750,7 +1752,8 @@ int set_spin_fault(int dev)
 }
 
 template <typename IdxT>
-int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, IdxT *d_sa, SortHints hints = SortHints())
+int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, IdxT *d_sa, SortHints hints = SortHints(),
+                   const uint8_t *text_src = nullptr)
 {
     const int frc = set_spin_fault<IdxT>(c.dev);
     if (frc != DQ_OK) return frc;
@@ -1758,6 +1761,7 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
     // (DQ_ASSUME_DOUBLED: the tests vouch for their inputs through the public entry points)
     if ((hints.doubled || env("DQ_ASSUME_DOUBLED")) && n % 2 == 0 && !env("DQ_NO_TWINS")) sorter.twin_half = n / 2;
     if (hints.run_period > 0 && !env("DQ_NO_PERIOD_HINT")) sorter.period_hint = hints.run_period;
+    sorter.text_src = text_src;
     return sorter.run();
 }
 
@@ -1863,9 +1867,12 @@ int sufsort_dev(const void *d_text, int64_t n, void *d_sa, int32_t device, void 
     if (rc != DQ_OK) return rc;
     w = carve<IdxT>(c.ws, n, false);
     hipStream_t st = stream ? (hipStream_t)stream : c.stream;
-    HIP_TRY(hipMemcpyAsync(w.text, d_text, (size_t)n, hipMemcpyDeviceToDevice, st));
+    // The library works on a padded, 16-byte aligned copy of the text.  The copy is made by the pass that reads the
+    // text first anyway (text_hist_kernel) when the caller's buffer is 16-byte aligned; DQ_TEXT_COPY=1: by a copy in front.
+    const bool fused_copy = (reinterpret_cast<uintptr_t>(d_text) & 15) == 0 && !env("DQ_TEXT_COPY");
+    if (!fused_copy) HIP_TRY(hipMemcpyAsync(w.text, d_text, (size_t)n, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemsetAsync(w.text + n, 0, 64, st));
-    rc = sufsort_device<IdxT>(c, st, w, n, (IdxT *)d_sa);
+    rc = sufsort_device<IdxT>(c, st, w, n, (IdxT *)d_sa, SortHints(), fused_copy ? (const uint8_t *)d_text : nullptr);
     if (rc != DQ_OK) { drop_pending(c, st); return rc; }
     HIP_TRY(hipStreamSynchronize(st));
     return DQ_OK;

@@ -435,6 +435,23 @@ def test_device_resident_entry_point(ldss, oracle_mod):
     assert np.array_equal(out.cpu().numpy(), oracle_mod.divsufsort(T[3:777_777]))
 
 
+@pytest.mark.parametrize("copy_in_front", [False, True])
+def test_device_text_is_copied_by_the_histogram_pass(ldss, oracle_mod, monkeypatch, copy_in_front):
+    """The library's padded copy of a device-resident text is written by the pass that reads the text first
+    (text_hist_kernel, 16-byte chunks + a byte tail) when the caller's buffer is 16-byte aligned, by a copy in front
+    otherwise (DQ_TEXT_COPY=1 forces that): lengths around the chunking, offsets 0 .. 17 into an allocation, and a
+    buffer that is followed by non-zero bytes (the pad behind the text must be the library's zeros, not the caller's)."""
+    import torch
+    if copy_in_front:
+        monkeypatch.setenv("DQ_TEXT_COPY", "1")
+    base = oracle_mod.gen_enwik_like(300_000, 9, 4096)
+    big = torch.from_numpy(np.concatenate([base, np.full(4096, 0x41, np.uint8)])).cuda()      # 'A's behind every slice
+    for off, n in [(0, 300_000), (0, 299_999), (0, 70_001), (16, 100_000), (16, 99_985), (1, 65_537), (17, 65_600), (32, 8_193), (0, 16_400)]:
+        dT = big[off:off + n]
+        got = ldss.Sort(dT).cpu().numpy()
+        assert np.array_equal(got, oracle_mod.divsufsort(base[off:off + n])), (off, n, copy_in_front)
+
+
 def test_full_size_config_by_properties(ldss, oracle_mod):
     """BASELINE configs[1]: 64 MiB uniform random, checked by the size-independent
     properties the reference's own Verify uses (sufcheck is O(n); sampled strict order)."""
