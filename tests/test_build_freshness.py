@@ -51,3 +51,15 @@ def test_object_freshness_follows_content_not_time(tmp_path, monkeypatch):
     # other flags, other object
     monkeypatch.setattr(b, "FLAGS", b.FLAGS + ["-DX"])
     assert b._obj_stale("unit.hip")
+
+
+def test_timing_experiment_patch_still_applies():
+    """The timing switches (DQ_EXPERIMENT_*) live outside the shipped kernels, as a patch: it must keep applying to them."""
+    import shutil
+    import subprocess
+    import pytest
+    if not shutil.which("git"):
+        pytest.skip("no git")
+    p = subprocess.run(["git", "apply", "--check", "-p1", os.path.join("tools", "exp", "timing_experiments.patch")],
+                       cwd=ROOT, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
