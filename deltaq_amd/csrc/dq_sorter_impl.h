@@ -347,7 +347,11 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
                                bool *packed_out, bool *coded_out, const uint8_t *text_src = nullptr)
 {
     *coded_out = false;
-    const int blocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 4) + kBlock - 1) / kBlock + 1);
+    // (256-thread workgroups: the pass is a chain of 16-byte loads and LDS adds, bound by how many are in flight.  512 / 1024 /
+    // 2048 / 4096 workgroups at 256 MiB: 165 / 131 / 139 / 143 us -- more waves hide more latency until the 256 global adds
+    // each workgroup ends with pile up.  DQ_TEXT_HIST_BLOCKS tries other grids.)
+    const int64_t hist_cap = env("DQ_TEXT_HIST_BLOCKS") ? std::max(1, std::min(8192, atoi(env("DQ_TEXT_HIST_BLOCKS")))) : 1024;
+    const int blocks = (int)std::min<int64_t>(hist_cap, ((n >> 4) + kBlock - 1) / kBlock + 1);
     HIP_TRY(hipMemsetAsync(w.bytehist, 0, (256 + 10) * 8, L.st));
     // (+1 workgroup: the k-gram sample, whose 8 counters sit right behind the byte histogram: one readback)
     LAUNCH(L, DQ_K_TEXT_HIST, n, n,
