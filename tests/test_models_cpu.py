@@ -629,3 +629,96 @@ def test_windowed_anchor_search_equals_the_loop(oracle_mod):
         assert np.array_equal(diff[:lens[1]], wd) and np.array_equal(extra[:lens[2]], we), trial
     assert stops > 100 and windows > 1000            # the stop-point path was exercised
     assert bound_stops > stops                       # ... and so were the bounds that could not decide
+
+
+# ---- dq_tail.h: the last doubling rounds in one workgroup; dq_mid_groups.h's shifted radix-list keys -----------------
+def tail_rounds_model(T, h0):
+    """tail_rounds_kernel on the CPU: start from the groups of suffixes that share their first h0 bytes (rank = the SA
+    index of the group's first member), keep only the tied ones as the list, then round after round: key2 = ISA[s + h] + h
+    (n - 1 - s past the end), place = #(smaller key2) + #(equal before), SA / ISA written for what is decided, the rest
+    compacted in slot order.  Returns (SA, rounds)."""
+    n = T.size
+    pad = np.concatenate([T, np.zeros(h0, np.uint8)]).astype(np.int64)
+    keys = [tuple(pad[i:i + h0]) + (min(h0, n - i),) for i in range(n)]       # (bytes, valid length): a proper prefix first
+    order = sorted(range(n), key=lambda i: keys[i])
+    SA = np.full(n, -1, np.int64)
+    ISA = np.zeros(n, np.int64)
+    lst = []                                                                  # (rank, suffix), groups adjacent
+    p = 0
+    while p < n:
+        q = p
+        while q < n and keys[order[q]] == keys[order[p]]:
+            q += 1
+        for j in range(p, q):
+            ISA[order[j]] = p
+        if q - p == 1:
+            SA[p] = order[p]
+        else:
+            lst += [(p, order[j]) for j in range(p, q)]
+        p = q
+    h, rounds = h0, 0
+    while lst:
+        rounds += 1
+        assert rounds < 80
+        key2 = [int(ISA[s + h]) + h if s + h < n else n - 1 - s for _, s in lst]
+        nxt, slots, i = [], [None] * len(lst), 0
+        while i < len(lst):
+            j = i
+            while j < len(lst) and lst[j][0] == lst[i][0]:
+                j += 1
+            for a in range(i, j):                                             # place inside the group
+                less = sum(1 for b in range(i, j) if key2[b] < key2[a])
+                eq = sum(1 for b in range(i, j) if key2[b] == key2[a])
+                eq_before = sum(1 for b in range(i, a) if key2[b] == key2[a])
+                slots[i + less + eq_before] = (lst[a][0] + less, lst[a][1], eq > 1, less != 0)
+            i = j
+        for r, s, tied, moved in slots:
+            if moved:
+                ISA[s] = r
+            if tied:
+                nxt.append((r, s))
+            else:
+                SA[r] = s
+        lst = nxt
+        h *= 2
+    return SA, rounds
+
+
+def test_tail_rounds_model_gives_the_suffix_array(oracle_mod):
+    rng = np.random.default_rng(41)
+    cases = [np.zeros(300, np.uint8), np.frombuffer(b"abracadabra" * 30, np.uint8), rng.integers(0, 2, 500).astype(np.uint8),
+             np.concatenate([rng.integers(0, 256, 400), np.zeros(9)]).astype(np.uint8)]
+    x = rng.integers(0, 4, 300).astype(np.uint8)
+    cases.append(np.concatenate([x, x[50:250], x[:100]]))                      # long repeats: many rounds
+    for T in cases:
+        T = np.ascontiguousarray(T)
+        for h0 in (1, 2, 4):
+            SA, rounds = tail_rounds_model(T, h0)
+            assert np.array_equal(SA, oracle_mod.divsufsort(T).astype(np.int64)), (T.size, h0)
+            assert rounds >= 1
+
+
+def test_shifted_rank_field_keeps_large_groups_apart_in_order():
+    """The radix list of an LDS-class round holds groups of MORE than cap members, so the ranks (first SA index) of two
+    of them differ by more than cap = 2^shift: rank >> shift is still strictly increasing over the groups, and
+    (rank >> shift) << (kbits + shift) | key2 << shift | (rank & (2^shift - 1)) sorts like rank << kbits | key2 when only
+    the bits above `shift` are looked at -- while the full rank can be put together again from both ends of the word."""
+    rng = np.random.default_rng(7)
+    for shift in (8, 9, 10):
+        cap = 1 << shift
+        sizes = rng.integers(cap + 1, 4 * cap, 200)
+        gaps = rng.integers(0, 3 * cap, 200)                                  # resolved suffixes / small groups in between
+        ranks, r = [], int(rng.integers(0, 1000))
+        for g, gap in zip(sizes, gaps):
+            ranks.append(r)
+            r += int(g) + int(gap)
+        kbits = 30
+        shifted = [x >> shift for x in ranks]
+        assert all(a < b for a, b in zip(shifted, shifted[1:]))
+        for x in ranks[:50]:
+            for k2 in (0, 1, (1 << kbits) - 1):
+                word = ((x >> shift) << (kbits + shift)) | (k2 << shift) | (x & (cap - 1))
+                assert word < (1 << 64)
+                field = word >> shift
+                assert field == ((x >> shift) << kbits) | k2                                  # what the digit passes sort by
+                assert ((field >> kbits) << shift) | (word & (cap - 1)) == x                  # what the rebucket pass reads back
