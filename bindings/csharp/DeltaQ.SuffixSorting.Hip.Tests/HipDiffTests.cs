@@ -88,6 +88,31 @@ public sealed class HipDiffTests
     }
 
     [Fact]
+    public void ACloneOfAnIndexGivesTheSamePatchesAndOutlivesItsSource()
+    {
+        // dq_bsdiff_index_clone: text + suffix array + prefix table copied device to device (xGMI between the devices of a
+        // node); here onto the same device, as tests/test_gpu_bsdiff.py::test_index_clone_gives_the_same_patches does
+        byte[] oldData = RandomBytes(1 << 20, 5);
+        byte[] newData = oldData.Take(300_000).Concat(RandomBytes(77, 9)).Concat(oldData.Skip(300_040)).ToArray();
+        HipDiffIndex copy;
+        using (var index = new HipDiffIndex(oldData))
+        {
+            copy = index.Clone(0);
+        }
+
+        using (copy)
+        {
+            byte[] patch = copy.Create(newData);
+            Assert.Equal(HipDiff.CreateBytes(oldData, newData, -1, out long len).AsSpan(0, (int)len).ToArray(), patch);
+            Assert.Equal(newData, ManagedApply(oldData, patch));
+            long[] info = HipDiff.LastDiffInfo();                 // searches, windows, stop points, host-loop fall-backs, workgroups
+            Assert.Equal(5, info.Length);
+            Assert.True(info[0] > 0);
+            Assert.Equal(0, info[3]);                             // an idle device: the scan ran on it
+        }
+    }
+
+    [Fact]
     public void CorruptPatchesAreRejectedLikeTheReference()
     {
         byte[] oldData = RandomBytes(4096, 1);
