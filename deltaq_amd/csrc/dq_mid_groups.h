@@ -36,9 +36,16 @@ constexpr int kMgSpan = kMgThreads * kMgItems;          // list positions whose 
 constexpr int kMgWaves = kMgThreads / kWave;
 template <int kG> constexpr int mg_tile() { return kMgSpan - kG; }      // heads it owns
 
-// (int32: 57-62 KB of LDS and <= 64 VGPRs, so that two workgroups share a CU -- twice the random gathers in flight)
-template <typename IdxT, int kG>
-__global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_group_round_kernel(
+// kSteps > 1 (round 5; short lists whose groups all fit the class -- the chained rounds): a member's key is the TUPLE
+// (ISA[s + h], ISA[s + 2h], ... ISA[s + kSteps h]) -- ranks at depth >= h of the next kSteps stretches of h bytes -- so a round
+// compares (kSteps + 1) h bytes and the depth grows (kSteps + 1)-fold instead of doubling: a repeat of L bytes keeps its
+// suffixes tied for log_{kSteps+1}(L / h) rounds instead of log2.  The rounds of a short list are latency, not traffic
+// (20 us + 7 us of launches each whatever the list's length), so three gathers per member instead of one are free there;
+// long lists are bound by the sectors their gathers move and keep kSteps = 1.  A suffix that ends inside
+// stretch j has (n - 1 - s) - j h there -- < h, below every in-range value, the shorter suffix first -- and 0 behind it.
+// (int32, kSteps = 1: 57-62 KB of LDS and <= 64 VGPRs, so that two workgroups share a CU -- twice the random gathers in flight)
+template <typename IdxT, int kG, int kSteps = 1>
+__global__ __launch_bounds__(kMgThreads, (sizeof(IdxT) == 4 && kSteps == 1) ? 8 : 4) void mid_group_round_kernel(
     const uint64_t *__restrict__ rank, const IdxT *__restrict__ suf, const IdxT *__restrict__ ISA,
     int64_t m, int64_t n, int64_t h, int kbits, IdxT *__restrict__ SA,
     uint64_t *__restrict__ t_rank, IdxT *__restrict__ t_suf,
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
     static_assert(kScan < 0x7fff, "head positions are 16-bit");
 
     __shared__ ElemT s_rank[kScan + 1];                 // [kScan] = the closer behind the span; later: slot_dest
-    __shared__ ElemT s_key2[kMgSpan];                   // later: slot_rank
+    __shared__ ElemT s_key2[kSteps][kMgSpan];           // [0] later: slot_rank
     constexpr int kMixBytes = 4 * kScan > kMgSpan * (int)sizeof(IdxT) ? 4 * kScan : kMgSpan * (int)sizeof(IdxT);
     __shared__ __attribute__((aligned(16))) char s_mix[kMixBytes];                  // s_head + s_gsize, later slot_suf
     __shared__ uint8_t slot_flag[kMgSpan];
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
     uint16_t *s_gsize = reinterpret_cast<uint16_t *>(s_mix) + kScan;   // [kScan] by head position
     IdxT *slot_suf = reinterpret_cast<IdxT *>(s_mix);
     ElemT *slot_dest = s_rank;
-    ElemT *slot_rank = s_key2;
+    ElemT *slot_rank = s_key2[0];
 
     const int t = threadIdx.x;
     const int lane = lane_id();
@@ -139,6 +146,7 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
 
     // ---- classify the span positions (striped from here on: e = k * kMgThreads + t) ----
     ElemT r[kMgItems], k2[kMgItems];
+    ElemT kx[kMgItems][kSteps > 1 ? kSteps - 1 : 1];  // the further elements of the key tuple (kSteps > 1)
     int ghead[kMgItems], gsize[kMgItems];               // span position of the group's head, its size (owned groups)
     bool own[kMgItems], own_large[kMgItems];
 #pragma unroll
@@ -158,6 +166,8 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
 #pragma unroll
     for (int k = 0; k < kMgItems; ++k) {
         k2[k] = 0;
+#pragma unroll
+        for (int j = 1; j < kSteps; ++j) kx[k][j - 1] = 0;
         if (own[k] || own_large[k]) {
             // (dq_runs.h: a member that starts with a run of >= h equal bytes takes the rank behind its run; in the
             // run-order round its key is the run's own order, and everybody else's 0 -- no split)
@@ -171,11 +181,25 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
             if (!keyed) {
                 const int64_t q = (int64_t)s[k] + off;
                 k2[k] = q < n ? (ElemT)((int64_t)ISA[q] + h) : (off > h ? (ElemT)0 : (ElemT)(n - 1 - (int64_t)s[k]));   // as gather_key2_kernel
+                if (kSteps > 1) {
+                    // (no run lengths on this path: the host takes kSteps > 1 only without them)
+#pragma unroll
+                    for (int j = 1; j < kSteps; ++j) {
+                        const int64_t qj = (int64_t)s[k] + (int64_t)(j + 1) * h, qp = (int64_t)s[k] + (int64_t)j * h;
+                        kx[k][j - 1] = qj < n ? (ElemT)((int64_t)ISA[qj] + h) : (qp < n ? (ElemT)(n - 1 - (int64_t)s[k] - (int64_t)j * h) : (ElemT)0);
+                    }
+                }
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < kMgItems; ++k) s_key2[k * kMgThreads + t] = k2[k];
+    for (int k = 0; k < kMgItems; ++k) {
+        s_key2[0][k * kMgThreads + t] = k2[k];
+        if (kSteps > 1) {
+#pragma unroll
+            for (int j = 1; j < kSteps; ++j) s_key2[j][k * kMgThreads + t] = kx[k][j - 1];
+        }
+    }
     __syncthreads();
 
     // ---- place: walk the group ----
@@ -192,10 +216,19 @@ __global__ __launch_bounds__(kMgThreads, sizeof(IdxT) == 4 ? 8 : 4) void mid_gro
             int less = 0, eq = 0, eq_before = 0;
             const int g0 = ghead[k], me = e - g0;
             for (int i = 0; i < gsize[k]; ++i) {
-                const ElemT o = s_key2[g0 + i];
-                less += o < k2[k];
-                eq += o == k2[k];
-                eq_before += (o == k2[k]) && i < me;
+                const ElemT o = s_key2[0][g0 + i];
+                bool lt = o < k2[k], same = o == k2[k];
+                if (kSteps > 1) {
+#pragma unroll
+                    for (int j = 1; j < kSteps; ++j) {
+                        const ElemT oj = s_key2[j][g0 + i];
+                        lt = lt || (same && oj < kx[k][j - 1]);
+                        same = same && oj == kx[k][j - 1];
+                    }
+                }
+                less += lt;
+                eq += same;
+                eq_before += same && i < me;
             }
             slot[k] = g0 + less + eq_before;
             nrank[k] = r[k] + (ElemT)less;

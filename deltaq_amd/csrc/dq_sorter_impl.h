@@ -1308,8 +1308,10 @@ struct SuffixSorter {
     }
 
     // one round of mid_group_round_kernel<kG> on the list (A, As)[0, mm); prev: the previous chained round's counters
+    // steps: elements of the key tuple (dq_mid_groups.h, kSteps): 1, or 3 on the chained rounds of short lists
+    static constexpr int kChainSteps = 3;
     int launch_mid_round(int g, int64_t mm, const uint64_t *A, const IdxT *As, const RoundLayout &lay, int64_t hh, int kbits,
-                         SmallGroupCounters *ctr, const SmallGroupCounters *prev, int64_t alg_bytes, int l_shift = 0)
+                         SmallGroupCounters *ctr, const SmallGroupCounters *prev, int64_t alg_bytes, int l_shift = 0, int steps = 1)
     {
         const int64_t tile = g == 256 ? mg_tile<256>() : g == 512 ? mg_tile<512>() : mg_tile<1024>();
         const dim3 grid((unsigned)((mm + tile - 1) / tile));
@@ -1320,6 +1322,11 @@ struct SuffixSorter {
                                       first_rank32, upd_ib(), l_shift));
             return DQ_OK;
         };
+        if constexpr (sizeof(IdxT) == 4) {               // (64-bit key tuples do not fit the LDS: int64 sorts keep one step)
+            if (steps == kChainSteps)
+                return g == 256 ? go(mid_group_round_kernel<IdxT, 256, kChainSteps>) : g == 512 ? go(mid_group_round_kernel<IdxT, 512, kChainSteps>)
+                                                                                                 : go(mid_group_round_kernel<IdxT, 1024, kChainSteps>);
+        }
         return g == 256 ? go(mid_group_round_kernel<IdxT, 256>) : g == 512 ? go(mid_group_round_kernel<IdxT, 512>)
                                                                             : go(mid_group_round_kernel<IdxT, 1024>);
     }
@@ -1330,6 +1337,12 @@ struct SuffixSorter {
         const int64_t m_in = m;
         HIP_TRY(hipMemsetAsync(w.sg_ctr, 0, (kSgChain + 2) * sizeof(SmallGroupCounters), st));
         int64_t hr = h;
+        // Short lists (launch-bound rounds) compare (kChainSteps + 1) h bytes a round instead of 2 h: the key of a member is
+        // the tuple of the ranks h, 2h, 3h bytes further on.  Not with run lengths in force (a member inside a run takes
+        // ONE rank, behind its run) and not on long lists, whose rounds are bound by the sectors their gathers move.
+        // DQ_CHAIN_STEPS = 1 | 3 overrides.
+        int steps = (kCap == 0 && sizeof(IdxT) == 4 && m_in < kSgShortList && !runs_on) ? kChainSteps : 1;
+        if (const char *v = env("DQ_CHAIN_STEPS")) steps = (atoi(v) >= kChainSteps && kCap == 0 && sizeof(IdxT) == 4 && !runs_on) ? kChainSteps : 1;
         for (int r = 0; r < chain_len; ++r) {
             uint64_t *A = Kr[rcur], *B = Kr[rcur ^ 1];
             IdxT *As = Vr[rcur], *Bs = Vr[rcur ^ 1];
@@ -1338,7 +1351,7 @@ struct SuffixSorter {
             const int kbits = std::min(bit_length((uint64_t)(n - 1) + (uint64_t)hr), 64 - rbits);   // (no radix keys are made)
             if constexpr (kCap == 0) {                                       // (every group has <= small_cap members here)
                 const int rc = launch_mid_round(small_cap, m_in, A, As, lay, hr, kbits, w.sg_ctr + r,
-                                                r == 0 ? (const SmallGroupCounters *)nullptr : w.sg_ctr + r - 1, 0);
+                                                r == 0 ? (const SmallGroupCounters *)nullptr : w.sg_ctr + r - 1, 0, 0, steps);
                 if (rc != DQ_OK) return rc;
             } else {
                 constexpr int kTile = sg_tile<kCap>();                       // (every group has <= kCap members here)
@@ -1353,7 +1366,7 @@ struct SuffixSorter {
                                       (const uint64_t *)lay.u_end, (const IdxT *)lay.u_suf_end, (int64_t)0, w.ISA,
                                       (const SmallGroupCounters *)(w.sg_ctr + r), kCap == 0 ? upd_ib() : 0));
             rcur ^= 1;
-            hr *= 2;
+            hr *= (kCap == 0 ? steps + 1 : 2);
         }
         // A list within reach of the tail kernel: it is launched right behind the chain, on the list and at the depth the
         // chain leaves, and reads the list's length on the device -- if that is <= kTailMax the sort ends in this same
@@ -1362,9 +1375,8 @@ struct SuffixSorter {
         const bool spec_tail = tail_behind_chain;
         if (spec_tail) {
             LAUNCH(L, DQ_K_SMALL_ROUND, m_in, 0,
-                   hipLaunchKernelGGL(tail_rounds_kernel<IdxT>, dim3(1), dim3(kTailThreads), 0, st, (const uint64_t *)Kr[rcur],
-                                      (const IdxT *)Vr[rcur], (int)0, n, hr, w.ISA, d_sa, rl(), res,
-                                      (const unsigned long long *)&w.sg_ctr[chain_len - 1].tied_moved));
+                   launch_tail((const uint64_t *)Kr[rcur], (const IdxT *)Vr[rcur], (int)0, hr, res,
+                               (const unsigned long long *)&w.sg_ctr[chain_len - 1].tied_moved));
         }
         HIP_TRY(hipMemcpyAsync(c.pinned, w.sg_ctr, (kSgChain + 2) * sizeof(SmallGroupCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1498,6 +1510,22 @@ struct SuffixSorter {
         return DQ_OK;
     }
 
+    // (the three-step form of the tail kernel where its 32-bit keys hold rank + h and no run lengths are in force)
+    void launch_tail(const uint64_t *rank, const IdxT *suf, int mm, int64_t hh, TailResult *res, const unsigned long long *m_dev)
+    {
+        const bool three = sizeof(IdxT) == 4 && !runs_on && !(env("DQ_CHAIN_STEPS") && atoi(env("DQ_CHAIN_STEPS")) < kChainSteps);
+        if constexpr (sizeof(IdxT) == 4) {
+            if (three) {
+                hipLaunchKernelGGL((tail_rounds_kernel<IdxT, uint32_t, kChainSteps>), dim3(1), dim3(kTailThreads), 0, st, rank, suf, mm, n, hh,
+                                   w.ISA, d_sa, (const uint32_t *)nullptr, res, m_dev);
+                return;
+            }
+        }
+        (void)three;
+        hipLaunchKernelGGL((tail_rounds_kernel<IdxT, uint64_t, 1>), dim3(1), dim3(kTailThreads), 0, st, rank, suf, mm, n, hh, w.ISA, d_sa,
+                           rl(), res, m_dev);
+    }
+
     // ---- the last rounds in one launch (dq_tail.h): at most kTailMax tied suffixes, one workgroup, the list in LDS
     int tail_rounds()
     {
@@ -1505,8 +1533,7 @@ struct SuffixSorter {
         static_assert(sizeof(TailResult) <= 2 * sizeof(SmallGroupCounters), "the result sits behind the chain counters");
         HIP_TRY(hipMemsetAsync(res, 0, sizeof(TailResult), st));
         LAUNCH(L, DQ_K_SMALL_ROUND, m, m * (8 + wb + wb + 64),
-               hipLaunchKernelGGL(tail_rounds_kernel<IdxT>, dim3(1), dim3(kTailThreads), 0, st, (const uint64_t *)Kr[rcur],
-                                  (const IdxT *)Vr[rcur], (int)m, n, h, w.ISA, d_sa, rl(), res));
+               launch_tail((const uint64_t *)Kr[rcur], (const IdxT *)Vr[rcur], (int)m, h, res, (const unsigned long long *)nullptr));
         HIP_TRY(hipMemcpyAsync(c.pinned, res, sizeof(TailResult), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const int64_t rounds = c.pinned[0], entries = c.pinned[1], left = c.pinned[2];

@@ -26,7 +26,7 @@ constexpr int kTailThreads = 1024;
 constexpr int kTailItems = 4;
 constexpr int kTailMax = kTailThreads * kTailItems;       // 4096 list entries
 constexpr int kTailWaves = kTailThreads / kWave;
-constexpr int kTailMaxRounds = 80;                        // h doubles: 64 rounds exhaust any int64 length
+constexpr int kTailMaxRounds = 80;                        // h at least doubles: 64 rounds exhaust any int64 length
 
 struct TailResult {
     unsigned long long rounds;        // rounds run
@@ -34,7 +34,10 @@ struct TailResult {
     unsigned long long left;          // entries still tied at the end (0 unless the round bound was hit)
 };
 
-template <typename IdxT>
+// KeyT / kSteps: key2 values as 32-bit words and three of them per member -- (ISA[s + h], ISA[s + 2h], ISA[s + 3h]), the depth
+// grows 4-fold a round, see dq_mid_groups.h -- where rank + h fits 32 bits (int32 indices) and no run lengths are in force;
+// one 64-bit key otherwise.
+template <typename IdxT, typename KeyT = uint64_t, int kSteps = 1>
 __global__ __launch_bounds__(kTailThreads) void tail_rounds_kernel(
     const uint64_t *__restrict__ rank_in, const IdxT *__restrict__ suf_in, int m, int64_t n, int64_t h,
     IdxT *__restrict__ ISA, IdxT *__restrict__ SA, const uint32_t *__restrict__ RL /* run lengths, or none */,
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_rounds_kernel(
 {
     // (n < 2^32 on this path: ranks and suffixes fit 32 bits; key2 = rank + h may not)
     __shared__ uint32_t s_rank[2][kTailMax], s_suf[2][kTailMax];
-    __shared__ uint64_t s_key[kTailMax];
+    __shared__ KeyT s_key[kSteps][kTailMax];
     __shared__ int16_t s_g0[kTailMax];                     // first list position of the entry's group
     __shared__ uint16_t s_gsz[kTailMax];                   // by head position: members of the group
     __shared__ uint8_t s_flag[kTailMax];                   // by slot: 1 resolved, 2 still tied, 4 rank moved
@@ -90,7 +93,15 @@ __global__ __launch_bounds__(kTailThreads) void tail_rounds_kernel(
                 uint64_t k2;
                 if (q < n) k2 = (uint64_t)__hip_atomic_load(&ISA[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (uint64_t)h;
                 else k2 = off > h ? 0ull : (uint64_t)(n - 1 - s);
-                s_key[i] = k2;
+                s_key[0][i] = (KeyT)k2;
+#pragma unroll
+                for (int j = 1; j < kSteps; ++j) {                // (kSteps > 1: no run lengths, off == h)
+                    const int64_t qj = s + (int64_t)(j + 1) * h, qp = s + (int64_t)j * h;
+                    uint64_t kj;
+                    if (qj < n) kj = (uint64_t)__hip_atomic_load(&ISA[qj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (uint64_t)h;
+                    else kj = qp < n ? (uint64_t)(n - 1 - s - (int64_t)j * h) : 0ull;
+                    s_key[j][i] = (KeyT)kj;
+                }
             }
         }
         // ---- group starts (blocked: thread t owns positions 4 t .. 4 t + 3): max-scan of the head positions ----
@@ -139,14 +150,23 @@ __global__ __launch_bounds__(kTailThreads) void tail_rounds_kernel(
             slot[k] = -1; nrank[k] = 0; mysuf[k] = 0; flag[k] = 0;
             if (i < m) {
                 const int g0 = s_g0[i];
-                const uint64_t mine = s_key[i];
+                KeyT mine[kSteps];
+#pragma unroll
+                for (int q = 0; q < kSteps; ++q) mine[q] = s_key[q][i];
                 int less = 0, eq = 0, eq_before = 0;
                 const int gs = s_gsz[g0], me = i - g0;
                 for (int j = 0; j < gs; ++j) {
-                    const uint64_t o = s_key[g0 + j];
-                    less += o < mine;
-                    eq += o == mine;
-                    eq_before += (o == mine) && j < me;
+                    const KeyT o = s_key[0][g0 + j];
+                    bool lt = o < mine[0], same = o == mine[0];
+#pragma unroll
+                    for (int q = 1; q < kSteps; ++q) {
+                        const KeyT oq = s_key[q][g0 + j];
+                        lt = lt || (same && oq < mine[q]);
+                        same = same && oq == mine[q];
+                    }
+                    less += lt;
+                    eq += same;
+                    eq_before += same && j < me;
                 }
                 slot[k] = g0 + less + eq_before;
                 nrank[k] = s_rank[cur][i] + (uint32_t)less;
@@ -202,7 +222,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_rounds_kernel(
         __syncthreads();
         m = s_m;
         cur = nxt;
-        h *= 2;
+        h *= (kSteps + 1);
         __syncthreads();                                  // (s_m is rewritten next round)
     }
     if (t == 0) { res->rounds = rounds; res->entries = entries; res->left = (unsigned long long)m; }

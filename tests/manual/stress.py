@@ -48,6 +48,9 @@ ENVS = [{}, {}, {}, {"DQ_SMALL_N": "0"}, {"DQ_NO_FUSED_TIES": "1"}, {"DQ_NO_SMAL
         {"DQ_TAIL_MAX": "0", "DQ_RUNS": "1"}, {"DQ_TAIL_MAX": "0", "DQ_MID_GROUPS": "0"}, {"DQ_TAIL_MAX": "0", "DQ_PAIR_CHAINS": "2"},
         {"DQ_TAIL_MAX": "77", "DQ_SMALL_N": "0"}, {"DQ_TAIL_MAX": "4096", "DQ_RUNS": "1", "DQ_SMALL_N": "0"},
         {"DQ_TAIL_MAX": "2000", "DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0"},
+        {"DQ_CHAIN_STEPS": "1"}, {"DQ_CHAIN_STEPS": "1", "DQ_TAIL_MAX": "0", "DQ_SMALL_N": "0"},
+        {"DQ_CHAIN_STEPS": "3", "DQ_TAIL_MAX": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
+        {"DQ_CHAIN_STEPS": "3", "DQ_TAIL_MAX": "0", "DQ_MID_GROUPS": "256", "DQ_SMALL_N": "0"},
         {"DQ_XCD_GROUP": "0"}, {"DQ_XCD_GROUP": "3", "DQ_SMALL_N": "0"}, {"DQ_XCD_GROUP": "64", "DQ_BUCKET": "1"}]
 KEYS = sorted({k for e in ENVS for k in e})
 s = HipSuffixSort(0)

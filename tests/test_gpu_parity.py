@@ -373,6 +373,10 @@ FUZZ_ENVS = [
     {"DQ_TAIL_MAX": "1000", "DQ_SMALL_N": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
     {"DQ_TAIL_MAX": "4096", "DQ_SMALL_N": "0", "DQ_RUNS": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0"},
     {"DQ_TAIL_MAX": "0", "DQ_SMALL_N": "0"},
+    # chained rounds and tail kernel with ONE rank per member and round (before round 5's three: dq_mid_groups.h kSteps)
+    {"DQ_CHAIN_STEPS": "1", "DQ_SMALL_N": "0"},
+    {"DQ_CHAIN_STEPS": "1", "DQ_TAIL_MAX": "0", "DQ_SMALL_N": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
+    {"DQ_CHAIN_STEPS": "3", "DQ_TAIL_MAX": "0", "DQ_SMALL_N": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_MID_GROUPS": "256"},
     {"DQ_PACKED": "0", "DQ_KEY_BYTES": "1", "DQ_SPARSE": "0", "DQ_SMALL_N": "0", "DQ_MID_GROUPS": "256", "DQ_PAIR_CHAINS": "0", "DQ_TAIL_MAX": "0"},  # ... many large groups, rank >> 8
 ]
 
@@ -547,6 +551,9 @@ FORCED_PATHS = [
     {"DQ_UPD_WINDOW": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
     {"DQ_TAIL_MAX": "0"},                                        # no tail kernel: the device-wide rounds to the end (before round 5)
     {"DQ_TAIL_MAX": "100"},
+    {"DQ_CHAIN_STEPS": "1"},                                     # one rank per member and round in the chains and the tail kernel
+    {"DQ_CHAIN_STEPS": "1", "DQ_TAIL_MAX": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
+    {"DQ_CHAIN_STEPS": "3", "DQ_TAIL_MAX": "0", "DQ_MID_GROUPS": "256", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
     {"DQ_TAIL_MAX": "4096", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_RUNS": "1"},
     {"DQ_NO_L_SHIFT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_MID_GROUPS": "256", "DQ_TAIL_MAX": "0"},
     {"DQ_NO_WIDE_SMALL": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0", "DQ_TAIL_MAX": "0"},

@@ -632,7 +632,7 @@ def test_windowed_anchor_search_equals_the_loop(oracle_mod):
 
 
 # ---- dq_tail.h: the last doubling rounds in one workgroup; dq_mid_groups.h's shifted radix-list keys -----------------
-def tail_rounds_model(T, h0):
+def tail_rounds_model(T, h0, steps=1):
     """tail_rounds_kernel on the CPU: start from the groups of suffixes that share their first h0 bytes (rank = the SA
     index of the group's first member), keep only the tied ones as the list, then round after round: key2 = ISA[s + h] + h
     (n - 1 - s past the end), place = #(smaller key2) + #(equal before), SA / ISA written for what is decided, the rest
@@ -660,7 +660,15 @@ def tail_rounds_model(T, h0):
     while lst:
         rounds += 1
         assert rounds < 80
-        key2 = [int(ISA[s + h]) + h if s + h < n else n - 1 - s for _, s in lst]
+        # steps > 1: the key is the tuple of the ranks h, 2h, ... steps*h bytes further on; a suffix that ends inside stretch
+        # j has (n - 1 - s) - j*h there (< h: below every in-range value, the shorter suffix first) and 0 behind it
+        def key_of(s):
+            out = []
+            for j in range(steps):
+                q, qp = s + (j + 1) * h, s + j * h
+                out.append(int(ISA[q]) + h if q < n else (n - 1 - s - j * h if qp < n else 0))
+            return tuple(out) if steps > 1 else out[0]
+        key2 = [key_of(s) for _, s in lst]
         nxt, slots, i = [], [None] * len(lst), 0
         while i < len(lst):
             j = i
@@ -680,7 +688,7 @@ def tail_rounds_model(T, h0):
             else:
                 SA[r] = s
         lst = nxt
-        h *= 2
+        h *= steps + 1
     return SA, rounds
 
 
@@ -696,6 +704,11 @@ def test_tail_rounds_model_gives_the_suffix_array(oracle_mod):
             SA, rounds = tail_rounds_model(T, h0)
             assert np.array_equal(SA, oracle_mod.divsufsort(T).astype(np.int64)), (T.size, h0)
             assert rounds >= 1
+            # three ranks a member and round (the chained rounds of short lists, the tail kernel): the same array in
+            # fewer rounds
+            SA3, rounds3 = tail_rounds_model(T, h0, steps=3)
+            assert np.array_equal(SA3, SA), (T.size, h0, "three steps")
+            assert rounds3 <= rounds
 
 
 def test_shifted_rank_field_keeps_large_groups_apart_in_order():
