@@ -992,9 +992,9 @@ struct SuffixSorter {
         // writes the ISA in the rebucket pass itself.  (Inputs whose order-0 entropy already promised
         // few ties -- packed words or a short key -- skip the sample and its host round trip.)
         bool predict_dense = false;
-        // (below 1 MiB the sample's host round trip costs more than a wrong guess: 8-byte pair keys were chosen because the
+        // (below 8 MiB the sample's host round trip costs more than a wrong guess: 8-byte pair keys were chosen because the
         // text repeats itself, so "many ties" is the guess, and the inverse suffix array of a short text is cheap either way)
-        if (n >= (1 << 16) && n < (1 << 20) && !packed && kb == 8 && !env("DQ_SAMPLE_TIES")) {
+        if (n >= (1 << 16) && n < (8 << 20) && !packed && kb == 8 && !env("DQ_SAMPLE_TIES")) {
             predict_dense = true;
         } else if (n >= (1 << 16) && !packed && kb == 8) {
             constexpr int kSamples = 4096;
