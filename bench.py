@@ -61,6 +61,12 @@ def main() -> int:
     ap.add_argument("--no-build", action="store_true",
                     help="never spawn a compiler (runs under rocprofv3, where the GPU is up before main())")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl == RCCL)")
+    ap.add_argument("--batch-count", type=int, default=BATCH_COUNT, help="buffers of the batch record (configs[4]: 128)")
+    ap.add_argument("--batch-mib", type=int, default=BATCH_BYTES >> 20, help="MiB per buffer of the batch record (configs[4]: 16)")
+    ap.add_argument("--many-new-per-rank", type=int, default=4, help="new files per rank of the one-old-many-new record")
+    ap.add_argument("--config3-cpu", action="store_true",
+                    help="opt-in (minutes of one host core, not in the driver's default run): time the oracle's LibDivSufSort "
+                         "restatement with 64-bit indices on the 2 GiB buffer of configs[3] and bit-compare (SURVEY 8(d) Config 4)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
@@ -72,7 +78,7 @@ def main() -> int:
         # started as `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as fresh child
         # processes, before this process has loaded the library or touched the GPU; relay their output (rank 0
         # prints the line) and leave with their status.  One rank can never stand in for N.
-        return launch_ranks(args.gpus)
+        return launch_ranks(args.gpus, args.share_gpu)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,6 +114,10 @@ def main() -> int:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     devices_seen = [torch.cuda.current_device()]
+    # one process per GPU: run on the CPUs of the NUMA node the device hangs off (host copies of the batch records
+    # and the through-ABI timing stay on that socket); nothing happens where the platform does not say, or at N = 1
+    # on a box whose only node it is anyway.  DQ_NUMA_BIND=0 turns it off.
+    numa_node = _abi.bind_process_to_device_numa_node(local_rank) if world > 1 else _abi.load().dq_device_numa_node(local_rank)
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -119,6 +129,9 @@ def main() -> int:
         dist.all_gather_object(seen, (int(torch.cuda.current_device()), os.environ.get("HIP_VISIBLE_DEVICES"),
                                       os.environ.get("ROCR_VISIBLE_DEVICES")))
         devices_seen = [x[0] for x in seen]
+        nodes = [None] * world
+        dist.all_gather_object(nodes, numa_node)
+        numa_node = nodes
         if not args.share_gpu and len(set(seen)) != world:
             raise SystemExit(f"bench.py: {world} ranks but devices {seen}: two ranks share a GPU")
 
@@ -186,10 +199,10 @@ def main() -> int:
     if extras and rank == 0:
         through_abi = time_through_abi(sorter, host, sa, reps=3)
     # the named configs[4] workload: every rank takes part
-    batch = batch_config4(world, rank, local_rank, dev, args.backend, sorter) if extras else None
+    batch = batch_config4(world, rank, local_rank, dev, args.backend, sorter, args.batch_count, args.batch_mib << 20, args.many_new_per_rank) if extras else None
     if extras and rank == 0 and world == 1:
         del text
-        configs = other_configs(sorter, dev)
+        configs = other_configs(sorter, dev, args.config3_cpu)
 
     out = None
     if rank == 0:
@@ -216,6 +229,7 @@ def main() -> int:
             "metric": "MB of text suffix-sorted per second (bit-exact SA)",
             "value": round(value, 2), "unit": "MB/s",
             "n_gpus": world, "gpus_flag": args.gpus, "devices_per_rank": devices_seen,
+            "numa_node_per_rank": numa_node if isinstance(numa_node, list) else [numa_node],
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -245,18 +259,38 @@ def main() -> int:
     return 0
 
 
-def launch_ranks(n):
+def visible_gpu_count():
+    """GPUs this node shows, counted WITHOUT loading torch or HIP in this process (the launcher must not open the
+    device: torch.cuda.device_count() falls through to hipGetDeviceCount on builds without amdsmi -- round-5 advice):
+    the KFD topology's nodes with SIMDs, cut down by HIP_/ROCR_VISIBLE_DEVICES when set.  None = cannot tell."""
+    import glob
+    count = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for p in nodes:
+        try:
+            with open(p) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0:
+            count += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            count = min(count, len([x for x in v.split(",") if x.strip() != ""]))
+    return count
+
+
+def launch_ranks(n, share_gpu=False):
     """`python bench.py --gpus N` with no launcher around it: run `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child process (nothing in
-    this process has initialised the GPU yet), pass its output through and return its exit status."""
+    this process has initialised the GPU -- or even imported torch), pass its output through and return its exit status."""
     import socket
     import subprocess
-    if not os.environ.get("DQ_BENCH_ALLOW_OVERSUBSCRIBE") and "--share-gpu" not in sys.argv:
-        try:
-            import torch
-            have = torch.cuda.device_count()            # (counts devices without initialising the runtime on this image)
-        except Exception:                               # noqa: BLE001
-            have = None
+    if not os.environ.get("DQ_BENCH_ALLOW_OVERSUBSCRIBE") and not share_gpu:
+        have = visible_gpu_count()
         if have is not None and have < n:
             print(f"bench.py: --gpus {n} but this node shows {have} GPU(s)", file=sys.stderr)
             return 2
@@ -378,7 +412,7 @@ def time_through_abi(sorter, host, sa_dev=None, reps=3):
     return rec
 
 
-def other_configs(sorter, dev):
+def other_configs(sorter, dev, config3_cpu=False):
     """One short record per BASELINE.json configuration that is not the timed workload."""
     from deltaq_amd import _abi
     from tools import datagen
@@ -399,14 +433,14 @@ def other_configs(sorter, dev):
     recs.append(match_search_record(sorter, dev))
     recs.append(reference_benchmark_shape(sorter))
     recs.append(bsdiff_create_record(dev))
-    recs.append(config3_record(sorter, dev))         # last: it leaves > 100 GiB of cached workspace, released at its end
+    recs.append(config3_record(sorter, dev, cpu=config3_cpu))         # last: it leaves > 100 GiB of cached workspace, released at its end
     return recs
 
 
 SEED_CONFIG3 = 0x5EED0004      # 2 GiB uniform, int64 SA
 
 
-def config3_record(sorter, dev, reps=3):
+def config3_record(sorter, dev, reps=3, cpu=False):
     """BASELINE configs[3]: 2 GiB uniform-random bytes, 64-bit suffix array (dq_sufsort_hip_dev_i64), text and SA
     resident in HBM.  The suffix array of the timed sorts is checked on the host by LDSSChecker.Check (the oracle's
     threaded evaluation) and 10^5 sampled strict pairs.  Skipped, with the reason, where the device or the host is
@@ -462,6 +496,16 @@ def config3_record(sorter, dev, reps=3):
         rec["sampled_strict_pairs_1e5_first_bad"] = int(oracle.verify_sampled(host, got, 100_000, 11))
         rec["check_s"] = round(time.perf_counter() - t0, 1)
         rec["checked_ok"] = bool(rec["sufcheck_mt"] == oracle.CHECK_DONE and rec["sampled_strict_pairs_1e5_first_bad"] == -1)
+        if cpu:
+            # SURVEY.md section 8(d), Config 4: "CPU baseline = restatement instantiated with 64-bit indices (the reference
+            # itself cannot represent this input)" -- ISuffixSort.cs:18,27 are `int`.  One host core, once.
+            t0 = time.perf_counter()
+            ref = oracle.divsufsort(host, dtype=np.int64)
+            cs = time.perf_counter() - t0
+            rec["cpu_restatement_i64"] = {"seconds": round(cs, 1), "MBps": round(n / 1e6 / cs, 2), "cores": 1, "kind": "port",
+                                          "bit_exact_vs_gpu": bool(np.array_equal(ref, got)),
+                                          "gpu_speedup_device_resident": round(cs * 1e3 / ms, 0)}
+            del ref
         return rec
     except Exception as e:                                  # noqa: BLE001 -- report, do not lose the bench line
         return {"config": name, "error": repr(e)[:300]}
@@ -619,7 +663,7 @@ def match_search_record(sorter, dev):
             "bit_exact_vs_oracle_sample": ok}
 
 
-def batch_config4(world, rank, local_rank, dev, backend, sorter):
+def batch_config4(world, rank, local_rank, dev, backend, sorter, BATCH_COUNT=BATCH_COUNT, BATCH_BYTES=BATCH_BYTES, many_per_rank=4):
     """BASELINE configs[4]: 128 x 16 MiB independent buffers, LPT-sharded over the ranks, host buffers in
     and out through dq_sufsort_hip_batch_i32 on each rank's GPU; no data-path collective.  Timed twice: with the
     pageable buffers a P/Invoke caller hands over, and with page-locked ones (what separates PCIe / host-memory
@@ -653,14 +697,18 @@ def batch_config4(world, rank, local_rank, dev, backend, sorter):
         t0 = time.perf_counter()
         _abi.check(L.dq_sufsort_hip_batch_i32(cnt, tp, ln, sp, 1, devs))
         mine_s = time.perf_counter() - t0
-        walls = [mine_s]
+        bi = _abi.last_batch_info()                  # busy time of this rank's three pipeline stages
+        row = [mine_s, bi["copy_in_ms"], bi["sort_ms"], bi["copy_out_ms"], float(bi["shares_bound_to_numa_node"])]
+        rows = [row]
         if world > 1:
-            t = torch.zeros(world, dtype=torch.float64, device=cdev)
-            t[rank] = mine_s
+            t = torch.zeros(world, len(row), dtype=torch.float64, device=cdev)
+            t[rank] = torch.tensor(row, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            walls = [float(x) for x in t.tolist()]
-        return walls
+            rows = [[float(x) for x in r] for r in t.tolist()]
+        stage_rows.append(rows)
+        return [r[0] for r in rows]
 
+    stage_rows = []
     walls = run(texts, sas)
     wall = max(walls)
     # the same call on page-locked buffers (torch's pinned allocator; the library sees plain pointers)
@@ -680,12 +728,21 @@ def batch_config4(world, rank, local_rank, dev, backend, sorter):
         import oracle
         ok = all(oracle.sufcheck_mt(texts[k], sas[k]) == 0 for k in range(min(cnt, 4)))
         per_rank_bytes = [len(p) * BATCH_BYTES * 5 for p in plan]                      # text in + SA out
-        rec = {"workload": "BASELINE configs[4]: 128 x 16 MiB uniform random (seeds 0x5EED0500+j), int32 SA",
+        named = BATCH_COUNT == 128 and BATCH_BYTES == 16 << 20
+        rec = {"workload": ("BASELINE configs[4]: " if named else "NOT configs[4] (a plumbing run): ") +
+                           f"{BATCH_COUNT} x {BATCH_BYTES >> 20} MiB uniform random (seeds 0x5EED0500+j), int32 SA",
                "entry": "dq_sufsort_hip_batch_i32 per rank (host pointers in/out, PCIe-inclusive)",
                "sharding": {"policy": "LPT over ranks (deltaq_amd.batch.plan_shards)",
                             "buffers_per_rank": [len(p) for p in plan]},
                "wall_ms": round(wall * 1e3, 2), "MBps": round(BATCH_COUNT * BATCH_BYTES / 1e6 / wall, 1),
                "host_copy_GBps_per_rank": [round(b / w / 1e9, 2) for b, w in zip(per_rank_bytes, walls)],
+               # busy time of each rank's pipeline stages (dq_last_batch_info): a rank whose sort_ms is close to its wall
+               # waits for its GPU, one whose copy stages are waits for host memory / PCIe
+               "wall_ms_per_rank": [round(r[0] * 1e3, 2) for r in stage_rows[0]],
+               "copy_in_ms_per_rank": [round(r[1], 2) for r in stage_rows[0]],
+               "sort_ms_per_rank": [round(r[2], 2) for r in stage_rows[0]],
+               "copy_out_ms_per_rank": [round(r[3], 2) for r in stage_rows[0]],
+               "ranks_with_numa_bound_threads": int(sum(1 for r in stage_rows[0] if r[4] > 0)),
                "device_resident_ms_per_buffer": round(dms, 3),
                "device_resident_MBps_per_gpu": round(BATCH_BYTES / 1e3 / dms, 1) if dms else None,
                "sufcheck_first_buffers": bool(ok)}
@@ -693,6 +750,7 @@ def batch_config4(world, rank, local_rank, dev, backend, sorter):
             rec["pinned_buffers"] = {"wall_ms": round(max(pin_walls) * 1e3, 2),
                                      "MBps": round(BATCH_COUNT * BATCH_BYTES / 1e6 / max(pin_walls), 1),
                                      "host_copy_GBps_per_rank": [round(b / w / 1e9, 2) for b, w in zip(per_rank_bytes, pin_walls)],
+                                     "sort_ms_per_rank": [round(r[2], 2) for r in stage_rows[-1]],
                                      "same_suffix_arrays": pinned_ok}
         if world == 1:
             rec["cpu_replicas"] = cpu_replica_baseline(texts)
@@ -711,13 +769,13 @@ def batch_config4(world, rank, local_rank, dev, backend, sorter):
         except Exception as e:                      # report, do not lose the bench line
             if rank == 0:
                 rec["rccl_scatter_sort_gather"] = {"backend": backend, "error": repr(e)[:300]}
-    many = one_old_many_new(world, rank, dev, backend)
+    many = one_old_many_new(world, rank, dev, backend, many_per_rank)
     if rank == 0 and many is not None:
         rec["one_old_many_new"] = many
     return rec
 
 
-def one_old_many_new(world, rank, dev, backend):
+def one_old_many_new(world, rank, dev, backend, per_rank=4):
     """The many-files bsdiff path with its one exchange step: a 16 MiB old file, 4 new files per rank (copies with
     ~200 small edits).  Rank 0 sorts the old file once, text + suffix array are broadcast (RCCL under nccl), every
     rank diffs its share against a DiffIndex on the received buffers, patches are gathered and applied on rank 0.
@@ -727,7 +785,6 @@ def one_old_many_new(world, rank, dev, backend):
     from deltaq_amd import Diff, DiffIndex, Patch
     from deltaq_amd.batch import diff_many_distributed
     from tools import datagen
-    per_rank = 4
     old = news = None
     if rank == 0:
         rng = np.random.default_rng(9)

@@ -32,7 +32,7 @@ EXPORTS = (
     "dq_sufsort_hip_workspace_bytes", "dq_sufsort_hip_release",
     "dq_profile_enable", "dq_profile_reset", "dq_profile_get", "dq_profile_kernel_name",
     "dq_profile_category_count",
-    "dq_last_sort_info", "dq_last_diff_info",
+    "dq_last_sort_info", "dq_last_diff_info", "dq_last_batch_info", "dq_device_numa_node",
 )
 
 
@@ -139,6 +139,10 @@ def load() -> ctypes.CDLL:
     L.dq_last_sort_info.argtypes = [ctypes.POINTER(i64)] * 3
     L.dq_last_diff_info.restype = i32
     L.dq_last_diff_info.argtypes = [ctypes.POINTER(i64), i32]
+    L.dq_last_batch_info.restype = i32
+    L.dq_last_batch_info.argtypes = [ctypes.POINTER(i64), i32]
+    L.dq_device_numa_node.restype = i32
+    L.dq_device_numa_node.argtypes = [i32]
     _lib = L
     return L
 
@@ -185,6 +189,42 @@ def last_diff_info() -> dict:
     v = (ctypes.c_int64 * 5)()
     L.dq_last_diff_info(v, 5)
     return {"searches": v[0], "windows": v[1], "exact": v[2], "host_loop_fallbacks": v[3], "scan_groups": v[4]}
+
+
+def last_batch_info() -> dict:
+    """Shape of the last dq_sufsort_hip_batch_i32 on this thread (dq_last_batch_info)."""
+    L = load()
+    v = (ctypes.c_int64 * 6)()
+    L.dq_last_batch_info(v, 6)
+    return {"pipelined": v[0], "copy_in_ms": v[1] / 1e3, "sort_ms": v[2] / 1e3, "copy_out_ms": v[3] / 1e3,
+            "slowest_share_ms": v[4] / 1e3, "shares_bound_to_numa_node": v[5]}
+
+
+def bind_process_to_device_numa_node(device: int) -> int | None:
+    """One process per GPU (bench.py's ranks, deltaq_amd.batch): run this process on the CPUs of the NUMA node the
+    device hangs off, so that its staged host copies do not cross the socket link.  Returns the node, or None where the
+    platform does not say / DQ_NUMA_BIND=0 / the node's CPUs are outside what the process may use (nothing is changed)."""
+    if os.environ.get("DQ_NUMA_BIND") == "0":
+        return None
+    node = load().dq_device_numa_node(device)
+    if node < 0:
+        return None
+    try:
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            if not part:
+                continue
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except (OSError, ValueError):
+        return None
 
 
 def last_sort_info() -> dict:

@@ -49,11 +49,16 @@ def _deps(src: str) -> list[str]:
     for p in text.split(":", 1)[-1].split():
         # the list holds absolute paths of the tree the object was compiled in; the tree may have been copied since
         # (the GPU box gets a snapshot under another path): re-root what belongs to the repository, drop system headers
+        # (only what really maps onto a file of this tree: a toolchain installed elsewhere -- ~/rocm/include/hip/... --
+        # also has "/include/" in its paths, and a re-rooted name that does not exist would make every object stale
+        # on every import; anything else is a system header)
         for mark, base in (("/deltaq_amd/csrc/", CSRC), ("/include/", os.path.join(root, "include"))):
             k = p.rfind(mark)
-            if k >= 0 and not p.startswith("/opt/") and not p.startswith("/usr/"):
-                out.append(os.path.join(base, p[k + len(mark):]))
-                break
+            if k >= 0:
+                mapped = os.path.join(base, p[k + len(mark):])
+                if os.path.exists(mapped):
+                    out.append(mapped)
+                    break
     return out
 
 

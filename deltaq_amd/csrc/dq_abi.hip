@@ -17,9 +17,21 @@ namespace {
 constexpr int kBatchSlots = 3;
 
 
-int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *const *texts, const int64_t *lens,
-                    int32_t *const *sas, std::string *err)
+// what one device share reports back (dq_last_batch_info): inputs through its pipeline, busy microseconds per stage
+struct ShareStats { int64_t piped = 0, in_us = 0, sort_us = 0, out_us = 0, wall_us = 0, bound = 0; };
+inline int64_t us_since(std::chrono::steady_clock::time_point t0)
 {
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+}
+
+int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *const *texts, const int64_t *lens,
+                    int32_t *const *sas, std::string *err, ShareStats *stats)
+{
+    const auto t_share = std::chrono::steady_clock::now();
+    // this thread was started by dq_sufsort_hip_batch_i32 for this device: it and the three stage threads below run on
+    // the CPUs of the device's NUMA node (dq_runtime.h; nothing happens where the platform does not say)
+    stats->bound = bind_this_thread_to_device(device) ? 1 : 0;
+    struct WallAtExit { ShareStats *s; std::chrono::steady_clock::time_point t0; ~WallAtExit() { s->wall_us = us_since(t0); } } wall_guard{stats, t_share};
     auto plain = [&](int j) -> int {
         int rc = sufsort_host<int32_t>(texts[j], lens[j], sas[j], device);
         if (rc != DQ_OK) *err = t_err;
@@ -88,16 +100,22 @@ int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *con
         cv.notify_all();
     };
 
+    // (busy time per stage: what tells a share that waits for the GPU from one that waits for host memory / PCIe)
+    int64_t busy_in = 0, busy_sort = 0, busy_out = 0, piped = 0;
     auto stage_in = [&]() {
         (void)hipSetDevice(device);
+        (void)bind_this_thread_to_device(device);
         for (int j : jobs) {
             if (lens[j] <= direct) continue;                                // handled after the pipeline
             const int k = take(freeq, nullptr);
             if (k < 0 || failed.load() != DQ_OK) break;
             slots[k].job = j;
+            const auto t0 = std::chrono::steady_clock::now();
             hipError_t e = hipMemcpyAsync(slots[k].text, texts[j], (size_t)lens[j], hipMemcpyHostToDevice, s_in);
             if (e == hipSuccess) e = hipStreamSynchronize(s_in);
+            busy_in += us_since(t0);
             if (e != hipSuccess) { fail_stage(0, DQ_ERR_HIP, std::string("batch copy-in: ") + hipGetErrorString(e)); break; }
+            ++piped;
             give(filled, k);
         }
         { std::lock_guard<std::mutex> lk(mu); in_done = true; }
@@ -105,11 +123,14 @@ int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *con
     };
     auto stage_sort = [&]() {
         (void)hipSetDevice(device);
+        (void)bind_this_thread_to_device(device);
         for (;;) {
             const int k = take(filled, &in_done);
             if (k < 0 || failed.load() != DQ_OK) break;
             const int j = slots[k].job;
+            const auto t0 = std::chrono::steady_clock::now();
             int rc = sufsort_dev<int32_t>(slots[k].text, lens[j], slots[k].sa, device, s_sort);
+            busy_sort += us_since(t0);
             if (rc != DQ_OK) { fail_stage(1, rc, t_err); break; }
             give(sorted, k);
         }
@@ -118,12 +139,15 @@ int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *con
     };
     auto stage_out = [&]() {
         (void)hipSetDevice(device);
+        (void)bind_this_thread_to_device(device);
         for (;;) {
             const int k = take(sorted, &sort_done);
             if (k < 0 || failed.load() != DQ_OK) break;
             const int j = slots[k].job;
+            const auto t0 = std::chrono::steady_clock::now();
             hipError_t e = hipMemcpyAsync(sas[j], slots[k].sa, (size_t)lens[j] * sizeof(int32_t), hipMemcpyDeviceToHost, s_out);
             if (e == hipSuccess) e = hipStreamSynchronize(s_out);
+            busy_out += us_since(t0);
             if (e != hipSuccess) { fail_stage(2, DQ_ERR_HIP, std::string("batch copy-out: ") + hipGetErrorString(e)); break; }
             give(freeq, k);
         }
@@ -140,6 +164,7 @@ int batch_on_device(int device, const std::vector<int> &jobs, const uint8_t *con
             fail_stage(0, DQ_ERR_OOM, std::string("batch: cannot start a pipeline thread: ") + e.what());
         }
     }
+    stats->piped = piped; stats->in_us = busy_in; stats->sort_us = busy_sort; stats->out_us = busy_out;    // (the stages are joined)
     if (failed.load() != DQ_OK) {
         for (const std::string &e : errs) if (!e.empty()) { *err = e; break; }
         return failed.load();
@@ -215,19 +240,26 @@ int32_t dq_sufsort_hip_batch_i32(int32_t count, const uint8_t *const *texts, con
     }
     std::vector<int> rcs(ndev, DQ_OK);
     std::vector<std::string> errs(ndev);
+    std::vector<ShareStats> stats(ndev);
+    for (int64_t &x : t_batch_info) x = 0;
     {
         JoinAll threads;
         for (int d = 0; d < ndev; ++d) {
             threads.v.emplace_back([&, d]() {
                 const int device = devs ? devs[d] : d;
                 try {
-                    rcs[d] = batch_on_device(device, share[d], texts, lens, sas, &errs[d]);
+                    rcs[d] = batch_on_device(device, share[d], texts, lens, sas, &errs[d], &stats[d]);
                 } catch (const std::exception &e) {
                     rcs[d] = DQ_ERR_OOM;
                     errs[d] = std::string("batch: ") + e.what();
                 }
             });
         }
+    }
+    for (const ShareStats &s : stats) {
+        t_batch_info[0] += s.piped; t_batch_info[1] += s.in_us; t_batch_info[2] += s.sort_us; t_batch_info[3] += s.out_us;
+        t_batch_info[4] = std::max(t_batch_info[4], s.wall_us);
+        t_batch_info[5] += s.bound;
     }
     for (int d = 0; d < ndev; ++d)
         if (rcs[d] != DQ_OK) { t_err = errs[d]; return rcs[d]; }
@@ -493,6 +525,20 @@ int32_t dq_last_sort_info(int64_t *rounds, int64_t *initial_active, int64_t *sum
     if (initial_active) *initial_active = t_info[1];
     if (sum_active) *sum_active = t_info[2];
     return DQ_OK;
+}
+
+int32_t dq_last_batch_info(int64_t *info, int32_t count)
+{
+    if (!info || count < 0) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
+    for (int32_t k = 0; k < count; ++k) info[k] = k < 6 ? t_batch_info[k] : 0;
+    return DQ_OK;
+}
+
+int32_t dq_device_numa_node(int32_t device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return -1;
+    return device_numa_node(device);
 }
 
 int32_t dq_last_diff_info(int64_t *info, int32_t count)

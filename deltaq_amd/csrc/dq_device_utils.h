@@ -10,11 +10,12 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
 
-// The bound every look-back spin of this translation unit's kernels gives up at (radix_rank_kernel, seg_fused_kernel):
-// kSpinLimit polls -- seconds -- in production; the fault-injection tests (DQ_FAULT=spin, dq_runtime.h) set it to 0 so
-// that the first empty poll raises the error word and the host's error path runs (set_spin_fault in dq_sorter_impl.h).
+// The bound every look-back spin gives up at (radix_rank_kernel, seg_fused_kernel): kSpinLimit polls -- seconds -- in
+// production.  It is a KERNEL ARGUMENT (spin_limit, last parameter of both kernels): the fault-injection tests
+// (DQ_FAULT=spin, dq_runtime.h) launch with 0, so that the first empty poll raises the error word and the host's error
+// path runs -- per launch of the calling thread, nothing device-wide that a concurrent caller could see or reset
+// (round-5 advice: it was a `static __device__` word per translation unit, rewritten through hipMemcpyToSymbol).
 constexpr uint32_t kSpinLimit = 1u << 24;
-static __device__ uint32_t g_spin_limit = kSpinLimit;
 
 __device__ __forceinline__ int lane_id()
 {

@@ -621,8 +621,12 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
     t_diff_info[4] = groups;
     if (groups < 8 || c.scan_skip > 0) {
         if (c.scan_skip > 0) --c.scan_skip;
+        // (not an error: the host loop takes the file and the call succeeds -- dq_last_error() must not be left saying
+        // otherwise behind a DQ_OK, so nothing goes through fail(); dq_last_diff_info counts the file, skipped ones too)
+        if (env("DQ_TRACE"))
+            fprintf(stderr, "[dq] %s\n", groups < 8 ? "anchor scan: the device holds fewer than 8 of its workgroups" : "anchor scan: skipped after a starved launch");
         *retry_on_host = true;
-        return fail(DQ_ERR_HIP, groups < 8 ? "anchor scan: the device holds fewer than 8 of its workgroups" : "anchor scan: skipped after a starved launch");
+        return DQ_ERR_HIP;
     }
     double emit_ms = 0;                                   // (DQ_TRACE: time inside the emitter)
     // Whatever way this function is left once a launch is out -- a failed copy, an exception out of the emitter -- the
@@ -703,8 +707,9 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         // device do not try again)
         if (st.error) {
             if (!t_fault.spin && !env("DQ_SCAN_SPIN_LOG2")) c.scan_skip = 16;     // (not under the tests' own bound)
+            if (env("DQ_TRACE")) fprintf(stderr, "[dq] anchor scan: grid barrier timed out\n");
             *retry_on_host = true;
-            return fail(DQ_ERR_HIP, "anchor scan: grid barrier timed out");
+            return DQ_ERR_HIP;                              // (no fail(): the host loop's DQ_OK must not carry this text)
         }
         const int64_t got = (int64_t)st.nrec;
         if (got < taken || got > kAnchorRecs) return fail(DQ_ERR_HIP, "anchor scan: bad record count");

@@ -54,7 +54,9 @@ __global__ __launch_bounds__(kPairThreads) void isa_from_pairs_kernel(const uint
 // span of the inverse suffix array into LDS, applies the span's updates there and writes the span back in full lines --
 // 8 bytes of array traffic per suffix of a touched span instead of one read-modify-write of a 64-byte sector per update
 // (isa_update_words_kernel on words binned by 8 bits: 8x write amplification, rocprof WRITE_SIZE, round 4).  Pays while
-// at least ~1/16 of the array is updated.  A word whose suffix field is >= n is an alignment filler and is skipped.
+// at least ~1/16 of the array is updated.  The all-ones word is the alignment filler in front of the list and is skipped
+// (a real word is rank << ib | suffix with 2 * ib <= 63: bit 63 clear.  Its suffix field alone does not tell: for n = 2^ib
+// it reads n - 1, a real suffix).
 template <typename IdxT, int kSpan>
 __global__ __launch_bounds__(kPairThreads) void isa_update_window_kernel(const uint64_t *__restrict__ words, const int64_t *__restrict__ bounds,
                                                                        int64_t n, int ib, IdxT *__restrict__ ISA)
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(kPairThreads) void isa_update_window_kernel(const u
     for (int64_t i = lo + threadIdx.x; i < hi; i += kPairThreads) {
         const uint64_t w = words[i];
         const int64_t sfx = (int64_t)(w & mask);
-        if (sfx < n) image[sfx - base] = (uint32_t)(w >> ib);
+        if (w != ~0ull && sfx < n) image[sfx - base] = (uint32_t)(w >> ib);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kSpan; i += kPairThreads)

@@ -207,7 +207,8 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
     int64_t *__restrict__ sticky_error, uint32_t *__restrict__ ebits = nullptr,
     uint64_t *__restrict__ seam_tab /*[ntiles][256][2]*/ = nullptr,
     const uint16_t *__restrict__ codetab /*[256], kCoded*/ = nullptr,
-    int xcd_group = 0 /* kAtomicBase: tiles per XCD and group of the XCD-aware tile order, 0 = blockIdx order */)
+    int xcd_group = 0 /* kAtomicBase: tiles per XCD and group of the XCD-aware tile order, 0 = blockIdx order */,
+    uint32_t spin_limit = kSpinLimit /* empty polls of the look-back before it gives up (DQ_FAULT=spin: 0) */)
 {
     constexpr bool kFromText = (kMode == kText || kMode == kTextPacked || kMode == kTextPackedExt);
     constexpr bool kPackedText = (kMode == kTextPacked || kMode == kTextPackedExt);
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(kThreads, kMinWaves) void radix_rank_kernel(
                 t -= used;
                 if (!done && used == 0) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > g_spin_limit) { atomicExch(&ctl->error, 1u); *sticky_error = 1; break; }
+                    if (++spins > spin_limit) { atomicExch(&ctl->error, 1u); *sticky_error = 1; break; }
                 }
             }
             status_store<StatusT>(mine, SB::kPrefix | (StatusT)(excl + tot));

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -20,6 +21,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <sched.h>
 
 #include "../../include/dq_sufsort.h"
 
@@ -33,6 +36,11 @@ inline thread_local int64_t t_info[3] = {0, 0, 0};
 // the last Diff.Create / index diff on this thread (dq_last_diff_info): Search calls of the loop, windows, positions
 // asked again exactly, launches of the device's anchor scan that were given back to the host loop, workgroups of its grid
 inline thread_local int64_t t_diff_info[5] = {0, 0, 0, 0, 0};
+
+// the last dq_sufsort_hip_batch_i32 on this thread (dq_last_batch_info): inputs through the pipelines, microseconds the
+// copy-in / sort / copy-out stages were busy (summed over the device shares), wall microseconds of the slowest share,
+// device shares whose host threads were bound to their device's NUMA node
+inline thread_local int64_t t_batch_info[6] = {0, 0, 0, 0, 0, 0};
 
 inline int fail(int code, const char *what, hipError_t e = hipSuccess)
 {
@@ -98,7 +106,8 @@ inline thread_local EnvCache t_env;
 // changes nothing.  Exempt: DQ_TRACE (prints, decides nothing) and DQ_HIP_DEVICE (which device "-1" means).
 inline bool env_gated(const char *name)
 {
-    return strcmp(name, "DQ_TRACE") != 0 && strcmp(name, "DQ_HIP_DEVICE") != 0 && strcmp(name, "DQ_DEBUG_FLAGS") != 0;
+    return strcmp(name, "DQ_TRACE") != 0 && strcmp(name, "DQ_HIP_DEVICE") != 0 && strcmp(name, "DQ_DEBUG_FLAGS") != 0 &&
+           strcmp(name, "DQ_NUMA_BIND") != 0;
 }
 
 inline const char *env(const char *name)
@@ -343,6 +352,78 @@ inline int resolve_device(int32_t device, int *out)
         return fail(DQ_ERR_BAD_ARGS, "device ordinal out of range");
     *out = device;
     return DQ_OK;
+}
+
+// ------------------------------------------------------------------ NUMA placement of a device's host threads
+// The batch pipeline's stage threads copy through pageable host memory: 8 devices x 50+ GB/s of staged copies meet in
+// host memory, and a thread on the far socket pays the inter-socket link both ways.  Each device's threads are
+// therefore bound to the CPUs of the NUMA node its PCIe function hangs off:
+//   hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<domain:bus:dev.fn>/numa_node -> /sys/devices/system/node/node<k>/cpulist
+// Nothing happens where any of these is absent or says -1 (single-socket hosts, containers without sysfs), or under
+// DQ_NUMA_BIND=0.  Only threads the library itself starts are bound -- never the caller's.
+inline int device_numa_node(int dev)
+{
+    static std::mutex mu;
+    static int cache[kMaxDevices];
+    static bool known[kMaxDevices];
+    if (dev < 0 || dev >= kMaxDevices) return -1;
+    std::lock_guard<std::mutex> lk(mu);
+    if (known[dev]) return cache[dev];
+    int node = -1;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, dev) == hipSuccess && bdf[0]) {
+        for (char *p = bdf; *p; ++p) *p = (char)tolower((unsigned char)*p);
+        char path[160];
+        snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+        if (FILE *f = fopen(path, "r")) {
+            if (fscanf(f, "%d", &node) != 1) node = -1;
+            fclose(f);
+        }
+    }
+    known[dev] = true;
+    cache[dev] = node;
+    return node;
+}
+
+// the CPUs of a NUMA node ("0-31,64-95"); false: unknown
+inline bool numa_node_cpus(int node, cpu_set_t *set)
+{
+    if (node < 0) return false;
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    char buf[4096] = {0};
+    const bool got = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    CPU_ZERO(set);
+    int any = 0;
+    for (char *p = buf; *p;) {
+        char *end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') { b = strtol(p + 1, &end, 10); if (end == p + 1) break; p = end; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { if (c >= 0) { CPU_SET((int)c, set); ++any; } }
+        while (*p == ',' || *p == ' ' || *p == '\n') ++p;
+    }
+    return any > 0;
+}
+
+// binds the CALLING thread (one the library started) to the device's NUMA node; true if it did
+inline bool bind_this_thread_to_device(int dev)
+{
+    if (const char *v = env("DQ_NUMA_BIND")) if (atoi(v) == 0) return false;
+    cpu_set_t want, have;
+    if (!numa_node_cpus(device_numa_node(dev), &want)) return false;
+    // (never widen what the process was given: a container's cpuset, taskset)
+    if (sched_getaffinity(0, sizeof have, &have) != 0) return false;
+    cpu_set_t both;
+    CPU_AND(&both, &want, &have);
+    if (CPU_COUNT(&both) == 0) return false;
+    return sched_setaffinity(0, sizeof both, &both) == 0;
 }
 
 struct JoinAll {                        // joins whatever was started, also when leaving by exception

@@ -42,7 +42,7 @@ constexpr int kSegFusedTile = kSegWaves * kSegWaveN;
 // Values are stored biased so that 0 is the identity of both.  Runs on one full wave.
 template <bool kSum>
 __device__ __forceinline__ uint64_t seg_lookback(uint64_t *st, int64_t tile, SegCtl *ctl,
-                                                 int64_t *sticky_error)
+                                                 int64_t *sticky_error, uint32_t spin_limit)
 {
     const int lane = lane_id();
     uint64_t acc = 0;
@@ -60,7 +60,7 @@ __device__ __forceinline__ uint64_t seg_lookback(uint64_t *st, int64_t tile, Seg
         const uint64_t below = p >= kWave ? ~0ull : ((1ull << p) - 1);
         if (notready & below) {                                         // a nearer tile has not published yet
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > g_spin_limit) { atomicExch(&ctl->error, 1u); *sticky_error = 1; return acc; }
+            if (++spins > spin_limit) { atomicExch(&ctl->error, 1u); *sticky_error = 1; return acc; }
             continue;
         }
         if (lane > p) v = 0;
@@ -90,7 +90,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
     IdxT *__restrict__ act_suf, uint64_t *__restrict__ status /*[3][ntiles]*/, int64_t ntiles,
     SegCtl *__restrict__ ctl, int64_t *__restrict__ totals, int64_t *__restrict__ sticky_error,
     int rank_from_isa = 0, uint32_t *__restrict__ list_rank = nullptr,
-    int rank_lo = 0 /* > 0: the rank field holds rank >> rank_lo, the low rank_lo bits of a key (below kshift) the rest */)
+    int rank_lo = 0 /* > 0: the rank field holds rank >> rank_lo, the low rank_lo bits of a key (below kshift) the rest */,
+    uint32_t spin_limit = kSpinLimit /* empty polls of the look-back before it gives up (DQ_FAULT=spin: 0) */)
 {
     __shared__ int64_t w_nh[kSegWaves], w_gh[kSegWaves], w_cnt[kSegWaves];
     __shared__ uint64_t s_prefix[3];
@@ -197,8 +198,8 @@ __global__ __launch_bounds__(kSegThreads) void seg_fused_kernel(
                                __HIP_MEMORY_SCOPE_AGENT);
         uint64_t pf = 0;
         if (tile > 0) {
-            pf = (w == 2) ? seg_lookback<true>(st, tile, ctl, sticky_error)
-                          : seg_lookback<false>(st, tile, ctl, sticky_error);
+            pf = (w == 2) ? seg_lookback<true>(st, tile, ctl, sticky_error, spin_limit)
+                          : seg_lookback<false>(st, tile, ctl, sticky_error, spin_limit);
             const uint64_t incl = (w == 2) ? pf + agg : (agg > pf ? agg : pf);
             if (lane == 0)
                 __hip_atomic_store(st + tile, kSegPrefix | incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

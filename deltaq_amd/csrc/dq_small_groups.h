@@ -246,7 +246,8 @@ __global__ __launch_bounds__(kBlock) void isa_update_kernel(const uint64_t *__re
 // The same for update words that have been BINNED by the top bits of the suffix first (two word passes of the radix
 // sorter): consecutive words then fall into one window of 2^(ib-16) suffixes -- the 4-byte writes of a workgroup
 // land in a few KB of the array and leave its L2 as whole lines instead of one read-modify-write per entry.
-// A word whose suffix field is >= n is padding (an alignment filler in front of the list) and is skipped.
+// The all-ones word is padding (an alignment filler in front of the list) and is skipped: a real word has bit 63 clear
+// (2 * ib <= 63), while the filler's suffix field reads n - 1 -- a real suffix -- when n is a power of two.
 template <typename IdxT>
 __global__ __launch_bounds__(kBlock) void isa_update_words_kernel(const uint64_t *__restrict__ words, int64_t count,
                                                                   int ib, int64_t n, IdxT *__restrict__ ISA)
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void isa_update_words_kernel(const uint64_t
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < count; p += (int64_t)gridDim.x * kBlock) {
         const uint64_t wd = words[p];
         const uint64_t sfx = wd & mask;
-        if ((int64_t)sfx < n) ISA[sfx] = (IdxT)(wd >> ib);
+        if (wd != ~0ull && (int64_t)sfx < n) ISA[sfx] = (IdxT)(wd >> ib);
     }
 }
 

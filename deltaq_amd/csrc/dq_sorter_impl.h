@@ -165,6 +165,9 @@ int prepare_status(Launcher &L, Workspace<IdxT> &w, int64_t m, int passes, int f
 
 // XCD-aware tile order of the first digit pass of a sort (radix_rank_kernel, kAtomicBase): tiles per XCD and group.
 // DQ_XCD_GROUP = 0 (blockIdx order) | 1 .. 64.
+// what the look-back spins of this call's launches give up at (dq_device_utils.h: a kernel argument)
+inline uint32_t spin_bound() { return t_fault.spin ? 0u : kSpinLimit; }
+
 inline int xcd_tile_group()
 {
     if (const char *v = env("DQ_XCD_GROUP")) return std::max(0, std::min(64, atoi(v)));
@@ -201,7 +204,7 @@ int launch_rank_pass(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const
                               shift_override >= 0 ? shift_override : pass * kRadixBits + ib,
                               keybits > 0 ? keybits : 8 * kb, ib,
                               (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1,
-                              ebits, seam_tab, (const uint16_t *)w.codetab, xcd_tile_group()));
+                              ebits, seam_tab, (const uint16_t *)w.codetab, xcd_tile_group(), spin_bound()));
     return DQ_OK;
 }
 
@@ -226,7 +229,7 @@ int rank_pass_ext(Launcher &L, Workspace<IdxT> &w, const uint64_t *kin, const ui
                                                      Cfg::kLdsMatch, Cfg::kRounds, Cfg::kAtomicBase, false, uint8_t>),
                                   dim3((unsigned)ntiles), dim3(Cfg::kThreads), 0, L.st, kin, ein, kout, eout, m, shift, keybits, ib,
                                   (const int64_t *)(w.digit_offset + pass * kRadixSize), status, ctl, w.totals + 1,
-                                  (uint32_t *)nullptr, (uint64_t *)nullptr, (const uint16_t *)w.codetab, xcd_tile_group()));
+                                  (uint32_t *)nullptr, (uint64_t *)nullptr, (const uint16_t *)w.codetab, xcd_tile_group(), spin_bound()));
         return DQ_OK;
     };
     return m < (1ll << 30) ? go(uint32_t{}) : go(uint64_t{});
@@ -550,7 +553,7 @@ int rebucket(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, const uint64_t *keys
                               dim3((unsigned)ntiles), dim3(kSegThreads), 0, L.st, keys, vals, m, kbits, kshift, SA, w.ISA, act_rank,
                               act_suf, reinterpret_cast<uint64_t *>(w.seg_status + 256), ntiles,
                               reinterpret_cast<SegCtl *>(w.seg_status), w.totals, w.totals + 1, rank_from_isa,
-                              (uint32_t *)nullptr, rank_lo));
+                              (uint32_t *)nullptr, rank_lo, spin_bound()));
     HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, L.st));
     HIP_TRY(hipStreamSynchronize(L.st));
     *active_out = c.pinned[0];
@@ -723,7 +726,7 @@ struct SuffixSorter {
                hipLaunchKernelGGL((seg_fused_kernel<IdxT, true, false, false, true>), dim3((unsigned)ntiles),
                                   dim3(kSegThreads), 0, st, (const uint64_t *)keys, (const IdxT *)d_sa, n, ib, kshift0,
                                   d_sa, w.ISA, P0, w.Va, reinterpret_cast<uint64_t *>(w.seg_status + 256), ntiles,
-                                  reinterpret_cast<SegCtl *>(w.seg_status), w.totals, w.totals + 1, 0, list_rank));
+                                  reinterpret_cast<SegCtl *>(w.seg_status), w.totals, w.totals + 1, 0, list_rank, 0, spin_bound()));
         // digit offsets of the two binning passes in closed form: every suffix 0..n-1 occurs once
         const int sh[2] = {ib - 16, ib - 8};
         HIP_TRY(hipMemcpyAsync(c.pinned, w.totals, 16, hipMemcpyDeviceToHost, st));
@@ -1176,7 +1179,8 @@ struct SuffixSorter {
             return DQ_OK;
         }
         // the word list starts on a 16-byte boundary (key loads of the histogram kernel): one filler word in
-        // front of it if need be -- all ones: a suffix field >= n, skipped by the update kernels
+        // front of it if need be -- all ones, which no real word is (bit 63 of rank << ib | suffix is clear): the update
+        // kernels skip exactly that word (not "suffix field >= n": for n = 2^ib the filler's field reads n - 1)
         uint64_t *U = u_end - mU;
         int64_t cnt = mU;
         if (reinterpret_cast<uintptr_t>(U) & 8) {
@@ -1767,27 +1771,10 @@ struct SuffixSorter {
     }
 };
 
-// DQ_FAULT=spin (dq_runtime.h): the look-back spins of this translation unit's kernels give up at their first empty poll
-// while a call asks for it; the production bound comes back with the next call that does not.
-template <typename IdxT>
-int set_spin_fault(int dev)
-{
-    static std::mutex mu;
-    static std::atomic<bool> lowered[kMaxDevices];
-    if (!t_fault.spin && !lowered[dev].load(std::memory_order_acquire)) return DQ_OK;
-    std::lock_guard<std::mutex> lk(mu);
-    const uint32_t want = t_fault.spin ? 0u : kSpinLimit;
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_spin_limit), &want, sizeof(want)));
-    lowered[dev].store(t_fault.spin, std::memory_order_release);
-    return DQ_OK;
-}
-
 template <typename IdxT>
 int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, IdxT *d_sa, SortHints hints = SortHints(),
                    const uint8_t *text_src = nullptr)
 {
-    const int frc = set_spin_fault<IdxT>(c.dev);
-    if (frc != DQ_OK) return frc;
     SuffixSorter<IdxT> sorter(c, st, w, n, d_sa);
     // (DQ_ASSUME_DOUBLED: the tests vouch for their inputs through the public entry points)
     if ((hints.doubled || env("DQ_ASSUME_DOUBLED")) && n % 2 == 0 && !env("DQ_NO_TWINS")) sorter.twin_half = n / 2;

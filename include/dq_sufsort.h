@@ -197,10 +197,25 @@ int32_t dq_last_sort_info(int64_t *rounds, int64_t *initial_active, int64_t *sum
 
 /* Shape of the last dq_bsdiff_create / dq_bsdiff_scan_i32 / dq_bsdiff_index_diff on this thread, `count` entries (5 are
  * defined, further ones read 0): Search calls the reference's loop makes (Diff.cs:106), windows of scan positions,
- * positions asked again exactly, launches of the device's anchor scan that were given back to the host loop (its
- * persistent grid waited in vain: a device kept full by other work -- the patch is the same, the call slower),
- * workgroups of that grid. */
+ * positions asked again exactly, files the host loop took instead of the device's anchor scan (host_loop_fallbacks: a
+ * launch whose persistent grid waited in vain -- a device kept full by other work --, AND each of the 16 diffs after it
+ * that skip the device scan on that device, and devices that hold fewer than 8 workgroups of the grid; the patch is
+ * the same, the call slower, dq_last_error() is left untouched by it), workgroups of that grid. */
 int32_t dq_last_diff_info(int64_t *info, int32_t count);
+
+/* Shape of the last dq_sufsort_hip_batch_i32 on this thread, `count` entries (6 are defined, further ones read 0):
+ * inputs that went through the three-stage pipelines; microseconds the copy-in, the sort and the copy-out stages were
+ * busy, each summed over the device shares (a share whose sort stage is busy all the time waits for the GPU, one whose
+ * copy stages are waits for host memory / PCIe: what an 8-GPU run needs to tell the two apart); wall microseconds of
+ * the slowest share; device shares whose host threads were bound to their device's NUMA node.  New API like the batch
+ * entry itself: the reference has no multi-file call ("Who calls it"). */
+int32_t dq_last_batch_info(int64_t *info, int32_t count);
+
+/* NUMA node the device's PCIe function hangs off (/sys/bus/pci/devices/<bdf>/numa_node), -1 where the platform does not
+ * say (single-socket hosts, containers without sysfs) or the ordinal is out of range.  The batch pipeline binds the host
+ * threads it starts for a device to that node's CPUs (never the caller's thread; DQ_NUMA_BIND=0 turns it off); a host
+ * that runs one process per GPU -- bench.py's ranks, deltaq_amd/batch.py -- binds itself with this. */
+int32_t dq_device_numa_node(int32_t device);
 
 #ifdef __cplusplus
 }

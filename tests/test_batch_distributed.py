@@ -299,8 +299,43 @@ def test_bench_line_of_two_ranks_sharing_the_gpu():
     assert b["sharding"]["buffers_per_rank"] == [64, 64]
     assert b["sufcheck_first_buffers"] is True
     assert len(b["host_copy_GBps_per_rank"]) == 2
+    assert len(b["sort_ms_per_rank"]) == 2 and all(x > 0 for x in b["sort_ms_per_rank"])
     ssg = b["rccl_scatter_sort_gather"]
     assert "error" not in ssg and ssg["sufcheck"] is True and ssg["buffers"] == 4, ssg
+    many = b["one_old_many_new"]
+    assert "error" not in many and many["patches_apply"] is True and many["new_files"] == 8, many
+
+
+@pytest.mark.gpu
+def test_bench_line_of_eight_ranks_sharing_the_gpu():
+    """The driver's first real 8-GPU run must not be the first time world 8 executes: bench.py as it launches it for N = 8,
+    all ranks on cuda:0 over gloo, at small sizes (16 MiB headline buffers, a 32 x 4 MiB batch, one new file per rank) --
+    scatter rows, gather, broadcast, the LPT plan, `devices_per_rank`, the per-rank stage times and the NUMA fields for
+    eight ranks."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in [k for k in env if k.startswith("DQ_")]:
+        env.pop(k)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--size-mib", "16", "--batch-count", "32", "--batch-mib", "4", "--many-new-per-rank", "1",
+           "--share-gpu", "--backend", "gloo", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["gpus_flag"] == 8 and rec["scaling"] == "weak"
+    assert rec["devices_per_rank"] == [0] * 8 and len(rec["numa_node_per_rank"]) == 8
+    b = rec["batch"]
+    assert b["workload"].startswith("NOT configs[4]")             # (the named workload is 128 x 16 MiB)
+    assert b["sharding"]["buffers_per_rank"] == [4] * 8
+    assert b["sufcheck_first_buffers"] is True
+    for key in ("host_copy_GBps_per_rank", "wall_ms_per_rank", "sort_ms_per_rank", "copy_in_ms_per_rank", "copy_out_ms_per_rank"):
+        assert len(b[key]) == 8 and all(x > 0 for x in b[key]), (key, b[key])
+    ssg = b["rccl_scatter_sort_gather"]
+    assert "error" not in ssg and ssg["sufcheck"] is True and ssg["buffers"] == 16, ssg
     many = b["one_old_many_new"]
     assert "error" not in many and many["patches_apply"] is True and many["new_files"] == 8, many
 

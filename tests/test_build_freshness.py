@@ -16,11 +16,12 @@ def test_dependency_lists_are_rerooted_into_this_tree(tmp_path, monkeypatch):
     (obj / "dq_abi.d").write_text(
         "/somewhere/else/repo/deltaq_amd/csrc/obj/dq_abi.o: /somewhere/else/repo/deltaq_amd/csrc/dq_abi.hip \\\n"
         "  /somewhere/else/repo/deltaq_amd/csrc/dq_runtime.h /opt/rocm/include/hip/hip_runtime.h \\\n"
+        "  /home/x/rocm/include/hip/hip_runtime_api.h \\\n"           # (a toolchain elsewhere: "/include/" in its path, not ours)
         "  /somewhere/else/repo/deltaq_amd/csrc/../../include/dq_sufsort.h\n")
     deps = b._deps("dq_abi.hip")
     assert os.path.join(b.CSRC, "dq_abi.hip") in deps and os.path.join(b.CSRC, "dq_runtime.h") in deps
     assert os.path.join(ROOT, "include", "dq_sufsort.h") in [os.path.normpath(p) for p in deps]
-    assert not any(p.startswith("/opt/") for p in deps)
+    assert not any(p.startswith("/opt/") for p in deps) and not any("hip_runtime_api" in p for p in deps)
     assert all(os.path.exists(p) for p in deps)
 
 
@@ -63,3 +64,24 @@ def test_timing_experiment_patch_still_applies():
     p = subprocess.run(["git", "apply", "--check", "-p1", os.path.join("tools", "exp", "timing_experiments.patch")],
                        cwd=ROOT, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
+
+
+def test_oracle_freshness_follows_content_not_time(tmp_path):
+    """oracle/__init__.py: the checker's library is current iff its manifest names the sources as they are now (round-5
+    verdict: it went by file times, the bug class build.py had)."""
+    import oracle
+    oracle.build()
+    assert not oracle._stale()
+    saved = open(oracle._MANIFEST).read()
+    try:
+        # newer file times alone change nothing ...
+        os.utime(os.path.join(oracle._HERE, "sais.c"))
+        assert not oracle._stale()
+        # ... a manifest that names other contents does, whatever the times say
+        with open(oracle._MANIFEST, "w") as f:
+            f.write("0" * 64 + "\n")
+        assert oracle._stale()
+    finally:
+        with open(oracle._MANIFEST, "w") as f:
+            f.write(saved)
+    assert not oracle._stale()

@@ -33,9 +33,15 @@ def host_ram_bytes():
 
 
 def need_ram(gib):
+    """A full-size config that is dropped must not pass for one that ran (round-5 verdict): the skip is printed (pytest
+    shows it with -rs, and the line below lands in the captured output either way), and a host that HAS the memory the
+    GPU boxes have (>= 64 GiB) and still comes out short is a failure, not a skip -- the case then asks for too much."""
     have = host_ram_bytes()
     if have and have < gib * GiB:
-        pytest.skip(f"host has {have / GiB:.0f} GiB of RAM, this case needs {gib} GiB (text + SA + checker)")
+        msg = f"host has {have / GiB:.0f} GiB of RAM, this case needs {gib} GiB (text + SA + checker): BASELINE config NOT exercised here"
+        print("SKIPPED full-size config: " + msg, flush=True)
+        assert have < 64 * GiB, msg
+        pytest.skip(msg)
 
 
 @pytest.fixture(scope="module")

@@ -500,8 +500,11 @@ def test_batch_entry_point_two_device_slots(backend_lib, oracle_mod):
     ln = (ctypes.c_int64 * cnt)(*[t.size for t in texts])
     tp = (ctypes.c_void_p * cnt)(*[t.ctypes.data if t.size else None for t in texts])
     expect = [oracle_mod.divsufsort(t) for t in texts]
-    ndevs = [(2, [0, 0]), (3, [0, 0, 0])]
+    # (8 slots: the fan-out of a full node -- 8 shares, 8 host threads + 24 stage threads -- on whatever devices there are)
+    ndevs = [(2, [0, 0]), (3, [0, 0, 0]), (8, [0] * 8)]
     have = backend_lib.dq_device_count()
+    if 1 < have < 8:
+        ndevs.append((8, [d % have for d in range(8)]))
     if have > 1:
         ndevs.append((have, list(range(have))))
     for ndev, devs in ndevs:
@@ -512,6 +515,18 @@ def test_batch_entry_point_two_device_slots(backend_lib, oracle_mod):
         assert rc == 0, backend_lib.dq_last_error()
         for j, (s, e) in enumerate(zip(sas, expect)):
             assert np.array_equal(s, e), (ndev, j)
+        info = _abi_mod().last_batch_info()             # dq_last_batch_info: what the shares report back
+        assert 0 <= info["pipelined"] <= cnt and info["slowest_share_ms"] > 0
+        assert 0 <= info["shares_bound_to_numa_node"] <= ndev
+        if info["pipelined"]:
+            assert info["sort_ms"] > 0 and info["copy_in_ms"] > 0 and info["copy_out_ms"] > 0
+    node = backend_lib.dq_device_numa_node(0)
+    assert node >= -1 and backend_lib.dq_device_numa_node(10_000) == -1
+
+
+def _abi_mod():
+    from deltaq_amd import _abi
+    return _abi
 
 
 FORCED_PATHS = [
@@ -586,6 +601,35 @@ def test_every_code_path_is_bit_exact(ldss, oracle_mod, monkeypatch, env):
         assert np.array_equal(SA, oracle_mod.divsufsort(T)), (env, T.size)
     T = oracle_mod.gen_uniform(1_000_003, 7)
     assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), oracle_mod.divsufsort(T).astype(np.int64))
+
+
+@pytest.mark.parametrize("env", [{"DQ_UPD_WINDOW": "1"}, {"DQ_UPD_BIN": "1", "DQ_UPD_BIN_MIN": "1"}, {"DQ_UPD_BIN": "2", "DQ_UPD_BIN_MIN": "1"}],
+                         ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
+def test_update_filler_word_when_n_is_a_power_of_two(ldss, oracle_mod, monkeypatch, env):
+    """The binned rank updates start on a 16-byte boundary: an all-ones filler word in front of an odd-placed list.  For
+    n = 2^ib the filler's suffix field reads n - 1, a real suffix (round-5 advice): it must be skipped as a word, not by
+    its suffix field.  Texts of 2^16 and 2^20 bytes whose end repeats an earlier stretch (so that suffix n - 1 - h is
+    still tied when a round gathers ISA[n - 1]) with a genuine zero tail on some, both index widths (an int64 rank of
+    2^(64 - ib) - 1 sorts last in its group; truncated to int32 it reads -1 and hides)."""
+    monkeypatch.setenv("DQ_SMALL_N", "0")
+    monkeypatch.setenv("DQ_TAIL_MAX", "0")
+    monkeypatch.setenv("DQ_PACKED", "0")
+    monkeypatch.setenv("DQ_SPARSE", "0")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for n in (1 << 16, 1 << 20):
+        for seed in range(6):
+            rng = np.random.default_rng(1000 + seed)
+            A = rng.integers(0, 3, 9000 + seed).astype(np.uint8)
+            if seed % 2:
+                A[-(3 + seed):] = 0                                 # genuine zeros against the zero padding
+            B = (oracle_mod.gen_uniform(n - 2 * A.size, 40 + seed) & 3).astype(np.uint8)
+            T = np.ascontiguousarray(np.concatenate([A, B, A]), dtype=np.uint8)
+            assert T.size == n
+            monkeypatch.setenv("DQ_KEY_BYTES", "2" if seed < 3 else "8")
+            ref = oracle_mod.divsufsort(T)
+            assert np.array_equal(ldss.Sort(T), ref), (env, n, seed, "int32")
+            assert np.array_equal(ldss.Sort(T, index_dtype=np.int64), ref.astype(np.int64)), (env, n, seed, "int64")
 
 
 def run_heavy_texts(oracle_mod):

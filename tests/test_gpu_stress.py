@@ -19,7 +19,9 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-BUDGET_S = int(os.environ.get("DQ_STRESS_SECONDS", "150"))
+# (90 s a slice: with the round-6 additions the GPU suite stays under 9 of its 20 minutes; longer slices are run by hand
+# -- `python tests/manual/stress.py 600 <seed>` -- and their logs kept under profiles/)
+BUDGET_S = int(os.environ.get("DQ_STRESS_SECONDS", "90"))
 
 
 def tree_seed() -> int:

@@ -17,10 +17,32 @@ _LIB = os.path.join(_HERE, "libdq_datagen.so")
 _lib = None
 
 
+_MANIFEST = os.path.join(_HERE, "libdq_datagen.manifest")
+
+
+def _source_digest() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gen.c", "Makefile"):
+        with open(os.path.join(_HERE, f), "rb") as fh:
+            h.update(f.encode() + fh.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "gen.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(src) > os.path.getmtime(_LIB):
-        subprocess.run(["make", "-C", _HERE, "-s", "libdq_datagen.so"], check=True)
+    """By content, not by file times (a copied tree's times order nothing): current iff the manifest beside the library
+    names gen.c as it is now."""
+    def stale() -> bool:
+        return not os.path.exists(_LIB) or not os.path.exists(_MANIFEST) or open(_MANIFEST).read().strip() != _source_digest()
+    if force or stale():
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:      # one builder at a time (bench.py's ranks)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or stale():
+                subprocess.run(["make", "-C", _HERE, "-s", "-B", "libdq_datagen.so"], check=True)
+                with open(_MANIFEST + ".tmp", "w") as f:
+                    f.write(_source_digest() + "\n")
+                os.replace(_MANIFEST + ".tmp", _MANIFEST)
     return _LIB
 
 
