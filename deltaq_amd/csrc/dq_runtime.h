@@ -154,7 +154,8 @@ inline const char *const kKernelNames[DQ_K_COUNT] = {
     "tie_seam_kernel", "tie_collect_kernel", "small_group_finish_kernel", "small_group_round_kernel",
     "isa_update_kernel", "isa_from_pairs_kernel", "key2_from_pairs_kernel", "gather_key2_kernel",
     "gather_text_key_kernel", "isa_from_sa_kernel", "small_sufsort_kernel", "bucket_sort_kernel",
-    "match_search_kernel", "pair_chain_kernels", "mid_group_round_kernel", "runlen_kernels"};
+    "match_search_kernel", "pair_chain_kernels", "mid_group_round_kernel", "runlen_kernels",
+    "split_pass_kernel", "bucket_finish_kernel", "split_round0_aux_kernels"};
 
 struct ProfRec { int cat; hipEvent_t a, b; int64_t elems, bytes; };
 

@@ -33,6 +33,7 @@
 #include "dq_bucket_sort.h"
 #include "dq_pair_chains.h"
 #include "dq_tail.h"
+#include "dq_split_round0.h"
 
 namespace dq {
 namespace {
@@ -75,8 +76,18 @@ struct Workspace {
     size_t ctl_status_stride;   // bytes per pass (set by prepare_status)
     char *seg_status;           // SegCtl (256 B) followed by 3 x ntiles status words
     size_t seg_status_bytes;
+    // round 0 as a sample sort (dq_split_round0.h; int32 indices, texts of >= kSplitMinN bytes): splitter tables, cursors, plans
+    uint64_t *sp_top, *sp_sub;
+    unsigned long long *sp_cnt_a, *sp_cursor_a, *sp_cursor_b;
+    int64_t *sp_off, *sp_out_base, *sp_ovf_start;
+    uint32_t *sp_tile_first, *sp_ovf_list;
+    ScanPart *sp_part;
+    SplitCtl *sp_ctl;
     size_t bytes;
 };
+
+// smallest text the sample-sort round 0 can take: its 2 Mi sampled keys are sorted in idle key buffers of 8 (n + 2) bytes
+constexpr int64_t kSplitMinN = 2ll << 20;
 
 template <typename IdxT>
 Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
@@ -121,6 +132,20 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
     w.ctl_status = take(w.ctl_status_bytes);
     w.seg_status_bytes = 256 + 3 * (un / kSegFusedTile + 2) * 8;
     w.seg_status = take(w.seg_status_bytes);
+    if (sizeof(IdxT) == 4 && n >= kSplitMinN) {             // ~4.7 MB of tables
+        w.sp_top = (uint64_t *)take((size_t)kSplitTop * 8);
+        w.sp_sub = (uint64_t *)take((size_t)kSplitBuckets * 8);
+        w.sp_cnt_a = (unsigned long long *)take((size_t)kSplitTop * 8);
+        w.sp_cursor_a = (unsigned long long *)take((size_t)kSplitTop * 8);
+        w.sp_cursor_b = (unsigned long long *)take((size_t)kSplitBuckets * 8);
+        w.sp_off = (int64_t *)take((size_t)(kSplitTop + 1) * 8);
+        w.sp_out_base = (int64_t *)take((size_t)(kSplitBuckets + 1) * 8);
+        w.sp_ovf_start = (int64_t *)take((size_t)kSplitBuckets * 8);
+        w.sp_tile_first = (uint32_t *)take((size_t)(kSplitTop + 1) * 4);
+        w.sp_ovf_list = (uint32_t *)take((size_t)kSplitBuckets * 4);
+        w.sp_part = (ScanPart *)take((size_t)kScanBlocks * sizeof(ScanPart));
+        w.sp_ctl = (SplitCtl *)take(sizeof(SplitCtl));
+    }
     w.bytes = off;
     return w;
 }
@@ -346,8 +371,37 @@ void choose_key_bytes(const int64_t *bytehist, const int64_t *kgram_coll, int64_
 
 // round 0, step 1: byte histogram of the text -> key width kb -> per-digit offsets
 template <typename IdxT>
+int launch_coded_hist(Launcher &L, Workspace<IdxT> &w, int64_t n)
+{
+    const int hblocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 2) + kHistThreads - 1) / kHistThreads + 1);
+    int rc2 = L.begin(DQ_K_RADIX_HIST, n, n);
+    if (rc2 != DQ_OK) return rc2;
+    HIP_TRY(hipMemsetAsync(w.hist_partial, 0, (size_t)kMaxPasses * kRadixSize * 8, L.st));
+    hipLaunchKernelGGL(text_coded_hist_kernel, dim3(hblocks), dim3(kHistThreads), 0, L.st,
+                       reinterpret_cast<const uint32_t *>(w.text), n, (const uint16_t *)w.codetab,
+                       reinterpret_cast<unsigned long long *>(w.hist_partial));
+    hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(kMaxPasses), dim3(kHistScanThreads), 0, L.st,
+                       (const unsigned long long *)w.hist_partial, w.digit_offset);
+    HIP_TRY(hipGetLastError());
+    return L.end();
+}
+
+// Round 0 as a sample sort (dq_split_round0.h) instead of eight digit passes: 8-byte pair keys (text-like inputs and real
+// binaries: many ties expected, coded or raw), int32 indices, from 32 MiB on (below, eight launch-bound passes over a
+// short text cost less than the ten launches of the split) and up to the size whose mean bucket is half the finish
+// kernel's capacity.  DQ_SPLIT = 0 | 1 overrides (1: from kSplitMinN on, for the tests).
+template <typename IdxT>
+bool split_round0_wanted(int64_t n, bool packed, int kb)
+{
+    if (sizeof(IdxT) != 4 || packed || kb != 8 || n < kSplitMinN || n > (int64_t)kSplitBuckets * (kFinCap / 2)) return false;
+    if (const char *v = env("DQ_SPLIT")) return atoi(v) != 0;
+    if (env("DQ_KEY_BYTES") || env("DQ_NO_BUCKET")) return false;     // (forced plain paths of the tests stay what they were)
+    return n >= (32ll << 20);
+}
+
+template <typename IdxT>
 int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, int64_t n, int *kb_out,
-                               bool *packed_out, bool *coded_out, const uint8_t *text_src = nullptr)
+                               bool *packed_out, bool *coded_out, const uint8_t *text_src = nullptr, bool *hist_deferred = nullptr)
 {
     *coded_out = false;
     // (256-thread workgroups: the pass is a chain of 16-byte loads and LDS adds, bound by how many are in flight.  512 / 1024 /
@@ -407,18 +461,14 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
             uint16_t *stage = reinterpret_cast<uint16_t *>(c.pinned + 512);          // the upload half of the pinned area
             memcpy(stage, code.tab, sizeof(code.tab));
             HIP_TRY(hipMemcpyAsync(w.codetab, stage, sizeof(code.tab), hipMemcpyHostToDevice, L.st));
-            const int hblocks = (int)std::min<int64_t>(kHistBlocks, ((n >> 2) + kHistThreads - 1) / kHistThreads + 1);
-            int rc2 = L.begin(DQ_K_RADIX_HIST, n, n);
-            if (rc2 != DQ_OK) return rc2;
-            HIP_TRY(hipMemsetAsync(w.hist_partial, 0, (size_t)kMaxPasses * kRadixSize * 8, L.st));
-            hipLaunchKernelGGL(text_coded_hist_kernel, dim3(hblocks), dim3(kHistThreads), 0, L.st,
-                               reinterpret_cast<const uint32_t *>(w.text), n, (const uint16_t *)w.codetab,
-                               reinterpret_cast<unsigned long long *>(w.hist_partial));
-            hipLaunchKernelGGL(radix_hist_scan_kernel, dim3(kMaxPasses), dim3(kHistScanThreads), 0, L.st,
-                               (const unsigned long long *)w.hist_partial, w.digit_offset);
-            HIP_TRY(hipGetLastError());
-            rc2 = L.end();
-            if (rc2 != DQ_OK) return rc2;
+            // (the eight digit histograms of the coded keys -- one more read of the text -- only if the digit passes
+            // will run: the sample-sort round 0 does not need them and launches them itself should it give up)
+            if (hist_deferred && split_round0_wanted<IdxT>(n, packed, kb)) {
+                *hist_deferred = true;
+            } else {
+                const int rc2 = launch_coded_hist<IdxT>(L, w, n);
+                if (rc2 != DQ_OK) return rc2;
+            }
             if (env("DQ_TRACE")) fprintf(stderr, "[dq] coded round 0: %d symbols, %.2f bits per byte\n", code.sigma, code.avg_len);
             *coded_out = true;
             return DQ_OK;
@@ -910,6 +960,131 @@ struct SuffixSorter {
         return DQ_OK;
     }
 
+    // ---- round 0 as a sample sort (dq_split_round0.h): on return with *done the 64-bit keys lie sorted in K[1] and the
+    //      suffixes in d_sa, as after the eight digit passes (which would have ended in K[0]).  *done = false: the
+    //      overflow list ran full (a text made of a few heavy keys) -- nothing the digit passes need has been touched
+    //      but the look-back state, which the caller zeroes again.
+    int round0_split(uint64_t *K[2], bool coded, bool *done)
+    {
+        *done = false;
+        if constexpr (sizeof(IdxT) != 4) {
+            return DQ_OK;
+        } else {
+            if (!w.sp_top || !w.X || !w.RL) return DQ_OK;
+            const int64_t cap = std::min<int64_t>(kFinCap, (n + 2) / (kSplitBuckets / 2));       // slot entries per bucket: twice the mean
+            if (cap < 2) return DQ_OK;
+            const uint32_t *t32 = reinterpret_cast<const uint32_t *>(w.text);
+            const uint64_t *text64 = reinterpret_cast<const uint64_t *>(w.text);
+            const uint16_t *ctab = (const uint16_t *)w.codetab;
+            // idle buffers: the sample and its sort, then the bucket slots -- keys in K[0] (first half of the buckets) and X,
+            // suffixes in Vb and Xs; pass A's pairs in (K[1], Va); the overflow list in the inverse suffix array's and
+            // the run lengths' memory (two halves each: the ping-pong of its sort)
+            uint64_t *Ks[2] = {K[0], w.X};
+            IdxT *Vs[2] = {w.Vb, w.Xs};
+            const int64_t ovf_cap = (n / 4) & ~(int64_t)1;       // (even: the second half starts on a 16-byte boundary, as the histogram kernel's key loads want)
+            uint64_t *ovf_k[2] = {reinterpret_cast<uint64_t *>(w.ISA), reinterpret_cast<uint64_t *>(w.ISA) + ovf_cap};
+            IdxT *ovf_v[2] = {reinterpret_cast<IdxT *>(w.RL), reinterpret_cast<IdxT *>(w.RL) + ovf_cap};
+            // (DQ_TRACE=2: the stream is drained after every phase and the phase named -- tests/manual/t_split_small.py)
+            const bool dbg = env("DQ_TRACE") && atoi(env("DQ_TRACE")) >= 2;
+            auto phase = [&](const char *what) -> int {
+                if (!dbg) return DQ_OK;
+                HIP_TRY(hipStreamSynchronize(st));
+                fprintf(stderr, "[dq] split round 0: %s done\n", what);
+                return DQ_OK;
+            };
+            const unsigned sgrid = (unsigned)((kSplitSample + kBlock - 1) / kBlock);
+            if (coded) {
+                LAUNCH(L, DQ_K_SPLIT_AUX, kSplitSample, kSplitSample * (20 + 8),
+                       hipLaunchKernelGGL(sample_keys_kernel<true>, dim3(sgrid), dim3(kBlock), 0, st, t32, n, ctab, kSplitSample, Ks[0]));
+            } else {
+                LAUNCH(L, DQ_K_SPLIT_AUX, kSplitSample, kSplitSample * (12 + 8),
+                       hipLaunchKernelGGL(sample_keys_kernel<false>, dim3(sgrid), dim3(kBlock), 0, st, t32, n, ctab, kSplitSample, Ks[0]));
+            }
+            int rc = phase("sample");
+            if (rc != DQ_OK) return rc;
+            int scur = 0;
+            rc = onesweep_sort_pairs<IdxT>(L, w, Ks, Vs, kSplitSample, 64, scur);
+            if (rc != DQ_OK) return rc;
+            if ((rc = phase("sample sort")) != DQ_OK) return rc;
+            // texts made of a few heavy keys (runs, short periods, tiny alphabets) would only fill the overflow list: the sorted
+            // sample tells before anything is moved (one small kernel and a host round trip)
+            HIP_TRY(hipMemsetAsync(w.sp_ctl, 0, sizeof(SplitCtl), st));
+            hipLaunchKernelGGL(sample_heavy_kernel, dim3(sgrid), dim3(kBlock), 0, st, (const uint64_t *)Ks[scur], &w.sp_ctl->ovf_count);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(c.pinned, w.sp_ctl, sizeof(SplitCtl), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const int64_t heavy = c.pinned[0];
+            if (env("DQ_TRACE"))
+                fprintf(stderr, "[dq] sample-sort round 0: %.1f %% of the sampled keys are copies of keys too heavy for a bucket%s\n",
+                        100.0 * (double)heavy / (double)kSplitSample, heavy * 6 > kSplitSample ? " -- the digit passes instead" : "");
+            if (heavy * 6 > kSplitSample && !(env("DQ_SPLIT") && atoi(env("DQ_SPLIT")) >= 2)) return DQ_OK;      // (DQ_SPLIT=2: the tests go on regardless)
+            HIP_TRY(hipMemsetAsync(w.sp_cnt_a, 0, (size_t)kSplitTop * 8, st));
+            HIP_TRY(hipMemsetAsync(w.sp_cursor_b, 0, (size_t)kSplitBuckets * 8, st));
+            HIP_TRY(hipMemsetAsync(w.sp_ctl, 0, sizeof(SplitCtl), st));
+            const int hblocks = (int)std::min<int64_t>(2 * kHistBlocks, ((n >> 2) + kHistThreads - 1) / kHistThreads + 1);
+            LAUNCH(L, DQ_K_SPLIT_AUX, n, n,
+                   hipLaunchKernelGGL(make_splitters_kernel, dim3(kSplitBuckets / kBlock), dim3(kBlock), 0, st, (const uint64_t *)Ks[scur], w.sp_top, w.sp_sub);
+                   if (coded) hipLaunchKernelGGL(split_hist_kernel<true>, dim3(hblocks), dim3(kHistThreads), 0, st, t32, n, ctab, (const uint64_t *)w.sp_top, w.sp_cnt_a);
+                   else hipLaunchKernelGGL(split_hist_kernel<false>, dim3(hblocks), dim3(kHistThreads), 0, st, t32, n, ctab, (const uint64_t *)w.sp_top, w.sp_cnt_a);
+                   hipLaunchKernelGGL(split_plan_kernel, dim3(1), dim3(kSplitTop), 0, st, (const unsigned long long *)w.sp_cnt_a, w.sp_off, w.sp_cursor_a,
+                                      w.sp_tile_first, w.sp_ctl));
+            if ((rc = phase("splitters, top-bucket histogram, plan")) != DQ_OK) return rc;
+            const unsigned grid_a = (unsigned)((n + kSplitTile - 1) / kSplitTile);
+            if (coded) {
+                LAUNCH(L, DQ_K_SPLIT_PASS, n, n * (1 + 8 + wb),
+                       hipLaunchKernelGGL((split_pass_kernel<IdxT, true, true>), dim3(grid_a), dim3(kSplitThreads), 0, st, text64, (const IdxT *)nullptr, n,
+                                          (const uint64_t *)w.sp_top, w.sp_cursor_a, (const int64_t *)w.sp_off, (const uint32_t *)w.sp_tile_first, K[1], w.Va,
+                                          (uint64_t *)nullptr, (IdxT *)nullptr, (int64_t)0, (uint64_t *)nullptr, (IdxT *)nullptr, (int64_t)0, w.sp_ctl, ctab));
+            } else {
+                LAUNCH(L, DQ_K_SPLIT_PASS, n, n * (1 + 8 + wb),
+                       hipLaunchKernelGGL((split_pass_kernel<IdxT, true, false>), dim3(grid_a), dim3(kSplitThreads), 0, st, text64, (const IdxT *)nullptr, n,
+                                          (const uint64_t *)w.sp_top, w.sp_cursor_a, (const int64_t *)w.sp_off, (const uint32_t *)w.sp_tile_first, K[1], w.Va,
+                                          (uint64_t *)nullptr, (IdxT *)nullptr, (int64_t)0, (uint64_t *)nullptr, (IdxT *)nullptr, (int64_t)0, w.sp_ctl, ctab));
+            }
+            if ((rc = phase("pass A")) != DQ_OK) return rc;
+            // (pass B's grid is an upper bound -- every top bucket may end in a ragged tile; the workgroups beyond the plan's count leave at once)
+            const unsigned grid_b = (unsigned)(n / kSplitTile + kSplitTop);
+            LAUNCH(L, DQ_K_SPLIT_PASS, n, n * 2 * (8 + wb),
+                   hipLaunchKernelGGL((split_pass_kernel<IdxT, false, false>), dim3(grid_b), dim3(kSplitThreads), 0, st, (const uint64_t *)K[1], (const IdxT *)w.Va, n,
+                                      (const uint64_t *)w.sp_sub, w.sp_cursor_b, (const int64_t *)w.sp_off, (const uint32_t *)w.sp_tile_first, Ks[0], Vs[0], Ks[1], Vs[1],
+                                      cap, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl, ctab));
+            if ((rc = phase("pass B")) != DQ_OK) return rc;
+            LAUNCH(L, DQ_K_SPLIT_AUX, kSplitBuckets, (int64_t)kSplitBuckets * 36,
+                   hipLaunchKernelGGL(bucket_sum_kernel, dim3(kScanBlocks), dim3(kScanThreads), 0, st, (const unsigned long long *)w.sp_cursor_b, cap, w.sp_part);
+                   hipLaunchKernelGGL(bucket_scan_kernel, dim3(kScanBlocks), dim3(kScanThreads), 0, st, (const unsigned long long *)w.sp_cursor_b, cap,
+                                      (const ScanPart *)w.sp_part, w.sp_out_base, w.sp_ovf_start, w.sp_ovf_list, w.sp_ctl));
+            if ((rc = phase("bucket scan")) != DQ_OK) return rc;
+            // (two geometries by bucket size, dq_split_round0.h; the last launch also moves the oversize buckets out)
+            const bool two = cap > kFinSmallCap;
+            LAUNCH(L, DQ_K_SPLIT_FINISH, n, n * 2 * (8 + wb),
+                   hipLaunchKernelGGL((bucket_finish_kernel<IdxT, 256, 8>), dim3(kSplitBuckets), dim3(256), 0, st, (const uint64_t *)Ks[0], (const IdxT *)Vs[0],
+                                      (const uint64_t *)Ks[1], (const IdxT *)Vs[1], cap, (int64_t)0, (int64_t)kFinSmallCap, !two,
+                                      (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl);
+                   if (two)
+                       hipLaunchKernelGGL((bucket_finish_kernel<IdxT, 512, 8>), dim3(kSplitBuckets), dim3(512), 0, st, (const uint64_t *)Ks[0], (const IdxT *)Vs[0],
+                                          (const uint64_t *)Ks[1], (const IdxT *)Vs[1], cap, (int64_t)kFinSmallCap, (int64_t)kFinCap, true,
+                                          (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl));
+            HIP_TRY(hipMemcpyAsync(c.pinned, w.sp_ctl, sizeof(SplitCtl), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const int64_t ovf = c.pinned[0], ovf_buckets = c.pinned[1], abandon = c.pinned[3];
+            if (env("DQ_TRACE"))
+                fprintf(stderr, "[dq] sample-sort round 0 (%s keys, %d buckets of <= %lld): %lld suffixes in %lld oversize buckets%s\n", coded ? "coded" : "raw",
+                        kSplitBuckets, (long long)cap, (long long)ovf, (long long)ovf_buckets, abandon ? " -- overflow list full, given up" : "");
+            if (abandon || ovf > ovf_cap) return DQ_OK;
+            if (ovf > 0) {
+                int xcur = 0;
+                rc = onesweep_sort_pairs<IdxT>(L, w, ovf_k, ovf_v, ovf, 64, xcur);
+                if (rc != DQ_OK) return rc;
+                LAUNCH(L, DQ_K_SPLIT_AUX, ovf, ovf * 2 * (8 + wb),
+                       hipLaunchKernelGGL(overflow_place_kernel<IdxT>, dim3((unsigned)ovf_buckets), dim3(kBlock), 0, st, (const uint32_t *)w.sp_ovf_list,
+                                          (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, (const int64_t *)w.sp_ovf_start,
+                                          (const uint64_t *)ovf_k[xcur], (const IdxT *)ovf_v[xcur], K[1], d_sa));
+            }
+            *done = true;
+            return DQ_OK;
+        }
+    }
+
     // ---- round 0: leading kb bytes of every suffix as a key (or packed word), full radix ranking,
     //      then the first rebucket: X = members of groups of size > 1.  *dense_built tells whether
     //      the rebucket pass already wrote the inverse suffix array.
@@ -921,7 +1096,8 @@ struct SuffixSorter {
         bool packed = false, coded = false;
         // pass p writes buffer (p+1)&1, so the last pass (kb-1) writes buffer kb&1: that one
         // must be the caller's SA, which is why the key width is chosen first
-        rc = onesweep_sort_text_prepare<IdxT>(L, c, w, n, &kb, &packed, &coded, text_src);
+        bool hist_deferred = false;
+        rc = onesweep_sort_text_prepare<IdxT>(L, c, w, n, &kb, &packed, &coded, text_src, &hist_deferred);
         if (rc != DQ_OK) return rc;
         // (c.pinned still holds the byte histogram, the k-gram sample and the long-run flag of text_hist_kernel)
         // (run lengths + the run-order round cost about one doubling round: worth it where a good part of the text lies
@@ -982,8 +1158,31 @@ struct SuffixSorter {
             rc = rank_pass<IdxT, kKeysLast>(L, w, K[cur ^ 1], (const IdxT *)nullptr, K[cur], d_sa, n, kb - 1, kb, ib);
             if (rc != DQ_OK) return rc;
         } else {
-            rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur, nullptr, nullptr, coded);
-            if (rc != DQ_OK) return rc;
+            bool split_done = false;
+            if (split_round0_wanted<IdxT>(n, packed, kb)) {
+                rc = round0_split(K, coded, &split_done);
+                if (rc != DQ_OK) return rc;
+                if (!split_done) {
+                    // given up (or not applicable after all): the digit passes, with the state they expect -- their digit
+                    // offsets (the sorts of the sample and of the overflow list have used the table since) and look-back state
+                    if (coded) {
+                        rc = launch_coded_hist<IdxT>(L, w, n);
+                        if (rc != DQ_OK) return rc;
+                    } else {
+                        hipLaunchKernelGGL(text_digit_offsets_kernel, dim3(kb), dim3(kBlock), 0, st,
+                                           (const int64_t *)w.bytehist, (const uint8_t *)w.text, n, kb, w.digit_offset);
+                        HIP_TRY(hipGetLastError());
+                    }
+                    rc = prepare_status<IdxT>(L, w, n, kb);
+                    if (rc != DQ_OK) return rc;
+                }
+            }
+            if (split_done) {
+                cur = 1;
+            } else {
+                rc = onesweep_sort_text_passes<IdxT>(L, w, n, K, V, kb, packed, d_sa, cur, nullptr, nullptr, coded);
+                if (rc != DQ_OK) return rc;
+            }
         }
         // sorted keys (or packed words) are in K[cur], suffixes in d_sa
         const int kshift0 = packed ? bit_length((uint64_t)(n - 1)) : 0;

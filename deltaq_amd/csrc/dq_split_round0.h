@@ -1,0 +1,641 @@
+// dq_split_round0.h -- round 0 of a text-like input as a SAMPLE SORT instead of eight stable digit passes (round 6).
+//
+// What it replaces: the 8-byte pair path of round 0 (dq_sorter_impl.h: one pass that builds 64-bit keys from the text
+// + seven stable pair passes of 24 B per suffix, 11.5 of the 28.8 ms of a 256 MiB text sort).  Fixed key bits cannot
+// be used MSD-first on skewed text (after the top 16 coded bits 73 % of the suffixes of the text config sit in buckets
+// too long for LDS); ORDER-PRESERVING SPLITTERS drawn from a sorted sample of the keys can: ranked
+// by splitter index the suffixes fall into near-equal buckets whatever the alphabet (tools/exp/splitter_buckets.cpp,
+// 65 536 buckets: 97.9 % of the suffixes of the 256 MiB text config and 91.1 % of 128 MiB of libtorch_cpu.so in buckets of
+// <= 12 288; what is left are keys that occur thousands of times, which no splitter separates).
+//
+//   sample_keys_kernel      kSplitSample keys at scattered text positions (the same coded / raw 64-bit keys the digit
+//                           passes build); sorted with the ordinary pair sorter (2 Mi keys: ~0.2 ms)
+//   sample_heavy_kernel     share of the sample inside runs of equal keys too long for a bucket: a text made of a few
+//                           heavy keys is left to the digit passes before anything is moved
+//   make_splitters_kernel   every 16th sorted sample key is a splitter: top[kSplitTop - 1] (every 4096th) and, per top
+//                           bucket t, sub[t][kSplitSub - 1].  bucket(key) = (t, s), t = #{top <= key}, s = #{sub[t] <= key}:
+//                           monotone in the key, so bucket order is key order
+//   split_hist_kernel       exact sizes of the kSplitTop top buckets (one read of the text, keys built on the fly, 9-step
+//                           search in an LDS table) -> pass A's output regions
+//   split_plan_kernel       region starts (cursors of pass A), tiles of pass B per top bucket
+//   split_pass_kernel<A>    text -> (key, suffix) pairs grouped by t.  A tile ranks its keys by arrival (LDS atomics: nothing
+//                           to be stable against), reserves its place in every region with one returning global add per
+//                           digit, stages the tile through LDS in digit order and writes runs -- the shape of
+//                           radix_rank_kernel's first pass with "digit = rank among the splitters"; the digits of a tile
+//                           are near-uniform BY CONSTRUCTION, whatever the text
+//   split_pass_kernel<B>    pairs of one top bucket (tiles never straddle two: their sub-splitter table is 2 KB of LDS) ->
+//                           the bucket's SLOT: kSplitBuckets slots of `cap` entries (twice the mean bucket) in idle
+//                           buffers, filled through one cursor per bucket; what does not fit goes to the overflow list
+//   bucket_sum / _scan      final position of every bucket (exclusive scan of the cursors), list of the oversize buckets
+//   bucket_finish_kernel    one workgroup per bucket: the bucket is sorted inside LDS by its full 64-bit keys -- a
+//                           sample sort again (see the kernel) -- and leaves as sorted keys + suffixes.  An oversize
+//                           bucket is moved to the overflow list instead.
+//   (host)                  the overflow list -- ALL members of the oversize buckets, a few per cent of the text -- is sorted by
+//                           the ordinary pair sorter; sorted by key it is sorted by bucket, so
+//   overflow_place_kernel   copies each oversize bucket's stretch of it to the bucket's final position.
+//
+// The result is what the digit passes leave: keys sorted in one buffer, suffixes in the suffix array, equal keys in
+// arbitrary order -- the rebucket pass and everything behind it run unchanged.  Per suffix: 1 (histogram) + 1 + 12
+// (pass A) + 12 + 12 (pass B) + 12 + 12 (finish) = 62 B against 1 + 21 + 7 x 24 = 190 B.
+// Reference context: the phase replaced is still LibDivSufSort.Sort (LibDivSufSort.cs:12-29; its B* substring sort,
+// SsSort.cs:934-1269, is what dominates the reference on text); the suffix array is unchanged by any of this.
+#pragma once
+#include "dq_onesweep.h"
+
+namespace dq {
+
+constexpr int kSplitTop = 512;                                   // top buckets = regions of pass A
+constexpr int kSplitSub = 256;                                   // parts of a top bucket = regions of pass B
+constexpr int kSplitBuckets = kSplitTop * kSplitSub;             // 131 072
+constexpr int kSplitOversample = 16;
+constexpr int64_t kSplitSample = (int64_t)kSplitBuckets * kSplitOversample;      // 2 Mi sampled keys
+constexpr int kSplitThreads = 512, kSplitItems = 20;
+constexpr int kSplitTile = kSplitThreads * kSplitItems;          // 10 240 keys per tile
+constexpr int kFinCap = 4096;                                    // the longest bucket the finish kernels sort (two geometries)
+constexpr int kFinSmallCap = 2048;
+
+struct SplitCtl {
+    unsigned long long ovf_count;       // entries of the overflow list (before that: heavy sampled keys, sample_heavy_kernel)
+    unsigned long long ovf_buckets;     // oversize buckets (bucket_scan_kernel)
+    unsigned long long tiles_b;         // tiles of pass B (split_plan_kernel)
+    unsigned long long abandon;         // the overflow list ran full: the caller takes the digit passes instead
+};
+
+// the 64-bit round-0 key of ONE suffix p, as the digit passes build it (coded: dq_coded_keys.h; raw: 8 bytes big-endian)
+template <bool kCoded>
+__device__ __forceinline__ uint64_t split_key_at(const uint32_t *__restrict__ t32, int64_t p, const uint16_t *ctab)
+{
+    const int64_t q = p >> 2;
+    const int c = (int)(p & 3);
+    if (kCoded) {
+        uint32_t tw[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) tw[i] = t32[q + i];
+        uint64_t key[4];
+        coded_keys4(tw, ctab, key);
+        return c == 0 ? key[0] : c == 1 ? key[1] : c == 2 ? key[2] : key[3];
+    }
+    const uint32_t w0 = t32[q], w1 = t32[q + 1], w2 = t32[q + 2];
+    const uint64_t x = __builtin_bswap64((uint64_t)w0 | ((uint64_t)w1 << 32));
+    const uint64_t y = (uint64_t)__builtin_bswap32(w2) << 32;
+    return c == 0 ? x : c == 1 ? ((x << 8) | (y >> 56)) : c == 2 ? ((x << 16) | (y >> 48)) : ((x << 24) | (y >> 40));
+}
+
+// the keys of a lane's 4 consecutive suffixes (q = index of their first dword)
+template <bool kCoded>
+__device__ __forceinline__ void split_keys4(const uint32_t *__restrict__ t32, int64_t q, const uint16_t *ctab, uint64_t key[4])
+{
+    if (kCoded) {
+        uint32_t tw[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) tw[i] = t32[q + i];
+        coded_keys4(tw, ctab, key);
+    } else {
+        const uint32_t w0 = t32[q], w1 = t32[q + 1], w2 = t32[q + 2];
+        const uint64_t x = __builtin_bswap64((uint64_t)w0 | ((uint64_t)w1 << 32));
+        const uint64_t y = (uint64_t)__builtin_bswap32(w2) << 32;
+        key[0] = x; key[1] = (x << 8) | (y >> 56); key[2] = (x << 16) | (y >> 48); key[3] = (x << 24) | (y >> 40);
+    }
+}
+
+// #{j < kN - 1 : tab[j] <= key}: a branch-free binary search over kN - 1 sorted splitters (kN a power of two)
+template <int kN>
+__device__ __forceinline__ uint32_t split_rank(const uint64_t *tab, uint64_t key)
+{
+    uint32_t d = 0;
+#pragma unroll
+    for (int step = kN / 2; step >= 1; step >>= 1) d += (tab[d + step - 1] <= key) ? (uint32_t)step : 0u;
+    return d;
+}
+
+// sample j sits at text position floor(frac(j * golden ratio) * n): scattered, reproducible, every position equally likely
+__device__ __forceinline__ int64_t split_sample_pos(int64_t j, int64_t n)
+{
+    return (int64_t)(((unsigned __int128)((uint64_t)j * 0x9E3779B97F4A7C15ull) * (unsigned __int128)(uint64_t)n) >> 64);
+}
+
+template <bool kCoded>
+__global__ __launch_bounds__(kBlock) void sample_keys_kernel(const uint32_t *__restrict__ t32, int64_t n, const uint16_t *__restrict__ codetab,
+                                                          int64_t count, uint64_t *__restrict__ out)
+{
+    __shared__ uint16_t ctab[256];
+    if (kCoded) ctab[threadIdx.x] = codetab[threadIdx.x];
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j < count) out[j] = split_key_at<kCoded>(t32, split_sample_pos(j, n), ctab);
+}
+
+// How much of the text would end on the overflow list?  A key whose copies fill more than one slot (cap entries; a bucket
+// holds cap / 2 on average = kSplitOversample sampled keys) shows in the sorted sample as a run of more than
+// 2 kSplitOversample equal keys: *heavy = sampled keys inside such runs.  (One thread per sampled key steps to the ends of
+// its run -- runs are short unless the text is made of a few keys, and then the count is all that matters: the walk
+// stops at 4 kSplitOversample.)
+static __global__ __launch_bounds__(kBlock) void sample_heavy_kernel(const uint64_t *__restrict__ sorted, unsigned long long *__restrict__ heavy)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool h = false;
+    if (i < kSplitSample) {
+        const uint64_t me = sorted[i];
+        int run = 1;
+        for (int64_t j = i - 1; j >= 0 && run <= 4 * kSplitOversample && sorted[j] == me; --j) ++run;
+        for (int64_t j = i + 1; j < kSplitSample && run <= 4 * kSplitOversample && sorted[j] == me; ++j) ++run;
+        h = run > 2 * kSplitOversample;
+    }
+    const uint64_t bal = __ballot(h);
+    if (lane_id() == 0 && bal) atomicAdd(heavy, (unsigned long long)__popcll(bal));
+}
+
+// top[t], t < kSplitTop - 1 and sub[t][s], s < kSplitSub - 1 from the sorted sample (the last entry of every table is
+// never read by split_rank; it is written as all ones)
+static __global__ __launch_bounds__(kBlock) void make_splitters_kernel(const uint64_t *__restrict__ sorted, uint64_t *__restrict__ top,
+                                                               uint64_t *__restrict__ sub)
+{
+    constexpr int64_t per_top = kSplitSample / kSplitTop, per_sub = kSplitSample / kSplitBuckets;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= kSplitBuckets) return;
+    const int t = (int)(i / kSplitSub), s = (int)(i % kSplitSub);
+    sub[i] = s == kSplitSub - 1 ? ~0ull : sorted[t * per_top + (s + 1) * per_sub];
+    if (s == 0) top[t] = t == kSplitTop - 1 ? ~0ull : sorted[(t + 1) * per_top];
+}
+
+// cnt[t] += suffixes whose key falls into top bucket t  (cnt zeroed by the caller)
+template <bool kCoded>
+__global__ __launch_bounds__(kHistThreads) void split_hist_kernel(const uint32_t *__restrict__ t32, int64_t n, const uint16_t *__restrict__ codetab,
+                                                               const uint64_t *__restrict__ top, unsigned long long *__restrict__ cnt)
+{
+    __shared__ uint64_t tab[kSplitTop];
+    __shared__ uint32_t hist[kSplitTop];
+    __shared__ uint16_t ctab[256];
+    const int tid = threadIdx.x;
+    const int lane = lane_id();
+    for (int i = tid; i < kSplitTop; i += kHistThreads) { tab[i] = top[i]; hist[i] = 0; }
+    if (kCoded && tid < 256) ctab[tid] = codetab[tid];
+    __syncthreads();
+    const int64_t quads = (n + 3) >> 2;
+    // (q0 is wave-uniform: a wave enters and leaves an iteration as a whole, so the shortcut below sees 64 lanes)
+    for (int64_t q0 = (int64_t)blockIdx.x * kHistThreads + (tid & ~(kWave - 1)); q0 < quads; q0 += (int64_t)gridDim.x * kHistThreads) {
+        const int64_t q = q0 + lane;
+        const bool in = q < quads;
+        uint64_t key[4] = {0, 0, 0, 0};
+        if (in) split_keys4<kCoded>(t32, q, ctab, key);
+        const int c = !in ? 0 : (n - q * 4) < 4 ? (int)(n - q * 4) : 4;
+        // (a run of one byte -- zero padding, a table of equal entries -- puts a whole wave into one bucket: 64 LDS adds on one
+        // address take 64 turns; such a wave adds once)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t d = split_rank<kSplitTop>(tab, key[k]);
+            const bool ok = k < c;
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane(d);
+            if (__all(ok && d == d0)) {
+                if (lane == 0) atomicAdd(&hist[d0], (uint32_t)kWave);
+            } else if (ok) {
+                atomicAdd(&hist[d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < kSplitTop; i += kHistThreads)
+        if (hist[i]) atomicAdd(&cnt[i], (unsigned long long)hist[i]);
+}
+
+// off[t] = start of region t in pass A's output (off[kSplitTop] = n), cursor_a[t] = off[t]; tile_first[t] = first tile of
+// pass B in top bucket t (tile_first[kSplitTop] = all of them).  One workgroup of kSplitTop threads.
+static __global__ __launch_bounds__(kSplitTop) void split_plan_kernel(const unsigned long long *__restrict__ cnt, int64_t *__restrict__ off,
+                                                                unsigned long long *__restrict__ cursor_a, uint32_t *__restrict__ tile_first,
+                                                                SplitCtl *__restrict__ ctl)
+{
+    __shared__ int64_t wsum[kSplitTop / kWave], wtl[kSplitTop / kWave];
+    const int t = threadIdx.x, lane = lane_id(), w = t >> 6;
+    const int64_t c = (int64_t)cnt[t];
+    const int64_t tiles = (c + kSplitTile - 1) / kSplitTile;
+    const int64_t ic = wave_incl_sum(c), it = wave_incl_sum(tiles);
+    if (lane == kWave - 1) { wsum[w] = ic; wtl[w] = it; }
+    __syncthreads();
+    int64_t bc = 0, bt = 0;
+    for (int i = 0; i < w; ++i) { bc += wsum[i]; bt += wtl[i]; }
+    off[t] = bc + ic - c;
+    cursor_a[t] = (unsigned long long)(bc + ic - c);
+    tile_first[t] = (uint32_t)(bt + it - tiles);
+    if (t == kSplitTop - 1) {
+        off[kSplitTop] = bc + ic;
+        tile_first[kSplitTop] = (uint32_t)(bt + it);
+        ctl->tiles_b = (unsigned long long)(bt + it);
+    }
+}
+
+// Pass A (kFromText): kin = the text, one tile = kSplitTile consecutive suffixes; digit = top bucket; output position from
+// cursor[digit] (preset to the region starts), written to (kout0, vout0).
+// Pass B: kin / vin = pass A's output; workgroup b takes tile b - tile_first[t] of top bucket t; digit = part s of t
+// (table = sub + t * kSplitSub); bucket = t * kSplitSub + s; the arrival number q of an entry in its bucket comes from
+// cursor[bucket]; q < cap: slot entry q of the bucket -- the slots of the first half of the buckets lie in (kout0, vout0),
+// the others in (kout1, vout1) --, else the overflow list.
+template <typename IdxT, bool kFromText, bool kCoded>
+__global__ __launch_bounds__(kSplitThreads, 2) void split_pass_kernel(
+    const uint64_t *__restrict__ kin, const IdxT *__restrict__ vin, int64_t n, const uint64_t *__restrict__ table,
+    unsigned long long *__restrict__ cursor, const int64_t *__restrict__ off, const uint32_t *__restrict__ tile_first,
+    uint64_t *__restrict__ kout0, IdxT *__restrict__ vout0, uint64_t *__restrict__ kout1, IdxT *__restrict__ vout1, int64_t cap,
+    uint64_t *__restrict__ ovf_key, IdxT *__restrict__ ovf_idx, int64_t ovf_cap, SplitCtl *__restrict__ ctl,
+    const uint16_t *__restrict__ codetab)
+{
+    constexpr int kDigits = kFromText ? kSplitTop : kSplitSub;
+    constexpr int kWavesB = kSplitThreads / kWave;
+    constexpr int kExchRounds = 2;
+    constexpr int kExchN = kSplitTile / kExchRounds;
+    static_assert(kSplitItems % 4 == 0 && kSplitItems % kExchRounds == 0, "tile geometry");
+    static_assert(kDigits <= kSplitThreads, "one thread per digit");
+    __shared__ __attribute__((aligned(16))) uint64_t exch[kExchN];
+    __shared__ uint64_t tab[kDigits];
+    __shared__ uint32_t cnt[kDigits];
+    __shared__ uint32_t tile_base[kDigits];
+    __shared__ long long gofs[kDigits];                     // global position (A) / arrival number in the bucket (B) of a run's first entry, minus its place in the tile
+    __shared__ uint16_t dig_of[kSplitTile];                 // digit of every position of the sorted tile
+    __shared__ uint32_t wtmp[kWavesB];
+    __shared__ uint16_t ctab[kCoded ? 256 : 1];
+    __shared__ int s_t;
+
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    int64_t base = 0;
+    int valid = 0;
+    int t_b = 0;
+    if (kFromText) {
+        base = (int64_t)blockIdx.x * kSplitTile;
+        valid = (n - base) < kSplitTile ? (int)(n - base) : kSplitTile;
+        for (int i = tid; i < kDigits; i += kSplitThreads) { tab[i] = table[i]; cnt[i] = 0; }
+        if (kCoded && tid < 256) ctab[tid] = codetab[tid];
+    } else {
+        if (blockIdx.x >= tile_first[kSplitTop]) return;    // (the grid is an upper bound)
+        if (tid == 0) {
+            int lo = 0, hi = kSplitTop;                     // last t with tile_first[t] <= blockIdx.x: the one that has this tile
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_first[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+            s_t = lo;
+        }
+        __syncthreads();
+        t_b = s_t;
+        base = off[t_b] + (int64_t)(blockIdx.x - tile_first[t_b]) * kSplitTile;
+        const int64_t left = off[t_b + 1] - base;
+        valid = left < kSplitTile ? (int)left : kSplitTile;
+        for (int i = tid; i < kDigits; i += kSplitThreads) { tab[i] = table[(int64_t)t_b * kSplitSub + i]; cnt[i] = 0; }
+    }
+    __syncthreads();
+
+    // element index (inside the tile) of this lane's item k
+    const int wbase = w * (kWave * kSplitItems) + lane;
+    auto elem = [&](int k) -> int { return kFromText ? ((k >> 2) * kSplitThreads + tid) * 4 + (k & 3) : wbase + k * kWave; };
+
+    uint64_t key[kSplitItems];
+    IdxT val[kSplitItems];
+    if (kFromText) {
+        const uint32_t *t32 = reinterpret_cast<const uint32_t *>(kin);
+#pragma unroll
+        for (int j = 0; j < kSplitItems / 4; ++j) {
+            const int e0 = (j * kSplitThreads + tid) * 4;
+            if (e0 < valid) split_keys4<kCoded>(t32, (base + e0) >> 2, ctab, &key[4 * j]);
+            else { key[4 * j] = key[4 * j + 1] = key[4 * j + 2] = key[4 * j + 3] = ~0ull; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) val[4 * j + c] = (IdxT)(base + e0 + c);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kSplitItems; ++k) {
+            const int e = wbase + k * kWave;
+            const int ec = e < valid ? e : valid - 1;       // (clamped, not predicated: the loads stay in flight together)
+            key[k] = kin[base + ec];
+            val[k] = vin[base + ec];
+        }
+    }
+
+    // ---- digit = rank among the splitters; place inside the tile's digit run = arrival number (one returning LDS add).
+    //      A wave whose 64 keys share a digit -- heavy keys come in runs: padding in text order, a heavy bucket's tiles in
+    //      pass B -- would be 64 adds on one LDS address: it adds once and its lanes take consecutive numbers. ----
+    uint32_t pd[kSplitItems];                                // digit << 16 | arrival number, then the place in the sorted tile
+#pragma unroll
+    for (int k = 0; k < kSplitItems; ++k) {
+        const uint32_t d = split_rank<kDigits>(tab, key[k]);
+        const bool ok = elem(k) < valid;
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane(d);
+        uint32_t a = 0;
+        if (__all(ok && d == d0)) {
+            uint32_t a0 = 0;
+            if (lane == 0) a0 = atomicAdd(&cnt[d0], (uint32_t)kWave);
+            a = (uint32_t)__builtin_amdgcn_readfirstlane(a0) + (uint32_t)lane;
+        } else if (ok) {
+            a = atomicAdd(&cnt[d], 1u);
+        }
+        pd[k] = ok ? ((d << 16) | a) : 0xffffffffu;
+    }
+    __syncthreads();
+
+    // ---- digit totals: reserve the tile's place in every output region / bucket, tile-local scan ----
+    unsigned long long abase = 0;
+    uint32_t tot = 0, incl = 0;
+    if (tid < kDigits) {
+        tot = cnt[tid];
+        if (tot) abase = atomicAdd(&cursor[kFromText ? tid : t_b * kSplitSub + tid], (unsigned long long)tot);
+    }
+    incl = wave_incl_sum(tot);
+    if (lane == kWave - 1) wtmp[w] = incl;
+    __syncthreads();
+    if (tid < kDigits) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < kWavesB; ++i) if (i < w) o += wtmp[i];
+        const uint32_t excl = o + incl - tot;
+        tile_base[tid] = excl;
+        gofs[tid] = (long long)abase - (long long)excl;
+    }
+    __syncthreads();
+
+    // ---- stage keys, then values, in digit order through LDS (two position ranges: half the footprint) ----
+#pragma unroll
+    for (int k = 0; k < kSplitItems; ++k) {
+        if (pd[k] != 0xffffffffu) {
+            const uint32_t d = pd[k] >> 16;
+            const uint32_t p = tile_base[d] + (pd[k] & 0xffffu);
+            dig_of[p] = (uint16_t)d;
+            pd[k] = p;
+        }
+    }
+    uint64_t skey[kSplitItems];
+#pragma unroll
+    for (int r = 0; r < kExchRounds; ++r) {
+        if (r > 0) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSplitItems; ++k) {
+            const uint32_t p = pd[k] - (uint32_t)(r * kExchN);
+            if (p < (uint32_t)kExchN) exch[p] = key[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = r * (kSplitItems / kExchRounds); k < (r + 1) * (kSplitItems / kExchRounds); ++k)
+            skey[k] = exch[k * kSplitThreads + tid - r * kExchN];
+    }
+    IdxT sval[kSplitItems];
+    {
+        constexpr int kValN = kExchN * (int)(sizeof(uint64_t) / sizeof(IdxT));
+        constexpr int kValRounds = kSplitTile / kValN > 0 ? kSplitTile / kValN : 1;
+        constexpr int kValCap = kSplitTile / kValRounds;
+        IdxT *exv = reinterpret_cast<IdxT *>(exch);
+#pragma unroll
+        for (int r = 0; r < kValRounds; ++r) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kSplitItems; ++k) {
+                const uint32_t p = pd[k] - (uint32_t)(r * kValCap);
+                if (p < (uint32_t)kValCap) exv[p] = val[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = r * (kSplitItems / kValRounds); k < (r + 1) * (kSplitItems / kValRounds); ++k)
+                sval[k] = exv[k * kSplitThreads + tid - r * kValCap];
+        }
+    }
+
+    // ---- out: position p of the sorted tile belongs to digit dig_of[p]; consecutive lanes write consecutive entries of a run ----
+#pragma unroll
+    for (int k = 0; k < kSplitItems; ++k) {
+        const int p = k * kSplitThreads + tid;
+        const bool ok = p < valid;
+        const uint32_t d = ok ? dig_of[p] : 0u;
+        const long long q = gofs[d] + p;                     // A: position in the output; B: arrival number in the bucket
+        if (kFromText) {
+            if (ok) { kout0[q] = skey[k]; vout0[q] = sval[k]; }
+        } else {
+            const bool fits = ok && q < cap;
+            if (fits) {
+                const int64_t b = (int64_t)t_b * kSplitSub + d;
+                if (b < kSplitBuckets / 2) { kout0[b * cap + q] = skey[k]; vout0[b * cap + q] = sval[k]; }
+                else { kout1[(b - kSplitBuckets / 2) * cap + q] = skey[k]; vout1[(b - kSplitBuckets / 2) * cap + q] = sval[k]; }
+            }
+            // what does not fit its slot: appended to the overflow list, one global add per wave and store instruction
+            const uint64_t over = __ballot(ok && !fits);
+            if (over) {
+                unsigned long long o0 = 0;
+                if (lane == 0) o0 = atomicAdd(&ctl->ovf_count, (unsigned long long)__popcll(over));
+                o0 = __shfl(o0, 0, kWave);
+                if (ok && !fits) {
+                    const long long o = (long long)o0 + mask_rank_lt(over);
+                    if (o < ovf_cap) { ovf_key[o] = skey[k]; ovf_idx[o] = sval[k]; }
+                    else ctl->abandon = 1;
+                }
+            }
+        }
+    }
+}
+
+// out_base[b] = final position of bucket b (exclusive scan of the bucket sizes = the cursors of pass B), out_base[NB] = n;
+// ovf_start[b] = position of an oversize bucket's first entry in the SORTED overflow list (exclusive scan of the sizes
+// of the oversize buckets); ovf_list = the oversize buckets in order.  Two launches of kScanBlocks workgroups, every
+// load coalesced: sums per 1024 buckets, then every workgroup adds up the sums in front of it and scans its own 1024.
+constexpr int kScanThreads = 1024;
+constexpr int kScanBlocks = kSplitBuckets / kScanThreads;
+struct ScanPart { long long sum, osum, ocnt; };
+
+static __global__ __launch_bounds__(kScanThreads) void bucket_sum_kernel(const unsigned long long *__restrict__ cursor, int64_t cap,
+                                                                   ScanPart *__restrict__ part)
+{
+    __shared__ long long ws[3][kScanThreads / kWave];
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const long long c = (long long)cursor[(int64_t)blockIdx.x * kScanThreads + tid];
+    const bool over = c > cap;
+    const long long a = wave_sum(c), o = wave_sum(over ? c : 0ll), k = wave_sum(over ? 1ll : 0ll);
+    if (lane == 0) { ws[0][w] = a; ws[1][w] = o; ws[2][w] = k; }
+    __syncthreads();
+    if (tid == 0) {
+        ScanPart p{0, 0, 0};
+        for (int i = 0; i < kScanThreads / kWave; ++i) { p.sum += ws[0][i]; p.osum += ws[1][i]; p.ocnt += ws[2][i]; }
+        part[blockIdx.x] = p;
+    }
+}
+
+static __global__ __launch_bounds__(kScanThreads) void bucket_scan_kernel(const unsigned long long *__restrict__ cursor, int64_t cap,
+                                                                    const ScanPart *__restrict__ part, int64_t *__restrict__ out_base,
+                                                                    int64_t *__restrict__ ovf_start, uint32_t *__restrict__ ovf_list,
+                                                                    SplitCtl *__restrict__ ctl)
+{
+    __shared__ long long ws[3][kScanThreads / kWave];
+    __shared__ long long s_pre[3];
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    if (w == 0) {                                            // what lies in front of this workgroup's 1024 buckets
+        long long a = 0, o = 0, k = 0;
+        for (int i = lane; i < (int)blockIdx.x; i += kWave) { a += part[i].sum; o += part[i].osum; k += part[i].ocnt; }
+        a = wave_sum(a); o = wave_sum(o); k = wave_sum(k);
+        if (lane == 0) { s_pre[0] = a; s_pre[1] = o; s_pre[2] = k; }
+    }
+    const int64_t b = (int64_t)blockIdx.x * kScanThreads + tid;
+    const long long c = (long long)cursor[b];
+    const bool over = c > cap;
+    const long long ia = wave_incl_sum(c), io = wave_incl_sum(over ? c : 0ll), ik = wave_incl_sum(over ? 1ll : 0ll);
+    if (lane == kWave - 1) { ws[0][w] = ia; ws[1][w] = io; ws[2][w] = ik; }
+    __syncthreads();
+    long long a = s_pre[0], o = s_pre[1], k = s_pre[2];
+    for (int i = 0; i < w; ++i) { a += ws[0][i]; o += ws[1][i]; k += ws[2][i]; }
+    out_base[b] = a + ia - c;
+    ovf_start[b] = o + io - (over ? c : 0ll);
+    if (over) ovf_list[k + ik - 1] = (uint32_t)b;
+    if (b == kSplitBuckets - 1) { out_base[kSplitBuckets] = a + ia; ctl->ovf_buckets = (unsigned long long)(k + ik); }
+}
+
+// One workgroup per bucket: sort its (key, suffix) entries by key inside LDS, write them to the bucket's final position.
+//   1. kThreads / 2 of the bucket's own keys, ranked by counting, are its local splitters: part of a key = 2 #{splitters <
+//      key} + (key is a splitter value) -- rank-based, so the parts are balanced whatever the keys look like, and a key that
+//      occurs often is a splitter value with near certainty: its copies form a part of their own, which needs no order
+//      (round 0 need not be stable)
+//   2. count, scan, scatter (key, suffix, part) into part order
+//   3. every POSITION of the part-ordered bucket (a wave = 64 consecutive positions = a few parts: the loop below has one
+//      trip count for most of the wave and reads the same LDS words in every lane -- broadcasts) counts the smaller keys
+//      of its part and the equal ones in front of it: its final place; the entry leaves from there, the 64 lanes writing
+//      inside one window of a few hundred bytes.
+// A bucket is a chain of dependent phases (a global round trip, eight barriers): what a CU gets through is set by how
+// many buckets it holds at once, i.e. by the LDS of a workgroup.  Hence two geometries, each launched over all buckets
+// and taking those of its size class (lo < size <= hi): <256, 8> for up to 2048 entries (31 KB: five per CU) -- the mean
+// bucket of a 256 MiB text -- and <512, 8> for up to 4096 (62 KB: two per CU).  The launch with `oversize` set also moves
+// the buckets that are longer than their slot to the overflow list.
+template <typename IdxT, int kThreads, int kItems>
+__global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_finish_kernel(
+    const uint64_t *__restrict__ kslot0, const IdxT *__restrict__ vslot0, const uint64_t *__restrict__ kslot1, const IdxT *__restrict__ vslot1,
+    int64_t cap, int64_t lo, int64_t hi, bool oversize, const unsigned long long *__restrict__ cursor, const int64_t *__restrict__ out_base,
+    uint64_t *__restrict__ kout, IdxT *__restrict__ sa, uint64_t *__restrict__ ovf_key, IdxT *__restrict__ ovf_idx, int64_t ovf_cap,
+    SplitCtl *__restrict__ ctl)
+{
+    constexpr int kCap = kThreads * kItems;
+    constexpr int kSample = kThreads / 2;                    // local splitters: one thread per part (the last thread takes two)
+    constexpr int kParts = 2 * kSample + 1;
+    __shared__ uint64_t skey[kCap];
+    __shared__ uint32_t sidx[kCap];
+    __shared__ uint16_t spart[kCap];
+    __shared__ uint64_t smp[kSample], srt[kSample];
+    __shared__ uint32_t pcnt[kParts + 1];
+    __shared__ uint32_t wtmp[kThreads / kWave];
+    __shared__ unsigned long long s_o0;
+    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const int64_t b = blockIdx.x;
+    const int64_t c64 = (int64_t)cursor[b];
+    const uint64_t *ks = b < kSplitBuckets / 2 ? kslot0 + b * cap : kslot1 + (b - kSplitBuckets / 2) * cap;
+    const IdxT *vs = b < kSplitBuckets / 2 ? vslot0 + b * cap : vslot1 + (b - kSplitBuckets / 2) * cap;
+    if (c64 > cap) {
+        if (!oversize) return;
+        // oversize: the entries that did fit the slot join the rest of the bucket on the overflow list
+        if (tid == 0) s_o0 = atomicAdd(&ctl->ovf_count, (unsigned long long)cap);
+        __syncthreads();
+        const long long o0 = (long long)s_o0;
+        if (o0 + cap > ovf_cap) { if (tid == 0) ctl->abandon = 1; return; }
+        for (int64_t i = tid; i < cap; i += kThreads) { ovf_key[o0 + i] = ks[i]; ovf_idx[o0 + i] = vs[i]; }
+        return;
+    }
+    if (c64 <= lo || c64 > hi) return;                       // (empty, or the other launch's)
+    const int c = (int)c64;                                  // <= kCap
+    uint64_t key[kItems];
+    uint32_t idx[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int e = k * kThreads + tid;
+        const int ec = e < c ? e : c - 1;                    // (clamped: the loads stay in flight together)
+        key[k] = ks[ec];
+        idx[k] = (uint32_t)vs[ec];
+    }
+    pcnt[tid] = 0;
+    if (tid == 0) { pcnt[kThreads] = 0; pcnt[kThreads + 1] = 0; }
+    // ---- local splitters: entry floor(i c / kSample) of the slot for i < kSample, taken from the registers that hold it ----
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int e = k * kThreads + tid;
+        if (e < c) {
+            for (int i = (int)(((int64_t)e * kSample + c - 1) / c); i < kSample && (int)(((int64_t)i * c) / kSample) == e; ++i) smp[i] = key[k];
+        }
+    }
+    __syncthreads();
+    {   // ranked by counting, two threads per splitter (half of the others each)
+        const int i = tid >> 1, half = tid & 1;
+        const uint64_t me = smp[i];
+        uint32_t r = 0;
+#pragma unroll 8
+        for (int j = half * (kSample / 2); j < (half + 1) * (kSample / 2); ++j) {
+            const uint64_t o = smp[j];
+            r += ((o < me) || (o == me && j < i)) ? 1u : 0u;
+        }
+        r += (uint32_t)__shfl_xor((int)r, 1, kWave);
+        if (half == 0) srt[r] = me;
+    }
+    __syncthreads();
+    // ---- part of every key; its arrival number in the part ----
+    uint32_t part[kItems];                                   // part << 16 | arrival number
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        uint32_t lb = 0;                                     // #{srt < key}
+#pragma unroll
+        for (int step = kSample / 2; step >= 1; step >>= 1) lb += (srt[lb + step - 1] < key[k]) ? (uint32_t)step : 0u;
+        lb += (srt[lb] < key[k]) ? 1u : 0u;                  // (kSample entries, not kSample - 1: one more step)
+        const uint32_t eq = (lb < (uint32_t)kSample && srt[lb < (uint32_t)kSample ? lb : 0] == key[k]) ? 1u : 0u;
+        const uint32_t p = 2 * lb + eq;
+        const bool ok = k * kThreads + tid < c;
+        const uint32_t a = ok ? atomicAdd(&pcnt[p], 1u) : 0u;
+        part[k] = ok ? ((p << 16) | a) : 0xffffffffu;
+    }
+    __syncthreads();
+    // ---- exclusive scan of the part sizes (thread t owns part t, the last thread part kParts - 1 as well) ----
+    {
+        const uint32_t mine = pcnt[tid];
+        const uint32_t v = mine + (tid == kThreads - 1 ? pcnt[kThreads] : 0u);
+        const uint32_t incl = wave_incl_sum(v);
+        if (lane == kWave - 1) wtmp[w] = incl;
+        __syncthreads();
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < kThreads / kWave; ++i) if (i < w) o += wtmp[i];
+        const uint32_t excl = o + incl - v;
+        pcnt[tid] = excl;                                    // (every count was read before the barrier above)
+        if (tid == kThreads - 1) { pcnt[kThreads] = excl + mine; pcnt[kThreads + 1] = (uint32_t)c; }
+    }
+    __syncthreads();
+    // ---- into part order ----
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        if (part[k] != 0xffffffffu) {
+            const uint32_t p = part[k] >> 16;
+            const uint32_t slot = pcnt[p] + (part[k] & 0xffffu);
+            skey[slot] = key[k];
+            sidx[slot] = idx[k];
+            spart[slot] = (uint16_t)p;
+        }
+    }
+    __syncthreads();
+    // ---- final place of every position; out ----
+    const int64_t ob = out_base[b];
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int pos = k * kThreads + tid;
+        if (pos < c) {
+            const uint64_t me = skey[pos];
+            const uint32_t p = spart[pos];
+            uint32_t r = (uint32_t)pos;                       // a splitter-valued key stays where it is
+            if (!(p & 1u)) {
+                const uint32_t s0 = pcnt[p], s1 = pcnt[p + 1];
+                r = s0;
+                for (uint32_t j = s0; j < s1; j += 4) {        // (four loads in flight; the clamped ones count nothing)
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        const uint32_t jj = j + i;
+                        const uint64_t o = skey[jj < s1 ? jj : s1 - 1];
+                        r += (jj < s1 && ((o < me) || (o == me && jj < (uint32_t)pos))) ? 1u : 0u;
+                    }
+                }
+            }
+            kout[ob + r] = me;
+            sa[ob + r] = (IdxT)sidx[pos];
+        }
+    }
+}
+
+// oversize bucket ovf_list[blockIdx.x]: its stretch of the sorted overflow list -> its final position
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void overflow_place_kernel(const uint32_t *__restrict__ ovf_list, const unsigned long long *__restrict__ cursor,
+                                                             const int64_t *__restrict__ out_base, const int64_t *__restrict__ ovf_start,
+                                                             const uint64_t *__restrict__ okey, const IdxT *__restrict__ oidx,
+                                                             uint64_t *__restrict__ kout, IdxT *__restrict__ sa)
+{
+    const uint32_t b = ovf_list[blockIdx.x];
+    const int64_t c = (int64_t)cursor[b], src = ovf_start[b], dst = out_base[b];
+    for (int64_t i = threadIdx.x; i < c; i += kBlock) { kout[dst + i] = okey[src + i]; sa[dst + i] = oidx[src + i]; }
+}
+
+}  // namespace dq

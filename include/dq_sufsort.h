@@ -179,7 +179,10 @@ void dq_sufsort_hip_release(void);
 #define DQ_K_PAIR_CHAINS         17   /* dq_pair_chains.h: tied pairs inside long repeats decided chain by chain    */
 #define DQ_K_MID_ROUND           18   /* dq_mid_groups.h: a doubling round for tie groups of up to 1024 members, inside LDS */
 #define DQ_K_RUNS                19   /* dq_runs.h: run lengths of the text (three small kernels)                          */
-#define DQ_K_COUNT               20
+#define DQ_K_SPLIT_PASS          20   /* dq_split_round0.h: split_pass_kernel, round 0 as a sample sort: text -> pairs by top bucket (1+12), pairs -> bucket slots (12+12) */
+#define DQ_K_SPLIT_FINISH        21   /* bucket_finish_kernel: every bucket sorted by its 64-bit keys inside LDS, 12+12           */
+#define DQ_K_SPLIT_AUX           22   /* sample, splitter tables, top-bucket histogram (1 B/text byte), plans, scans, overflow placement */
+#define DQ_K_COUNT               23
 
 /* 0 off, 1 every kernel, 2 only radix_rank_kernel, 100 + c only category c (cheapest: the timed region) */
 int32_t dq_profile_enable(int32_t on);
