@@ -79,8 +79,8 @@ struct Workspace {
     // round 0 as a sample sort (dq_split_round0.h; int32 indices, texts of >= kSplitMinN bytes): splitter tables, cursors, plans
     uint64_t *sp_top, *sp_sub;
     unsigned long long *sp_cnt_a, *sp_cursor_a, *sp_cursor_b;
-    int64_t *sp_off, *sp_out_base, *sp_ovf_start;
-    uint32_t *sp_tile_first, *sp_ovf_list;
+    int64_t *sp_off, *sp_out_base, *sp_ovf_src, *sp_ovf_dst;
+    uint32_t *sp_tile_first;
     ScanPart *sp_part;
     SplitCtl *sp_ctl;
     size_t bytes;
@@ -140,9 +140,9 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
         w.sp_cursor_b = (unsigned long long *)take((size_t)kSplitBuckets * 8);
         w.sp_off = (int64_t *)take((size_t)(kSplitTop + 1) * 8);
         w.sp_out_base = (int64_t *)take((size_t)(kSplitBuckets + 1) * 8);
-        w.sp_ovf_start = (int64_t *)take((size_t)kSplitBuckets * 8);
+        w.sp_ovf_src = (int64_t *)take((size_t)kSplitBuckets * 8);
+        w.sp_ovf_dst = (int64_t *)take((size_t)kSplitBuckets * 8);
         w.sp_tile_first = (uint32_t *)take((size_t)(kSplitTop + 1) * 4);
-        w.sp_ovf_list = (uint32_t *)take((size_t)kSplitBuckets * 4);
         w.sp_part = (ScanPart *)take((size_t)kScanBlocks * sizeof(ScanPart));
         w.sp_ctl = (SplitCtl *)take(sizeof(SplitCtl));
     }
@@ -1052,7 +1052,7 @@ struct SuffixSorter {
             LAUNCH(L, DQ_K_SPLIT_AUX, kSplitBuckets, (int64_t)kSplitBuckets * 36,
                    hipLaunchKernelGGL(bucket_sum_kernel, dim3(kScanBlocks), dim3(kScanThreads), 0, st, (const unsigned long long *)w.sp_cursor_b, cap, w.sp_part);
                    hipLaunchKernelGGL(bucket_scan_kernel, dim3(kScanBlocks), dim3(kScanThreads), 0, st, (const unsigned long long *)w.sp_cursor_b, cap,
-                                      (const ScanPart *)w.sp_part, w.sp_out_base, w.sp_ovf_start, w.sp_ovf_list, w.sp_ctl));
+                                      (const ScanPart *)w.sp_part, w.sp_out_base, w.sp_ovf_src, w.sp_ovf_dst, w.sp_ctl));
             if ((rc = phase("bucket scan")) != DQ_OK) return rc;
             // (two geometries by bucket size, dq_split_round0.h; the last launch also moves the oversize buckets out)
             const bool two = cap > kFinSmallCap;
@@ -1076,8 +1076,8 @@ struct SuffixSorter {
                 rc = onesweep_sort_pairs<IdxT>(L, w, ovf_k, ovf_v, ovf, 64, xcur);
                 if (rc != DQ_OK) return rc;
                 LAUNCH(L, DQ_K_SPLIT_AUX, ovf, ovf * 2 * (8 + wb),
-                       hipLaunchKernelGGL(overflow_place_kernel<IdxT>, dim3((unsigned)ovf_buckets), dim3(kBlock), 0, st, (const uint32_t *)w.sp_ovf_list,
-                                          (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, (const int64_t *)w.sp_ovf_start,
+                       hipLaunchKernelGGL(overflow_place_kernel<IdxT>, dim3((unsigned)((ovf + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, ovf, ovf_buckets,
+                                          (const int64_t *)w.sp_ovf_src, (const int64_t *)w.sp_ovf_dst,
                                           (const uint64_t *)ovf_k[xcur], (const IdxT *)ovf_v[xcur], K[1], d_sa));
             }
             *done = true;

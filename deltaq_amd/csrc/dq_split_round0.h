@@ -248,8 +248,10 @@ __global__ __launch_bounds__(kSplitThreads, 2) void split_pass_kernel(
     __shared__ uint32_t cnt[kDigits];
     __shared__ uint32_t tile_base[kDigits];
     __shared__ long long gofs[kDigits];                     // global position (A) / arrival number in the bucket (B) of a run's first entry, minus its place in the tile
+    __shared__ long long oofs[kFromText ? 1 : kDigits];     // B: place on the overflow list of a run's first entry that does not fit, minus its place in the tile
     __shared__ uint16_t dig_of[kSplitTile];                 // digit of every position of the sorted tile
     __shared__ uint32_t wtmp[kWavesB];
+    __shared__ unsigned long long s_obase;
     __shared__ uint16_t ctab[kCoded ? 256 : 1];
     __shared__ int s_t;
 
@@ -325,9 +327,10 @@ __global__ __launch_bounds__(kSplitThreads, 2) void split_pass_kernel(
     }
     __syncthreads();
 
-    // ---- digit totals: reserve the tile's place in every output region / bucket, tile-local scan ----
+    // ---- digit totals: reserve the tile's place in every output region / bucket (the returned value is not needed
+    //      before the LDS exchanges are done: the round trip overlaps them), tile-local scan ----
     unsigned long long abase = 0;
-    uint32_t tot = 0, incl = 0;
+    uint32_t tot = 0, incl = 0, excl = 0;
     if (tid < kDigits) {
         tot = cnt[tid];
         if (tot) abase = atomicAdd(&cursor[kFromText ? tid : t_b * kSplitSub + tid], (unsigned long long)tot);
@@ -339,9 +342,8 @@ __global__ __launch_bounds__(kSplitThreads, 2) void split_pass_kernel(
         uint32_t o = 0;
 #pragma unroll
         for (int i = 0; i < kWavesB; ++i) if (i < w) o += wtmp[i];
-        const uint32_t excl = o + incl - tot;
+        excl = o + incl - tot;
         tile_base[tid] = excl;
-        gofs[tid] = (long long)abase - (long long)excl;
     }
     __syncthreads();
 
@@ -390,6 +392,32 @@ __global__ __launch_bounds__(kSplitThreads, 2) void split_pass_kernel(
         }
     }
 
+    // ---- now the reserved places.  B: the entries of a digit run that do not fit their slot (arrival number >= cap) are
+    //      its tail; the tile takes ONE stretch of the overflow list for all of them (one global add per tile that has
+    //      any -- a heavy bucket sends whole tiles there: one add per wave and store instruction was 300 000 adds on one
+    //      address for libtorch_cpu.so) ----
+    if (tid < kDigits) gofs[tid] = (long long)abase - (long long)excl;
+    if (!kFromText) {
+        uint32_t fit = 0, over_n = 0;
+        if (tid < kDigits) {
+            const long long room = cap - (long long)abase;
+            fit = room <= 0 ? 0u : room >= (long long)tot ? tot : (uint32_t)room;
+            over_n = tot - fit;
+        }
+        const uint32_t oincl = wave_incl_sum(over_n);
+        if (lane == kWave - 1) wtmp[w] = oincl;
+        __syncthreads();
+        uint32_t o = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < kWavesB; ++i) { if (i < w) o += wtmp[i]; total += wtmp[i]; }
+        if (total) {                                         // (the same for every thread)
+            if (tid == 0) s_obase = atomicAdd(&ctl->ovf_count, (unsigned long long)total);
+            __syncthreads();
+            if (tid < kDigits) oofs[tid] = (long long)s_obase + (long long)(o + oincl - over_n) - (long long)fit - (long long)excl;
+        }
+    }
+    __syncthreads();
+
     // ---- out: position p of the sorted tile belongs to digit dig_of[p]; consecutive lanes write consecutive entries of a run ----
 #pragma unroll
     for (int k = 0; k < kSplitItems; ++k) {
@@ -399,32 +427,23 @@ __global__ __launch_bounds__(kSplitThreads, 2) void split_pass_kernel(
         const long long q = gofs[d] + p;                     // A: position in the output; B: arrival number in the bucket
         if (kFromText) {
             if (ok) { kout0[q] = skey[k]; vout0[q] = sval[k]; }
-        } else {
-            const bool fits = ok && q < cap;
-            if (fits) {
+        } else if (ok) {
+            if (q < cap) {
                 const int64_t b = (int64_t)t_b * kSplitSub + d;
                 if (b < kSplitBuckets / 2) { kout0[b * cap + q] = skey[k]; vout0[b * cap + q] = sval[k]; }
                 else { kout1[(b - kSplitBuckets / 2) * cap + q] = skey[k]; vout1[(b - kSplitBuckets / 2) * cap + q] = sval[k]; }
-            }
-            // what does not fit its slot: appended to the overflow list, one global add per wave and store instruction
-            const uint64_t over = __ballot(ok && !fits);
-            if (over) {
-                unsigned long long o0 = 0;
-                if (lane == 0) o0 = atomicAdd(&ctl->ovf_count, (unsigned long long)__popcll(over));
-                o0 = __shfl(o0, 0, kWave);
-                if (ok && !fits) {
-                    const long long o = (long long)o0 + mask_rank_lt(over);
-                    if (o < ovf_cap) { ovf_key[o] = skey[k]; ovf_idx[o] = sval[k]; }
-                    else ctl->abandon = 1;
-                }
+            } else {
+                const long long o = oofs[d] + p;
+                if (o < ovf_cap) { ovf_key[o] = skey[k]; ovf_idx[o] = sval[k]; }
+                else ctl->abandon = 1;
             }
         }
     }
 }
 
 // out_base[b] = final position of bucket b (exclusive scan of the bucket sizes = the cursors of pass B), out_base[NB] = n;
-// ovf_start[b] = position of an oversize bucket's first entry in the SORTED overflow list (exclusive scan of the sizes
-// of the oversize buckets); ovf_list = the oversize buckets in order.  Two launches of kScanBlocks workgroups, every
+// for the k-th oversize bucket: ovf_src[k] = position of its first entry in the SORTED overflow list (exclusive scan of the
+// sizes of the oversize buckets), ovf_dst[k] = its final position.  Two launches of kScanBlocks workgroups, every
 // load coalesced: sums per 1024 buckets, then every workgroup adds up the sums in front of it and scans its own 1024.
 constexpr int kScanThreads = 1024;
 constexpr int kScanBlocks = kSplitBuckets / kScanThreads;
@@ -449,7 +468,7 @@ static __global__ __launch_bounds__(kScanThreads) void bucket_sum_kernel(const u
 
 static __global__ __launch_bounds__(kScanThreads) void bucket_scan_kernel(const unsigned long long *__restrict__ cursor, int64_t cap,
                                                                     const ScanPart *__restrict__ part, int64_t *__restrict__ out_base,
-                                                                    int64_t *__restrict__ ovf_start, uint32_t *__restrict__ ovf_list,
+                                                                    int64_t *__restrict__ ovf_src, int64_t *__restrict__ ovf_dst,
                                                                     SplitCtl *__restrict__ ctl)
 {
     __shared__ long long ws[3][kScanThreads / kWave];
@@ -470,8 +489,7 @@ static __global__ __launch_bounds__(kScanThreads) void bucket_scan_kernel(const 
     long long a = s_pre[0], o = s_pre[1], k = s_pre[2];
     for (int i = 0; i < w; ++i) { a += ws[0][i]; o += ws[1][i]; k += ws[2][i]; }
     out_base[b] = a + ia - c;
-    ovf_start[b] = o + io - (over ? c : 0ll);
-    if (over) ovf_list[k + ik - 1] = (uint32_t)b;
+    if (over) { ovf_src[k + ik - 1] = o + io - c; ovf_dst[k + ik - 1] = a + ia - c; }
     if (b == kSplitBuckets - 1) { out_base[kSplitBuckets] = a + ia; ctl->ovf_buckets = (unsigned long long)(k + ik); }
 }
 
@@ -524,6 +542,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     }
     if (c64 <= lo || c64 > hi) return;                       // (empty, or the other launch's)
     const int c = (int)c64;                                  // <= kCap
+    const int64_t ob = out_base[b];                           // (asked for up front: not a round trip of its own at the end)
     uint64_t key[kItems];
     uint32_t idx[kItems];
 #pragma unroll
@@ -600,7 +619,6 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     }
     __syncthreads();
     // ---- final place of every position; out ----
-    const int64_t ob = out_base[b];
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const int pos = k * kThreads + tid;
@@ -626,16 +644,21 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     }
 }
 
-// oversize bucket ovf_list[blockIdx.x]: its stretch of the sorted overflow list -> its final position
+// entry j of the sorted overflow list belongs to the last oversize bucket k with ovf_src[k] <= j (binary search: a few
+// thousand buckets at most) and goes to ovf_dst[k] + (j - ovf_src[k]).  One thread per ENTRY: one bucket may hold
+// millions (a run of 5.5 MB of 'X' in libtorch_cpu.so; a workgroup per bucket took 10 ms over it).
 template <typename IdxT>
-__global__ __launch_bounds__(kBlock) void overflow_place_kernel(const uint32_t *__restrict__ ovf_list, const unsigned long long *__restrict__ cursor,
-                                                             const int64_t *__restrict__ out_base, const int64_t *__restrict__ ovf_start,
-                                                             const uint64_t *__restrict__ okey, const IdxT *__restrict__ oidx,
-                                                             uint64_t *__restrict__ kout, IdxT *__restrict__ sa)
+__global__ __launch_bounds__(kBlock) void overflow_place_kernel(int64_t count, int64_t nbuckets, const int64_t *__restrict__ ovf_src,
+                                                             const int64_t *__restrict__ ovf_dst, const uint64_t *__restrict__ okey,
+                                                             const IdxT *__restrict__ oidx, uint64_t *__restrict__ kout, IdxT *__restrict__ sa)
 {
-    const uint32_t b = ovf_list[blockIdx.x];
-    const int64_t c = (int64_t)cursor[b], src = ovf_start[b], dst = out_base[b];
-    for (int64_t i = threadIdx.x; i < c; i += kBlock) { kout[dst + i] = okey[src + i]; sa[dst + i] = oidx[src + i]; }
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= count) return;
+    int64_t lo = 0, hi = nbuckets;                           // ovf_src[0] = 0 <= j
+    while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (ovf_src[mid] <= j) lo = mid; else hi = mid; }
+    const int64_t dst = ovf_dst[lo] + (j - ovf_src[lo]);
+    kout[dst] = okey[j];
+    sa[dst] = oidx[j];
 }
 
 }  // namespace dq
