@@ -1029,7 +1029,7 @@ struct SuffixSorter {
                    hipLaunchKernelGGL(split_plan_kernel, dim3(1), dim3(kSplitTop), 0, st, (const unsigned long long *)w.sp_cnt_a, w.sp_off, w.sp_cursor_a,
                                       w.sp_tile_first, w.sp_ctl));
             if ((rc = phase("splitters, top-bucket histogram, plan")) != DQ_OK) return rc;
-            const unsigned grid_a = (unsigned)((n + kSplitTile - 1) / kSplitTile);
+            const unsigned grid_a = (unsigned)((n + kSplitTileA - 1) / kSplitTileA);
             if (coded) {
                 LAUNCH(L, DQ_K_SPLIT_PASS, n, n * (1 + 8 + wb),
                        hipLaunchKernelGGL((split_pass_kernel<IdxT, true, true>), dim3(grid_a), dim3(kSplitThreads), 0, st, text64, (const IdxT *)nullptr, n,
@@ -1043,7 +1043,7 @@ struct SuffixSorter {
             }
             if ((rc = phase("pass A")) != DQ_OK) return rc;
             // (pass B's grid is an upper bound -- every top bucket may end in a ragged tile; the workgroups beyond the plan's count leave at once)
-            const unsigned grid_b = (unsigned)(n / kSplitTile + kSplitTop);
+            const unsigned grid_b = (unsigned)(n / kSplitTileB + kSplitTop);
             LAUNCH(L, DQ_K_SPLIT_PASS, n, n * 2 * (8 + wb),
                    hipLaunchKernelGGL((split_pass_kernel<IdxT, false, false>), dim3(grid_b), dim3(kSplitThreads), 0, st, (const uint64_t *)K[1], (const IdxT *)w.Va, n,
                                       (const uint64_t *)w.sp_sub, w.sp_cursor_b, (const int64_t *)w.sp_off, (const uint32_t *)w.sp_tile_first, Ks[0], Vs[0], Ks[1], Vs[1],

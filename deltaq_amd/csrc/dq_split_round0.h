@@ -49,8 +49,10 @@ constexpr int kSplitSub = 256;                                   // parts of a t
 constexpr int kSplitBuckets = kSplitTop * kSplitSub;             // 131 072
 constexpr int kSplitOversample = 16;
 constexpr int64_t kSplitSample = (int64_t)kSplitBuckets * kSplitOversample;      // 2 Mi sampled keys
-constexpr int kSplitThreads = 512, kSplitItems = 20;
-constexpr int kSplitTile = kSplitThreads * kSplitItems;          // 10 240 keys per tile
+constexpr int kSplitThreads = 512;
+constexpr int kSplitItemsA = 20, kSplitItemsB = 16;              // keys per thread: pass A (text -> pairs), pass B (pairs -> slots: 16 keep it inside 128 registers)
+constexpr int kSplitTileA = kSplitThreads * kSplitItemsA;        // 10 240 keys per tile
+constexpr int kSplitTileB = kSplitThreads * kSplitItemsB;        // 8 192
 constexpr int kFinCap = 4096;                                    // the longest bucket the finish kernels sort (two geometries)
 constexpr int kFinSmallCap = 2048;
 
@@ -207,7 +209,7 @@ static __global__ __launch_bounds__(kSplitTop) void split_plan_kernel(const unsi
     __shared__ int64_t wsum[kSplitTop / kWave], wtl[kSplitTop / kWave];
     const int t = threadIdx.x, lane = lane_id(), w = t >> 6;
     const int64_t c = (int64_t)cnt[t];
-    const int64_t tiles = (c + kSplitTile - 1) / kSplitTile;
+    const int64_t tiles = (c + kSplitTileB - 1) / kSplitTileB;
     const int64_t ic = wave_incl_sum(c), it = wave_incl_sum(tiles);
     if (lane == kWave - 1) { wsum[w] = ic; wtl[w] = it; }
     __syncthreads();
@@ -230,7 +232,7 @@ static __global__ __launch_bounds__(kSplitTop) void split_plan_kernel(const unsi
 // cursor[bucket]; q < cap: slot entry q of the bucket -- the slots of the first half of the buckets lie in (kout0, vout0),
 // the others in (kout1, vout1) --, else the overflow list.
 template <typename IdxT, bool kFromText, bool kCoded>
-__global__ __launch_bounds__(kSplitThreads, 2) void split_pass_kernel(
+__global__ __launch_bounds__(kSplitThreads, 4) void split_pass_kernel(
     const uint64_t *__restrict__ kin, const IdxT *__restrict__ vin, int64_t n, const uint64_t *__restrict__ table,
     unsigned long long *__restrict__ cursor, const int64_t *__restrict__ off, const uint32_t *__restrict__ tile_first,
     uint64_t *__restrict__ kout0, IdxT *__restrict__ vout0, uint64_t *__restrict__ kout1, IdxT *__restrict__ vout1, int64_t cap,
@@ -238,6 +240,8 @@ __global__ __launch_bounds__(kSplitThreads, 2) void split_pass_kernel(
     const uint16_t *__restrict__ codetab)
 {
     constexpr int kDigits = kFromText ? kSplitTop : kSplitSub;
+    constexpr int kSplitItems = kFromText ? kSplitItemsA : kSplitItemsB;
+    constexpr int kSplitTile = kSplitThreads * kSplitItems;
     constexpr int kWavesB = kSplitThreads / kWave;
     constexpr int kExchRounds = 2;
     constexpr int kExchN = kSplitTile / kExchRounds;
