@@ -86,8 +86,8 @@ struct Workspace {
     size_t bytes;
 };
 
-// smallest text the sample-sort round 0 can take: its 2 Mi sampled keys are sorted in idle key buffers of 8 (n + 2) bytes
-constexpr int64_t kSplitMinN = 2ll << 20;
+// smallest text the sample-sort round 0 can take: its 4 Mi sampled keys are sorted in idle key buffers of 8 (n + 2) bytes
+constexpr int64_t kSplitMinN = 4ll << 20;
 
 template <typename IdxT>
 Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
@@ -1054,16 +1054,10 @@ struct SuffixSorter {
                    hipLaunchKernelGGL(bucket_scan_kernel, dim3(kScanBlocks), dim3(kScanThreads), 0, st, (const unsigned long long *)w.sp_cursor_b, cap,
                                       (const ScanPart *)w.sp_part, w.sp_out_base, w.sp_ovf_src, w.sp_ovf_dst, w.sp_ctl));
             if ((rc = phase("bucket scan")) != DQ_OK) return rc;
-            // (two geometries by bucket size, dq_split_round0.h; the last launch also moves the oversize buckets out)
-            const bool two = cap > kFinSmallCap;
             LAUNCH(L, DQ_K_SPLIT_FINISH, n, n * 2 * (8 + wb),
                    hipLaunchKernelGGL((bucket_finish_kernel<IdxT, 256, 8>), dim3(kSplitBuckets), dim3(256), 0, st, (const uint64_t *)Ks[0], (const IdxT *)Vs[0],
-                                      (const uint64_t *)Ks[1], (const IdxT *)Vs[1], cap, (int64_t)0, (int64_t)kFinSmallCap, !two,
-                                      (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl);
-                   if (two)
-                       hipLaunchKernelGGL((bucket_finish_kernel<IdxT, 512, 8>), dim3(kSplitBuckets), dim3(512), 0, st, (const uint64_t *)Ks[0], (const IdxT *)Vs[0],
-                                          (const uint64_t *)Ks[1], (const IdxT *)Vs[1], cap, (int64_t)kFinSmallCap, (int64_t)kFinCap, true,
-                                          (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl));
+                                      (const uint64_t *)Ks[1], (const IdxT *)Vs[1], cap, (int64_t)0, (int64_t)kFinCap, true,
+                                      (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl));
             HIP_TRY(hipMemcpyAsync(c.pinned, w.sp_ctl, sizeof(SplitCtl), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             const int64_t ovf = c.pinned[0], ovf_buckets = c.pinned[1], abandon = c.pinned[3];

@@ -45,16 +45,15 @@
 namespace dq {
 
 constexpr int kSplitTop = 512;                                   // top buckets = regions of pass A
-constexpr int kSplitSub = 256;                                   // parts of a top bucket = regions of pass B
-constexpr int kSplitBuckets = kSplitTop * kSplitSub;             // 131 072
+constexpr int kSplitSub = 512;                                   // parts of a top bucket = regions of pass B
+constexpr int kSplitBuckets = kSplitTop * kSplitSub;             // 262 144: a 256 MiB text has 1024 suffixes per bucket
 constexpr int kSplitOversample = 16;
 constexpr int64_t kSplitSample = (int64_t)kSplitBuckets * kSplitOversample;      // 2 Mi sampled keys
 constexpr int kSplitThreads = 512;
 constexpr int kSplitItemsA = 20, kSplitItemsB = 16;              // keys per thread: pass A (text -> pairs), pass B (pairs -> slots: 16 keep it inside 128 registers)
 constexpr int kSplitTileA = kSplitThreads * kSplitItemsA;        // 10 240 keys per tile
 constexpr int kSplitTileB = kSplitThreads * kSplitItemsB;        // 8 192
-constexpr int kFinCap = 4096;                                    // the longest bucket the finish kernels sort (two geometries)
-constexpr int kFinSmallCap = 2048;
+constexpr int kFinCap = 2048;                                    // the longest bucket the finish kernel sorts
 
 struct SplitCtl {
     unsigned long long ovf_count;       // entries of the overflow list (before that: heavy sampled keys, sample_heavy_kernel)
@@ -531,9 +530,22 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     __shared__ unsigned long long s_o0;
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const int64_t b = blockIdx.x;
-    const int64_t c64 = (int64_t)cursor[b];
     const uint64_t *ks = b < kSplitBuckets / 2 ? kslot0 + b * cap : kslot1 + (b - kSplitBuckets / 2) * cap;
     const IdxT *vs = b < kSplitBuckets / 2 ? vslot0 + b * cap : vslot1 + (b - kSplitBuckets / 2) * cap;
+    // The slot is asked for at once, beside the bucket's size and final position (not behind them: one global round trip
+    // instead of two): entries beyond the size are never used, and every index stays inside the slot.
+    uint64_t key[kItems];
+    uint32_t idx[kItems];
+    const int last = (int)(cap < kCap ? cap : kCap) - 1;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int e = k * kThreads + tid;
+        const int ec = e < last ? e : last;
+        key[k] = ks[ec];
+        idx[k] = (uint32_t)vs[ec];
+    }
+    const int64_t c64 = (int64_t)cursor[b];
+    const int64_t ob = out_base[b];
     if (c64 > cap) {
         if (!oversize) return;
         // oversize: the entries that did fit the slot join the rest of the bucket on the overflow list
@@ -546,23 +558,14 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     }
     if (c64 <= lo || c64 > hi) return;                       // (empty, or the other launch's)
     const int c = (int)c64;                                  // <= kCap
-    const int64_t ob = out_base[b];                           // (asked for up front: not a round trip of its own at the end)
-    uint64_t key[kItems];
-    uint32_t idx[kItems];
-#pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const int e = k * kThreads + tid;
-        const int ec = e < c ? e : c - 1;                    // (clamped: the loads stay in flight together)
-        key[k] = ks[ec];
-        idx[k] = (uint32_t)vs[ec];
-    }
+    const int kmax = (c + kThreads - 1) / kThreads;          // item slots in use (the same for every thread: the others are skipped as a whole)
     pcnt[tid] = 0;
     if (tid == 0) { pcnt[kThreads] = 0; pcnt[kThreads + 1] = 0; }
     // ---- local splitters: entry floor(i c / kSample) of the slot for i < kSample, taken from the registers that hold it ----
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const int e = k * kThreads + tid;
-        if (e < c) {
+        if (k < kmax && e < c) {
             for (int i = (int)(((int64_t)e * kSample + c - 1) / c); i < kSample && (int)(((int64_t)i * c) / kSample) == e; ++i) smp[i] = key[k];
         }
     }
@@ -584,6 +587,8 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     uint32_t part[kItems];                                   // part << 16 | arrival number
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
+        part[k] = 0xffffffffu;
+        if (k >= kmax) continue;
         uint32_t lb = 0;                                     // #{srt < key}
 #pragma unroll
         for (int step = kSample / 2; step >= 1; step >>= 1) lb += (srt[lb + step - 1] < key[k]) ? (uint32_t)step : 0u;
@@ -613,7 +618,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     // ---- into part order ----
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
-        if (part[k] != 0xffffffffu) {
+        if (k < kmax && part[k] != 0xffffffffu) {
             const uint32_t p = part[k] >> 16;
             const uint32_t slot = pcnt[p] + (part[k] & 0xffffu);
             skey[slot] = key[k];
@@ -626,7 +631,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const int pos = k * kThreads + tid;
-        if (pos < c) {
+        if (k < kmax && pos < c) {
             const uint64_t me = skey[pos];
             const uint32_t p = spart[pos];
             uint32_t r = (uint32_t)pos;                       // a splitter-valued key stays where it is

@@ -3,7 +3,8 @@
 (DQ_TRACE=2 synchronises after every phase): where does a failing case die?   usage: t_split_small.py [case substring]"""
 import os, sys
 os.environ.setdefault("DQ_DEBUG_FLAGS", "1")
-os.environ.update({"DQ_SPLIT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8"})
+os.environ.setdefault("DQ_SPLIT", "1")
+os.environ.update({"DQ_PACKED": "0", "DQ_KEY_BYTES": "8"})
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -11,15 +12,15 @@ import oracle
 from deltaq_amd import HipSuffixSort
 from tools import datagen
 rnd = datagen.gen_uniform
-rep = rnd(700_000, 5)
+rep = rnd(1_200_000, 5)
 cases = {
-    "uniform 3 MB": rnd(3_000_000, 0x5EED0002),
+    "uniform 5 MB": rnd(5_000_000, 0x5EED0002),
     "text 9 MiB": datagen.gen_enwik_like(9 << 20, 21, 65536),
-    "text 2 MiB + 5": datagen.gen_enwik_like((2 << 20) + 5, 22, 16384),
-    "16 symbols": rnd(4_000_000, 8) & 15,
-    "2 symbols": rnd(2_500_000, 9) & 1,
-    "zeros": np.zeros((2 << 20) + 1, np.uint8),
-    "repeats + zero tail": np.concatenate([rep, rnd(900_000, 6), rep[:400_000], rep, np.zeros(13, np.uint8)]),
+    "text 4 MiB + 5": datagen.gen_enwik_like((4 << 20) + 5, 22, 16384),
+    "16 symbols": rnd(4_500_000, 8) & 15,
+    "2 symbols": rnd(4_300_000, 9) & 1,
+    "zeros": np.zeros((4 << 20) + 1, np.uint8),
+    "repeats + zero tail": np.concatenate([rep, rnd(1_500_000, 6), rep[:400_000], rep, np.zeros(13, np.uint8)]),
 }
 s = HipSuffixSort(0)
 want = sys.argv[1] if len(sys.argv) > 1 else ""
