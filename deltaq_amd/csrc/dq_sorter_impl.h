@@ -386,17 +386,21 @@ int launch_coded_hist(Launcher &L, Workspace<IdxT> &w, int64_t n)
     return L.end();
 }
 
-// Round 0 as a sample sort (dq_split_round0.h) instead of eight digit passes: 8-byte pair keys (text-like inputs and real
-// binaries: many ties expected, coded or raw), int32 indices, from 32 MiB on (below, eight launch-bound passes over a
-// short text cost less than the ten launches of the split) and up to the size whose mean bucket is half the finish
-// kernel's capacity.  DQ_SPLIT = 0 | 1 overrides (1: from kSplitMinN on, for the tests).
+// Round 0 as a sample sort (dq_split_round0.h) instead of eight digit passes: the 8-byte pair path with CODED keys (text-like
+// input), int32 indices, from 96 MiB on -- measured on enwik-style text, sample sort against digit passes: 32 MiB 5.54 / 4.60
+// ms, 64 MiB 8.02 / 7.62, 128 MiB 13.57 / 14.31, 256 MiB 27.3 / 28.6: its fixed costs (a 2 Mi-key sample sorted, 262 144
+// workgroups of the finish kernel) want a long text -- and up to the size whose mean bucket is half the finish kernel's
+// capacity (256 MiB).  Raw 8-byte keys (real binaries) stay with the digit passes: 128 MiB of libtorch_cpu.so 22.7 against
+// 21.8 ms -- 15 % of its suffixes sit in keys too heavy for any bucket and take the overflow route.
+// DQ_SPLIT = 0 | 1 | 2 overrides (1: any 8-byte pair input from kSplitMinN on; 2: also past what the sample says about
+// heavy keys -- for the tests).
 template <typename IdxT>
-bool split_round0_wanted(int64_t n, bool packed, int kb)
+bool split_round0_wanted(int64_t n, bool packed, int kb, bool coded)
 {
     if (sizeof(IdxT) != 4 || packed || kb != 8 || n < kSplitMinN || n > (int64_t)kSplitBuckets * (kFinCap / 2)) return false;
     if (const char *v = env("DQ_SPLIT")) return atoi(v) != 0;
     if (env("DQ_KEY_BYTES") || env("DQ_NO_BUCKET")) return false;     // (forced plain paths of the tests stay what they were)
-    return n >= (32ll << 20);
+    return coded && n >= (96ll << 20);
 }
 
 template <typename IdxT>
@@ -463,7 +467,7 @@ int onesweep_sort_text_prepare(Launcher &L, DeviceCtx &c, Workspace<IdxT> &w, in
             HIP_TRY(hipMemcpyAsync(w.codetab, stage, sizeof(code.tab), hipMemcpyHostToDevice, L.st));
             // (the eight digit histograms of the coded keys -- one more read of the text -- only if the digit passes
             // will run: the sample-sort round 0 does not need them and launches them itself should it give up)
-            if (hist_deferred && split_round0_wanted<IdxT>(n, packed, kb)) {
+            if (hist_deferred && split_round0_wanted<IdxT>(n, packed, kb, true)) {
                 *hist_deferred = true;
             } else {
                 const int rc2 = launch_coded_hist<IdxT>(L, w, n);
@@ -1153,7 +1157,7 @@ struct SuffixSorter {
             if (rc != DQ_OK) return rc;
         } else {
             bool split_done = false;
-            if (split_round0_wanted<IdxT>(n, packed, kb)) {
+            if (split_round0_wanted<IdxT>(n, packed, kb, coded)) {
                 rc = round0_split(K, coded, &split_done);
                 if (rc != DQ_OK) return rc;
                 if (!split_done) {

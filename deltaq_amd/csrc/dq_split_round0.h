@@ -47,7 +47,9 @@ namespace dq {
 constexpr int kSplitTop = 512;                                   // top buckets = regions of pass A
 constexpr int kSplitSub = 512;                                   // parts of a top bucket = regions of pass B
 constexpr int kSplitBuckets = kSplitTop * kSplitSub;             // 262 144: a 256 MiB text has 1024 suffixes per bucket
-constexpr int kSplitOversample = 16;
+// sampled keys per bucket: 8 -> bucket sizes spread like Gamma(8) around the mean (sigma 35 %): one bucket in ~250 grows past
+// twice the mean, its slot, and takes the overflow route -- cheaper than sorting a sample twice as long (16: 0.25 ms more)
+constexpr int kSplitOversample = 8;
 constexpr int64_t kSplitSample = (int64_t)kSplitBuckets * kSplitOversample;      // 2 Mi sampled keys
 constexpr int kSplitThreads = 512;
 constexpr int kSplitItemsA = 20, kSplitItemsB = 16;              // keys per thread: pass A (text -> pairs), pass B (pairs -> slots: 16 keep it inside 128 registers)

@@ -51,7 +51,11 @@ ENVS = [{}, {}, {}, {"DQ_SMALL_N": "0"}, {"DQ_NO_FUSED_TIES": "1"}, {"DQ_NO_SMAL
         {"DQ_CHAIN_STEPS": "1"}, {"DQ_CHAIN_STEPS": "1", "DQ_TAIL_MAX": "0", "DQ_SMALL_N": "0"},
         {"DQ_CHAIN_STEPS": "3", "DQ_TAIL_MAX": "0", "DQ_PACKED": "0", "DQ_KEY_BYTES": "2", "DQ_SPARSE": "0"},
         {"DQ_CHAIN_STEPS": "3", "DQ_TAIL_MAX": "0", "DQ_MID_GROUPS": "256", "DQ_SMALL_N": "0"},
-        {"DQ_XCD_GROUP": "0"}, {"DQ_XCD_GROUP": "3", "DQ_SMALL_N": "0"}, {"DQ_XCD_GROUP": "64", "DQ_BUCKET": "1"}]
+        {"DQ_XCD_GROUP": "0"}, {"DQ_XCD_GROUP": "3", "DQ_SMALL_N": "0"}, {"DQ_XCD_GROUP": "64", "DQ_BUCKET": "1"},
+        # round 6: round 0 as a sample sort (dq_split_round0.h), forced from 4 MiB on: raw / coded keys, past the heavy-key check
+        {"DQ_SPLIT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8"}, {"DQ_SPLIT": "2", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_CODED": "1"},
+        {"DQ_SPLIT": "2", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_CODED": "0", "DQ_BINNED_ISA": "1"},
+        {"DQ_SPLIT": "1", "DQ_PACKED": "0", "DQ_KEY_BYTES": "8", "DQ_CODED": "1", "DQ_RUNS": "1"}]
 KEYS = sorted({k for e in ENVS for k in e})
 s = HipSuffixSort(0)
 t_end = time.time() + budget
@@ -60,8 +64,10 @@ while time.time() < t_end:
     u = rng.random()
     n = int(rng.integers(1, 3000)) if u < 0.25 else int(rng.integers(3000, 200_000)) if u < 0.7 else \
         int(rng.integers(200_000, 3_000_000)) if u < 0.95 else int(rng.integers(3_000_000, 24_000_000))
-    T = structured_text(rng, n)
     env = ENVS[int(rng.integers(0, len(ENVS)))]
+    if "DQ_SPLIT" in env:                               # (the path takes texts of >= 4 MiB)
+        n = int(rng.integers(4_200_000, 9_000_000))
+    T = structured_text(rng, n)
     for k in KEYS: os.environ.pop(k, None)
     os.environ.update(env)
     ref = oracle.divsufsort(T)
