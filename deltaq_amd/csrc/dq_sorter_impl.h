@@ -86,8 +86,9 @@ struct Workspace {
     size_t bytes;
 };
 
-// smallest text the sample-sort round 0 can take: its 4 Mi sampled keys are sorted in idle key buffers of 8 (n + 2) bytes
-constexpr int64_t kSplitMinN = 4ll << 20;
+// smallest text the sample-sort round 0 can take: its 2 Mi sampled keys are sorted in idle key buffers, and pass A's spill (n / 8
+// + 1024 entries per top bucket) must fit a quarter of the suffix array
+constexpr int64_t kSplitMinN = 5ll << 20;
 
 template <typename IdxT>
 Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
@@ -1022,35 +1023,42 @@ struct SuffixSorter {
                 fprintf(stderr, "[dq] sample-sort round 0: %.1f %% of the sampled keys are copies of keys too heavy for a bucket%s\n",
                         100.0 * (double)heavy / (double)kSplitSample, heavy * 6 > kSplitSample ? " -- the digit passes instead" : "");
             if (heavy * 6 > kSplitSample && !(env("DQ_SPLIT") && atoi(env("DQ_SPLIT")) >= 2)) return DQ_OK;      // (DQ_SPLIT=2: the tests go on regardless)
-            HIP_TRY(hipMemsetAsync(w.sp_cnt_a, 0, (size_t)kSplitTop * 8, st));
             HIP_TRY(hipMemsetAsync(w.sp_cursor_b, 0, (size_t)kSplitBuckets * 8, st));
             HIP_TRY(hipMemsetAsync(w.sp_ctl, 0, sizeof(SplitCtl), st));
-            const int hblocks = (int)std::min<int64_t>(2 * kHistBlocks, ((n >> 2) + kHistThreads - 1) / kHistThreads + 1);
-            LAUNCH(L, DQ_K_SPLIT_AUX, n, n,
+            // pass A's output: a virtual array of ~1.13 n entries -- the first n_main in (K[1], Va), the rest spilled into the
+            // suffix array's memory (keys from its start, suffixes from its middle: 0.13 n x 12 bytes of its 4 n)
+            const int64_t n_main = n & ~(int64_t)1;
+            uint64_t *spill_k = reinterpret_cast<uint64_t *>(d_sa);
+            IdxT *spill_v = d_sa + (n / 2 + 1);
+            if (n / 8 + 1024 * (int64_t)kSplitTop + 64 > n / 4) return DQ_OK;                   // (the spill must fit a quarter of the array twice over)
+            LAUNCH(L, DQ_K_SPLIT_AUX, kSplitBuckets, (int64_t)kSplitBuckets * 16,
                    hipLaunchKernelGGL(make_splitters_kernel, dim3(kSplitBuckets / kBlock), dim3(kBlock), 0, st, (const uint64_t *)Ks[scur], w.sp_top, w.sp_sub);
-                   if (coded) hipLaunchKernelGGL(split_hist_kernel<true>, dim3(hblocks), dim3(kHistThreads), 0, st, t32, n, ctab, (const uint64_t *)w.sp_top, w.sp_cnt_a);
-                   else hipLaunchKernelGGL(split_hist_kernel<false>, dim3(hblocks), dim3(kHistThreads), 0, st, t32, n, ctab, (const uint64_t *)w.sp_top, w.sp_cnt_a);
-                   hipLaunchKernelGGL(split_plan_kernel, dim3(1), dim3(kSplitTop), 0, st, (const unsigned long long *)w.sp_cnt_a, w.sp_off, w.sp_cursor_a,
-                                      w.sp_tile_first, w.sp_ctl));
-            if ((rc = phase("splitters, top-bucket histogram, plan")) != DQ_OK) return rc;
+                   hipLaunchKernelGGL(split_estimate_kernel, dim3(1), dim3(kSplitTop), 0, st, (const uint64_t *)Ks[scur], (const uint64_t *)w.sp_top, n, w.sp_off,
+                                      w.sp_cursor_a));
+            if ((rc = phase("splitters, region estimates")) != DQ_OK) return rc;
             const unsigned grid_a = (unsigned)((n + kSplitTileA - 1) / kSplitTileA);
             if (coded) {
                 LAUNCH(L, DQ_K_SPLIT_PASS, n, n * (1 + 8 + wb),
-                       hipLaunchKernelGGL((split_pass_kernel<IdxT, true, true>), dim3(grid_a), dim3(kSplitThreads), 0, st, text64, (const IdxT *)nullptr, n,
-                                          (const uint64_t *)w.sp_top, w.sp_cursor_a, (const int64_t *)w.sp_off, (const uint32_t *)w.sp_tile_first, K[1], w.Va,
-                                          (uint64_t *)nullptr, (IdxT *)nullptr, (int64_t)0, (uint64_t *)nullptr, (IdxT *)nullptr, (int64_t)0, w.sp_ctl, ctab));
+                       hipLaunchKernelGGL((split_pass_kernel<IdxT, true, true>), dim3(grid_a), dim3(kSplitThreads), 0, st, text64, (const IdxT *)nullptr,
+                                          (const uint64_t *)nullptr, (const IdxT *)nullptr, (int64_t)0, n, (const uint64_t *)w.sp_top, w.sp_cursor_a,
+                                          (const int64_t *)w.sp_off, (const unsigned long long *)nullptr, (const uint32_t *)w.sp_tile_first, K[1], w.Va, spill_k, spill_v,
+                                          n_main, (uint64_t *)nullptr, (IdxT *)nullptr, (int64_t)0, w.sp_ctl, ctab));
             } else {
                 LAUNCH(L, DQ_K_SPLIT_PASS, n, n * (1 + 8 + wb),
-                       hipLaunchKernelGGL((split_pass_kernel<IdxT, true, false>), dim3(grid_a), dim3(kSplitThreads), 0, st, text64, (const IdxT *)nullptr, n,
-                                          (const uint64_t *)w.sp_top, w.sp_cursor_a, (const int64_t *)w.sp_off, (const uint32_t *)w.sp_tile_first, K[1], w.Va,
-                                          (uint64_t *)nullptr, (IdxT *)nullptr, (int64_t)0, (uint64_t *)nullptr, (IdxT *)nullptr, (int64_t)0, w.sp_ctl, ctab));
+                       hipLaunchKernelGGL((split_pass_kernel<IdxT, true, false>), dim3(grid_a), dim3(kSplitThreads), 0, st, text64, (const IdxT *)nullptr,
+                                          (const uint64_t *)nullptr, (const IdxT *)nullptr, (int64_t)0, n, (const uint64_t *)w.sp_top, w.sp_cursor_a,
+                                          (const int64_t *)w.sp_off, (const unsigned long long *)nullptr, (const uint32_t *)w.sp_tile_first, K[1], w.Va, spill_k, spill_v,
+                                          n_main, (uint64_t *)nullptr, (IdxT *)nullptr, (int64_t)0, w.sp_ctl, ctab));
             }
             if ((rc = phase("pass A")) != DQ_OK) return rc;
             // (pass B's grid is an upper bound -- every top bucket may end in a ragged tile; the workgroups beyond the plan's count leave at once)
             const unsigned grid_b = (unsigned)(n / kSplitTileB + kSplitTop);
             LAUNCH(L, DQ_K_SPLIT_PASS, n, n * 2 * (8 + wb),
-                   hipLaunchKernelGGL((split_pass_kernel<IdxT, false, false>), dim3(grid_b), dim3(kSplitThreads), 0, st, (const uint64_t *)K[1], (const IdxT *)w.Va, n,
-                                      (const uint64_t *)w.sp_sub, w.sp_cursor_b, (const int64_t *)w.sp_off, (const uint32_t *)w.sp_tile_first, Ks[0], Vs[0], Ks[1], Vs[1],
+                   hipLaunchKernelGGL(split_plan_kernel, dim3(1), dim3(kSplitTop), 0, st, (const unsigned long long *)w.sp_cursor_a, (const int64_t *)w.sp_off, w.sp_cnt_a,
+                                      w.sp_tile_first, w.sp_ctl);
+                   hipLaunchKernelGGL((split_pass_kernel<IdxT, false, false>), dim3(grid_b), dim3(kSplitThreads), 0, st, (const uint64_t *)K[1], (const IdxT *)w.Va,
+                                      (const uint64_t *)spill_k, (const IdxT *)spill_v, n_main, n, (const uint64_t *)w.sp_sub, w.sp_cursor_b, (const int64_t *)w.sp_off,
+                                      (const unsigned long long *)w.sp_cnt_a, (const uint32_t *)w.sp_tile_first, Ks[0], Vs[0], Ks[1], Vs[1],
                                       cap, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl, ctab));
             if ((rc = phase("pass B")) != DQ_OK) return rc;
             LAUNCH(L, DQ_K_SPLIT_AUX, kSplitBuckets, (int64_t)kSplitBuckets * 36,

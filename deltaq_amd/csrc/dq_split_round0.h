@@ -161,81 +161,76 @@ static __global__ __launch_bounds__(kBlock) void make_splitters_kernel(const uin
     if (s == 0) top[t] = t == kSplitTop - 1 ? ~0ull : sorted[(t + 1) * per_top];
 }
 
-// cnt[t] += suffixes whose key falls into top bucket t  (cnt zeroed by the caller)
-template <bool kCoded>
-__global__ __launch_bounds__(kHistThreads) void split_hist_kernel(const uint32_t *__restrict__ t32, int64_t n, const uint16_t *__restrict__ codetab,
-                                                               const uint64_t *__restrict__ top, unsigned long long *__restrict__ cnt)
+// Pass A's output regions WITHOUT counting the text first (an exact histogram of the top buckets is one more read of the text
+// with a 9-step search per key: 1.08 ms of the 256 MiB text sort): the sorted sample already says how many suffixes a
+// top bucket holds -- k_t sampled keys fall into bucket t (two binary searches per bucket; 4096 of them unless a heavy key
+// swallows splitters), so n k_t / S suffixes, to within 1 / sqrt(k_t) = 1.6 % (one sigma).  Region t gets room for 1/8 more
+// than that + 1024 entries (eight sigma); the regions lie one after the other in a VIRTUAL array of ~1.13 n entries
+// whose first `n_main` entries are pass A's output buffers and whose rest spills into the idle suffix array.  Pass A fills
+// a region through its cursor; should one run full all the same, the sort is left to the digit passes (`abandon`).
+//   start[t] = first virtual entry of region t, start[kSplitTop] = end of the last; cursor_a[t] = start[t]
+static __global__ __launch_bounds__(kSplitTop) void split_estimate_kernel(const uint64_t *__restrict__ sorted, const uint64_t *__restrict__ top, int64_t n,
+                                                                    int64_t *__restrict__ start, unsigned long long *__restrict__ cursor_a)
 {
-    __shared__ uint64_t tab[kSplitTop];
-    __shared__ uint32_t hist[kSplitTop];
-    __shared__ uint16_t ctab[256];
-    const int tid = threadIdx.x;
-    const int lane = lane_id();
-    for (int i = tid; i < kSplitTop; i += kHistThreads) { tab[i] = top[i]; hist[i] = 0; }
-    if (kCoded && tid < 256) ctab[tid] = codetab[tid];
+    __shared__ int64_t wsum[kSplitTop / kWave];
+    const int t = threadIdx.x, lane = lane_id(), w = t >> 6;
+    auto lower = [&](uint64_t x) -> int64_t {               // first sampled key >= x
+        int64_t lo = 0, hi = kSplitSample;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted[mid] < x) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    // bucket t holds the keys with top[t - 1] <= key < top[t]  (split_rank counts the splitters <= key)
+    const int64_t lo = t == 0 ? 0 : lower(top[t - 1]);
+    const int64_t hi = t == kSplitTop - 1 ? kSplitSample : lower(top[t]);
+    const int64_t k = hi - lo;
+    const int64_t est = (int64_t)(((unsigned __int128)(uint64_t)k * (uint64_t)n + kSplitSample - 1) / kSplitSample);
+    const int64_t room = est + est / 8 + 1024;
+    const int64_t incl = wave_incl_sum(room);
+    if (lane == kWave - 1) wsum[w] = incl;
     __syncthreads();
-    const int64_t quads = (n + 3) >> 2;
-    // (q0 is wave-uniform: a wave enters and leaves an iteration as a whole, so the shortcut below sees 64 lanes)
-    for (int64_t q0 = (int64_t)blockIdx.x * kHistThreads + (tid & ~(kWave - 1)); q0 < quads; q0 += (int64_t)gridDim.x * kHistThreads) {
-        const int64_t q = q0 + lane;
-        const bool in = q < quads;
-        uint64_t key[4] = {0, 0, 0, 0};
-        if (in) split_keys4<kCoded>(t32, q, ctab, key);
-        const int c = !in ? 0 : (n - q * 4) < 4 ? (int)(n - q * 4) : 4;
-        // (a run of one byte -- zero padding, a table of equal entries -- puts a whole wave into one bucket: 64 LDS adds on one
-        // address take 64 turns; such a wave adds once)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t d = split_rank<kSplitTop>(tab, key[k]);
-            const bool ok = k < c;
-            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane(d);
-            if (__all(ok && d == d0)) {
-                if (lane == 0) atomicAdd(&hist[d0], (uint32_t)kWave);
-            } else if (ok) {
-                atomicAdd(&hist[d], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < kSplitTop; i += kHistThreads)
-        if (hist[i]) atomicAdd(&cnt[i], (unsigned long long)hist[i]);
+    int64_t b = 0;
+    for (int i = 0; i < w; ++i) b += wsum[i];
+    start[t] = b + incl - room;
+    cursor_a[t] = (unsigned long long)(b + incl - room);
+    if (t == kSplitTop - 1) start[kSplitTop] = b + incl;
 }
 
-// off[t] = start of region t in pass A's output (off[kSplitTop] = n), cursor_a[t] = off[t]; tile_first[t] = first tile of
-// pass B in top bucket t (tile_first[kSplitTop] = all of them).  One workgroup of kSplitTop threads.
-static __global__ __launch_bounds__(kSplitTop) void split_plan_kernel(const unsigned long long *__restrict__ cnt, int64_t *__restrict__ off,
-                                                                unsigned long long *__restrict__ cursor_a, uint32_t *__restrict__ tile_first,
+// After pass A: cnt[t] = entries region t received (its cursor minus its start), tile_first[t] = first tile of pass B in top
+// bucket t (tile_first[kSplitTop] = all of them).  One workgroup of kSplitTop threads.
+static __global__ __launch_bounds__(kSplitTop) void split_plan_kernel(const unsigned long long *__restrict__ cursor_a, const int64_t *__restrict__ start,
+                                                                unsigned long long *__restrict__ cnt, uint32_t *__restrict__ tile_first,
                                                                 SplitCtl *__restrict__ ctl)
 {
-    __shared__ int64_t wsum[kSplitTop / kWave], wtl[kSplitTop / kWave];
+    __shared__ int64_t wtl[kSplitTop / kWave];
     const int t = threadIdx.x, lane = lane_id(), w = t >> 6;
-    const int64_t c = (int64_t)cnt[t];
+    const int64_t c = (int64_t)cursor_a[t] - start[t];
+    cnt[t] = (unsigned long long)c;
     const int64_t tiles = (c + kSplitTileB - 1) / kSplitTileB;
-    const int64_t ic = wave_incl_sum(c), it = wave_incl_sum(tiles);
-    if (lane == kWave - 1) { wsum[w] = ic; wtl[w] = it; }
+    const int64_t it = wave_incl_sum(tiles);
+    if (lane == kWave - 1) wtl[w] = it;
     __syncthreads();
-    int64_t bc = 0, bt = 0;
-    for (int i = 0; i < w; ++i) { bc += wsum[i]; bt += wtl[i]; }
-    off[t] = bc + ic - c;
-    cursor_a[t] = (unsigned long long)(bc + ic - c);
+    int64_t bt = 0;
+    for (int i = 0; i < w; ++i) bt += wtl[i];
     tile_first[t] = (uint32_t)(bt + it - tiles);
     if (t == kSplitTop - 1) {
-        off[kSplitTop] = bc + ic;
         tile_first[kSplitTop] = (uint32_t)(bt + it);
         ctl->tiles_b = (unsigned long long)(bt + it);
     }
 }
 
-// Pass A (kFromText): kin = the text, one tile = kSplitTile consecutive suffixes; digit = top bucket; output position from
-// cursor[digit] (preset to the region starts), written to (kout0, vout0).
-// Pass B: kin / vin = pass A's output; workgroup b takes tile b - tile_first[t] of top bucket t; digit = part s of t
+// Pass A (kFromText): kin = the text, one tile = kSplitTileA consecutive suffixes; digit = top bucket; output position = a
+// VIRTUAL entry from cursor[digit] (preset to the region starts, split_estimate_kernel): entries below `cap` (= n_main for
+// this pass) lie in (kout0, vout0), the others in (kout1, vout1); an entry at or past its region's end raises `abandon`.
+// Pass B: (kin, vin) / (kin1, vin1) = pass A's output, main and spill part (n_main = the boundary); workgroup b takes tile
+// b - tile_first[t] of top bucket t, whose entries are region t's first cnt_a[t]; digit = part s of t
 // (table = sub + t * kSplitSub); bucket = t * kSplitSub + s; the arrival number q of an entry in its bucket comes from
 // cursor[bucket]; q < cap: slot entry q of the bucket -- the slots of the first half of the buckets lie in (kout0, vout0),
 // the others in (kout1, vout1) --, else the overflow list.
 template <typename IdxT, bool kFromText, bool kCoded>
 __global__ __launch_bounds__(kSplitThreads, 4) void split_pass_kernel(
-    const uint64_t *__restrict__ kin, const IdxT *__restrict__ vin, int64_t n, const uint64_t *__restrict__ table,
-    unsigned long long *__restrict__ cursor, const int64_t *__restrict__ off, const uint32_t *__restrict__ tile_first,
+    const uint64_t *__restrict__ kin, const IdxT *__restrict__ vin, const uint64_t *__restrict__ kin1, const IdxT *__restrict__ vin1, int64_t n_main,
+    int64_t n, const uint64_t *__restrict__ table, unsigned long long *__restrict__ cursor, const int64_t *__restrict__ off /* region starts */,
+    const unsigned long long *__restrict__ cnt_a /* B: entries per region */, const uint32_t *__restrict__ tile_first,
     uint64_t *__restrict__ kout0, IdxT *__restrict__ vout0, uint64_t *__restrict__ kout1, IdxT *__restrict__ vout1, int64_t cap,
     uint64_t *__restrict__ ovf_key, IdxT *__restrict__ ovf_idx, int64_t ovf_cap, SplitCtl *__restrict__ ctl,
     const uint16_t *__restrict__ codetab)
@@ -279,7 +274,7 @@ __global__ __launch_bounds__(kSplitThreads, 4) void split_pass_kernel(
         __syncthreads();
         t_b = s_t;
         base = off[t_b] + (int64_t)(blockIdx.x - tile_first[t_b]) * kSplitTile;
-        const int64_t left = off[t_b + 1] - base;
+        const int64_t left = off[t_b] + (int64_t)cnt_a[t_b] - base;
         valid = left < kSplitTile ? (int)left : kSplitTile;
         for (int i = tid; i < kDigits; i += kSplitThreads) { tab[i] = table[(int64_t)t_b * kSplitSub + i]; cnt[i] = 0; }
     }
@@ -305,9 +300,9 @@ __global__ __launch_bounds__(kSplitThreads, 4) void split_pass_kernel(
 #pragma unroll
         for (int k = 0; k < kSplitItems; ++k) {
             const int e = wbase + k * kWave;
-            const int ec = e < valid ? e : valid - 1;       // (clamped, not predicated: the loads stay in flight together)
-            key[k] = kin[base + ec];
-            val[k] = vin[base + ec];
+            const int64_t v = base + (e < valid ? e : valid - 1);       // (clamped, not predicated: the loads stay in flight together)
+            key[k] = v < n_main ? kin[v] : kin1[v - n_main];
+            val[k] = v < n_main ? vin[v] : vin1[v - n_main];
         }
     }
 
@@ -401,7 +396,15 @@ __global__ __launch_bounds__(kSplitThreads, 4) void split_pass_kernel(
     //      its tail; the tile takes ONE stretch of the overflow list for all of them (one global add per tile that has
     //      any -- a heavy bucket sends whole tiles there: one add per wave and store instruction was 300 000 adds on one
     //      address for libtorch_cpu.so) ----
-    if (tid < kDigits) gofs[tid] = (long long)abase - (long long)excl;
+    if (tid < kDigits) {
+        gofs[tid] = (long long)abase - (long long)excl;
+        if (kFromText && tot && (long long)(abase + tot) > off[tid + 1]) {
+            // the region is full (the estimate was off by more than its eight sigma of room): nothing of this run is written,
+            // the caller takes the digit passes instead
+            ctl->abandon = 1;
+            gofs[tid] = -(1ll << 60);
+        }
+    }
     if (!kFromText) {
         uint32_t fit = 0, over_n = 0;
         if (tid < kDigits) {
@@ -431,7 +434,10 @@ __global__ __launch_bounds__(kSplitThreads, 4) void split_pass_kernel(
         const uint32_t d = ok ? dig_of[p] : 0u;
         const long long q = gofs[d] + p;                     // A: position in the output; B: arrival number in the bucket
         if (kFromText) {
-            if (ok) { kout0[q] = skey[k]; vout0[q] = sval[k]; }
+            if (ok && q >= 0) {                              // (q < 0: a run whose region ran full, see above)
+                if (q < cap) { kout0[q] = skey[k]; vout0[q] = sval[k]; }
+                else { kout1[q - cap] = skey[k]; vout1[q - cap] = sval[k]; }
+            }
         } else if (ok) {
             if (q < cap) {
                 const int64_t b = (int64_t)t_b * kSplitSub + d;

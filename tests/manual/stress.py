@@ -65,8 +65,8 @@ while time.time() < t_end:
     n = int(rng.integers(1, 3000)) if u < 0.25 else int(rng.integers(3000, 200_000)) if u < 0.7 else \
         int(rng.integers(200_000, 3_000_000)) if u < 0.95 else int(rng.integers(3_000_000, 24_000_000))
     env = ENVS[int(rng.integers(0, len(ENVS)))]
-    if "DQ_SPLIT" in env:                               # (the path takes texts of >= 4 MiB)
-        n = int(rng.integers(4_200_000, 9_000_000))
+    if "DQ_SPLIT" in env:                               # (the path takes texts of >= 5 MiB)
+        n = int(rng.integers(5_300_000, 9_000_000))
     T = structured_text(rng, n)
     for k in KEYS: os.environ.pop(k, None)
     os.environ.update(env)

@@ -14,13 +14,13 @@ from tools import datagen
 rnd = datagen.gen_uniform
 rep = rnd(1_200_000, 5)
 cases = {
-    "uniform 5 MB": rnd(5_000_000, 0x5EED0002),
+    "uniform 6 MB": rnd(6_000_000, 0x5EED0002),
     "text 9 MiB": datagen.gen_enwik_like(9 << 20, 21, 65536),
-    "text 4 MiB + 5": datagen.gen_enwik_like((4 << 20) + 5, 22, 16384),
-    "16 symbols": rnd(4_500_000, 8) & 15,
-    "2 symbols": rnd(4_300_000, 9) & 1,
-    "zeros": np.zeros((4 << 20) + 1, np.uint8),
-    "repeats + zero tail": np.concatenate([rep, rnd(1_500_000, 6), rep[:400_000], rep, np.zeros(13, np.uint8)]),
+    "text 5 MiB + 5": datagen.gen_enwik_like((5 << 20) + 5, 22, 16384),
+    "16 symbols": rnd(5_500_000, 8) & 15,
+    "2 symbols": rnd(5_300_000, 9) & 1,
+    "zeros": np.zeros((5 << 20) + 1, np.uint8),
+    "repeats + zero tail": np.concatenate([rep, rnd(1_500_000, 6), rep[:400_000], rep, rnd(900_000, 7), np.zeros(13, np.uint8)]),
 }
 s = HipSuffixSort(0)
 want = sys.argv[1] if len(sys.argv) > 1 else ""

@@ -637,7 +637,7 @@ def test_update_filler_word_when_n_is_a_power_of_two(ldss, oracle_mod, monkeypat
                          ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()))
 def test_split_round0(ldss, oracle_mod, backend_lib, monkeypatch, env):
     """Round 0 as a sample sort (dq_split_round0.h; the default from 32 MiB of text-like input on, test_gpu_full_configs.py
-    runs it at full size): forced on texts of 4 ... 9 MiB -- slots of 32 ... 72 entries, so every text has oversize buckets
+    runs it at full size): forced on texts of 5 ... 9 MiB -- slots of 40 ... 72 entries, so every text has oversize buckets
     and the overflow list, its sort and the placement run; raw and coded keys; texts made of a few heavy keys, which the
     sorted sample gives away (DQ_SPLIT=1: left to the digit passes) or which fill the overflow list and fall back
     (DQ_SPLIT=2: the path is taken whatever the sample says); device and host entry points."""
@@ -653,13 +653,13 @@ def test_split_round0(ldss, oracle_mod, backend_lib, monkeypatch, env):
     # name -> (text, does the finish kernel run under DQ_SPLIT=1?  None: depends on what the sample says)
     cases = {
         "text 9 MiB": (oracle_mod.gen_enwik_like(9 << 20, 21, 65536), True),
-        "text 4 MiB + 5": (oracle_mod.gen_enwik_like((4 << 20) + 5, 22, 16384), None),
-        "uniform 5 MB": (rnd(5_000_000, 0x5EED0002), True),
-        "16 symbols": (rnd(4_500_000, 8) & 15, True),
-        "2 symbols (heavy keys)": (rnd(4_300_000, 9) & 1, False),
-        "zeros (one key)": (np.zeros((4 << 20) + 1, np.uint8), False),
-        "repeats + zero tail": (np.concatenate([rep, rnd(1_500_000, 6), rep[:400_000], rep, np.zeros(13, np.uint8)]), True),
-        "below the size the path takes": (oracle_mod.gen_enwik_like((4 << 20) - 1, 23, 16384), False),
+        "text 5 MiB + 5": (oracle_mod.gen_enwik_like((5 << 20) + 5, 22, 16384), None),
+        "uniform 6 MB": (rnd(6_000_000, 0x5EED0002), True),
+        "16 symbols": (rnd(5_500_000, 8) & 15, True),
+        "2 symbols (heavy keys)": (rnd(5_300_000, 9) & 1, False),
+        "zeros (one key)": (np.zeros((5 << 20) + 1, np.uint8), False),
+        "repeats + zero tail": (np.concatenate([rep, rnd(1_500_000, 6), rep[:400_000], rep, rnd(900_000, 7), np.zeros(13, np.uint8)]), True),
+        "below the size the path takes": (oracle_mod.gen_enwik_like((5 << 20) - 1, 23, 16384), False),
     }
 
     def sort_counting_launches(T):
@@ -676,7 +676,7 @@ def test_split_round0(ldss, oracle_mod, backend_lib, monkeypatch, env):
         ref = oracle_mod.divsufsort(T)
         sa, launched = sort_counting_launches(T)
         assert np.array_equal(sa, ref), (env, name, "host")
-        if mode == "0" or T.size < (4 << 20):
+        if mode == "0" or T.size < (5 << 20):
             assert launched == 0, (env, name, launched)
         elif mode == "2":
             assert launched == 1, (env, name, launched)                  # taken whatever the sample says
