@@ -4,39 +4,43 @@
 // + seven stable pair passes of 24 B per suffix, 11.5 of the 28.8 ms of a 256 MiB text sort).  Fixed key bits cannot
 // be used MSD-first on skewed text (after the top 16 coded bits 73 % of the suffixes of the text config sit in buckets
 // too long for LDS); ORDER-PRESERVING SPLITTERS drawn from a sorted sample of the keys can: ranked
-// by splitter index the suffixes fall into near-equal buckets whatever the alphabet (tools/exp/splitter_buckets.cpp,
-// 65 536 buckets: 97.9 % of the suffixes of the 256 MiB text config and 91.1 % of 128 MiB of libtorch_cpu.so in buckets of
-// <= 12 288; what is left are keys that occur thousands of times, which no splitter separates).
+// by splitter index the suffixes fall into near-equal buckets whatever the alphabet (tools/exp/splitter_buckets.cpp, the
+// go / no-go measurement with 65 536 buckets: 97.9 % of the suffixes of the 256 MiB text config and 91.1 % of 128 MiB of
+// libtorch_cpu.so in buckets of <= 12 288; what is left are keys that occur thousands of times, which no splitter separates).
 //
-//   sample_keys_kernel      kSplitSample keys at scattered text positions (the same coded / raw 64-bit keys the digit
-//                           passes build); sorted with the ordinary pair sorter (2 Mi keys: ~0.2 ms)
+//   sample_keys_kernel      kSplitSample = 2 Mi keys at scattered text positions (the same coded / raw 64-bit keys the digit
+//                           passes build); sorted with the ordinary pair sorter (~0.2 ms)
 //   sample_heavy_kernel     share of the sample inside runs of equal keys too long for a bucket: a text made of a few
 //                           heavy keys is left to the digit passes before anything is moved
-//   make_splitters_kernel   every 16th sorted sample key is a splitter: top[kSplitTop - 1] (every 4096th) and, per top
+//   make_splitters_kernel   every 8th sorted sample key is a splitter: top[kSplitTop - 1] (every 4096th) and, per top
 //                           bucket t, sub[t][kSplitSub - 1].  bucket(key) = (t, s), t = #{top <= key}, s = #{sub[t] <= key}:
 //                           monotone in the key, so bucket order is key order
-//   split_hist_kernel       exact sizes of the kSplitTop top buckets (one read of the text, keys built on the fly, 9-step
-//                           search in an LDS table) -> pass A's output regions
-//   split_plan_kernel       region starts (cursors of pass A), tiles of pass B per top bucket
+//   split_estimate_kernel   pass A's output regions from the sample alone: k_t sampled keys in top bucket t => n k_t / S
+//                           suffixes +- 1.6 %; room for 1/8 more (no counting pass over the text: it cost 1.08 ms)
 //   split_pass_kernel<A>    text -> (key, suffix) pairs grouped by t.  A tile ranks its keys by arrival (LDS atomics: nothing
 //                           to be stable against), reserves its place in every region with one returning global add per
 //                           digit, stages the tile through LDS in digit order and writes runs -- the shape of
 //                           radix_rank_kernel's first pass with "digit = rank among the splitters"; the digits of a tile
 //                           are near-uniform BY CONSTRUCTION, whatever the text
-//   split_pass_kernel<B>    pairs of one top bucket (tiles never straddle two: their sub-splitter table is 2 KB of LDS) ->
+//   split_plan_kernel       what every region received; tiles of pass B per top bucket
+//   split_pass_kernel<B>    pairs of one top bucket (tiles never straddle two: their sub-splitter table is 4 KB of LDS) ->
 //                           the bucket's SLOT: kSplitBuckets slots of `cap` entries (twice the mean bucket) in idle
 //                           buffers, filled through one cursor per bucket; what does not fit goes to the overflow list
-//   bucket_sum / _scan      final position of every bucket (exclusive scan of the cursors), list of the oversize buckets
+//   bucket_sum / _scan      final position of every bucket (exclusive scan of the cursors), the oversize buckets
 //   bucket_finish_kernel    one workgroup per bucket: the bucket is sorted inside LDS by its full 64-bit keys -- a
 //                           sample sort again (see the kernel) -- and leaves as sorted keys + suffixes.  An oversize
 //                           bucket is moved to the overflow list instead.
 //   (host)                  the overflow list -- ALL members of the oversize buckets, a few per cent of the text -- is sorted by
 //                           the ordinary pair sorter; sorted by key it is sorted by bucket, so
-//   overflow_place_kernel   copies each oversize bucket's stretch of it to the bucket's final position.
+//   overflow_place_kernel   copies every entry of it to its place in its bucket's final stretch.
+//
+// Measured (1 x MI355X, 256 MiB of enwik-style text, profiles/r06/): pass A 1.69 ms, pass B 1.83, finish 3.48, sample +
+// its sort + overflow sort + placement ~1.0 -- 8.0 ms against 11.6 for the histograms + eight digit passes; the sort
+// 28.6 -> 25.5 ms; 128 MiB 14.1 -> 12.8.
 //
 // The result is what the digit passes leave: keys sorted in one buffer, suffixes in the suffix array, equal keys in
-// arbitrary order -- the rebucket pass and everything behind it run unchanged.  Per suffix: 1 (histogram) + 1 + 12
-// (pass A) + 12 + 12 (pass B) + 12 + 12 (finish) = 62 B against 1 + 21 + 7 x 24 = 190 B.
+// arbitrary order -- the rebucket pass and everything behind it run unchanged.  Per suffix: 1 + 12 (pass A) + 12 + 12
+// (pass B) + 12 + 12 (finish) = 61 B against 1 (histograms) + 21 + 7 x 24 = 190 B.
 // Reference context: the phase replaced is still LibDivSufSort.Sort (LibDivSufSort.cs:12-29; its B* substring sort,
 // SsSort.cs:934-1269, is what dominates the reference on text); the suffix array is unchanged by any of this.
 #pragma once
@@ -514,11 +518,13 @@ static __global__ __launch_bounds__(kScanThreads) void bucket_scan_kernel(const 
 //      trip count for most of the wave and reads the same LDS words in every lane -- broadcasts) counts the smaller keys
 //      of its part and the equal ones in front of it: its final place; the entry leaves from there, the 64 lanes writing
 //      inside one window of a few hundred bytes.
-// A bucket is a chain of dependent phases (a global round trip, eight barriers): what a CU gets through is set by how
-// many buckets it holds at once, i.e. by the LDS of a workgroup.  Hence two geometries, each launched over all buckets
-// and taking those of its size class (lo < size <= hi): <256, 8> for up to 2048 entries (31 KB: five per CU) -- the mean
-// bucket of a 256 MiB text -- and <512, 8> for up to 4096 (62 KB: two per CU).  The launch with `oversize` set also moves
-// the buckets that are longer than their slot to the overflow list.
+// What a CU gets through is set by its LDS (~47 LDS instructions per entry: the searches' random 8-byte reads, the scatter,
+// the broadcast reads of the ranking and of the walk) and by how many buckets it holds at once: 256 threads x 8 entries,
+// 31 KB of LDS, five workgroups per CU; item slots beyond the bucket's size are skipped as a whole (a 256 MiB text has 1024
+// entries per bucket: four of the eight).  A <512, 8> geometry for 4096-entry buckets (62 KB: two per CU) took twice as
+// long per entry -- hence 2^18 buckets of <= 2048 rather than 2^17 of <= 4096.  lo < size <= hi selects the buckets of a
+// launch (one launch today); the launch with `oversize` set also moves the buckets that are longer than their slot to
+// the overflow list.
 template <typename IdxT, int kThreads, int kItems>
 __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_finish_kernel(
     const uint64_t *__restrict__ kslot0, const IdxT *__restrict__ vslot0, const uint64_t *__restrict__ kslot1, const IdxT *__restrict__ vslot1,
