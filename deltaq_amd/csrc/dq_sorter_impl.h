@@ -1030,7 +1030,7 @@ struct SuffixSorter {
             const int64_t n_main = n & ~(int64_t)1;
             uint64_t *spill_k = reinterpret_cast<uint64_t *>(d_sa);
             IdxT *spill_v = d_sa + (n / 2 + 1);
-            if (n / 8 + 1024 * (int64_t)kSplitTop + 64 > n / 4) return DQ_OK;                   // (the spill must fit a quarter of the array twice over)
+            if (n / 8 + 1025 * (int64_t)kSplitTop + 1024 > n / 4) return DQ_OK;                 // (the spill -- sum of the regions' room minus n -- must fit n / 4 entries: keys below the middle of the array, suffixes above)
             LAUNCH(L, DQ_K_SPLIT_AUX, kSplitBuckets, (int64_t)kSplitBuckets * 16,
                    hipLaunchKernelGGL(make_splitters_kernel, dim3(kSplitBuckets / kBlock), dim3(kBlock), 0, st, (const uint64_t *)Ks[scur], w.sp_top, w.sp_sub);
                    hipLaunchKernelGGL(split_estimate_kernel, dim3(1), dim3(kSplitTop), 0, st, (const uint64_t *)Ks[scur], (const uint64_t *)w.sp_top, n, w.sp_off,

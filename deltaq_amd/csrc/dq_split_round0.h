@@ -525,7 +525,7 @@ static __global__ __launch_bounds__(kScanThreads) void bucket_scan_kernel(const 
 // long per entry -- hence 2^18 buckets of <= 2048 rather than 2^17 of <= 4096.  lo < size <= hi selects the buckets of a
 // launch (one launch today); the launch with `oversize` set also moves the buckets that are longer than their slot to
 // the overflow list.
-template <typename IdxT, int kThreads, int kItems>
+template <typename IdxT, int kThreads, int kItems, int kSample = 64>
 __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_finish_kernel(
     const uint64_t *__restrict__ kslot0, const IdxT *__restrict__ vslot0, const uint64_t *__restrict__ kslot1, const IdxT *__restrict__ vslot1,
     int64_t cap, int64_t lo, int64_t hi, bool oversize, const unsigned long long *__restrict__ cursor, const int64_t *__restrict__ out_base,
@@ -533,8 +533,11 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     SplitCtl *__restrict__ ctl)
 {
     constexpr int kCap = kThreads * kItems;
-    constexpr int kSample = kThreads / 2;                    // local splitters: one thread per part (the last thread takes two)
+    // local splitters.  Per entry of a 1024-entry bucket: log2(kSample) + 2 random LDS reads for its search, kSample^2 / 1024
+    // broadcast reads for ranking the sample, ~2 * 1024 / (2 kSample) for the walk over its part: 128 splitters 9 + 16 + 8,
+    // 64 splitters 8 + 4 + 16, 32 splitters 7 + 1 + 32
     constexpr int kParts = 2 * kSample + 1;
+    static_assert(2 * kSample <= kThreads && kParts <= kThreads, "two threads rank a splitter, one thread owns a part");
     __shared__ uint64_t skey[kCap];
     __shared__ uint32_t sidx[kCap];
     __shared__ uint16_t spart[kCap];
@@ -573,8 +576,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     if (c64 <= lo || c64 > hi) return;                       // (empty, or the other launch's)
     const int c = (int)c64;                                  // <= kCap
     const int kmax = (c + kThreads - 1) / kThreads;          // item slots in use (the same for every thread: the others are skipped as a whole)
-    pcnt[tid] = 0;
-    if (tid == 0) { pcnt[kThreads] = 0; pcnt[kThreads + 1] = 0; }
+    if (tid <= kParts) pcnt[tid] = 0;
     // ---- local splitters: entry floor(i c / kSample) of the slot for i < kSample, taken from the registers that hold it ----
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
         }
     }
     __syncthreads();
-    {   // ranked by counting, two threads per splitter (half of the others each)
+    if (tid < 2 * kSample) {   // ranked by counting, two threads per splitter (half of the others each); whole waves take part
         const int i = tid >> 1, half = tid & 1;
         const uint64_t me = smp[i];
         uint32_t r = 0;
@@ -614,19 +616,17 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
         part[k] = ok ? ((p << 16) | a) : 0xffffffffu;
     }
     __syncthreads();
-    // ---- exclusive scan of the part sizes (thread t owns part t, the last thread part kParts - 1 as well) ----
+    // ---- exclusive scan of the part sizes (thread t < kParts owns part t) ----
     {
-        const uint32_t mine = pcnt[tid];
-        const uint32_t v = mine + (tid == kThreads - 1 ? pcnt[kThreads] : 0u);
+        const uint32_t v = tid < kParts ? pcnt[tid] : 0u;
         const uint32_t incl = wave_incl_sum(v);
         if (lane == kWave - 1) wtmp[w] = incl;
         __syncthreads();
         uint32_t o = 0;
 #pragma unroll
         for (int i = 0; i < kThreads / kWave; ++i) if (i < w) o += wtmp[i];
-        const uint32_t excl = o + incl - v;
-        pcnt[tid] = excl;                                    // (every count was read before the barrier above)
-        if (tid == kThreads - 1) { pcnt[kThreads] = excl + mine; pcnt[kThreads + 1] = (uint32_t)c; }
+        if (tid < kParts) pcnt[tid] = o + incl - v;          // (every count was read before the barrier above)
+        if (tid == 0) pcnt[kParts] = (uint32_t)c;
     }
     __syncthreads();
     // ---- into part order ----
