@@ -525,7 +525,7 @@ static __global__ __launch_bounds__(kScanThreads) void bucket_scan_kernel(const 
 // long per entry -- hence 2^18 buckets of <= 2048 rather than 2^17 of <= 4096.  lo < size <= hi selects the buckets of a
 // launch (one launch today); the launch with `oversize` set also moves the buckets that are longer than their slot to
 // the overflow list.
-template <typename IdxT, int kThreads, int kItems, int kSample = 64>
+template <typename IdxT, int kThreads, int kItems, int kSample = kThreads / 2>
 __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_finish_kernel(
     const uint64_t *__restrict__ kslot0, const IdxT *__restrict__ vslot0, const uint64_t *__restrict__ kslot1, const IdxT *__restrict__ vslot1,
     int64_t cap, int64_t lo, int64_t hi, bool oversize, const unsigned long long *__restrict__ cursor, const int64_t *__restrict__ out_base,
@@ -534,8 +534,8 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
 {
     constexpr int kCap = kThreads * kItems;
     // local splitters.  Per entry of a 1024-entry bucket: log2(kSample) + 2 random LDS reads for its search, kSample^2 / 1024
-    // broadcast reads for ranking the sample, ~2 * 1024 / (2 kSample) for the walk over its part: 128 splitters 9 + 16 + 8,
-    // 64 splitters 8 + 4 + 16, 32 splitters 7 + 1 + 32
+    // broadcast reads for ranking the sample, ~1024 / kSample steps of the walk over its part (a broadcast read + ~8 VALU
+    // each).  Measured on the 256 MiB text: 128 splitters 3.48 ms, 64 splitters 4.17 -- the walk costs more than its reads
     constexpr int kParts = 2 * kSample + 1;
     static_assert(2 * kSample <= kThreads && kParts <= kThreads, "two threads rank a splitter, one thread owns a part");
     __shared__ uint64_t skey[kCap];
