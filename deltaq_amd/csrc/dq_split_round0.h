@@ -537,7 +537,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     // broadcast reads for ranking the sample, ~1024 / kSample steps of the walk over its part (a broadcast read + ~8 VALU
     // each).  Measured on the 256 MiB text: 128 splitters 3.48 ms, 64 splitters 4.17 -- the walk costs more than its reads
     constexpr int kParts = 2 * kSample + 1;
-    static_assert(2 * kSample <= kThreads && kParts <= kThreads, "two threads rank a splitter, one thread owns a part");
+    static_assert(2 * kSample <= kThreads && kParts <= kThreads + 1, "two threads rank a splitter, one thread owns a part (the last one two)");
     __shared__ uint64_t skey[kCap];
     __shared__ uint32_t sidx[kCap];
     __shared__ uint16_t spart[kCap];
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     if (c64 <= lo || c64 > hi) return;                       // (empty, or the other launch's)
     const int c = (int)c64;                                  // <= kCap
     const int kmax = (c + kThreads - 1) / kThreads;          // item slots in use (the same for every thread: the others are skipped as a whole)
-    if (tid <= kParts) pcnt[tid] = 0;
+    for (int i = tid; i <= kParts; i += kThreads) pcnt[i] = 0;
     // ---- local splitters: entry floor(i c / kSample) of the slot for i < kSample, taken from the registers that hold it ----
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
@@ -616,16 +616,19 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
         part[k] = ok ? ((p << 16) | a) : 0xffffffffu;
     }
     __syncthreads();
-    // ---- exclusive scan of the part sizes (thread t < kParts owns part t) ----
+    // ---- exclusive scan of the part sizes (thread t owns part t; the last thread also part kThreads if there is one) ----
     {
-        const uint32_t v = tid < kParts ? pcnt[tid] : 0u;
+        const uint32_t mine = tid < kParts ? pcnt[tid] : 0u;
+        const uint32_t v = mine + ((kParts > kThreads && tid == kThreads - 1) ? pcnt[kThreads] : 0u);
         const uint32_t incl = wave_incl_sum(v);
         if (lane == kWave - 1) wtmp[w] = incl;
         __syncthreads();
         uint32_t o = 0;
 #pragma unroll
         for (int i = 0; i < kThreads / kWave; ++i) if (i < w) o += wtmp[i];
-        if (tid < kParts) pcnt[tid] = o + incl - v;          // (every count was read before the barrier above)
+        const uint32_t excl = o + incl - v;
+        if (tid < kParts) pcnt[tid] = excl;                  // (every count was read before the barrier above)
+        if (kParts > kThreads && tid == kThreads - 1) pcnt[kThreads] = excl + mine;
         if (tid == 0) pcnt[kParts] = (uint32_t)c;
     }
     __syncthreads();
