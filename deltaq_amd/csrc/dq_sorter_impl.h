@@ -1066,21 +1066,19 @@ struct SuffixSorter {
                    hipLaunchKernelGGL(bucket_scan_kernel, dim3(kScanBlocks), dim3(kScanThreads), 0, st, (const unsigned long long *)w.sp_cursor_b, cap,
                                       (const ScanPart *)w.sp_part, w.sp_out_base, w.sp_ovf_src, w.sp_ovf_dst, w.sp_ctl));
             if ((rc = phase("bucket scan")) != DQ_OK) return rc;
-            if (env("DQ_SPLIT_BITONIC") && atoi(env("DQ_SPLIT_BITONIC")) != 0) {
-                // (experiment: the buckets sorted by bitonic networks in registers, one / two waves per bucket)
-                LAUNCH(L, DQ_K_SPLIT_FINISH, n, n * 2 * (8 + wb),
-                       hipLaunchKernelGGL(bucket_bitonic_kernel<IdxT>, dim3(kSplitBuckets / kBitWaves), dim3(kBitWaves * kWave), 0, st, (const uint64_t *)Ks[0],
-                                          (const IdxT *)Vs[0], (const uint64_t *)Ks[1], (const IdxT *)Vs[1], cap, (const unsigned long long *)w.sp_cursor_b,
-                                          (const int64_t *)w.sp_out_base, K[1], d_sa);
-                       hipLaunchKernelGGL(bucket_bitonic2_kernel<IdxT>, dim3(kSplitBuckets), dim3(2 * kWave), 0, st, (const uint64_t *)Ks[0], (const IdxT *)Vs[0],
-                                          (const uint64_t *)Ks[1], (const IdxT *)Vs[1], cap, (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base,
-                                          K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl));
-            } else {
+            // two geometries by bucket size (dq_split_round0.h: what a CU gets through is set by how many buckets it holds at
+            // once): <= 1024 entries with 16 KB of LDS, eight workgroups per CU; the others with 31 KB, five.  The last launch
+            // also moves the oversize buckets to the overflow list.
+            const bool two = cap > kFinSmallCap && !env("DQ_SPLIT_ONE_CLASS");
             LAUNCH(L, DQ_K_SPLIT_FINISH, n, n * 2 * (8 + wb),
-                   hipLaunchKernelGGL((bucket_finish_kernel<IdxT, 256, 8>), dim3(kSplitBuckets), dim3(256), 0, st, (const uint64_t *)Ks[0], (const IdxT *)Vs[0],
-                                      (const uint64_t *)Ks[1], (const IdxT *)Vs[1], cap, (int64_t)0, (int64_t)kFinCap, true,
-                                      (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl));
-            }
+                   if (two || cap <= kFinSmallCap)
+                       hipLaunchKernelGGL((bucket_finish_kernel<IdxT, 256, 4>), dim3(kSplitBuckets), dim3(256), 0, st, (const uint64_t *)Ks[0], (const IdxT *)Vs[0],
+                                          (const uint64_t *)Ks[1], (const IdxT *)Vs[1], cap, (int64_t)0, (int64_t)kFinSmallCap, !two,
+                                          (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl);
+                   if (cap > kFinSmallCap)
+                       hipLaunchKernelGGL((bucket_finish_kernel<IdxT, 256, 8>), dim3(kSplitBuckets), dim3(256), 0, st, (const uint64_t *)Ks[0], (const IdxT *)Vs[0],
+                                          (const uint64_t *)Ks[1], (const IdxT *)Vs[1], cap, (int64_t)(two ? kFinSmallCap : 0), (int64_t)kFinCap, true,
+                                          (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl));
             HIP_TRY(hipMemcpyAsync(c.pinned, w.sp_ctl, sizeof(SplitCtl), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             const int64_t ovf = c.pinned[0], ovf_buckets = c.pinned[1], abandon = c.pinned[3];

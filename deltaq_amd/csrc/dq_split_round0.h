@@ -60,6 +60,7 @@ constexpr int kSplitItemsA = 20, kSplitItemsB = 16;              // keys per thr
 constexpr int kSplitTileA = kSplitThreads * kSplitItemsA;        // 10 240 keys per tile
 constexpr int kSplitTileB = kSplitThreads * kSplitItemsB;        // 8 192
 constexpr int kFinCap = 2048;                                    // the longest bucket the finish kernel sorts
+constexpr int kFinSmallCap = 1024;                               // ... and what its small geometry takes
 
 struct SplitCtl {
     unsigned long long ovf_count;       // entries of the overflow list (before that: heavy sampled keys, sample_heavy_kernel)
@@ -526,7 +527,7 @@ static __global__ __launch_bounds__(kScanThreads) void bucket_scan_kernel(const 
 // launch (one launch today); the launch with `oversize` set also moves the buckets that are longer than their slot to
 // the overflow list.
 template <typename IdxT, int kThreads, int kItems, int kSample = kThreads / 2>
-__global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_finish_kernel(
+__global__ __launch_bounds__(kThreads, kThreads * kItems <= 1024 ? 8 : kThreads == 256 ? 5 : 4) void bucket_finish_kernel(
     const uint64_t *__restrict__ kslot0, const IdxT *__restrict__ vslot0, const uint64_t *__restrict__ kslot1, const IdxT *__restrict__ vslot1,
     int64_t cap, int64_t lo, int64_t hi, bool oversize, const unsigned long long *__restrict__ cursor, const int64_t *__restrict__ out_base,
     uint64_t *__restrict__ kout, IdxT *__restrict__ sa, uint64_t *__restrict__ ovf_key, IdxT *__restrict__ ovf_idx, int64_t ovf_cap,
@@ -549,20 +550,20 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     const int64_t b = blockIdx.x;
     const uint64_t *ks = b < kSplitBuckets / 2 ? kslot0 + b * cap : kslot1 + (b - kSplitBuckets / 2) * cap;
     const IdxT *vs = b < kSplitBuckets / 2 ? vslot0 + b * cap : vslot1 + (b - kSplitBuckets / 2) * cap;
-    // The slot is asked for at once, beside the bucket's size and final position (not behind them: one global round trip
-    // instead of two): entries beyond the size are never used, and every index stays inside the slot.
+    // (the size first: a bucket of the other launch's class costs one load, not its slot)
+    const int64_t c64 = (int64_t)cursor[b];
+    const int64_t ob = out_base[b];
+    if (c64 <= cap && (c64 <= lo || c64 > hi)) return;       // (empty, or the other launch's)
     uint64_t key[kItems];
     uint32_t idx[kItems];
     const int last = (int)(cap < kCap ? cap : kCap) - 1;
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const int e = k * kThreads + tid;
-        const int ec = e < last ? e : last;
+        const int ec = e < last ? e : last;                  // (inside the slot whatever the size: the loads do not wait for it)
         key[k] = ks[ec];
         idx[k] = (uint32_t)vs[ec];
     }
-    const int64_t c64 = (int64_t)cursor[b];
-    const int64_t ob = out_base[b];
     if (c64 > cap) {
         if (!oversize) return;
         // oversize: the entries that did fit the slot join the rest of the bucket on the overflow list
@@ -573,7 +574,6 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
         for (int64_t i = tid; i < cap; i += kThreads) { ovf_key[o0 + i] = ks[i]; ovf_idx[o0 + i] = vs[i]; }
         return;
     }
-    if (c64 <= lo || c64 > hi) return;                       // (empty, or the other launch's)
     const int c = (int)c64;                                  // <= kCap
     const int kmax = (c + kThreads - 1) / kThreads;          // item slots in use (the same for every thread: the others are skipped as a whole)
     for (int i = tid; i <= kParts; i += kThreads) pcnt[i] = 0;
@@ -670,189 +670,11 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 5 : 4) void bucket_fini
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The same finish as a BITONIC SORT IN REGISTERS, one wave per bucket (experiment, DQ_SPLIT_BITONIC=1): the sample sort above
-// issues ~5 000 wave instructions per 1024-entry bucket but spends most of its time waiting for LDS round trips between its
-// barriers (IPC ~0.16); a sorting network is straight-line VALU work on registers.  A lane holds E consecutive positions
-// (i = lane * E + e): compare-exchange distances below E stay inside the lane (static register indices after unrolling),
-// the 21 stages with larger distances exchange with lane ^ (j / E) by shuffles.  Entries compare as 96-bit numbers
-// (key, suffix): pads are (all ones, all ones) and sort behind every entry, and no two entries are equal.
-// Buckets of up to 1024 entries: one wave, E = 4 / 8 / 16 by size.  1025 ... 2048: two waves sort a half each, exchange
-// through LDS (entry i of one half against entry 1023 - i of the other: minimum down, maximum up) and merge their halves.
-template <int E>
-__device__ __forceinline__ void bitonic_stage(uint64_t (&k)[E], uint32_t (&v)[E], int lane, int kk, int j, bool force_up)
-{
-    if (j >= E) {
-        const int lx = j / E;
-        const bool up = force_up || (lane & (kk / E)) == 0;
-        const bool keep_min = ((lane & lx) == 0) == up;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint64_t pk = __shfl_xor(k[e], lx, kWave);
-            const uint32_t pv = __shfl_xor(v[e], lx, kWave);
-            const bool mine_gt = k[e] > pk || (k[e] == pk && v[e] > pv);
-            const bool take = keep_min ? mine_gt : !mine_gt;
-            k[e] = take ? pk : k[e];
-            v[e] = take ? pv : v[e];
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if ((e & j) == 0) {
-                const int f = e | j;
-                const bool up = force_up || (kk < E ? (e & kk) == 0 : (lane & (kk / E)) == 0);
-                const bool gt = k[e] > k[f] || (k[e] == k[f] && v[e] > v[f]);
-                const bool sw = gt == up;
-                const uint64_t ka = k[e], kb = k[f];
-                const uint32_t va = v[e], vb = v[f];
-                k[e] = sw ? kb : ka; k[f] = sw ? ka : kb;
-                v[e] = sw ? vb : va; v[f] = sw ? va : vb;
-            }
-        }
-    }
-}
-
-template <int E>
-__device__ __forceinline__ void bitonic_sort_wave(uint64_t (&k)[E], uint32_t (&v)[E], int lane)
-{
-#pragma unroll
-    for (int kk = 2; kk <= 64 * E; kk <<= 1) {
-#pragma unroll
-        for (int j = kk >> 1; j > 0; j >>= 1) bitonic_stage<E>(k, v, lane, kk, j, false);
-    }
-}
-
-// both halves of a bitonic sequence of 64 E entries ascending: distances 32 E ... 1
-template <int E>
-__device__ __forceinline__ void bitonic_merge_wave(uint64_t (&k)[E], uint32_t (&v)[E], int lane)
-{
-#pragma unroll
-    for (int j = 32 * E; j > 0; j >>= 1) bitonic_stage<E>(k, v, lane, 64 * E, j, true);
-}
-
-// LDS image of one wave's 64 E entries, a row of E + 1 per lane: written / read in position order (coalesced global side) on
-// one side and lane-major on the other without bank conflicts
-template <int E> struct BitonicStage {
-    uint64_t k[64 * (E + 1)];
-    uint32_t v[64 * (E + 1)];
-    static __device__ __forceinline__ int at(int i) { return (i / E) * (E + 1) + (i % E); }
-};
-
-template <typename IdxT, int E>
-__device__ __forceinline__ void bitonic_load(const uint64_t *ks, const IdxT *vs, int first, int c, BitonicStage<E> &st, int lane,
-                                             uint64_t (&k)[E], uint32_t (&v)[E])
-{
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-        const int p = q * kWave + lane;
-        const bool in = first + p < c;
-        st.k[BitonicStage<E>::at(p)] = in ? ks[first + p] : ~0ull;
-        st.v[BitonicStage<E>::at(p)] = in ? (uint32_t)vs[first + p] : ~0u;
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int e = 0; e < E; ++e) { k[e] = st.k[lane * (E + 1) + e]; v[e] = st.v[lane * (E + 1) + e]; }
-    __builtin_amdgcn_wave_barrier();
-}
-
-template <typename IdxT, int E>
-__device__ __forceinline__ void bitonic_store(uint64_t *kout, IdxT *sa, int64_t ob, int first, int c, BitonicStage<E> &st, int lane,
-                                              const uint64_t (&k)[E], const uint32_t (&v)[E])
-{
-#pragma unroll
-    for (int e = 0; e < E; ++e) { st.k[lane * (E + 1) + e] = k[e]; st.v[lane * (E + 1) + e] = v[e]; }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-        const int p = q * kWave + lane;
-        if (first + p < c) { kout[ob + first + p] = st.k[BitonicStage<E>::at(p)]; sa[ob + first + p] = (IdxT)st.v[BitonicStage<E>::at(p)]; }
-    }
-}
-
-template <typename IdxT, int E>
-__device__ __forceinline__ void bitonic_bucket(const uint64_t *ks, const IdxT *vs, int c, int64_t ob, uint64_t *kout, IdxT *sa,
-                                               BitonicStage<16> &stage, int lane)
-{
-    BitonicStage<E> &st = reinterpret_cast<BitonicStage<E> &>(stage);
-    uint64_t k[E];
-    uint32_t v[E];
-    bitonic_load<IdxT, E>(ks, vs, 0, c, st, lane, k, v);
-    bitonic_sort_wave<E>(k, v, lane);
-    bitonic_store<IdxT, E>(kout, sa, ob, 0, c, st, lane, k, v);
-}
-
-constexpr int kBitWaves = 4;            // buckets per workgroup of the one-wave launch
-
-// buckets of 1 ... 1024 entries: wave w of workgroup g takes bucket g * kBitWaves + w
-template <typename IdxT>
-__global__ __launch_bounds__(kBitWaves * kWave, 3) void bucket_bitonic_kernel(
-    const uint64_t *__restrict__ kslot0, const IdxT *__restrict__ vslot0, const uint64_t *__restrict__ kslot1, const IdxT *__restrict__ vslot1,
-    int64_t cap, const unsigned long long *__restrict__ cursor, const int64_t *__restrict__ out_base, uint64_t *__restrict__ kout, IdxT *__restrict__ sa)
-{
-    __shared__ BitonicStage<16> stage[kBitWaves];
-    const int lane = lane_id(), w = threadIdx.x >> 6;
-    const int64_t b = (int64_t)blockIdx.x * kBitWaves + w;
-    if (b >= kSplitBuckets) return;
-    const int64_t c64 = (int64_t)cursor[b];
-    if (c64 == 0 || c64 > 1024 || c64 > cap) return;         // (empty; the two-wave launch's; oversize: the overflow route)
-    const int64_t ob = out_base[b];
-    const uint64_t *ks = b < kSplitBuckets / 2 ? kslot0 + b * cap : kslot1 + (b - kSplitBuckets / 2) * cap;
-    const IdxT *vs = b < kSplitBuckets / 2 ? vslot0 + b * cap : vslot1 + (b - kSplitBuckets / 2) * cap;
-    const int c = (int)c64;
-    if (c <= 256) bitonic_bucket<IdxT, 4>(ks, vs, c, ob, kout, sa, stage[w], lane);
-    else if (c <= 512) bitonic_bucket<IdxT, 8>(ks, vs, c, ob, kout, sa, stage[w], lane);
-    else bitonic_bucket<IdxT, 16>(ks, vs, c, ob, kout, sa, stage[w], lane);
-}
-
-// buckets of 1025 ... 2048 entries (and the oversize ones, which it moves to the overflow list): two waves per bucket
-template <typename IdxT>
-__global__ __launch_bounds__(2 * kWave, 3) void bucket_bitonic2_kernel(
-    const uint64_t *__restrict__ kslot0, const IdxT *__restrict__ vslot0, const uint64_t *__restrict__ kslot1, const IdxT *__restrict__ vslot1,
-    int64_t cap, const unsigned long long *__restrict__ cursor, const int64_t *__restrict__ out_base, uint64_t *__restrict__ kout, IdxT *__restrict__ sa,
-    uint64_t *__restrict__ ovf_key, IdxT *__restrict__ ovf_idx, int64_t ovf_cap, SplitCtl *__restrict__ ctl)
-{
-    constexpr int E = 16;
-    __shared__ BitonicStage<E> stage[2];
-    __shared__ unsigned long long s_o0;
-    const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-    const int64_t b = blockIdx.x;
-    const int64_t c64 = (int64_t)cursor[b];
-    const uint64_t *ks = b < kSplitBuckets / 2 ? kslot0 + b * cap : kslot1 + (b - kSplitBuckets / 2) * cap;
-    const IdxT *vs = b < kSplitBuckets / 2 ? vslot0 + b * cap : vslot1 + (b - kSplitBuckets / 2) * cap;
-    if (c64 > cap) {
-        if (tid == 0) s_o0 = atomicAdd(&ctl->ovf_count, (unsigned long long)cap);
-        __syncthreads();
-        const long long o0 = (long long)s_o0;
-        if (o0 + cap > ovf_cap) { if (tid == 0) ctl->abandon = 1; return; }
-        for (int64_t i = tid; i < cap; i += 2 * kWave) { ovf_key[o0 + i] = ks[i]; ovf_idx[o0 + i] = vs[i]; }
-        return;
-    }
-    if (c64 <= 1024) return;
-    const int c = (int)c64;                                  // 1025 ... 2048
-    const int64_t ob = out_base[b];
-    uint64_t k[E];
-    uint32_t v[E];
-    const int first = w * 1024;
-    bitonic_load<IdxT, E>(ks, vs, first, c, stage[w], lane, k, v);
-    bitonic_sort_wave<E>(k, v, lane);
-    // entry i of this half against entry 1023 - i of the other: the lower half keeps the minimum, the upper the maximum
-#pragma unroll
-    for (int e = 0; e < E; ++e) { stage[w].k[lane * (E + 1) + e] = k[e]; stage[w].v[lane * (E + 1) + e] = v[e]; }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int pi = (63 - lane) * (E + 1) + (E - 1 - e);
-        const uint64_t pk = stage[w ^ 1].k[pi];
-        const uint32_t pv = stage[w ^ 1].v[pi];
-        const bool mine_gt = k[e] > pk || (k[e] == pk && v[e] > pv);
-        const bool take = w == 0 ? mine_gt : !mine_gt;
-        k[e] = take ? pk : k[e];
-        v[e] = take ? pv : v[e];
-    }
-    __syncthreads();                                          // (the images are written again by the stores)
-    bitonic_merge_wave<E>(k, v, lane);
-    bitonic_store<IdxT, E>(kout, sa, ob, first, c, stage[w], lane, k, v);
-}
+// (Measured against this kernel and dropped, round 6: the same finish as BITONIC NETWORKS IN REGISTERS, one wave per bucket of
+// <= 1024 entries (16 per lane, distances below 16 inside the lane, 21 shuffle stages across lanes, 96-bit compares so that
+// pads sort last), two waves + an LDS exchange for 1025 ... 2048 -- straight-line VALU work instead of LDS round trips between
+// barriers, bit-exact on every test: 7.60 ms against 3.46 on the 256 MiB text, 3.21 against 1.91 on 128 MiB.  144 / 168 VGPRs
+// leave three waves per SIMD and O(log^2) stages of dependent selects do not beat ~47 LDS instructions per entry.)
 
 // entry j of the sorted overflow list belongs to the last oversize bucket k with ovf_src[k] <= j (binary search: a few
 // thousand buckets at most) and goes to ovf_dst[k] + (j - ovf_src[k]).  One thread per ENTRY: one bucket may hold
