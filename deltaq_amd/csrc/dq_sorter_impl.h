@@ -388,10 +388,10 @@ int launch_coded_hist(Launcher &L, Workspace<IdxT> &w, int64_t n)
 }
 
 // Round 0 as a sample sort (dq_split_round0.h) instead of eight digit passes: the 8-byte pair path with CODED keys (text-like
-// input), int32 indices, from 96 MiB on -- measured on enwik-style text, sample sort against digit passes: 32 MiB 5.54 / 4.60
-// ms, 64 MiB 8.02 / 7.62, 128 MiB 13.57 / 14.31, 256 MiB 27.3 / 28.6: its fixed costs (a 2 Mi-key sample sorted, 262 144
-// workgroups of the finish kernel) want a long text -- and up to the size whose mean bucket is half the finish kernel's
-// capacity (256 MiB).  Raw 8-byte keys (real binaries) stay with the digit passes: 128 MiB of libtorch_cpu.so 22.7 against
+// input), int32 indices, from 64 MiB on -- measured on enwik-style text, sample sort against digit passes in one process:
+// 64 MiB 7.36 / 7.86 ms, 96 MiB 9.87 / 11.11, 128 MiB 12.73 / 14.12, 256 MiB 25.2 / 28.6 (32 MiB, an earlier build: 5.54 /
+// 4.60: its fixed costs -- a 2 Mi-key sample sorted, 262 144 workgroups of the finish kernel -- want a long text) -- and up
+// to the size whose mean bucket is half the finish kernel's capacity (256 MiB).  Raw 8-byte keys (real binaries) stay with the digit passes: 128 MiB of libtorch_cpu.so 22.7 against
 // 21.8 ms -- 15 % of its suffixes sit in keys too heavy for any bucket and take the overflow route.
 // DQ_SPLIT = 0 | 1 | 2 overrides (1: any 8-byte pair input from kSplitMinN on; 2: also past what the sample says about
 // heavy keys -- for the tests).
@@ -401,7 +401,7 @@ bool split_round0_wanted(int64_t n, bool packed, int kb, bool coded)
     if (sizeof(IdxT) != 4 || packed || kb != 8 || n < kSplitMinN || n > (int64_t)kSplitBuckets * (kFinCap / 2)) return false;
     if (const char *v = env("DQ_SPLIT")) return atoi(v) != 0;
     if (env("DQ_KEY_BYTES") || env("DQ_NO_BUCKET")) return false;     // (forced plain paths of the tests stay what they were)
-    return coded && n >= (96ll << 20);
+    return coded && n >= (64ll << 20);
 }
 
 template <typename IdxT>
