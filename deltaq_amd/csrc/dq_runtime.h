@@ -201,7 +201,7 @@ constexpr int kMaxDevices = 64;
 constexpr int kCtxSlots = 4;
 constexpr int64_t kSlotSmallN = 4ll << 20;
 constexpr size_t kSmallTextArea = kSmallMaxN + 64;
-constexpr size_t kSmallIoBytes = kSmallTextArea + (size_t)kSmallMaxN * 8 + 64;       // text, suffix array, the kernel's "done" word
+constexpr size_t kSmallIoBytes = kSmallTextArea + (size_t)kSmallMaxN * 8;
 struct DeviceState {
     DeviceCtx slot[kCtxSlots];
     std::atomic<unsigned> next{0};

@@ -142,8 +142,7 @@ __device__ __forceinline__ int small_bits(uint32_t x) { return x ? 32 - __builti
 
 template <typename IdxT>
 __global__ __launch_bounds__(kSmallThreads) void small_sufsort_kernel(const uint8_t *__restrict__ text, int n,
-                                                                      IdxT *__restrict__ sa,
-                                                                      uint32_t *__restrict__ done = nullptr /* host-visible word, set last */)
+                                                                      IdxT *__restrict__ sa)
 {
     __shared__ SmallLds L;
     const int t = threadIdx.x;
@@ -177,14 +176,6 @@ __global__ __launch_bounds__(kSmallThreads) void small_sufsort_kernel(const uint
         groups = small_rebucket(L, cur, n, E);
     }
     for (int p = t; p < n; p += kSmallThreads) sa[p] = (IdxT)L.val[cur][p];
-    if (done) {
-        // The host interface reads the suffix array from pinned memory the kernel wrote itself; it waits for THIS word
-        // instead of for the stream (round 6: the completion signal of a 15 us kernel took ~10 us to reach a
-        // hipStreamSynchronize).  Every thread's stores are ordered before the word: system-scope fence, barrier, store.
-        __threadfence_system();
-        __syncthreads();
-        if (t == 0) __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 }  // namespace dq

@@ -1998,26 +1998,12 @@ int sufsort_device(DeviceCtx &c, hipStream_t st, Workspace<IdxT> &w, int64_t n, 
 }
 
 template <typename IdxT>
-int sufsort_small(DeviceCtx &c, hipStream_t st, const uint8_t *text, int64_t n, IdxT *sa, uint32_t *done = nullptr)
+int sufsort_small(DeviceCtx &c, hipStream_t st, const uint8_t *text, int64_t n, IdxT *sa)
 {
     Launcher L{c, st, g_prof_on.load()};
     t_info[0] = t_info[1] = t_info[2] = 0;
-    // `done` (host interface only: a word in the context's pinned area): the kernel sets it behind its last store and
-    // the host polls it instead of waiting for the stream's completion signal.  Not under the profiler (its events are
-    // waited for anyway), not under fault injection, and never for longer than a kernel of this size can take: after
-    // that the stream is waited for as before.  DQ_SMALL_POLL=0 turns it off.
-    const bool poll = done && g_prof_on.load() == 0 && !t_fault.hip_at && !(env("DQ_SMALL_POLL") && atoi(env("DQ_SMALL_POLL")) == 0);
-    if (poll) __atomic_store_n(done, 0u, __ATOMIC_RELEASE);
     LAUNCH(L, DQ_K_SMALL_SORT, n, n * (1 + (int64_t)sizeof(IdxT)),
-           hipLaunchKernelGGL(small_sufsort_kernel<IdxT>, dim3(1), dim3(kSmallThreads), 0, st, text, (int)n, sa, poll ? done : (uint32_t *)nullptr));
-    if (poll) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t spins = 0;; ++spins) {
-            if (__atomic_load_n(done, __ATOMIC_ACQUIRE) != 0) return DQ_OK;
-            if ((spins & 1023u) == 1023u &&
-                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 2000) break;
-        }
-    }
+           hipLaunchKernelGGL(small_sufsort_kernel<IdxT>, dim3(1), dim3(kSmallThreads), 0, st, text, (int)n, sa));
     HIP_TRY(hipStreamSynchronize(st));
     return flush_profile(c);
 }
@@ -2062,8 +2048,7 @@ int sufsort_host(const uint8_t *text, int64_t n, IdxT *sa, int32_t device, SortH
         // the kernel reads the text from, and writes the SA to, pinned host memory: one launch, no copies
         IdxT *io_sa = reinterpret_cast<IdxT *>(c.pinned_io + kSmallTextArea);
         memcpy(c.pinned_io, text, (size_t)n);
-        rc = sufsort_small<IdxT>(c, c.stream, c.pinned_io, n, io_sa,
-                                 reinterpret_cast<uint32_t *>(c.pinned_io + kSmallTextArea + (size_t)kSmallMaxN * 8));
+        rc = sufsort_small<IdxT>(c, c.stream, c.pinned_io, n, io_sa);
         if (rc != DQ_OK) { drop_pending(c, c.stream); return rc; }
         memcpy(sa, io_sa, (size_t)n * sizeof(IdxT));
         return DQ_OK;
