@@ -80,6 +80,8 @@ struct Workspace {
     uint64_t *sp_top, *sp_sub;
     unsigned long long *sp_cnt_a, *sp_cursor_a, *sp_cursor_b;
     int64_t *sp_off, *sp_out_base, *sp_ovf_src, *sp_ovf_dst;
+    uint64_t *sp_low;           // lower key bound of every bucket
+    uint8_t *sp_pure;           // bucket holds copies of one key only
     uint32_t *sp_tile_first;
     ScanPart *sp_part;
     SplitCtl *sp_ctl;
@@ -143,6 +145,8 @@ Workspace<IdxT> carve(char *base, int64_t n, bool with_sa)
         w.sp_out_base = (int64_t *)take((size_t)(kSplitBuckets + 1) * 8);
         w.sp_ovf_src = (int64_t *)take((size_t)kSplitBuckets * 8);
         w.sp_ovf_dst = (int64_t *)take((size_t)kSplitBuckets * 8);
+        w.sp_low = (uint64_t *)take((size_t)kSplitBuckets * 8);
+        w.sp_pure = (uint8_t *)take((size_t)kSplitBuckets);
         w.sp_tile_first = (uint32_t *)take((size_t)(kSplitTop + 1) * 4);
         w.sp_part = (ScanPart *)take((size_t)kScanBlocks * sizeof(ScanPart));
         w.sp_ctl = (SplitCtl *)take(sizeof(SplitCtl));
@@ -387,21 +391,21 @@ int launch_coded_hist(Launcher &L, Workspace<IdxT> &w, int64_t n)
     return L.end();
 }
 
-// Round 0 as a sample sort (dq_split_round0.h) instead of eight digit passes: the 8-byte pair path with CODED keys (text-like
-// input), int32 indices, from 64 MiB on -- measured on enwik-style text, sample sort against digit passes in one process:
-// 64 MiB 7.36 / 7.86 ms, 96 MiB 9.87 / 11.11, 128 MiB 12.73 / 14.12, 256 MiB 25.2 / 28.6 (32 MiB, an earlier build: 5.54 /
-// 4.60: its fixed costs -- a 2 Mi-key sample sorted, 262 144 workgroups of the finish kernel -- want a long text) -- and up
-// to the size whose mean bucket is half the finish kernel's capacity (256 MiB).  Raw 8-byte keys (real binaries) stay with the digit passes: 128 MiB of libtorch_cpu.so 22.7 against
-// 21.8 ms -- 15 % of its suffixes sit in keys too heavy for any bucket and take the overflow route.
-// DQ_SPLIT = 0 | 1 | 2 overrides (1: any 8-byte pair input from kSplitMinN on; 2: also past what the sample says about
-// heavy keys -- for the tests).
+// Round 0 as a sample sort (dq_split_round0.h) instead of eight digit passes: the 8-byte pair path -- coded keys (text-like
+// input) or raw ones (real binaries) --, int32 indices, from 64 MiB on.  Measured, sample sort against digit passes in one
+// process: enwik-style text 64 MiB 7.29 / 7.86 ms, 96 MiB 9.87 / 11.11, 128 MiB 12.42 / 14.12, 256 MiB 24.9 / 29.3 (32 MiB, an
+// earlier build: 5.54 / 4.60 -- its fixed costs, a 2 Mi-key sample sorted and 262 144 workgroups of the finish kernel, want
+// a long text); first 128 MiB of libtorch_cpu.so 19.9 / 21.75 (17 M copies of heavy keys placed unsorted; while they
+// took the sorted overflow route: 22.7).  Up to the size whose mean bucket is half the finish kernel's capacity (256 MiB).
+// DQ_SPLIT = 0 | 1 | 2 overrides (1: from kSplitMinN on; 2: also past what the sample says about heavy keys -- for the tests).
 template <typename IdxT>
 bool split_round0_wanted(int64_t n, bool packed, int kb, bool coded)
 {
     if (sizeof(IdxT) != 4 || packed || kb != 8 || n < kSplitMinN || n > (int64_t)kSplitBuckets * (kFinCap / 2)) return false;
     if (const char *v = env("DQ_SPLIT")) return atoi(v) != 0;
     if (env("DQ_KEY_BYTES") || env("DQ_NO_BUCKET")) return false;     // (forced plain paths of the tests stay what they were)
-    return coded && n >= (64ll << 20);
+    (void)coded;
+    return n >= (64ll << 20);
 }
 
 template <typename IdxT>
@@ -1019,10 +1023,12 @@ struct SuffixSorter {
             HIP_TRY(hipMemcpyAsync(c.pinned, w.sp_ctl, sizeof(SplitCtl), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             const int64_t heavy = c.pinned[0];
+            // (heavy keys have buckets of their own and are placed unsorted; but their copies beyond a slot wait in the
+            // same arena of n / 4 entries as the oversize buckets: a text that is mostly heavy keys does not fit it)
             if (env("DQ_TRACE"))
                 fprintf(stderr, "[dq] sample-sort round 0: %.1f %% of the sampled keys are copies of keys too heavy for a bucket%s\n",
-                        100.0 * (double)heavy / (double)kSplitSample, heavy * 6 > kSplitSample ? " -- the digit passes instead" : "");
-            if (heavy * 6 > kSplitSample && !(env("DQ_SPLIT") && atoi(env("DQ_SPLIT")) >= 2)) return DQ_OK;      // (DQ_SPLIT=2: the tests go on regardless)
+                        100.0 * (double)heavy / (double)kSplitSample, heavy * 5 > kSplitSample ? " -- the digit passes instead" : "");
+            if (heavy * 5 > kSplitSample && !(env("DQ_SPLIT") && atoi(env("DQ_SPLIT")) >= 2)) return DQ_OK;      // (DQ_SPLIT=2: the tests go on regardless)
             HIP_TRY(hipMemsetAsync(w.sp_cursor_b, 0, (size_t)kSplitBuckets * 8, st));
             HIP_TRY(hipMemsetAsync(w.sp_ctl, 0, sizeof(SplitCtl), st));
             // pass A's output: a virtual array of ~1.13 n entries -- the first n_main in (K[1], Va), the rest spilled into the
@@ -1032,7 +1038,8 @@ struct SuffixSorter {
             IdxT *spill_v = d_sa + (n / 2 + 1);
             if (n / 8 + 1025 * (int64_t)kSplitTop + 1024 > n / 4) return DQ_OK;                 // (the spill -- sum of the regions' room minus n -- must fit n / 4 entries: keys below the middle of the array, suffixes above)
             LAUNCH(L, DQ_K_SPLIT_AUX, kSplitBuckets, (int64_t)kSplitBuckets * 16,
-                   hipLaunchKernelGGL(make_splitters_kernel, dim3(kSplitBuckets / kBlock), dim3(kBlock), 0, st, (const uint64_t *)Ks[scur], w.sp_top, w.sp_sub);
+                   hipLaunchKernelGGL(make_splitters_kernel, dim3(kSplitBuckets / kBlock), dim3(kBlock), 0, st, (const uint64_t *)Ks[scur], w.sp_top, w.sp_sub,
+                                      w.sp_low, w.sp_pure);
                    hipLaunchKernelGGL(split_estimate_kernel, dim3(1), dim3(kSplitTop), 0, st, (const uint64_t *)Ks[scur], (const uint64_t *)w.sp_top, n, w.sp_off,
                                       w.sp_cursor_a));
             if ((rc = phase("splitters, region estimates")) != DQ_OK) return rc;
@@ -1059,12 +1066,13 @@ struct SuffixSorter {
                    hipLaunchKernelGGL((split_pass_kernel<IdxT, false, false>), dim3(grid_b), dim3(kSplitThreads), 0, st, (const uint64_t *)K[1], (const IdxT *)w.Va,
                                       (const uint64_t *)spill_k, (const IdxT *)spill_v, n_main, n, (const uint64_t *)w.sp_sub, w.sp_cursor_b, (const int64_t *)w.sp_off,
                                       (const unsigned long long *)w.sp_cnt_a, (const uint32_t *)w.sp_tile_first, Ks[0], Vs[0], Ks[1], Vs[1],
-                                      cap, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl, ctab));
+                                      cap, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl, ctab, (const uint8_t *)w.sp_pure));
             if ((rc = phase("pass B")) != DQ_OK) return rc;
             LAUNCH(L, DQ_K_SPLIT_AUX, kSplitBuckets, (int64_t)kSplitBuckets * 36,
-                   hipLaunchKernelGGL(bucket_sum_kernel, dim3(kScanBlocks), dim3(kScanThreads), 0, st, (const unsigned long long *)w.sp_cursor_b, cap, w.sp_part);
+                   hipLaunchKernelGGL(bucket_sum_kernel, dim3(kScanBlocks), dim3(kScanThreads), 0, st, (const unsigned long long *)w.sp_cursor_b, cap,
+                                      (const uint8_t *)w.sp_pure, w.sp_part);
                    hipLaunchKernelGGL(bucket_scan_kernel, dim3(kScanBlocks), dim3(kScanThreads), 0, st, (const unsigned long long *)w.sp_cursor_b, cap,
-                                      (const ScanPart *)w.sp_part, w.sp_out_base, w.sp_ovf_src, w.sp_ovf_dst, w.sp_ctl));
+                                      (const uint8_t *)w.sp_pure, (const ScanPart *)w.sp_part, w.sp_out_base, w.sp_ovf_src, w.sp_ovf_dst, w.sp_ctl));
             if ((rc = phase("bucket scan")) != DQ_OK) return rc;
             // two geometries by bucket size (dq_split_round0.h: what a CU gets through is set by how many buckets it holds at
             // once): <= 1024 entries with 16 KB of LDS, eight workgroups per CU; the others with 31 KB, five.  The last launch
@@ -1074,18 +1082,25 @@ struct SuffixSorter {
                    if (two || cap <= kFinSmallCap)
                        hipLaunchKernelGGL((bucket_finish_kernel<IdxT, 256, 4>), dim3(kSplitBuckets), dim3(256), 0, st, (const uint64_t *)Ks[0], (const IdxT *)Vs[0],
                                           (const uint64_t *)Ks[1], (const IdxT *)Vs[1], cap, (int64_t)0, (int64_t)kFinSmallCap, !two,
-                                          (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl);
+                                          (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl, (const uint8_t *)w.sp_pure);
                    if (cap > kFinSmallCap)
                        hipLaunchKernelGGL((bucket_finish_kernel<IdxT, 256, 8>), dim3(kSplitBuckets), dim3(256), 0, st, (const uint64_t *)Ks[0], (const IdxT *)Vs[0],
                                           (const uint64_t *)Ks[1], (const IdxT *)Vs[1], cap, (int64_t)(two ? kFinSmallCap : 0), (int64_t)kFinCap, true,
-                                          (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl));
+                                          (const unsigned long long *)w.sp_cursor_b, (const int64_t *)w.sp_out_base, K[1], d_sa, ovf_k[0], ovf_v[0], ovf_cap, w.sp_ctl, (const uint8_t *)w.sp_pure));
             HIP_TRY(hipMemcpyAsync(c.pinned, w.sp_ctl, sizeof(SplitCtl), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            const int64_t ovf = c.pinned[0], ovf_buckets = c.pinned[1], abandon = c.pinned[3];
+            const int64_t ovf = c.pinned[0], ovf_buckets = c.pinned[1], npure = c.pinned[4];
+            const bool abandon = c.pinned[3] != 0 || ovf + npure > ovf_cap;            // (the two lists share one arena, from either end)
             if (env("DQ_TRACE"))
-                fprintf(stderr, "[dq] sample-sort round 0 (%s keys, %d buckets of <= %lld): %lld suffixes in %lld oversize buckets%s\n", coded ? "coded" : "raw",
-                        kSplitBuckets, (long long)cap, (long long)ovf, (long long)ovf_buckets, abandon ? " -- overflow list full, given up" : "");
-            if (abandon || ovf > ovf_cap) return DQ_OK;
+                fprintf(stderr, "[dq] sample-sort round 0 (%s keys, %d buckets of <= %lld): %lld suffixes in %lld oversize buckets, %lld copies of heavy keys placed unsorted%s\n",
+                        coded ? "coded" : "raw", kSplitBuckets, (long long)cap, (long long)ovf, (long long)ovf_buckets, (long long)npure,
+                        abandon ? " -- overflow lists full, given up" : "");
+            if (abandon) return DQ_OK;
+            if (npure > 0) {
+                LAUNCH(L, DQ_K_SPLIT_AUX, npure, npure * 2 * (8 + wb),
+                       hipLaunchKernelGGL(pure_place_kernel<IdxT>, dim3((unsigned)((npure + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, npure, ovf_cap,
+                                          (const uint64_t *)ovf_k[0], (const IdxT *)ovf_v[0], (const int64_t *)w.sp_out_base, (const uint64_t *)w.sp_low, K[1], d_sa));
+            }
             if (ovf > 0) {
                 int xcur = 0;
                 rc = onesweep_sort_pairs<IdxT>(L, w, ovf_k, ovf_v, ovf, 64, xcur);

@@ -67,6 +67,7 @@ struct SplitCtl {
     unsigned long long ovf_buckets;     // oversize buckets (bucket_scan_kernel)
     unsigned long long tiles_b;         // tiles of pass B (split_plan_kernel)
     unsigned long long abandon;         // the overflow list ran full: the caller takes the digit passes instead
+    unsigned long long pure_count;      // entries of the pure list (copies of heavy keys that did not fit their bucket's slot)
 };
 
 // the 64-bit round-0 key of ONE suffix p, as the digit passes build it (coded: dq_coded_keys.h; raw: 8 bytes big-endian)
@@ -153,17 +154,31 @@ static __global__ __launch_bounds__(kBlock) void sample_heavy_kernel(const uint6
     if (lane_id() == 0 && bal) atomicAdd(heavy, (unsigned long long)__popcll(bal));
 }
 
-// top[t], t < kSplitTop - 1 and sub[t][s], s < kSplitSub - 1 from the sorted sample (the last entry of every table is
-// never read by split_rank; it is written as all ones)
+// The bucket boundaries: U[b] = sorted sample key (b + 1) * kSplitOversample for b < kSplitBuckets - 1 -- top[t] is U[t * kSplitSub
+// + kSplitSub - 1], sub[t][s] is U[t * kSplitSub + s]; the last entry of every table is never read by split_rank (all ones).
+// HEAVY KEYS GET A BUCKET OF THEIR OWN: a key K that occurs more often than two mean buckets hold shows up as two or more
+// consecutive boundaries; the second becomes K + 1 (keys are integers, the sequence stays non-decreasing), so that bucket
+// [K, K + 1) holds exactly the copies of K.  Such a bucket is PURE (pure[b] = 1, low[b] = K): its entries need no order
+// (round 0 need not be stable), however many there are -- pass B sends what does not fit its slot to a list of (bucket,
+// arrival number, suffix) triples that is placed WITHOUT being sorted, and the finish kernel copies its slot as it is.
+// (Before: 7 % of the suffixes of the 256 MiB text went through the overflow list's eight digit passes; most were copies of
+// a few thousand heavy keys.)
 static __global__ __launch_bounds__(kBlock) void make_splitters_kernel(const uint64_t *__restrict__ sorted, uint64_t *__restrict__ top,
-                                                               uint64_t *__restrict__ sub)
+                                                               uint64_t *__restrict__ sub, uint64_t *__restrict__ low, uint8_t *__restrict__ pure)
 {
-    constexpr int64_t per_top = kSplitSample / kSplitTop, per_sub = kSplitSample / kSplitBuckets;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= kSplitBuckets) return;
-    const int t = (int)(i / kSplitSub), s = (int)(i % kSplitSub);
-    sub[i] = s == kSplitSub - 1 ? ~0ull : sorted[t * per_top + (s + 1) * per_sub];
-    if (s == 0) top[t] = t == kSplitTop - 1 ? ~0ull : sorted[(t + 1) * per_top];
+    constexpr int64_t per_sub = kSplitSample / kSplitBuckets;
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (b >= kSplitBuckets) return;
+    auto U = [&](int64_t i) -> uint64_t { return i < 0 ? 0ull : i >= kSplitBuckets - 1 ? ~0ull : sorted[(i + 1) * per_sub]; };
+    auto fixed = [&](int64_t i) -> uint64_t {               // U'[i]
+        const uint64_t u = U(i);
+        return (i >= 1 && i < kSplitBuckets - 1 && u == U(i - 1) && u != ~0ull) ? u + 1 : u;
+    };
+    const uint64_t up = fixed(b), lo = b == 0 ? 0ull : fixed(b - 1);
+    sub[b] = up;
+    if (b % kSplitSub == kSplitSub - 1) top[b / kSplitSub] = up;
+    low[b] = lo;
+    pure[b] = (b >= 1 && b < kSplitBuckets - 1 && lo != ~0ull && up == lo + 1) ? 1 : 0;
 }
 
 // Pass A's output regions WITHOUT counting the text first (an exact histogram of the top buckets is one more read of the text
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(kSplitThreads, 4) void split_pass_kernel(
     const unsigned long long *__restrict__ cnt_a /* B: entries per region */, const uint32_t *__restrict__ tile_first,
     uint64_t *__restrict__ kout0, IdxT *__restrict__ vout0, uint64_t *__restrict__ kout1, IdxT *__restrict__ vout1, int64_t cap,
     uint64_t *__restrict__ ovf_key, IdxT *__restrict__ ovf_idx, int64_t ovf_cap, SplitCtl *__restrict__ ctl,
-    const uint16_t *__restrict__ codetab)
+    const uint16_t *__restrict__ codetab, const uint8_t *__restrict__ pure = nullptr /* B: bucket holds copies of one key only */)
 {
     constexpr int kDigits = kFromText ? kSplitTop : kSplitSub;
     constexpr int kSplitItems = kFromText ? kSplitItemsA : kSplitItemsB;
@@ -256,7 +271,7 @@ __global__ __launch_bounds__(kSplitThreads, 4) void split_pass_kernel(
     __shared__ long long oofs[kFromText ? 1 : kDigits];     // B: place on the overflow list of a run's first entry that does not fit, minus its place in the tile
     __shared__ uint16_t dig_of[kSplitTile];                 // digit of every position of the sorted tile
     __shared__ uint32_t wtmp[kWavesB];
-    __shared__ unsigned long long s_obase;
+    __shared__ unsigned long long s_obase, s_pbase;
     __shared__ uint16_t ctab[kCoded ? 256 : 1];
     __shared__ int s_t;
 
@@ -411,22 +426,37 @@ __global__ __launch_bounds__(kSplitThreads, 4) void split_pass_kernel(
         }
     }
     if (!kFromText) {
-        uint32_t fit = 0, over_n = 0;
+        // (a PURE bucket's overflow -- copies of one heavy key -- goes to the pure list instead: triples (bucket, arrival
+        // number, suffix), growing downward from the end of the same arena, placed later without a sort; oofs of such a
+        // digit is negative: -(1 + place of its first overflowing entry, counted from the arena's end) - ...)
+        uint32_t fit = 0, over_n = 0, pure_n = 0;
+        bool is_pure = false;
         if (tid < kDigits) {
             const long long room = cap - (long long)abase;
             fit = room <= 0 ? 0u : room >= (long long)tot ? tot : (uint32_t)room;
             over_n = tot - fit;
+            is_pure = over_n != 0 && pure[(int64_t)t_b * kSplitSub + tid] != 0;
+            if (is_pure) { pure_n = over_n; over_n = 0; }
         }
-        const uint32_t oincl = wave_incl_sum(over_n);
+        // two counts in one scan: the pure ones in the upper half of the word (a tile holds < 2^16 entries)
+        const uint32_t both = over_n | (pure_n << 16);
+        const uint32_t oincl = wave_incl_sum(both);
         if (lane == kWave - 1) wtmp[w] = oincl;
         __syncthreads();
         uint32_t o = 0, total = 0;
 #pragma unroll
         for (int i = 0; i < kWavesB; ++i) { if (i < w) o += wtmp[i]; total += wtmp[i]; }
         if (total) {                                         // (the same for every thread)
-            if (tid == 0) s_obase = atomicAdd(&ctl->ovf_count, (unsigned long long)total);
+            if (tid == 0) {
+                s_obase = (total & 0xffffu) ? atomicAdd(&ctl->ovf_count, (unsigned long long)(total & 0xffffu)) : 0ull;
+                s_pbase = (total >> 16) ? atomicAdd(&ctl->pure_count, (unsigned long long)(total >> 16)) : 0ull;
+            }
             __syncthreads();
-            if (tid < kDigits) oofs[tid] = (long long)s_obase + (long long)(o + oincl - over_n) - (long long)fit - (long long)excl;
+            if (tid < kDigits) {
+                const uint32_t ex = o + oincl - both;       // exclusive counts of the digits in front: low half normal, high half pure
+                if (is_pure) oofs[tid] = -(1ll << 62) + (long long)s_pbase + (long long)(ex >> 16) - (long long)fit - (long long)excl;
+                else oofs[tid] = (long long)s_obase + (long long)(ex & 0xffffu) - (long long)fit - (long long)excl;
+            }
         }
     }
     __syncthreads();
@@ -450,7 +480,13 @@ __global__ __launch_bounds__(kSplitThreads, 4) void split_pass_kernel(
                 else { kout1[(b - kSplitBuckets / 2) * cap + q] = skey[k]; vout1[(b - kSplitBuckets / 2) * cap + q] = sval[k]; }
             } else {
                 const long long o = oofs[d] + p;
-                if (o < ovf_cap) { ovf_key[o] = skey[k]; ovf_idx[o] = sval[k]; }
+                if (o < 0) {                                 // a pure bucket's: (bucket, arrival number), downward from the arena's end
+                    const long long j = o + (1ll << 62);
+                    if (j < ovf_cap) {
+                        ovf_key[ovf_cap - 1 - j] = ((uint64_t)((int64_t)t_b * kSplitSub + d) << 32) | (uint64_t)q;
+                        ovf_idx[ovf_cap - 1 - j] = sval[k];
+                    } else ctl->abandon = 1;
+                } else if (o < ovf_cap) { ovf_key[o] = skey[k]; ovf_idx[o] = sval[k]; }
                 else ctl->abandon = 1;
             }
         }
@@ -466,12 +502,12 @@ constexpr int kScanBlocks = kSplitBuckets / kScanThreads;
 struct ScanPart { long long sum, osum, ocnt; };
 
 static __global__ __launch_bounds__(kScanThreads) void bucket_sum_kernel(const unsigned long long *__restrict__ cursor, int64_t cap,
-                                                                   ScanPart *__restrict__ part)
+                                                                   const uint8_t *__restrict__ pure, ScanPart *__restrict__ part)
 {
     __shared__ long long ws[3][kScanThreads / kWave];
     const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
     const long long c = (long long)cursor[(int64_t)blockIdx.x * kScanThreads + tid];
-    const bool over = c > cap;
+    const bool over = c > cap && !pure[(int64_t)blockIdx.x * kScanThreads + tid];      // (a pure bucket's overflow is not on the sorted list)
     const long long a = wave_sum(c), o = wave_sum(over ? c : 0ll), k = wave_sum(over ? 1ll : 0ll);
     if (lane == 0) { ws[0][w] = a; ws[1][w] = o; ws[2][w] = k; }
     __syncthreads();
@@ -483,7 +519,7 @@ static __global__ __launch_bounds__(kScanThreads) void bucket_sum_kernel(const u
 }
 
 static __global__ __launch_bounds__(kScanThreads) void bucket_scan_kernel(const unsigned long long *__restrict__ cursor, int64_t cap,
-                                                                    const ScanPart *__restrict__ part, int64_t *__restrict__ out_base,
+                                                                    const uint8_t *__restrict__ pure, const ScanPart *__restrict__ part, int64_t *__restrict__ out_base,
                                                                     int64_t *__restrict__ ovf_src, int64_t *__restrict__ ovf_dst,
                                                                     SplitCtl *__restrict__ ctl)
 {
@@ -498,7 +534,7 @@ static __global__ __launch_bounds__(kScanThreads) void bucket_scan_kernel(const 
     }
     const int64_t b = (int64_t)blockIdx.x * kScanThreads + tid;
     const long long c = (long long)cursor[b];
-    const bool over = c > cap;
+    const bool over = c > cap && !pure[b];
     const long long ia = wave_incl_sum(c), io = wave_incl_sum(over ? c : 0ll), ik = wave_incl_sum(over ? 1ll : 0ll);
     if (lane == kWave - 1) { ws[0][w] = ia; ws[1][w] = io; ws[2][w] = ik; }
     __syncthreads();
@@ -531,7 +567,7 @@ __global__ __launch_bounds__(kThreads, kThreads * kItems <= 1024 ? 8 : kThreads 
     const uint64_t *__restrict__ kslot0, const IdxT *__restrict__ vslot0, const uint64_t *__restrict__ kslot1, const IdxT *__restrict__ vslot1,
     int64_t cap, int64_t lo, int64_t hi, bool oversize, const unsigned long long *__restrict__ cursor, const int64_t *__restrict__ out_base,
     uint64_t *__restrict__ kout, IdxT *__restrict__ sa, uint64_t *__restrict__ ovf_key, IdxT *__restrict__ ovf_idx, int64_t ovf_cap,
-    SplitCtl *__restrict__ ctl)
+    SplitCtl *__restrict__ ctl, const uint8_t *__restrict__ pure)
 {
     constexpr int kCap = kThreads * kItems;
     // local splitters.  Per entry of a 1024-entry bucket: log2(kSample) + 2 random LDS reads for its search, kSample^2 / 1024
@@ -553,7 +589,15 @@ __global__ __launch_bounds__(kThreads, kThreads * kItems <= 1024 ? 8 : kThreads 
     // (the size first: a bucket of the other launch's class costs one load, not its slot)
     const int64_t c64 = (int64_t)cursor[b];
     const int64_t ob = out_base[b];
-    if (c64 <= cap && (c64 <= lo || c64 > hi)) return;       // (empty, or the other launch's)
+    if (pure[b]) {
+        // copies of one key: nothing to sort -- the slot's entries (what did not fit is on the pure list) go out as they
+        // are, by the launch that also takes the oversize buckets
+        if (!oversize) return;
+        const int64_t cnt = c64 < cap ? c64 : cap;
+        for (int64_t i = tid; i < cnt; i += kThreads) { kout[ob + i] = ks[i]; sa[ob + i] = vs[i]; }
+        return;
+    }
+    if (c64 <= cap ? (c64 <= lo || c64 > hi) : !oversize) return;       // (empty, or the other launch's)
     uint64_t key[kItems];
     uint32_t idx[kItems];
     const int last = (int)(cap < kCap ? cap : kCap) - 1;
@@ -565,7 +609,6 @@ __global__ __launch_bounds__(kThreads, kThreads * kItems <= 1024 ? 8 : kThreads 
         idx[k] = (uint32_t)vs[ec];
     }
     if (c64 > cap) {
-        if (!oversize) return;
         // oversize: the entries that did fit the slot join the rest of the bucket on the overflow list
         if (tid == 0) s_o0 = atomicAdd(&ctl->ovf_count, (unsigned long long)cap);
         __syncthreads();
@@ -691,6 +734,21 @@ __global__ __launch_bounds__(kBlock) void overflow_place_kernel(int64_t count, i
     const int64_t dst = ovf_dst[lo] + (j - ovf_src[lo]);
     kout[dst] = okey[j];
     sa[dst] = oidx[j];
+}
+
+// entry j of the pure list (stored downward from the end of the overflow arena): copy number q of bucket b's one key ->
+// position out_base[b] + q, key low[b].  No sort: one thread per entry.
+template <typename IdxT>
+__global__ __launch_bounds__(kBlock) void pure_place_kernel(int64_t count, int64_t ovf_cap, const uint64_t *__restrict__ pkey,
+                                                         const IdxT *__restrict__ pidx, const int64_t *__restrict__ out_base,
+                                                         const uint64_t *__restrict__ low, uint64_t *__restrict__ kout, IdxT *__restrict__ sa)
+{
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= count) return;
+    const uint64_t w = pkey[ovf_cap - 1 - j];
+    const int64_t b = (int64_t)(w >> 32), q = (int64_t)(w & 0xffffffffull);
+    kout[out_base[b] + q] = low[b];
+    sa[out_base[b] + q] = pidx[ovf_cap - 1 - j];
 }
 
 }  // namespace dq

@@ -658,7 +658,7 @@ def test_split_round0(ldss, oracle_mod, backend_lib, monkeypatch, env):
         "16 symbols": (rnd(5_500_000, 8) & 15, True),
         "2 symbols (heavy keys)": (rnd(5_300_000, 9) & 1, False),
         "zeros (one key)": (np.zeros((5 << 20) + 1, np.uint8), False),
-        "repeats + zero tail": (np.concatenate([rep, rnd(1_500_000, 6), rep[:400_000], rep, rnd(900_000, 7), np.zeros(13, np.uint8)]), True),
+        "repeats + zero tail": (np.concatenate([rep, rnd(1_500_000, 6), rep[:400_000], rep, rnd(1_300_000, 7), np.zeros(13, np.uint8)]), True),
         "below the size the path takes": (oracle_mod.gen_enwik_like((5 << 20) - 1, 23, 16384), False),
     }
 
