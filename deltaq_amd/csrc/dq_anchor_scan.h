@@ -27,6 +27,16 @@
 // it needs and on nothing else (no grid-wide barrier, no arrival flags; a lagging barrier of one window keeps the two
 // answer buffers apart).  Every exchanged word is an agent-scope atomic (the L2s of the 8 XCDs are not coherent with
 // each other); every spin is bounded and ends in an error flag, on which the host falls back to its own loop.
+//
+// Several grids on one file (dq_diff.hip, "chains").  What the loop does from the end of an iteration on is a function of
+// two numbers only -- where the iteration ended and the shift in force (an emitted triple sets the shift to hit_pos -
+// cursor, and Search(cursor) is a function of cursor) -- so a second grid started speculatively in the middle of the file,
+// under a shift no real alignment can have, walks the same iterations as the grid that comes from the front as soon as
+// the two end ONE iteration at the same place under the same shift; between similar files that is the first or second
+// iteration.  Every iteration end is therefore written to the list (emitted ones as before, the others with bit 63 set),
+// a grid can be told to leave after `extra` iteration ends behind `stop_at` (the start of the next grid) or, in the
+// middle of an iteration, after `lane_budget` one-lane-per-position windows (unrelated data: speculation buys nothing
+// there), and a grid can resume in the middle of an iteration from the state another launch left.
 #pragma once
 #include "dq_match_search.h"
 
@@ -40,7 +50,11 @@ constexpr int kAsGroups = 128;                            // workgroups of the p
 constexpr int kAsMaxGroups = 128;
 constexpr int kAsMaxLaneWin = kAsMaxGroups * kAsWaves * kWave;   // positions of the largest one-lane-per-position window
 constexpr int64_t kAsCap = 64;                            // comparison cap of the speculative positions
-constexpr int kAsWaveWins = 3;                            // wave windows walked over before the lane windows take over
+constexpr int kAsWaveWins = 3;                            // wave windows walked over before the lane windows take over: those of
+constexpr int kAsWaveWinsMax = 16;                        // a whole grid of kAsGroups workgroups (1536 positions); a narrower grid
+                                                          // walks as many positions in more of them, 16 at most (a window costs
+                                                          // ~15 us whatever its width, a lane window ~0.4 ms: 8 grids of 32 workgroups
+                                                          // on the 16 MiB pair with 2000 edits of up to 400 bytes 46.9 ms before, 4 x 64 20.0)
 // An answer is two words, each with the tag of its window in the top two bits: tag << 62 | len << 31 | pos, and
 // tag << 62 | cnt(j, j + len).  The windows of a kind (one position per wave / per lane) take the two answer buffers of
 // their kind in turn; the k-th use of a buffer has tag k % 3, the host fills the buffers with ones (tag 3) before a
@@ -65,6 +79,41 @@ struct AnchorCtl {
                                                           // workgroup (k - 1) sleeps before it publishes a window's answers
     unsigned long long t_search, t_wait, t_eval, t_stop;  // workgroup 0's time searching / waiting for answers / evaluating /
                                                           // at stop points, in 100 MHz ticks (DQ_TRACE prints them)
+    // ---- several grids on one file ----
+    long long stop_at, extra;                             // in: leave after `extra` iteration ends at cursor >= stop_at (extra <= 0: never)
+    long long lane_budget;                                // in: leave, in the middle of an iteration, before one-lane-per-position window
+                                                          // number lane_budget + 1 of this launch (0: never)
+    long long mid;                                        // in: 1 = resume in the middle of an iteration from the fields below;
+                                                          // out: 1 = left in the middle of one (they are filled in)
+    long long base, i, M, C, S, last_pos, last_len;
+    int lane_mode, streak, passed, any_search;
+    unsigned long long t_begin, t_end;                    // out: the device's 100 MHz clock when workgroup 0 began and ended (DQ_TRACE)
+};
+constexpr unsigned long long kAsSilent = 1ull << 63;      // list entry of an iteration end that emitted nothing: kAsSilent | cursor << 32
+static_assert(sizeof(AnchorCtl) <= 248, "a control block and the word behind it fill 256 bytes");
+
+// One launch carries up to kScanMaxChains grids ("chains"): workgroup b belongs to chain b / groups and works on that
+// chain's slot of the buffers below.  (One launch on one stream, not a launch per chain on streams of their own: streams
+// share the device's few hardware queues, and a chain's completion was reported one whole kernel late behind another
+// chain's -- 16 MiB pair with 2000 edits 26 ms, 21 ms with GPU_MAX_HW_QUEUES=8.  For the same reason a chain's result does
+// not wait for the stream either: the chain writes it to pinned memory itself, the launch's number behind it.)
+constexpr int kScanMaxChains = 8;
+constexpr int64_t kAnchorRecs = 1 << 16;                  // list entries per chain and launch
+constexpr size_t kAnchorAnswers = ((size_t)kAsMaxLaneWin + (size_t)kAsMaxGroups * kAsWaves) * 32;    // two buffers of either kind, 16 B a slot
+// device scratch: control blocks (in: the state to start from; the error word), completion words, answer buffers
+constexpr size_t kAsFinishedAt = (size_t)kScanMaxChains * 256;
+constexpr size_t kAsAnswersAt = kAsFinishedAt + (size_t)kScanMaxChains * 2048;
+constexpr size_t kAnchorScratch = kAsAnswersAt + (size_t)kScanMaxChains * kAnchorAnswers;
+static_assert(kAsMaxGroups * 8 <= 2048, "completion words");
+// pinned host memory: upload blocks, then per slot the list, the Search counts beside it, the result block and, in its
+// last word, the number of the launch that wrote it
+constexpr size_t kAsSlotAt = (size_t)kScanMaxChains * 256;
+constexpr size_t kAsSlotBytes = (size_t)kAnchorRecs * 16 + 256;
+constexpr size_t kAnchorPinned = kAsSlotAt + (size_t)kScanMaxChains * kAsSlotBytes;
+struct AnchorLaunch {
+    int chains, groups;                                   // grids in this launch, workgroups of each
+    int slot[kScanMaxChains];                             // buffers of chain k
+    unsigned long long seq;                               // this launch's number (never 0)
 };
 
 template <typename T>
@@ -115,15 +164,27 @@ __device__ __forceinline__ int64_t as_wave_count_equal(const uint8_t *po, int64_
 template <typename IdxT>
 __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa, const uint8_t *__restrict__ nw, int64_t m,
-    const IdxT *__restrict__ ptab, int pk,
-    unsigned long long *__restrict__ ans /* [2][lane window][2] then [2][wave window][2]: tagged answers, all ones before the launch */,
-    unsigned long long *__restrict__ rec /* [rec_cap] in PINNED HOST memory: cursor << 32 | hit_pos, one store each */,
-    int64_t rec_cap, AnchorCtl *__restrict__ ctl,
-    unsigned long long *__restrict__ finished /* [gridDim.x], zeroed: windows workgroup w has finished evaluating */)
+    const IdxT *__restrict__ ptab, int pk, char *__restrict__ scratch, char *__restrict__ pinned, const AnchorLaunch ln)
 {
+    const int n_groups = ln.groups;                       // workgroups of this chain
+    const int chain = (int)blockIdx.x / n_groups, bid = (int)blockIdx.x - chain * n_groups;
+    const int slot = ln.slot[chain];
+    AnchorCtl *__restrict__ ctl = reinterpret_cast<AnchorCtl *>(scratch + (size_t)slot * 256);      // read-only here but for the error word
+    // [n_groups], zeroed: windows workgroup w has finished evaluating
+    unsigned long long *__restrict__ finished = reinterpret_cast<unsigned long long *>(scratch + kAsFinishedAt + (size_t)slot * 2048);
+    // [2][lane window][2] then [2][wave window][2]: tagged answers, all ones before the launch
+    unsigned long long *__restrict__ ans = reinterpret_cast<unsigned long long *>(scratch + kAsAnswersAt + (size_t)slot * kAnchorAnswers);
+    // PINNED HOST memory: the list (cursor << 32 | hit_pos, one store each), Search calls of the reference's loop up to
+    // each entry, and what this launch leaves (the host does not wait for the stream to learn it)
+    unsigned long long *__restrict__ rec = reinterpret_cast<unsigned long long *>(pinned + kAsSlotAt + (size_t)slot * kAsSlotBytes);
+    unsigned long long *__restrict__ cum = rec + kAnchorRecs;
+    AnchorCtl *__restrict__ out = reinterpret_cast<AnchorCtl *>(rec + 2 * kAnchorRecs);
+    constexpr int64_t rec_cap = kAnchorRecs;
     __shared__ uint16_t agp[kAsMaxLaneWin + 2];           // agp[x] = cnt(i, i + x), x = 0 .. c
-    const int64_t kAsWaveWin = (int64_t)gridDim.x * kAsWaves;      // positions of a one-wave-per-position window
+    const int64_t kAsWaveWin = (int64_t)n_groups * kAsWaves;       // positions of a one-wave-per-position window
     const int64_t kAsLaneWin = kAsWaveWin * kWave;                 // ... of a one-lane-per-position window
+    const int wave_wins = (int)((kAsWaveWins * kAsGroups * kAsWaves + kAsWaveWin - 1) / kAsWaveWin) < kAsWaveWinsMax
+                              ? (int)((kAsWaveWins * kAsGroups * kAsWaves + kAsWaveWin - 1) / kAsWaveWin) : kAsWaveWinsMax;
     __shared__ int64_t w_e[kAsWaves], w_c[kAsWaves];
     __shared__ uint32_t w_u32[kAsWaves];
     __shared__ int32_t w_brk[kAsWaves], w_stp[kAsWaves];
@@ -133,12 +194,17 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     const int tid = threadIdx.x;
     const int lane = lane_id();
     const int wv = tid >> 6;
-    const int gwave = blockIdx.x * kAsWaves + wv;         // this wave's place in the grid
+    const int gwave = bid * kAsWaves + wv;                // this wave's place in its chain's grid
 
     // ---- uniform state (every thread of every workgroup carries the same values) ----
     int64_t cursor = ctl->cursor, hit_len = ctl->hit_len, hit_pos = ctl->hit_pos, shift = ctl->shift;
     int64_t nrec = 0;
-    unsigned long long n_search = 0, n_win = 0, n_stop = 0;
+    unsigned long long n_search = ctl->searches, n_win = 0, n_stop = 0;     // (the Search count runs on from launch to launch)
+    const int64_t stop_at = ctl->stop_at, extra = ctl->extra, lane_budget = ctl->lane_budget;
+    int64_t past = 0;                                     // iteration ends at cursor >= stop_at so far
+    bool resume = ctl->mid != 0, left_mid = false;
+    int64_t mid_v[7] = {0, 0, 0, 0, 0, 0, 0};
+    int mid_f[4] = {0, 0, 0, 0};
     unsigned long long n_wave_win = 0, n_lane_win = 0;  // windows of either kind so far
     bool failed = false;
     unsigned long long t_search = 0, t_wait = 0, t_eval = 0, t_stop = 0, t0 = __builtin_readcyclecounter();
@@ -149,7 +215,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     // (DQ_FAULT=spin), under which the launch reports its error and the host loop takes the file
     const uint32_t spin_bound = 1u << (((ctl->pad >> 16) & 31u) ? ((ctl->pad >> 16) & 31u) : 24u);
     // (DQ_SCAN_SLOW_GROUP=k: workgroup k - 1 is the straggler of every window -- the adversarial schedule of the tests)
-    const bool slow_me = ((ctl->pad >> 24) & 255u) == (unsigned)blockIdx.x + 1u;
+    const bool slow_me = ((ctl->pad >> 24) & 255u) == (unsigned)bid + 1u;
     auto lap = [&](unsigned long long &acc) {
         if (!timed) return;
         const unsigned long long t1 = wall_clock64();
@@ -157,6 +223,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
         t0 = t1;
     };
     t0 = wall_clock64();
+    const unsigned long long t_begin = t0;
 
     auto agree = [&](int64_t k) -> bool { return k + shift < n && old[k + shift] == nw[k]; };
     // cnt(j, j + l) for the match (p, l) found at position j, by one wave: a match under the previous alignment agrees
@@ -197,11 +264,11 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     // (every workgroup on its own word -- a sum over the workgroups says nothing: half of them two windows ahead
     // would make it look as if everybody had finished one)
     auto lagging_load = [&](unsigned long long win_no) -> unsigned long long {       // issued before the search ...
-        if (win_no < 2 || tid >= (int)gridDim.x) return ~0ull;
+        if (win_no < 2 || tid >= n_groups) return ~0ull;
         return __hip_atomic_load(&finished[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto await_lagging = [&](unsigned long long win_no, unsigned long long seen) {   // ... checked before publishing window win_no
-        if (win_no >= 2 && tid < (int)gridDim.x) {
+        if (win_no >= 2 && tid < n_groups) {
             uint32_t spins = 0;
             while (seen < win_no - 1) {
                 __builtin_amdgcn_s_sleep(1);
@@ -215,7 +282,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     unsigned long long n_finished = 0;
     auto window_done = [&]() {
         ++n_finished;
-        if (tid == 0) __hip_atomic_store(&finished[blockIdx.x], n_finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(&finished[bid], n_finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // (two answer buffers, taken in turn by the windows: a workgroup that is through with window k publishes window
     // k + 1 while a slower one still reads window k; nobody reaches window k + 2 before everybody has left window k)
@@ -253,8 +320,9 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
 
     while (cursor < m && !failed) {
         if (nrec >= rec_cap) break;                       // the host empties the list and launches again from this state
-        cursor += hit_len;
-        const int64_t base = cursor;
+        if (extra > 0 && past >= extra) break;            // (far enough behind the start of the next grid)
+        if (!resume) cursor += hit_len;
+        int64_t base = cursor;
         int64_t i = base, M = base, C = 0, S = 0;         // C = cnt(base, M), S = cnt(base, i), M >= i
         bool found = false, lane_mode = false;
         int streak = 0;                                   // stop points in a row that did not break
@@ -262,7 +330,18 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
         int64_t carried_at = 0;
         bool any_search = false;
         int64_t last_pos = 0, last_len = 0;               // answer at the last position walked over
+        if (resume) {                                     // the middle of an iteration, as another launch left it
+            base = ctl->base; i = ctl->i; M = ctl->M; C = ctl->C; S = ctl->S; last_pos = ctl->last_pos; last_len = ctl->last_len;
+            lane_mode = ctl->lane_mode != 0; streak = ctl->streak; passed = ctl->passed; any_search = ctl->any_search != 0;
+            resume = false;
+        }
         while (i < m && !found && !failed) {
+            if (lane_budget > 0 && (int64_t)n_lane_win >= lane_budget) {       // a long differing stretch: leave between two windows
+                left_mid = true;
+                mid_v[0] = base; mid_v[1] = i; mid_v[2] = M; mid_v[3] = C; mid_v[4] = S; mid_v[5] = last_pos; mid_v[6] = last_len;
+                mid_f[0] = lane_mode ? 1 : 0; mid_f[1] = streak; mid_f[2] = passed; mid_f[3] = any_search ? 1 : 0;
+                break;
+            }
             const int64_t win = lane_mode ? kAsLaneWin : kAsWaveWin;
             const int64_t c = (m - i) < win ? (m - i) : win;
             const unsigned long long win_no = n_win;        // windows are numbered from 0, the same everywhere
@@ -469,7 +548,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 i += c;
                 // a long differing stretch: after kAsWaveWins windows of one position per wave, one per lane (an edit of a
                 // few hundred bytes is walked over by the cheaper wave windows; unrelated data by 8192 positions a step)
-                if (++passed >= kAsWaveWins) lane_mode = true;
+                if (++passed >= wave_wins) lane_mode = true;
             } else {
                 // ---- 3. the stop point, on its own: searched again without the cap (by the first wave of every workgroup) ----
                 window_done();                             // (nothing below reads the window's answers)
@@ -508,7 +587,7 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
                 M = i;
             }
         }
-        if (failed) break;
+        if (failed || left_mid) break;
         bool emit = true;
         if (!found) {
             n_search += (unsigned long long)(m - base > 0 ? m - base : 0);
@@ -517,22 +596,39 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
         } else if (hit_len == carried_at) {
             emit = false;                                  // the old alignment explains it: keep scanning behind it
         }
-        if (emit) {
-            // (the host works on the pairs while the scan goes on: it polls the slots in order; position and match
-            // travel in ONE 64-bit store, which is also the slot's "filled" mark -- no pair of values is ever ~0)
-            if (blockIdx.x == 0 && tid == 0)
-                __hip_atomic_store(&rec[nrec], ((unsigned long long)cursor << 32) | (unsigned long long)(uint32_t)hit_pos,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            ++nrec;
-            shift = hit_pos - cursor;
+        // (the host works on the pairs while the scan goes on: it polls the slots in order; position and match
+        // travel in ONE 64-bit store, which is also the slot's "filled" mark -- no entry is ever ~0; the count of
+        // Search calls beside it is read only once the launch has left the stream)
+        if (bid == 0 && tid == 0) {
+            __hip_atomic_store(&cum[nrec], n_search, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&rec[nrec], emit ? ((unsigned long long)cursor << 32) | (unsigned long long)(uint32_t)hit_pos
+                                                : kAsSilent | ((unsigned long long)cursor << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        ++nrec;
+        if (cursor >= stop_at) ++past;
+        if (emit) shift = hit_pos - cursor;
     }
-    if (blockIdx.x == 0 && tid == 0) {
-        ctl->nrec = (unsigned long long)nrec;
-        ctl->cursor = cursor; ctl->hit_len = hit_len; ctl->hit_pos = hit_pos; ctl->shift = shift;
-        ctl->done = (!failed && cursor >= m) ? 1 : 0;
-        ctl->searches = n_search; ctl->windows = n_win; ctl->stops = n_stop;
-        ctl->t_search = t_search; ctl->t_wait = t_wait; ctl->t_eval = t_eval; ctl->t_stop = t_stop;
+    if (bid == 0 && tid == 0) {
+        // (to the pinned result block, not to ctl: a workgroup that starts late still reads what the launch began with)
+        AnchorCtl r = *ctl;
+        r.nrec = (unsigned long long)nrec;
+        r.cursor = cursor; r.hit_len = hit_len; r.hit_pos = hit_pos; r.shift = shift;
+        r.done = (!failed && !left_mid && cursor >= m) ? 1 : 0;
+        r.searches = n_search; r.windows = n_win; r.stops = n_stop;
+        r.error = (failed || others_gave_up()) ? 1u : 0u;
+        r.t_search = t_search; r.t_wait = t_wait; r.t_eval = t_eval; r.t_stop = t_stop;
+        r.t_begin = t_begin; r.t_end = wall_clock64();
+        r.mid = left_mid ? 1 : 0;
+        r.base = mid_v[0]; r.i = mid_v[1]; r.M = mid_v[2]; r.C = mid_v[3]; r.S = mid_v[4];
+        r.last_pos = mid_v[5]; r.last_len = mid_v[6];
+        r.lane_mode = mid_f[0]; r.streak = mid_f[1]; r.passed = mid_f[2]; r.any_search = mid_f[3];
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&r);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(out);
+        static_assert(sizeof(AnchorCtl) % 8 == 0, "copied as words");
+        for (size_t q = 0; q < sizeof(AnchorCtl) / 8; ++q) __hip_atomic_store(&dst[q], src[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (the launch's number last, after everything this thread has written to the host: list, counts, result)
+        __hip_atomic_store(&dst[31], ln.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -321,7 +321,8 @@ struct DiffIndex {
     int pk = 0;
 };
 
-constexpr size_t kDiffPinnedBytes = 2 * ((size_t)(65536 + 2) * 4 + 256) + (size_t)(2048 + 2 * (1024 + 1)) * 8 + 256;
+constexpr size_t kDiffWindowBytes = 1 << 20;               // SearchWindows' part of the pinned area (asserted where it is laid out)
+constexpr size_t kDiffPinnedBytes = kDiffWindowBytes + kAnchorPinned;      // + lists, counts and control blocks of the device scan's chains
 
 size_t diff_tab_bytes(int64_t n, int *pk_out)
 {
@@ -573,42 +574,67 @@ public:
     double busy_ms[2] = {0, 0};                           // time inside feed() (DQ_TRACE prints it)
 };
 
-// Step 1 of the scan loop on the device (dq_anchor_scan.h): one persistent launch walks the whole new file and leaves the
-// (cursor, hit_pos) pair of every control triple; steps 2 and 3 run here on those pairs.  The list has room for
-// kAnchorRecs pairs per launch -- a new file that needs more (text with a short match every few bytes) continues from
+// Step 1 of the scan loop on the device (dq_anchor_scan.h): persistent launches walk the new file and leave the
+// (cursor, hit_pos) pair of every control triple; steps 2 and 3 run here on those pairs.  A list has room for
+// kAnchorRecs entries per launch -- a new file that needs more (text with a short match every few bytes) continues from
 // the state the kernel left.
-constexpr int64_t kAnchorRecs = 1 << 16;
-constexpr size_t kAnchorAnswers = ((size_t)kAsMaxLaneWin + (size_t)kAsMaxGroups * kAsWaves) * 32;    // two buffers of either kind, 16 B a slot
-constexpr size_t kAnchorScratch = 256 + 2048 + kAnchorAnswers;
+//
+// Several grids per file ("chains").  A window costs ~15 us whatever its width -- the latency of a search and an exchange
+// -- and the chain of windows is the whole cost of a diff between similar files, so up to kScanChains grids walk the file
+// at once (one launch, each grid on its own lists and answer buffers): the first from the front (the chain this thread
+// FOLLOWS: its entries go to the emitter), the others from equally spaced places under a shift no alignment can have.
+// Where the followed chain ends an iteration at the place and under the shift where another chain ended one, that chain's
+// entries ARE what the followed one would write from there on (dq_anchor_scan.h), and this thread follows it instead
+// ("joins").  Every grid leaves by itself: kScanExtra iteration ends behind the start of the next chain, or -- in the
+// middle of an iteration -- after kScanLaneBudget one-lane-per-position windows (a long differing stretch: the followed
+// chain then takes it with the whole grid, alone, until that iteration ends).  Nothing is decided by a guess: a chain that
+// is never joined is dropped, and the followed chain is launched again from where it stood.
 constexpr unsigned long long kAnchorPending = ~0ull;
+constexpr int kScanChains = 8;                            // grids on one new file (DQ_SCAN_CHAINS) and workgroups of each when there are
+constexpr int kScanChainGroups = 32;                      // several (DQ_SCAN_GROUPS).  16 MiB pairs, Diff.Create in ms -- random bytes with
+                                                          // 2000 edits / text with 2000 / random with 20 000 small edits / 4 MiB of
+                                                          // unrelated bytes: one grid of 128 workgroups 38.8 / 67.1 / 261.5 / 83.2,
+                                                          // 4 x 64: 19.8 / 29.9 / 76.7 / 87.1, 6 x 40: 17.9 / 25.6 / 55.2 / 82.9,
+                                                          // 8 x 32: 17.1 / 23.1 / 46.1 / 85.7 (profiles/r06/r06s_chains_variants.log)
+constexpr int64_t kScanMinSegment = 1ll << 20;            // bytes of new per grid below which no further one is started (DQ_SCAN_MIN_SEG)
+constexpr int64_t kScanExtra = 8;                         // iteration ends a grid walks on into the next one's part
+constexpr int64_t kScanLaneBudget = 2;                    // one-lane-per-position windows after which a grid that is not alone leaves
+static_assert(kDiffPinnedBytes >= kDiffWindowBytes + kAnchorPinned, "pinned area of the chains");
 
-// ring: kAnchorRecs words of pinned host memory the kernel writes the pairs into (one 64-bit store each) and this
-// thread reads while the kernel runs -- steps 2 and 3 of a triple overlap the device's search for the next anchors
-int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch, unsigned long long *ring, const uint8_t *nw,
+struct ScanChain {
+    AnchorCtl *d_ctl = nullptr, *h_up = nullptr;
+    const AnchorCtl *h_out = nullptr;                     // pinned: what the chain's launch left ...
+    const unsigned long long *h_landed = nullptr;         // ... and, behind it, that launch's number
+    unsigned long long *ring = nullptr, *cum = nullptr;
+    int64_t *dirty = nullptr;                             // list slots that may not read "pending" (kept in the device context)
+    AnchorCtl st{};                                       // what the next launch starts from / what the last one left
+    int64_t start = 0;                                    // first position of the chain
+    bool alive = false;                                   // followed, or its entries may still be joined
+    bool running = false;                                 // its part of a launch has not said it is over
+    unsigned long long seq = 0;                           // that launch's number
+    int groups = 0;
+    int64_t taken = 0;                                    // entries of the current launch read (followed or stepped over)
+    int64_t nent = 0;                                     // entries of the launch once it is over
+    int64_t shift = 0;                                    // shift in force behind the entries read so far
+};
+
+int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch, char *pinned_chains, const uint8_t *nw,
                    int64_t m, bsdiff::RawStreams &raw, bool *retry_on_host, PatchFramer *framer)
 {
     *retry_on_host = false;
-    AnchorCtl *d_ctl = reinterpret_cast<AnchorCtl *>(scratch);
-    unsigned long long *d_finished = reinterpret_cast<unsigned long long *>(scratch + 256);      // [kAsMaxGroups]
-    static_assert(kAsMaxGroups * 8 <= 2048, "completion words");
-    unsigned long long *d_ans = reinterpret_cast<unsigned long long *>(scratch + 256 + 2048);
-    static_assert(sizeof(AnchorCtl) <= 256, "control block");
     bsdiff::TripleEmitter em(ix.old, ix.n, nw, m, raw);
     // (short files: two more threads cost more than the framing they would hide)
     const int64_t follow_min = env("DQ_FRAME_FOLLOW_MIN") ? atoll(env("DQ_FRAME_FOLLOW_MIN")) : (int64_t)256 << 10;
     if (framer && m >= follow_min && framer->start(raw, m)) em.progress = framer->final_len;
-    AnchorCtl st{};
     std::lock_guard<std::mutex> lk(c.mu);                 // (the device context's stream and pinned areas)
     int rc = init_ctx(c, ix.dev);
     if (rc != DQ_OK) return rc;
-    AnchorCtl *h_up = reinterpret_cast<AnchorCtl *>(c.pinned + 512), *h_back = reinterpret_cast<AnchorCtl *>(c.pinned);
     const bool trace = env("DQ_TRACE") != nullptr;
-    int groups = env("DQ_SCAN_GROUPS") ? std::max(8, std::min(kAsMaxGroups, atoi(env("DQ_SCAN_GROUPS")))) : kAsGroups;
-    // The grid is persistent and its workgroups wait for each other's answers: all of them must be on the device at
+    // The grids are persistent and their workgroups wait for each other's answers: all of them must be on the device at
     // once.  What the device holds (occupancy of this kernel x compute units; a partitioned or smaller part holds
-    // fewer than 128) bounds the grid; below 8 workgroups, or for a while after a launch whose workgroups waited in
-    // vain (a device kept full by other streams or processes -- every such launch costs its spin bound), the host
-    // loop over windows takes the file instead.
+    // fewer) bounds them; below 8 workgroups, or for a while after a launch whose workgroups waited in vain (a device
+    // kept full by other streams or processes -- every such launch costs its spin bound), the host loop over windows
+    // takes the file instead.
     if (c.scan_groups_cap < 0) {
         int per_cu = 0, ncu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, anchor_scan_kernel<int32_t>, kAsThreads, 0) != hipSuccess) per_cu = 0;
@@ -616,118 +642,351 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         c.scan_groups_cap = per_cu > 0 && ncu > 0 ? per_cu * ncu : kAsGroups;       // (unknown: as before)
         if (trace) fprintf(stderr, "[dq] anchor scan: %d workgroups per compute unit x %d compute units resident\n", per_cu, ncu);
     }
-    if (const char *v = env("DQ_SCAN_GROUPS_CAP")) groups = std::min(groups, std::max(0, atoi(v)));      // (tests: a small device)
-    groups = std::min(groups, c.scan_groups_cap);
-    t_diff_info[4] = groups;
-    if (groups < 8 || c.scan_skip > 0) {
+    int cap = c.scan_groups_cap;
+    if (const char *v = env("DQ_SCAN_GROUPS_CAP")) cap = std::min(cap, std::max(0, atoi(v)));           // (tests: a small device)
+    const int asked = env("DQ_SCAN_GROUPS") ? std::max(8, std::min(kAsMaxGroups, atoi(env("DQ_SCAN_GROUPS")))) : 0;
+    const int groups_alone = std::min(asked ? asked : kAsGroups, cap);                 // a grid that is alone on the file
+    const int groups_chain = std::min(asked ? asked : kScanChainGroups, cap);          // one of several
+    int chains_max = env("DQ_SCAN_CHAINS") ? std::max(1, std::min(kScanMaxChains, atoi(env("DQ_SCAN_CHAINS")))) : kScanChains;
+    if (groups_chain >= 8) chains_max = std::min(chains_max, cap / groups_chain);
+    const int64_t min_seg = env("DQ_SCAN_MIN_SEG") ? std::max<int64_t>(64, atoll(env("DQ_SCAN_MIN_SEG"))) : kScanMinSegment;
+    const int64_t extra_ends = env("DQ_SCAN_EXTRA") ? std::max<int64_t>(1, atoll(env("DQ_SCAN_EXTRA"))) : kScanExtra;
+    const int64_t lane_budget = env("DQ_SCAN_LANE_BUDGET") ? std::max<int64_t>(1, atoll(env("DQ_SCAN_LANE_BUDGET"))) : kScanLaneBudget;
+    t_diff_info[4] = chains_max > 1 && m >= 2 * min_seg ? groups_chain : groups_alone;
+    if (groups_alone < 8 || c.scan_skip > 0) {
         if (c.scan_skip > 0) --c.scan_skip;
         // (not an error: the host loop takes the file and the call succeeds -- dq_last_error() must not be left saying
         // otherwise behind a DQ_OK, so nothing goes through fail(); dq_last_diff_info counts the file, skipped ones too)
-        if (env("DQ_TRACE"))
-            fprintf(stderr, "[dq] %s\n", groups < 8 ? "anchor scan: the device holds fewer than 8 of its workgroups" : "anchor scan: skipped after a starved launch");
+        if (trace)
+            fprintf(stderr, "[dq] %s\n", groups_alone < 8 ? "anchor scan: the device holds fewer than 8 of its workgroups" : "anchor scan: skipped after a starved launch");
         *retry_on_host = true;
         return DQ_ERR_HIP;
     }
+    ScanChain ch[kScanMaxChains];
+    for (int k = 0; k < kScanMaxChains; ++k) {
+        ScanChain &x = ch[k];
+        char *hp = pinned_chains + kAsSlotAt + (size_t)k * kAsSlotBytes;
+        x.d_ctl = reinterpret_cast<AnchorCtl *>(scratch + (size_t)k * 256);
+        x.h_up = reinterpret_cast<AnchorCtl *>(pinned_chains + (size_t)k * 256);
+        x.ring = reinterpret_cast<unsigned long long *>(hp);
+        x.cum = x.ring + kAnchorRecs;
+        x.h_out = reinterpret_cast<const AnchorCtl *>(x.ring + 2 * kAnchorRecs);
+        x.h_landed = x.ring + 2 * kAnchorRecs + 31;
+        x.dirty = &c.scan_dirty[k];
+    }
     double emit_ms = 0;                                   // (DQ_TRACE: time inside the emitter)
-    // Whatever way this function is left once a launch is out -- a failed copy, an exception out of the emitter -- the
-    // kernel must be off the stream before anybody refills the ring or the answer buffers: it is told to stop (the
-    // error word every spin looks at), the stream drains, the timing events go back to their pool.
+    const auto t_host0 = std::chrono::steady_clock::now();
+    auto host_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(); };
+    // Whatever way this function is left while a launch is out -- a failed copy, an exception out of the emitter -- the
+    // kernel must be off the stream before anybody refills the lists or the answer buffers: its chains are told to stop
+    // (the error word every spin looks at), the stream drains, the timing events go back to their pool.
+    bool launch_out = false;                              // a launch may still be on the stream
     struct LaunchGuard {
-        DeviceCtx &c; AnchorCtl *d_ctl; bool armed = false;
+        DeviceCtx &c; ScanChain *ch; bool &out;
         ~LaunchGuard()
         {
-            if (!armed) return;
+            if (!out) return;
             hipStream_t side = nullptr;
             if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess) {
                 static const unsigned int one = 1;
-                (void)hipMemcpyAsync(&d_ctl->error, &one, sizeof(one), hipMemcpyHostToDevice, side);
+                for (int k = 0; k < kScanMaxChains; ++k)
+                    if (ch[k].running) (void)hipMemcpyAsync(&ch[k].d_ctl->error, &one, sizeof(one), hipMemcpyHostToDevice, side);
                 (void)hipStreamSynchronize(side);
                 (void)hipStreamDestroy(side);
             }
+            for (int k = 0; k < kScanMaxChains; ++k) if (ch[k].running) *ch[k].dirty = kAnchorRecs;
             drop_pending(c, c.stream);                    // (synchronises c.stream first)
         }
-    } guard{c, d_ctl};
-    for (;;) {
-        Launcher L{c, c.stream, g_prof_on.load()};
-        *h_up = AnchorCtl{};
-        h_up->cursor = st.cursor; h_up->hit_len = st.hit_len; h_up->hit_pos = st.hit_pos; h_up->shift = st.shift;
-        h_up->pad = (trace ? 1u : 0u) | ((unsigned)(env("DQ_SCAN_POLL_SLEEP") ? std::max(1, std::min(32, atoi(env("DQ_SCAN_POLL_SLEEP")))) : 16) << 8);
-        // (the tests: a spin bound of 2^k polls -- DQ_FAULT=spin: 2 --, and workgroup k - 1 as the straggler of every window)
-        if (t_fault.spin) h_up->pad |= 1u << 16;
-        else if (const char *v = env("DQ_SCAN_SPIN_LOG2")) h_up->pad |= (unsigned)std::max(1, std::min(24, atoi(v))) << 16;
-        if (const char *v = env("DQ_SCAN_SLOW_GROUP")) h_up->pad |= (unsigned)std::max(0, std::min(255, atoi(v))) << 24;
-        for (int64_t k = 0; k < kAnchorRecs; ++k) ring[k] = kAnchorPending;
-        std::atomic_thread_fence(std::memory_order_seq_cst);
-        HIP_TRY(hipMemcpyAsync(d_ctl, h_up, sizeof(AnchorCtl), hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(hipMemsetAsync(d_finished, 0, 2048, c.stream));
-        HIP_TRY(hipMemsetAsync(d_ans, 0xff, kAnchorAnswers, c.stream));                   // (no answer word carries a window's tag yet)
-        auto launch = [&]() -> int {
-            LAUNCH(L, DQ_K_MATCH_SEARCH, m, m * 2,
-                   hipLaunchKernelGGL(anchor_scan_kernel<int32_t>, dim3(groups), dim3(kAsThreads), 0, c.stream,
-                                      (const uint8_t *)ix.d_old, ix.n, (const int32_t *)ix.d_sa, (const uint8_t *)d_new, m,
-                                      (const int32_t *)ix.d_tab, ix.pk, d_ans, ring, kAnchorRecs, d_ctl, d_finished));
-            return DQ_OK;
-        };
-        rc = launch();
-        if (rc != DQ_OK) { drop_pending(c, c.stream); return rc; }
-        guard.armed = true;
-        HIP_TRY(hipMemcpyAsync(h_back, d_ctl, sizeof(AnchorCtl), hipMemcpyDeviceToHost, c.stream));
-        // ---- the pairs as they come: slot k is filled once it no longer reads "pending" ----
-        int64_t taken = 0;
-        auto take_filled = [&]() -> bool {
-            const unsigned long long v = __atomic_load_n(&ring[taken], __ATOMIC_ACQUIRE);
-            if (v == kAnchorPending) return false;
-            if (trace) {
-                const auto t0 = std::chrono::steady_clock::now();
-                em.take((int64_t)(v >> 32), (int64_t)(uint32_t)v);
-                emit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    } guard{c, ch, launch_out};
+
+    // Search counts along the path this thread followed: the last chain's own count + (count at the entry a chain was
+    // left at - count at the entry its successor was joined at) over the joins; the counts beside the entries are read
+    // once the launch that wrote them has said it is over.
+    struct Join { int from, to; int64_t from_at, to_at; bool have_from, have_to; unsigned long long from_v, to_v; };
+    std::vector<Join> joins;
+    auto settle = [&](int k) {
+        for (Join &j : joins) {
+            if (j.from == k && !j.have_from) { j.from_v = ch[k].cum[j.from_at]; j.have_from = true; }
+            if (j.to == k && !j.have_to) { j.to_v = ch[k].cum[j.to_at]; j.have_to = true; }
+        }
+    };
+    bool gave_up = false;
+    unsigned long long t_first = 0;                       // (DQ_TRACE: device clock of the first chain that came back)
+    // is chain k's part of its launch over?  (x.st, x.nent are what it left)  1 yes, 0 not yet, < 0 error
+    auto landed = [&](int k, bool wait) -> int {
+        ScanChain &x = ch[k];
+        if (!x.running) return 1;
+        for (uint32_t spins = 0;;) {
+            if (__atomic_load_n(x.h_landed, __ATOMIC_ACQUIRE) == x.seq) break;
+            if (!wait) return 0;
+            if ((++spins & 4095u) == 0) {                  // (a launch that died leaves no word: ask the stream now and then)
+                const hipError_t q = hipStreamQuery(c.stream);
+                if (q == hipSuccess) {
+                    if (__atomic_load_n(x.h_landed, __ATOMIC_ACQUIRE) == x.seq) break;
+                    return fail(DQ_ERR_HIP, "anchor scan: a launch ended without its result");
+                }
+                if (q != hipErrorNotReady) return fail(DQ_ERR_HIP, "anchor scan: stream query failed", q);
+                std::this_thread::yield();
             } else {
-                em.take((int64_t)(v >> 32), (int64_t)(uint32_t)v);
+                __builtin_ia32_pause();
             }
-            ++taken;
-            return true;
-        };
-        for (uint32_t idle = 0;;) {
-            if (taken < kAnchorRecs && take_filled()) { idle = 0; continue; }
-            if ((++idle & 63u) != 0) { if ((idle & 7u) == 0) __builtin_ia32_pause(); continue; }   // (a stream query costs more than a look at the slot)
-            const hipError_t q = hipStreamQuery(c.stream);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) return fail(DQ_ERR_HIP, "anchor scan: stream query failed", q);
-            // (nothing new for thousands of looks: the kernel is inside a long search -- leave the core to the framing
-            // and encoder threads of this and other callers for a moment)
-            if (idle >= (1u << 14)) std::this_thread::yield();
+        }
+        x.running = false;
+        AnchorCtl back;
+        std::memcpy(&back, x.h_out, sizeof(back));
+        if (back.error) { gave_up = true; return 1; }
+        if ((int64_t)back.nrec < x.taken || (int64_t)back.nrec > kAnchorRecs) return fail(DQ_ERR_HIP, "anchor scan: bad record count");
+        x.st = back;
+        x.nent = (int64_t)back.nrec;
+        *x.dirty = x.nent;
+        raw.windows += (int64_t)back.windows;
+        raw.exact += (int64_t)back.stops;
+        settle(k);
+        if (trace && (t_first == 0 || back.t_begin < t_first)) t_first = back.t_begin;
+        if (trace)
+            fprintf(stderr, "[dq] anchor scan, chain %d from %lld, %d workgroups: over at %.3f ms (%lld of %lld entries read), %llu windows, %llu stop points, "
+                    "left at %lld%s; on the device from %.3f to %.3f ms; workgroup 0: search %.2f ms, waiting for answers %.2f ms, evaluation %.2f ms, "
+                    "stop points %.2f ms\n", k, (long long)x.start, x.groups, host_ms(), (long long)x.taken, (long long)x.nent, back.windows, back.stops,
+                    (long long)(back.mid ? back.i : back.cursor), back.done ? " (end of file)" : back.mid ? " (in the middle of an iteration)" : "",
+                    (double)(back.t_begin - t_first) * 1e-5, (double)(back.t_end - t_first) * 1e-5, back.t_search * 1e-5, back.t_wait * 1e-5,
+                    back.t_eval * 1e-5, back.t_stop * 1e-5);
+        return 1;
+    };
+    // every chain of the launch that is out over, the stream drained (before the buffers of any chain are touched again)
+    auto drain = [&]() -> int {
+        if (!launch_out) return DQ_OK;
+        for (int k = 0; k < kScanMaxChains; ++k) {
+            const int r = landed(k, true);
+            if (r < 0) return r;
         }
         HIP_TRY(hipStreamSynchronize(c.stream));
-        guard.armed = false;                              // (the kernel has left the stream)
-        rc = flush_profile(c);
+        launch_out = false;
+        return flush_profile(c);
+    };
+    // ---- one launch: the chains in `slots`, each from its x.st ----
+    auto launch = [&](const std::vector<int> &slots, int groups) -> int {
+        AnchorLaunch ln{};
+        ln.chains = (int)slots.size();
+        ln.groups = groups;
+        ln.seq = ++c.scan_seq;
+        Launcher L{c, c.stream, g_prof_on.load()};
+        for (size_t q = 0; q < slots.size(); ++q) {
+            ScanChain &x = ch[slots[q]];
+            ln.slot[q] = slots[q];
+            AnchorCtl up = x.st;
+            up.nrec = 0; up.done = 0; up.windows = 0; up.stops = 0; up.error = 0;
+            up.t_search = up.t_wait = up.t_eval = up.t_stop = 0;
+            up.pad = (trace ? 1u : 0u) | ((unsigned)(env("DQ_SCAN_POLL_SLEEP") ? std::max(1, std::min(32, atoi(env("DQ_SCAN_POLL_SLEEP")))) : 16) << 8);
+            // (the tests: a spin bound of 2^k polls -- DQ_FAULT=spin: 2 --, and workgroup k - 1 as the straggler of every window)
+            if (t_fault.spin) up.pad |= 1u << 16;
+            else if (const char *v = env("DQ_SCAN_SPIN_LOG2")) up.pad |= (unsigned)std::max(1, std::min(24, atoi(v))) << 16;
+            if (const char *v = env("DQ_SCAN_SLOW_GROUP")) up.pad |= (unsigned)std::max(0, std::min(255, atoi(v))) << 24;
+            *x.h_up = up;
+            const int64_t refill = std::min<int64_t>(*x.dirty, kAnchorRecs);
+            for (int64_t r = 0; r < refill; ++r) x.ring[r] = kAnchorPending;
+            *x.dirty = kAnchorRecs;                       // (until the chain has said how many it wrote)
+        }
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        HIP_TRY(hipMemcpyAsync(scratch, pinned_chains, (size_t)kScanMaxChains * 256, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipMemsetAsync(scratch + kAsFinishedAt, 0, (size_t)kScanMaxChains * 2048, c.stream));
+        for (int s : slots)                                // (no answer word carries a window's tag yet)
+            HIP_TRY(hipMemsetAsync(scratch + kAsAnswersAt + (size_t)s * kAnchorAnswers, 0xff, kAnchorAnswers, c.stream));
+        LAUNCH(L, DQ_K_MATCH_SEARCH, m, m * 2,
+               hipLaunchKernelGGL(anchor_scan_kernel<int32_t>, dim3(groups * ln.chains), dim3(kAsThreads), 0, c.stream,
+                                  (const uint8_t *)ix.d_old, ix.n, (const int32_t *)ix.d_sa, (const uint8_t *)d_new, m,
+                                  (const int32_t *)ix.d_tab, ix.pk, scratch, pinned_chains, ln));
+        launch_out = true;
+        for (int s : slots) {
+            ScanChain &x = ch[s];
+            x.running = true; x.seq = ln.seq; x.groups = groups; x.taken = 0; x.nent = 0;
+        }
+        return DQ_OK;
+    };
+    auto entry_cursor = [](unsigned long long v) -> int64_t { return (int64_t)((v & ~kAsSilent) >> 32); };
+
+    int cur = 0;                                          // the chain this thread follows
+    ch[0].alive = true;                                   // (from the loop's initial state: all zero)
+    int serial_log2 = 0;                                  // iteration ends the next launch that is alone on purpose walks: 2^this
+    bool serial_next = false;
+    int64_t n_joins = 0, n_launches = 0, n_dropped = 0;
+    // Launch the followed chain (again) from its state -- and, when no other chain is left and enough of the file is,
+    // new chains over the rest of it.
+    auto relaunch = [&]() -> int {
+        rc = drain();                                     // (one launch at a time: chains that were left behind end by themselves)
+        if (rc != DQ_OK || gave_up) return rc;
+        ScanChain &t = ch[cur];
+        const int64_t pos = t.st.mid ? t.st.i : t.st.cursor + t.st.hit_len;
+        bool others = false;
+        for (int k = 0; k < kScanMaxChains; ++k) others = others || (k != cur && ch[k].alive);
+        int spawn = 0;
+        if (!others && !serial_next && chains_max > 1 && groups_chain >= 8 && m - pos >= 2 * min_seg)
+            spawn = (int)std::min<int64_t>(chains_max, (m - pos) / min_seg);
+        t.st.lane_budget = 0; t.st.extra = 0; t.st.stop_at = 0;
+        std::vector<int> slots{cur};
+        if (spawn > 1) {
+            const int64_t seg = (m - pos) / spawn;
+            int slot = 0;
+            for (int j = 1; j < spawn; ++j) {
+                while (slot == cur) ++slot;
+                ScanChain &x = ch[slot];
+                x.st = AnchorCtl{};
+                x.start = pos + j * seg;
+                x.st.cursor = x.start; x.st.shift = ix.n;  // (agree() is false everywhere under it: no alignment has this shift)
+                x.shift = ix.n;
+                x.alive = true;
+                x.st.lane_budget = lane_budget;
+                if (slots.size() > 1) { ch[slots.back()].st.stop_at = x.start; ch[slots.back()].st.extra = extra_ends; }
+                slots.push_back(slot);
+                ++slot;
+            }
+            t.st.stop_at = ch[slots[1]].start; t.st.extra = extra_ends; t.st.lane_budget = lane_budget;
+        } else if (serial_next) {
+            t.st.extra = (int64_t)1 << serial_log2;       // (stop_at 0: every iteration end counts)
+        } else if (others) {
+            // as far as the start of the next chain that is still worth reaching; a long differing stretch is left to a
+            // launch of its own
+            int64_t next_start = -1;
+            for (int k = 0; k < kScanMaxChains; ++k)
+                if (k != cur && ch[k].alive && ch[k].start > pos && (next_start < 0 || ch[k].start < next_start)) next_start = ch[k].start;
+            if (next_start >= 0) { t.st.stop_at = next_start; t.st.extra = extra_ends; }
+            t.st.lane_budget = lane_budget;
+        }
+        serial_next = false;
+        rc = launch(slots, slots.size() > 1 ? groups_chain : groups_alone);
         if (rc != DQ_OK) return rc;
-        st = *h_back;
-        // (a workgroup of the persistent grid did not get onto the device in time -- a device kept full by other work:
-        // the caller runs the host loop over windows instead; nothing of this attempt is kept; the next 16 diffs on this
-        // device do not try again)
-        if (st.error) {
-            if (!t_fault.spin && !env("DQ_SCAN_SPIN_LOG2")) c.scan_skip = 16;     // (not under the tests' own bound)
-            if (env("DQ_TRACE")) fprintf(stderr, "[dq] anchor scan: grid barrier timed out\n");
-            *retry_on_host = true;
-            return DQ_ERR_HIP;                              // (no fail(): the host loop's DQ_OK must not carry this text)
+        n_launches += (int64_t)slots.size();
+        return DQ_OK;
+    };
+    // The followed chain has just ended an iteration at c (silent: without a triple; under shift s): is that where
+    // another chain ended one under the same shift?  (Entries of that chain in front of c are stepped over for good:
+    // the followed chain's ends only grow.)
+    auto try_join = [&](int64_t cpos, bool silent, int64_t s) -> int {
+        for (;;) {
+            int best = -1;
+            for (int k = 0; k < kScanMaxChains; ++k)
+                if (k != cur && ch[k].alive && ch[k].start <= cpos && (best < 0 || ch[k].start > ch[best].start)) best = k;
+            if (best < 0) return 0;
+            ScanChain &x = ch[best];
+            bool again = false;
+            for (uint32_t idle = 0;;) {
+                if ((x.running || x.taken < x.nent) && x.taken < kAnchorRecs) {
+                    const unsigned long long v = __atomic_load_n(&x.ring[x.taken], __ATOMIC_ACQUIRE);
+                    if (v != kAnchorPending) {
+                        idle = 0;
+                        const int64_t cj = entry_cursor(v);
+                        const bool sj = (v & kAsSilent) != 0;
+                        if (cj < cpos) {
+                            if (!sj) x.shift = (int64_t)(uint32_t)v - cj;
+                            ++x.taken;
+                            continue;
+                        }
+                        if (cj == cpos && sj == silent && (!silent || x.shift == s)) {
+                            if (!sj) x.shift = (int64_t)(uint32_t)v - cj;
+                            joins.push_back(Join{cur, best, ch[cur].taken - 1, x.taken, false, false, 0, 0});
+                            ++x.taken;
+                            if (!ch[cur].running) settle(cur);
+                            if (!x.running) settle(best);
+                            ch[cur].alive = false;        // (its grid leaves by itself a few iterations on)
+                            cur = best;
+                            ++n_joins;
+                            serial_log2 = 0;
+                            if (trace) fprintf(stderr, "[dq] anchor scan: chain %d joined at %lld, %.3f ms (emitter %.2f ms so far)\n", best, (long long)cpos, host_ms(), emit_ms);
+                            return 1;
+                        }
+                        break;                            // its next end lies behind c, or at c under another shift
+                    }
+                }
+                if (!x.running) {
+                    if (x.taken >= x.nent) { x.alive = false; ++n_dropped; again = true; break; }      // nothing of it lies behind c
+                    return fail(DQ_ERR_HIP, "anchor scan: a record slot was left unfilled");
+                }
+                // the chain has not got there yet (it started when the followed one did: rare): wait for its entry or its end
+                if ((++idle & 63u) != 0) { __builtin_ia32_pause(); continue; }
+                const int r = landed(best, false);
+                if (r < 0) return r;
+                if (gave_up) return 0;
+            }
+            if (!again) return 0;
         }
-        const int64_t got = (int64_t)st.nrec;
-        if (got < taken || got > kAnchorRecs) return fail(DQ_ERR_HIP, "anchor scan: bad record count");
-        while (taken < got) {                              // what the kernel wrote after the last look
-            if (!take_filled()) return fail(DQ_ERR_HIP, "anchor scan: a record slot was left unfilled");
+    };
+
+    rc = relaunch();
+    if (rc != DQ_OK) return rc;
+    if (trace) fprintf(stderr, "[dq] anchor scan: first launch out at %.3f ms\n", host_ms());
+    for (uint32_t idle = 0; !gave_up;) {
+        ScanChain &t = ch[cur];
+        if ((t.running || t.taken < t.nent) && t.taken < kAnchorRecs) {
+            const unsigned long long v = __atomic_load_n(&t.ring[t.taken], __ATOMIC_ACQUIRE);
+            if (v != kAnchorPending) {
+                idle = 0;
+                ++t.taken;
+                const int64_t cpos = entry_cursor(v);
+                const bool silent = (v & kAsSilent) != 0;
+                if (!silent) {
+                    if (trace) {
+                        const auto t0 = std::chrono::steady_clock::now();
+                        em.take(cpos, (int64_t)(uint32_t)v);
+                        emit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                    } else {
+                        em.take(cpos, (int64_t)(uint32_t)v);
+                    }
+                    t.shift = (int64_t)(uint32_t)v - cpos;
+                }
+                const int j = try_join(cpos, silent, t.shift);
+                if (j < 0) return j;
+                continue;
+            }
         }
-        if (trace)
-            fprintf(stderr, "[dq] anchor scan launch: %llu windows, %llu stop points, %lld pairs; workgroup 0: search %.2f ms, waiting for answers "
-                    "%.2f ms, evaluation %.2f ms, stop points %.2f ms\n", st.windows, st.stops, (long long)got, st.t_search * 1e-5,
-                    st.t_wait * 1e-5, st.t_eval * 1e-5, st.t_stop * 1e-5);
-        raw.searches += (int64_t)st.searches;
-        raw.windows += (int64_t)st.windows;
-        raw.exact += (int64_t)st.stops;
-        if (st.done) break;
-        if (got == 0) return fail(DQ_ERR_HIP, "anchor scan: no progress");
+        if (t.running) {
+            if ((++idle & 63u) != 0) { if ((idle & 7u) == 0) __builtin_ia32_pause(); continue; }
+            const int r = landed(cur, false);
+            if (r < 0) return r;
+            // (nothing new for thousands of looks: the kernel is inside a long search -- leave the core to the framing
+            // and encoder threads of this and other callers for a moment)
+            if (r == 0) {
+                if ((idle & 0xffffu) == 0) {               // (a launch that died would never say so: ask the stream now and then)
+                    const hipError_t q = hipStreamQuery(c.stream);
+                    if (q != hipSuccess && q != hipErrorNotReady) return fail(DQ_ERR_HIP, "anchor scan: stream query failed", q);
+                    if (q == hipSuccess && landed(cur, false) == 0) return fail(DQ_ERR_HIP, "anchor scan: a launch ended without its result");
+                }
+                if (idle >= (1u << 14)) std::this_thread::yield();
+            }
+            continue;
+        }
+        if (t.taken < t.nent) return fail(DQ_ERR_HIP, "anchor scan: a record slot was left unfilled");
+        // the followed chain's launch is over and read to its end
+        if (t.st.done) break;
+        if (t.nent == 0 && !t.st.mid) return fail(DQ_ERR_HIP, "anchor scan: no progress");
+        if (t.st.mid) {                                   // it left a long differing stretch: that iteration alone, with all it can get
+            serial_next = true;
+        } else if (t.st.extra > 0 && t.st.stop_at == 0) { // a launch that was alone on purpose has ended its iterations
+            serial_log2 = std::min(serial_log2 + 1, 12);
+        }
+        rc = relaunch();
+        if (rc != DQ_OK) return rc;
     }
+    if (trace) fprintf(stderr, "[dq] anchor scan: end of file at %.3f ms\n", host_ms());
+    rc = drain();                                         // (chains that were left behind end by themselves)
+    if (rc != DQ_OK) return rc;
+    // (a workgroup of a persistent grid did not get onto the device in time -- a device kept full by other work: the
+    // caller runs the host loop over windows instead; nothing of this attempt is kept; the next 16 diffs on this device
+    // do not try again)
+    if (gave_up) {
+        if (!t_fault.spin && !env("DQ_SCAN_SPIN_LOG2")) c.scan_skip = 16;     // (not under the tests' own bound)
+        if (trace) fprintf(stderr, "[dq] anchor scan: grid barrier timed out\n");
+        *retry_on_host = true;
+        return DQ_ERR_HIP;                                  // (no fail(): the host loop's DQ_OK must not carry this text)
+    }
+    unsigned long long searches = ch[cur].st.searches;
+    for (const Join &j : joins) {
+        if (!j.have_from || !j.have_to) return fail(DQ_ERR_HIP, "anchor scan: a join was left unsettled");
+        searches += j.from_v - j.to_v;
+    }
+    raw.searches += (int64_t)searches;
     if (em.progress) framer->complete();
-    if (trace) fprintf(stderr, "[dq] emitter (steps 2 and 3 on the host, beside the kernel): %.2f ms\n", emit_ms);
+    if (trace)
+        fprintf(stderr, "[dq] anchor scan: %lld chain launches, %lld joins, %lld chains dropped in %.3f ms; emitter (steps 2 and 3 on the host, beside the kernels): %.2f ms\n",
+                (long long)n_launches, (long long)n_joins, (long long)n_dropped, host_ms(), emit_ms);
     return DQ_OK;
 }
 
@@ -754,10 +1013,11 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
     if (!c.diff_pinned) {
         hipError_t e = dq_host_malloc((void **)&c.diff_pinned, kDiffPinnedBytes, hipHostMallocCoherent);   // (windows + the packed answers the loop polls)
         if (e != hipSuccess) return fail(DQ_ERR_OOM, "hipHostMalloc(search windows)", e);
+        std::memset(c.diff_pinned, 0, kDiffPinnedBytes);   // (no chain's "over" word may read as a launch number to come)
     }
     char *pinned = c.diff_pinned;
     const size_t b_win = align_up((size_t)(SearchWindows::kMaxWindow + 2) * 4);
-    static_assert(kDiffPinnedBytes >= 2 * ((size_t)(SearchWindows::kMaxWindow + 2) * 4 + 256) +
+    static_assert(kDiffWindowBytes >= 2 * ((size_t)(SearchWindows::kMaxWindow + 2) * 4 + 256) +
                   (size_t)(SearchWindows::kWaveWindow + 2 * (SearchWindows::kSecond + 1)) * 8 + 256, "pinned window area");
     char *d_new = c.diff_dev;
     stamp("buffers");
@@ -768,8 +1028,7 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
     const bool device_scan = (env("DQ_SCAN_DEVICE") ? atoi(env("DQ_SCAN_DEVICE")) != 0 : true) && ix.n < 0x7fffffffLL && m < 0x7fffffffLL;
     if (device_scan) {
         bool retry_on_host = false;
-        static_assert(kDiffPinnedBytes >= (size_t)kAnchorRecs * 8, "the pinned window area holds the anchor ring");
-        rc = scan_on_device(ix, c, d_new, d_new + b_new + 256, reinterpret_cast<unsigned long long *>(pinned), nw, m, raw, &retry_on_host, framer);
+        rc = scan_on_device(ix, c, d_new, d_new + b_new + 256, pinned + kDiffWindowBytes, nw, m, raw, &retry_on_host, framer);
         stamp("scan (device)");
         if (trace)
             fprintf(stderr, "[dq] device scan: %lld searches, %lld windows, %lld stop points, %zu triples%s\n", (long long)raw.searches,

@@ -192,6 +192,10 @@ struct DeviceCtx {
     // scan after a launch whose workgroups waited in vain for each other (a device kept full by other work)
     int scan_groups_cap = -1;
     int scan_skip = 0;
+    // several grids on one new file: how many slots of each one's pinned list may not read "pending" any more (all of
+    // them before the first use)
+    unsigned long long scan_seq = 0;    // launches of the device scan so far (a chain writes its launch's number behind its result)
+    int64_t scan_dirty[8] = {1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16};
 };
 constexpr int kMaxDevices = 64;
 // A device has several contexts ("slots": stream + workspace + pinned areas each).  Texts of up to kSlotSmallN bytes

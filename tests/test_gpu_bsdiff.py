@@ -61,7 +61,12 @@ def pairs(oracle_mod):
 
 # the anchor search of the scan loop runs on the device by default (dq_anchor_scan.h: one persistent launch per new
 # file); the host loop over windows of device answers stays as the path a starved launch falls back to
-SCAN_PATHS = [{}, {"DQ_SCAN_DEVICE": "0"}, {"DQ_SCAN_GROUPS": "8"}, {"DQ_SCAN_GROUPS": "48"}]
+# (several grids on one new file -- "chains", dq_diff.hip -- start from 2 MiB of new by default: forced onto the small
+# pairs here, 4 grids of 64 workgroups from 4 KiB on, and 8 grids of 16 that leave after one iteration end behind the next
+# grid's start and after one window of one position per lane)
+SCAN_PATHS = [{}, {"DQ_SCAN_DEVICE": "0"}, {"DQ_SCAN_GROUPS": "8"}, {"DQ_SCAN_GROUPS": "48"},
+              {"DQ_SCAN_CHAINS": "4", "DQ_SCAN_MIN_SEG": "2048"},
+              {"DQ_SCAN_CHAINS": "8", "DQ_SCAN_MIN_SEG": "300", "DQ_SCAN_GROUPS": "16", "DQ_SCAN_EXTRA": "1", "DQ_SCAN_LANE_BUDGET": "1"}]
 
 
 @pytest.mark.parametrize("env", SCAN_PATHS, ids=lambda e: ",".join(f"{k[3:]}={v}" for k, v in e.items()) or "device-scan")
