@@ -463,6 +463,7 @@ void dq_sufsort_hip_release(void)
         c0.bslot_cap = 0;
         for (hipStream_t *st : {&c0.b_in, &c0.b_sort, &c0.b_out}) { if (*st) (void)hipStreamDestroy(*st); *st = nullptr; }
         for (int64_t &d : c0.scan_dirty) d = 1 << 16;
+        c0.scan_pool.reset();
         if (c0.diff_dev) (void)hipFree(c0.diff_dev);
         if (c0.diff_idx) (void)hipFree(c0.diff_idx);
         if (c0.diff_pinned) (void)hipHostFree(c0.diff_pinned);

@@ -21,6 +21,7 @@
 // (tests/test_gpu_bsdiff.py compares them with the oracle's restatement); the bzip2 framing is a valid encoding of
 // them, not necessarily SharpZipLib's bytes (which the reference does not pin either).
 #pragma once
+#include <chrono>
 #include <stdint.h>
 
 #include <atomic>
@@ -138,6 +139,7 @@ struct TripleEmitter {
     // if set: the lengths of out.diff / out.extra that are final, published after every triple for a thread that
     // frames the streams while they grow (the vectors must have their full capacity reserved: they may not move)
     std::atomic<size_t> *progress = nullptr;
+    double *phase_ms = nullptr;                              // (DQ_TRACE) [3]: time in the extensions, in the diff bytes, in the rest
 
     TripleEmitter(const uint8_t *old_, int64_t n_, const uint8_t *nw_, int64_t m_, RawStreams &out_)
         : old(old_), n(n_), nw(nw_), m(m_), out(out_) {}
@@ -153,6 +155,7 @@ struct TripleEmitter {
     void take(int64_t cursor, int64_t hit_pos)
     {
         // ---- 2. extensions ----
+        const auto t_a = phase_ms ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         int64_t fwd = 0;                                     // forward from prev, under prev's alignment
         int64_t equal_front = 0;                             // bytes at the front of the extension known to be equal
         for (int64_t i = 0, good = 0, best = 0; prev.at + i < cursor && prev.in_old + i < n;) {
@@ -212,6 +215,7 @@ struct TripleEmitter {
         }
 
         // ---- 3. one control triple ----
+        const auto t_b = phase_ms ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         const size_t d0 = out.diff.size();
         out.diff.resize(d0 + (size_t)fwd);                   // (zeros)
         {
@@ -227,6 +231,7 @@ struct TripleEmitter {
             }
             for (; i < fwd; ++i) dst[i] = (uint8_t)(a[i] - b[i]);
         }
+        const auto t_c = phase_ms ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         const int64_t gap = (cursor - back) - (prev.at + fwd);
         if (gap > 0) out.extra.insert(out.extra.end(), nw + prev.at + fwd, nw + prev.at + fwd + gap);
         emit_packed(fwd);
@@ -237,6 +242,12 @@ struct TripleEmitter {
         if (progress) {
             progress[0].store(out.diff.size(), std::memory_order_release);
             progress[1].store(out.extra.size(), std::memory_order_release);
+        }
+        if (phase_ms) {
+            const auto t_d = std::chrono::steady_clock::now();
+            phase_ms[0] += std::chrono::duration<double, std::milli>(t_b - t_a).count();
+            phase_ms[1] += std::chrono::duration<double, std::milli>(t_c - t_b).count();
+            phase_ms[2] += std::chrono::duration<double, std::milli>(t_d - t_c).count();
         }
     }
 };

@@ -601,6 +601,88 @@ constexpr int64_t kScanExtra = 8;                         // iteration ends a gr
 constexpr int64_t kScanLaneBudget = 2;                    // one-lane-per-position windows after which a grid that is not alone leaves
 static_assert(kDiffPinnedBytes >= kDiffWindowBytes + kAnchorPinned, "pinned area of the chains");
 
+// Steps 2 and 3 for the entries of ONE speculative chain, on a thread of its own, into streams of its own: what
+// TripleEmitter::take writes for an entry is a function of the entry and of `prev` (the end of the last forward extension),
+// so from the first entry on at which this emitter's `prev` equals the followed emitter's, its output IS the followed
+// one's and is copied instead of computed (the extensions walk every byte of both files: 5 of the 6 ms the emitter takes
+// for a 16 MiB pair, and behind 8 grids it was the longest thing left).  Again nothing rests on a guess: until the two
+// states have been seen equal the thread that follows the chains computes the entries itself.
+struct ChainEmitter {
+    struct Mark { int64_t entry; bsdiff::TripleEmitter::Anchor prev; size_t ctrl, diff, extra; };     // after an emitted entry: state, stream lengths
+    bsdiff::RawStreams priv;
+    std::vector<Mark> marks;                              // (full capacity reserved: read by the following thread while this one appends)
+    std::atomic<int64_t> n_marks{0}, seen{0};             // marks published; list entries this thread is through with
+    std::atomic<int64_t> nent{-1};                        // entries of the chain's launch once it is over (from the following thread)
+    std::atomic<int> stop{0}, failed{0};
+    bsdiff::TripleEmitter::Anchor first;                  // the state it began with
+    std::thread th;
+
+    void run(const uint8_t *old, int64_t n, const uint8_t *nw, int64_t m, const unsigned long long *ring, int64_t start)
+    {
+        try {
+            bsdiff::TripleEmitter em(old, n, nw, m, priv);
+            em.prev = first;
+            (void)start;
+            for (int64_t i = 0; !stop.load(std::memory_order_relaxed);) {
+                const int64_t over = nent.load(std::memory_order_acquire);
+                if (over >= 0 && i >= over) return;
+                if (i >= kAnchorRecs) return;
+                const unsigned long long v = __atomic_load_n(&ring[i], __ATOMIC_ACQUIRE);
+                if (v == ~0ull) {
+                    for (int q = 0; q < 64; ++q) __builtin_ia32_pause();
+                    std::this_thread::yield();
+                    continue;
+                }
+                if (!(v & kAsSilent)) {
+                    // (a triple adds at most the bytes between the last extension and this anchor to either stream; the
+                    // vectors may not move under the thread that reads them: out of room means out of this thread's job)
+                    const size_t span = (size_t)((int64_t)(v >> 32) - em.prev.at) + 16;
+                    if (priv.diff.size() + span > priv.diff.capacity() || priv.extra.size() + span > priv.extra.capacity() ||
+                        priv.ctrl.size() + 24 > priv.ctrl.capacity() || marks.size() + 1 > marks.capacity()) {
+                        failed.store(1, std::memory_order_release);
+                        return;
+                    }
+                    em.take((int64_t)(v >> 32), (int64_t)(uint32_t)v);
+                    marks.push_back(Mark{i, em.prev, priv.ctrl.size(), priv.diff.size(), priv.extra.size()});
+                    n_marks.store((int64_t)marks.size(), std::memory_order_release);
+                }
+                ++i;
+                seen.store(i, std::memory_order_release);
+            }
+        } catch (...) {
+            failed.store(1, std::memory_order_release);
+        }
+    }
+    void halt()
+    {
+        stop.store(1, std::memory_order_relaxed);
+        if (th.joinable()) th.join();
+    }
+    // for another chain: room for `bytes` of either stream (the buffers are kept from diff to diff -- fresh ones cost their
+    // page faults on the way in and 1.6 ms of munmap on the way out of a 16 MiB pair -- unless they have grown large)
+    void reset(int64_t start, size_t bytes)
+    {
+        halt();
+        stop.store(0); failed.store(0); n_marks.store(0); seen.store(0); nent.store(-1);
+        marks.clear(); priv.ctrl.clear(); priv.diff.clear(); priv.extra.clear();
+        first.at = start; first.in_old = 0;
+        marks.reserve(1 << 14);
+        priv.ctrl.reserve((size_t)24 << 14);
+        priv.diff.reserve(bytes);
+        priv.extra.reserve(bytes);
+    }
+    void trim()
+    {
+        halt();
+        if (priv.diff.capacity() + priv.extra.capacity() > ((size_t)16 << 20)) {
+            std::vector<uint8_t>().swap(priv.diff);
+            std::vector<uint8_t>().swap(priv.extra);
+        }
+    }
+    ~ChainEmitter() { halt(); }
+};
+struct ScanPool { std::unique_ptr<ChainEmitter> em[kScanMaxChains]; };
+
 struct ScanChain {
     AnchorCtl *d_ctl = nullptr, *h_up = nullptr;
     const AnchorCtl *h_out = nullptr;                     // pinned: what the chain's launch left ...
@@ -616,6 +698,8 @@ struct ScanChain {
     int64_t taken = 0;                                    // entries of the current launch read (followed or stepped over)
     int64_t nent = 0;                                     // entries of the launch once it is over
     int64_t shift = 0;                                    // shift in force behind the entries read so far
+    ChainEmitter *em = nullptr;                           // its own emitter thread (speculative chains of a launch; kept in the device context)
+    int64_t mark_at = 0;                                  // marks of it whose entries the following thread has passed
 };
 
 int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch, char *pinned_chains, const uint8_t *nw,
@@ -674,7 +758,18 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         x.h_landed = x.ring + 2 * kAnchorRecs + 31;
         x.dirty = &c.scan_dirty[k];
     }
+    struct EmitterGuard {                                 // (no emitter thread outlives this call, however it is left)
+        DeviceCtx &c;
+        ~EmitterGuard()
+        {
+            if (!c.scan_pool) return;
+            ScanPool &pool = *static_cast<ScanPool *>(c.scan_pool.get());
+            for (auto &e : pool.em) if (e) e->trim();
+        }
+    } emitter_guard{c};
     double emit_ms = 0;                                   // (DQ_TRACE: time inside the emitter)
+    double emit_phase_ms[3] = {0, 0, 0};
+    if (trace) em.phase_ms = emit_phase_ms;
     const auto t_host0 = std::chrono::steady_clock::now();
     auto host_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(); };
     // Whatever way this function is left while a launch is out -- a failed copy, an exception out of the emitter -- the
@@ -734,10 +829,11 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         x.running = false;
         AnchorCtl back;
         std::memcpy(&back, x.h_out, sizeof(back));
-        if (back.error) { gave_up = true; return 1; }
+        if (back.error) { gave_up = true; if (x.em) x.em->stop.store(1); return 1; }
         if ((int64_t)back.nrec < x.taken || (int64_t)back.nrec > kAnchorRecs) return fail(DQ_ERR_HIP, "anchor scan: bad record count");
         x.st = back;
         x.nent = (int64_t)back.nrec;
+        if (x.em) x.em->nent.store(x.nent, std::memory_order_release);
         *x.dirty = x.nent;
         raw.windows += (int64_t)back.windows;
         raw.exact += (int64_t)back.stops;
@@ -808,7 +904,11 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
     ch[0].alive = true;                                   // (from the loop's initial state: all zero)
     int serial_log2 = 0;                                  // iteration ends the next launch that is alone on purpose walks: 2^this
     bool serial_next = false;
-    int64_t n_joins = 0, n_launches = 0, n_dropped = 0;
+    int64_t n_joins = 0, n_launches = 0, n_dropped = 0, n_adopted = 0;
+    // emitters of the speculative chains on threads of their own (DQ_SCAN_PAR_EMIT=0: everything on this thread)
+    const bool par_emit = env("DQ_SCAN_PAR_EMIT") ? atoi(env("DQ_SCAN_PAR_EMIT")) != 0 : true;
+    bool want_adopt = false;                              // the followed chain has an emitter whose state has not been seen equal to em's yet
+    bool adopting = false;                                // ... it has: its output is copied
     // Launch the followed chain (again) from its state -- and, when no other chain is left and enough of the file is,
     // new chains over the rest of it.
     auto relaunch = [&]() -> int {
@@ -852,9 +952,38 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
             t.st.lane_budget = lane_budget;
         }
         serial_next = false;
+        for (int sl : slots) {                             // (their lists are about to be refilled: the threads that read them end first)
+            if (ch[sl].em) ch[sl].em->halt();
+            ch[sl].em = nullptr;
+        }
+        adopting = false; want_adopt = false;             // (the followed chain's new entries are computed here)
         rc = launch(slots, slots.size() > 1 ? groups_chain : groups_alone);
         if (rc != DQ_OK) return rc;
         n_launches += (int64_t)slots.size();
+        if (par_emit) {
+            try {
+                if (!c.scan_pool) c.scan_pool = std::make_shared<ScanPool>();
+                ScanPool &pool = *static_cast<ScanPool *>(c.scan_pool.get());
+                for (size_t q = 1; q < slots.size(); ++q) {
+                    ScanChain &x = ch[slots[q]];
+                    if (!pool.em[slots[q]]) pool.em[slots[q]].reset(new ChainEmitter);
+                    ChainEmitter &e = *pool.em[slots[q]];
+                    // (its own part of the file and a quarter more; a chain that walks further -- nothing joined it for a
+                    // long time -- leaves the rest to the thread that follows it)
+                    const int64_t upto = q + 1 < slots.size() ? ch[slots[q + 1]].start : m;
+                    const int64_t part = upto - x.start;
+                    e.reset(x.start, (size_t)std::min<int64_t>(m - x.start, part + part / 4 + (64 << 10)) + 64);
+                    x.mark_at = 0;
+                    e.th = std::thread([&e, &ix, nw, m, ring = x.ring, start = x.start] { e.run(ix.old, ix.n, nw, m, ring, start); });
+                    x.em = &e;
+                }
+            } catch (const std::exception &) {
+                for (int sl : slots) {                     // (no memory or no thread: everything is computed here, as without them)
+                    if (ch[sl].em) ch[sl].em->halt();
+                    ch[sl].em = nullptr;
+                }
+            }
+        }
         return DQ_OK;
     };
     // The followed chain has just ended an iteration at c (silent: without a triple; under shift s): is that where
@@ -887,6 +1016,9 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
                             if (!ch[cur].running) settle(cur);
                             if (!x.running) settle(best);
                             ch[cur].alive = false;        // (its grid leaves by itself a few iterations on)
+                            if (ch[cur].em) ch[cur].em->stop.store(1, std::memory_order_relaxed);
+                            adopting = false;
+                            want_adopt = x.em != nullptr;
                             cur = best;
                             ++n_joins;
                             serial_log2 = 0;
@@ -897,7 +1029,11 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
                     }
                 }
                 if (!x.running) {
-                    if (x.taken >= x.nent) { x.alive = false; ++n_dropped; again = true; break; }      // nothing of it lies behind c
+                    if (x.taken >= x.nent) {                   // nothing of it lies behind c
+                        x.alive = false; ++n_dropped; again = true;
+                        if (x.em) x.em->stop.store(1, std::memory_order_relaxed);
+                        break;
+                    }
                     return fail(DQ_ERR_HIP, "anchor scan: a record slot was left unfilled");
                 }
                 // the chain has not got there yet (it started when the followed one did: rare): wait for its entry or its end
@@ -918,11 +1054,44 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         if ((t.running || t.taken < t.nent) && t.taken < kAnchorRecs) {
             const unsigned long long v = __atomic_load_n(&t.ring[t.taken], __ATOMIC_ACQUIRE);
             if (v != kAnchorPending) {
-                idle = 0;
-                ++t.taken;
                 const int64_t cpos = entry_cursor(v);
                 const bool silent = (v & kAsSilent) != 0;
-                if (!silent) {
+                // Has the chain's own emitter been through the entries passed so far, and does it stand where em stands?
+                // Then what it writes from here on is what em would write.
+                if (want_adopt && !adopting && t.em) {
+                    ChainEmitter &e = *t.em;
+                    if (e.failed.load(std::memory_order_acquire)) want_adopt = false;
+                    else if (e.seen.load(std::memory_order_acquire) >= t.taken) {
+                        const int64_t nm = e.n_marks.load(std::memory_order_acquire);
+                        while (t.mark_at < nm && e.marks[(size_t)t.mark_at].entry < t.taken) ++t.mark_at;
+                        const bsdiff::TripleEmitter::Anchor theirs = t.mark_at > 0 ? e.marks[(size_t)t.mark_at - 1].prev : e.first;
+                        if (theirs.at == em.prev.at && theirs.in_old == em.prev.in_old) { adopting = true; want_adopt = false; }
+                    }
+                }
+                if (!silent && adopting) {
+                    // the chain's emitter has this entry's triple and bytes, or is about to
+                    ChainEmitter &e = *t.em;
+                    if (e.n_marks.load(std::memory_order_acquire) <= t.mark_at) {
+                        if (e.failed.load(std::memory_order_acquire)) { adopting = false; continue; }       // (computed here from now on)
+                        if ((++idle & 63u) == 0) std::this_thread::yield(); else __builtin_ia32_pause();
+                        continue;
+                    }
+                    const ChainEmitter::Mark &mk = e.marks[(size_t)t.mark_at];
+                    if (mk.entry != t.taken) return fail(DQ_ERR_HIP, "anchor scan: a chain's emitter lost step with its list");
+                    const size_t c0 = t.mark_at > 0 ? e.marks[(size_t)t.mark_at - 1].ctrl : 0, d0 = t.mark_at > 0 ? e.marks[(size_t)t.mark_at - 1].diff : 0,
+                                 x0 = t.mark_at > 0 ? e.marks[(size_t)t.mark_at - 1].extra : 0;
+                    raw.ctrl.insert(raw.ctrl.end(), e.priv.ctrl.data() + c0, e.priv.ctrl.data() + mk.ctrl);
+                    raw.diff.insert(raw.diff.end(), e.priv.diff.data() + d0, e.priv.diff.data() + mk.diff);
+                    raw.extra.insert(raw.extra.end(), e.priv.extra.data() + x0, e.priv.extra.data() + mk.extra);
+                    em.prev = mk.prev;
+                    if (em.progress) {
+                        em.progress[0].store(raw.diff.size(), std::memory_order_release);
+                        em.progress[1].store(raw.extra.size(), std::memory_order_release);
+                    }
+                    ++t.mark_at;
+                    ++n_adopted;
+                    t.shift = (int64_t)(uint32_t)v - cpos;
+                } else if (!silent) {
                     if (trace) {
                         const auto t0 = std::chrono::steady_clock::now();
                         em.take(cpos, (int64_t)(uint32_t)v);
@@ -932,6 +1101,8 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
                     }
                     t.shift = (int64_t)(uint32_t)v - cpos;
                 }
+                idle = 0;
+                ++t.taken;
                 const int j = try_join(cpos, silent, t.shift);
                 if (j < 0) return j;
                 continue;
@@ -985,8 +1156,10 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
     raw.searches += (int64_t)searches;
     if (em.progress) framer->complete();
     if (trace)
-        fprintf(stderr, "[dq] anchor scan: %lld chain launches, %lld joins, %lld chains dropped in %.3f ms; emitter (steps 2 and 3 on the host, beside the kernels): %.2f ms\n",
-                (long long)n_launches, (long long)n_joins, (long long)n_dropped, host_ms(), emit_ms);
+        fprintf(stderr, "[dq] anchor scan: %lld chain launches, %lld joins, %lld chains dropped in %.3f ms; emitter (steps 2 and 3 on the host, beside the kernels): %.2f ms "
+                "on this thread, %lld triples taken from the chains' own emitters\n", (long long)n_launches, (long long)n_joins, (long long)n_dropped, host_ms(), emit_ms,
+                (long long)n_adopted);
+    if (trace) fprintf(stderr, "[dq] emitter: extensions %.2f ms, diff bytes %.2f ms, extra bytes and triple %.2f ms\n", emit_phase_ms[0], emit_phase_ms[1], emit_phase_ms[2]);
     return DQ_OK;
 }
 

@@ -19,6 +19,7 @@
 #include <chrono>
 #include <mutex>
 #include <string>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -194,6 +195,7 @@ struct DeviceCtx {
     int scan_skip = 0;
     // several grids on one new file: how many slots of each one's pinned list may not read "pending" any more (all of
     // them before the first use)
+    std::shared_ptr<void> scan_pool;    // emitter threads' buffers of the device scan's chains (dq_diff.hip: ScanPool), kept between diffs
     unsigned long long scan_seq = 0;    // launches of the device scan so far (a chain writes its launch's number behind its result)
     int64_t scan_dirty[8] = {1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16};
 };

@@ -51,18 +51,27 @@ while time.time() < t_end:
             f.write(repr(dict(count=count, n=n, m=int(new.size), t=round(time.time() - (t_end - budget), 1))) + "\n")
         np.save(os.environ["STRESS_LOG"] + ".old.npy", old); np.save(os.environ["STRESS_LOG"] + ".new.npy", new)
     # (the device's anchor search with grids of several sizes, and the host loop over windows it falls back to)
-    os.environ.pop("DQ_SCAN_DEVICE", None); os.environ.pop("DQ_SCAN_GROUPS", None)
-    mode = int(rng.integers(0, 6))
+    # (several grids on one file -- "chains", dq_diff.hip -- start at 2 MiB of new by default: forced onto these short
+    # files with segments from 64 bytes on, 2 .. 8 grids, 1 .. 8 iteration ends walked into the next grid's part)
+    for k in ("DQ_SCAN_DEVICE", "DQ_SCAN_GROUPS", "DQ_SCAN_CHAINS", "DQ_SCAN_MIN_SEG", "DQ_SCAN_EXTRA", "DQ_SCAN_LANE_BUDGET", "DQ_SCAN_PAR_EMIT"): os.environ.pop(k, None)
+    mode = int(rng.integers(0, 10))
     if mode == 0: os.environ["DQ_SCAN_DEVICE"] = "0"
     elif mode == 1: os.environ["DQ_SCAN_GROUPS"] = "8"
     elif mode == 2: os.environ["DQ_SCAN_GROUPS"] = "48"
+    elif mode >= 5:
+        os.environ["DQ_SCAN_CHAINS"] = str(int(rng.integers(2, 9)))
+        os.environ["DQ_SCAN_MIN_SEG"] = str(int(rng.choice([64, 500, 4096, 30_000, 200_000])))
+        os.environ["DQ_SCAN_GROUPS"] = str(int(rng.choice([8, 16, 32])))
+        os.environ["DQ_SCAN_EXTRA"] = str(int(rng.choice([1, 2, 8])))
+        os.environ["DQ_SCAN_LANE_BUDGET"] = str(int(rng.choice([1, 2, 4])))
+        if rng.random() < 0.25: os.environ["DQ_SCAN_PAR_EMIT"] = "0"       # (no emitter threads of the chains' own)
     t0 = time.time(); ctrl, diff, extra, st = Diff.Scan(old, new); t1 = time.time()
     sa = oracle.divsufsort(old)
     wc, wd, we, ns = oracle.bsdiff_scan(old, sa, new); t2 = time.time()
     if t2 - t0 > 5.0:
         print(f"slow pair {count}: n={n} m={new.size} device {t1-t0:.1f} s, oracle {t2-t1:.1f} s, {st}, old[:8]={old[:8].tolist()}", flush=True)
-    ok = np.array_equal(ctrl, wc) and np.array_equal(diff, wd) and np.array_equal(extra, we)
-    what = "raw streams"
+    ok = np.array_equal(ctrl, wc) and np.array_equal(diff, wd) and np.array_equal(extra, we) and st["searches"] == ns
+    what = "raw streams / Search count"
     if ok and count % 4 == 0:
         # framing: behind the running scan from the first byte / behind it by default (files >= 256 KiB) / after it;
         # block transform with and without the shortcuts for doubled blocks and run-length coded diff streams
@@ -86,7 +95,7 @@ while time.time() < t_end:
                   [plong(got[0][i:i + 8]) for i in range(0, len(got[0]), 8)] == wc.ravel().tolist())
             what = "streams as libbz2 reads them"
     if not ok:
-        print("failed:", what, "stats", st, flush=True)
+        print("failed:", what, "stats", st, "oracle searches", ns, {k: v for k, v in os.environ.items() if k.startswith("DQ_")}, flush=True)
         for rep in range(3):                              # the same pair again, in this process
             c2, d2, e2, st2 = Diff.Scan(old, new)
             p2 = Diff.CreateBytes(old, new)

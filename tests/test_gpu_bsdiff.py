@@ -66,6 +66,7 @@ def pairs(oracle_mod):
 # grid's start and after one window of one position per lane)
 SCAN_PATHS = [{}, {"DQ_SCAN_DEVICE": "0"}, {"DQ_SCAN_GROUPS": "8"}, {"DQ_SCAN_GROUPS": "48"},
               {"DQ_SCAN_CHAINS": "4", "DQ_SCAN_MIN_SEG": "2048"},
+              {"DQ_SCAN_CHAINS": "5", "DQ_SCAN_MIN_SEG": "1000", "DQ_SCAN_PAR_EMIT": "0"},       # (every triple computed on the calling thread)
               {"DQ_SCAN_CHAINS": "8", "DQ_SCAN_MIN_SEG": "300", "DQ_SCAN_GROUPS": "16", "DQ_SCAN_EXTRA": "1", "DQ_SCAN_LANE_BUDGET": "1"}]
 
 
