@@ -97,8 +97,8 @@ static_assert(sizeof(AnchorCtl) <= 248, "a control block and the word behind it 
 // share the device's few hardware queues, and a chain's completion was reported one whole kernel late behind another
 // chain's -- 16 MiB pair with 2000 edits 26 ms, 21 ms with GPU_MAX_HW_QUEUES=8.  For the same reason a chain's result does
 // not wait for the stream either: the chain writes it to pinned memory itself, the launch's number behind it.)
-constexpr int kScanMaxChains = 8;
-constexpr int64_t kAnchorRecs = 1 << 16;                  // list entries per chain and launch
+constexpr int kScanMaxChains = 16;
+constexpr int64_t kAnchorRecs = 1 << 15;                  // list entries per chain and launch
 constexpr size_t kAnchorAnswers = ((size_t)kAsMaxLaneWin + (size_t)kAsMaxGroups * kAsWaves) * 32;    // two buffers of either kind, 16 B a slot
 // device scratch: control blocks (in: the state to start from; the error word), completion words, answer buffers
 constexpr size_t kAsFinishedAt = (size_t)kScanMaxChains * 256;
@@ -161,8 +161,14 @@ __device__ __forceinline__ int64_t as_wave_count_equal(const uint8_t *po, int64_
     return (int64_t)__shfl(wave_incl_sum(c), kWave - 1, kWave);
 }
 
-template <typename IdxT>
-__global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
+inline size_t as_agp_bytes(int groups) { return ((size_t)groups * kAsThreads + 2) * 2 + 12 & ~(size_t)15; }
+
+// kMinBlocks 1: all the registers the search wants (352), one workgroup per compute unit; 2: 256 registers, 117 spilled
+// (a window ~11 % slower), two workgroups per compute unit -- for launches of more narrow grids than the device holds
+// otherwise (16 MiB pair with 2000 edits, Diff.Create: 8 grids of 32 with all registers 14.0 ms, 16 with half 12.5;
+// 20 000 small edits 40.7 / 31.7)
+template <typename IdxT, int kMinBlocks>
+__global__ __launch_bounds__(kAsThreads, kMinBlocks) void anchor_scan_kernel(
     const uint8_t *__restrict__ old, int64_t n, const IdxT *__restrict__ sa, const uint8_t *__restrict__ nw, int64_t m,
     const IdxT *__restrict__ ptab, int pk, char *__restrict__ scratch, char *__restrict__ pinned, const AnchorLaunch ln)
 {
@@ -180,7 +186,9 @@ __global__ __launch_bounds__(kAsThreads) void anchor_scan_kernel(
     unsigned long long *__restrict__ cum = rec + kAnchorRecs;
     AnchorCtl *__restrict__ out = reinterpret_cast<AnchorCtl *>(rec + 2 * kAnchorRecs);
     constexpr int64_t rec_cap = kAnchorRecs;
-    __shared__ uint16_t agp[kAsMaxLaneWin + 2];           // agp[x] = cnt(i, i + x), x = 0 .. c
+    // agp[x] = cnt(i, i + x), x = 0 .. c: as_agp_bytes(groups) of dynamic LDS -- a narrow grid's workgroups are small, and
+    // more of them fit the device at once (16 grids of 32 workgroups: 16 KB each; 64 KB for a grid of 128)
+    extern __shared__ uint16_t agp[];
     const int64_t kAsWaveWin = (int64_t)n_groups * kAsWaves;       // positions of a one-wave-per-position window
     const int64_t kAsLaneWin = kAsWaveWin * kWave;                 // ... of a one-lane-per-position window
     const int wave_wins = (int)((kAsWaveWins * kAsGroups * kAsWaves + kAsWaveWin - 1) / kAsWaveWin) < kAsWaveWinsMax

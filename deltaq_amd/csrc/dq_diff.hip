@@ -590,7 +590,7 @@ public:
 // chain then takes it with the whole grid, alone, until that iteration ends).  Nothing is decided by a guess: a chain that
 // is never joined is dropped, and the followed chain is launched again from where it stood.
 constexpr unsigned long long kAnchorPending = ~0ull;
-constexpr int kScanChains = 8;                            // grids on one new file (DQ_SCAN_CHAINS) and workgroups of each when there are
+constexpr int kScanChains = 16;                           // grids on one new file (DQ_SCAN_CHAINS) and workgroups of each when there are
 constexpr int kScanChainGroups = 32;                      // several (DQ_SCAN_GROUPS).  16 MiB pairs, Diff.Create in ms -- random bytes with
                                                           // 2000 edits / text with 2000 / random with 20 000 small edits / 4 MiB of
                                                           // unrelated bytes: one grid of 128 workgroups 38.8 / 67.1 / 261.5 / 83.2,
@@ -720,19 +720,31 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
     // kept full by other streams or processes -- every such launch costs its spin bound), the host loop over windows
     // takes the file instead.
     if (c.scan_groups_cap < 0) {
-        int per_cu = 0, ncu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, anchor_scan_kernel<int32_t>, kAsThreads, 0) != hipSuccess) per_cu = 0;
+        int per_cu = 0, per_cu_narrow = 0, ncu = 0;
+        // (the widest grid's workgroups ask for a little more than 64 KB of dynamic LDS)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&anchor_scan_kernel<int32_t, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)as_agp_bytes(kAsMaxGroups)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&anchor_scan_kernel<int32_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)as_agp_bytes(kAsMaxGroups)));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, anchor_scan_kernel<int32_t, 1>, kAsThreads, as_agp_bytes(kAsMaxGroups)) != hipSuccess) per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_narrow, anchor_scan_kernel<int32_t, 2>, kAsThreads, as_agp_bytes(kScanChainGroups)) != hipSuccess)
+            per_cu_narrow = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ix.dev) != hipSuccess) ncu = 0;
         c.scan_groups_cap = per_cu > 0 && ncu > 0 ? per_cu * ncu : kAsGroups;       // (unknown: as before)
-        if (trace) fprintf(stderr, "[dq] anchor scan: %d workgroups per compute unit x %d compute units resident\n", per_cu, ncu);
+        c.scan_groups_cap_narrow = per_cu_narrow > 0 && ncu > 0 ? per_cu_narrow * ncu : c.scan_groups_cap;
+        if (trace) fprintf(stderr, "[dq] anchor scan: %d workgroups per compute unit (%d of a grid of %d) x %d compute units resident\n", per_cu, per_cu_narrow,
+                           kScanChainGroups, ncu);
     }
     int cap = c.scan_groups_cap;
     if (const char *v = env("DQ_SCAN_GROUPS_CAP")) cap = std::min(cap, std::max(0, atoi(v)));           // (tests: a small device)
     const int asked = env("DQ_SCAN_GROUPS") ? std::max(8, std::min(kAsMaxGroups, atoi(env("DQ_SCAN_GROUPS")))) : 0;
     const int groups_alone = std::min(asked ? asked : kAsGroups, cap);                 // a grid that is alone on the file
     const int groups_chain = std::min(asked ? asked : kScanChainGroups, cap);          // one of several
+    // (workgroups of narrow grids the device holds at once: more than of the widest, their LDS is a quarter)
+    int cap_chains = groups_chain <= kScanChainGroups ? std::max(cap, c.scan_groups_cap_narrow) : cap;
+    if (const char *v = env("DQ_SCAN_GROUPS_CAP")) cap_chains = std::min(cap_chains, std::max(0, atoi(v)));
     int chains_max = env("DQ_SCAN_CHAINS") ? std::max(1, std::min(kScanMaxChains, atoi(env("DQ_SCAN_CHAINS")))) : kScanChains;
-    if (groups_chain >= 8) chains_max = std::min(chains_max, cap / groups_chain);
+    if (groups_chain >= 8) chains_max = std::min(chains_max, cap_chains / groups_chain);
     const int64_t min_seg = env("DQ_SCAN_MIN_SEG") ? std::max<int64_t>(64, atoll(env("DQ_SCAN_MIN_SEG"))) : kScanMinSegment;
     const int64_t extra_ends = env("DQ_SCAN_EXTRA") ? std::max<int64_t>(1, atoll(env("DQ_SCAN_EXTRA"))) : kScanExtra;
     const int64_t lane_budget = env("DQ_SCAN_LANE_BUDGET") ? std::max<int64_t>(1, atoll(env("DQ_SCAN_LANE_BUDGET"))) : kScanLaneBudget;
@@ -887,10 +899,17 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         HIP_TRY(hipMemsetAsync(scratch + kAsFinishedAt, 0, (size_t)kScanMaxChains * 2048, c.stream));
         for (int s : slots)                                // (no answer word carries a window's tag yet)
             HIP_TRY(hipMemsetAsync(scratch + kAsAnswersAt + (size_t)s * kAnchorAnswers, 0xff, kAnchorAnswers, c.stream));
-        LAUNCH(L, DQ_K_MATCH_SEARCH, m, m * 2,
-               hipLaunchKernelGGL(anchor_scan_kernel<int32_t>, dim3(groups * ln.chains), dim3(kAsThreads), 0, c.stream,
-                                  (const uint8_t *)ix.d_old, ix.n, (const int32_t *)ix.d_sa, (const uint8_t *)d_new, m,
-                                  (const int32_t *)ix.d_tab, ix.pk, scratch, pinned_chains, ln));
+        // (all its registers where the launch fits the device with one workgroup per compute unit)
+        if (groups * ln.chains <= cap)
+            LAUNCH(L, DQ_K_MATCH_SEARCH, m, m * 2,
+                   hipLaunchKernelGGL((anchor_scan_kernel<int32_t, 1>), dim3(groups * ln.chains), dim3(kAsThreads), as_agp_bytes(groups), c.stream,
+                                      (const uint8_t *)ix.d_old, ix.n, (const int32_t *)ix.d_sa, (const uint8_t *)d_new, m,
+                                      (const int32_t *)ix.d_tab, ix.pk, scratch, pinned_chains, ln));
+        else
+            LAUNCH(L, DQ_K_MATCH_SEARCH, m, m * 2,
+                   hipLaunchKernelGGL((anchor_scan_kernel<int32_t, 2>), dim3(groups * ln.chains), dim3(kAsThreads), as_agp_bytes(groups), c.stream,
+                                      (const uint8_t *)ix.d_old, ix.n, (const int32_t *)ix.d_sa, (const uint8_t *)d_new, m,
+                                      (const int32_t *)ix.d_tab, ix.pk, scratch, pinned_chains, ln));
         launch_out = true;
         for (int s : slots) {
             ScanChain &x = ch[s];

@@ -191,13 +191,15 @@ struct DeviceCtx {
     // the persistent grid of the device's anchor scan (dq_anchor_scan.h) must be resident as a whole: workgroups the
     // device holds at once (occupancy x compute units; -1: not asked yet), and how many diffs still skip the device
     // scan after a launch whose workgroups waited in vain for each other (a device kept full by other work)
-    int scan_groups_cap = -1;
+    int scan_groups_cap = -1;           // (a grid of kAsGroups workgroups, the widest: 64 KB of LDS each)
+    int scan_groups_cap_narrow = -1;    // (grids of 32 workgroups, 16 KB of LDS each)
     int scan_skip = 0;
     // several grids on one new file: how many slots of each one's pinned list may not read "pending" any more (all of
     // them before the first use)
     std::shared_ptr<void> scan_pool;    // emitter threads' buffers of the device scan's chains (dq_diff.hip: ScanPool), kept between diffs
     unsigned long long scan_seq = 0;    // launches of the device scan so far (a chain writes its launch's number behind its result)
-    int64_t scan_dirty[8] = {1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16};
+    int64_t scan_dirty[16] = {1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16,
+                              1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16, 1 << 16};
 };
 constexpr int kMaxDevices = 64;
 // A device has several contexts ("slots": stream + workspace + pinned areas each).  Texts of up to kSlotSmallN bytes
