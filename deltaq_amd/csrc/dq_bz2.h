@@ -658,6 +658,8 @@ inline int framing_threads_acquire(int want)
 }
 inline void framing_threads_release(int n) { if (n > 0) framing_threads_in_use().fetch_sub(n); }
 
+constexpr size_t kBlockSpan = (size_t)4 << 20;              // bytes of a stream one block covers at most (StreamEncoder)
+
 // One stream, encoded while its bytes are still being produced.  feed() follows the producer with the run-length
 // pre-pass and the block CRCs (which fix the block boundaries exactly as one sweep over the finished stream would: a
 // run is only taken once the 255 bytes it may cover are known); a block that fills up goes to an encoder thread of
@@ -668,8 +670,13 @@ inline void framing_threads_release(int n) { if (n > 0) framing_threads_in_use()
 // One thread calls feed() / finish(); the sorter must be callable from several threads at once.
 class StreamEncoder {
 public:
-    explicit StreamEncoder(DoubledSorter sorter_, int level_ = 9)
-        : sorter(std::move(sorter_)), level(level_), block_max((size_t)level_ * 100000 - 19) {}
+    // span_max: a block also ends once it covers this many bytes of the stream.  (libbz2 cuts by coded size alone, which
+    // makes the 16 MiB of mostly zeros of a diff stream ONE block of 425 KB that can only be transformed when the stream
+    // is over -- 4.6 ms behind the scan of a Diff.Create that takes 12; blocks of at most 4 MiB of input are encoded
+    // while the stream still grows, a quarter is left behind it, and the stream is ~1 % longer for their tables.  Which
+    // blocks a stream is cut into depends on its bytes alone, never on how it was fed.)
+    explicit StreamEncoder(DoubledSorter sorter_, int level_ = 9, size_t span_max_ = kBlockSpan)
+        : sorter(std::move(sorter_)), level(level_), block_max((size_t)level_ * 100000 - 19), span_max(span_max_ ? span_max_ : (size_t)-1) {}
     StreamEncoder(const StreamEncoder &) = delete;
     StreamEncoder &operator=(const StreamEncoder &) = delete;
     ~StreamEncoder() { join_all(); }
@@ -687,11 +694,12 @@ public:
                 open = true;
                 crc = 0xffffffffu;
                 crc_done = pos;
+                block_from = pos;
             }
             std::vector<uint8_t> &blk = blocks.back().rle;
             size_t i = pos;
             // run-length pre-pass: a run of 4..255 equal bytes becomes 4 bytes + (length - 4)
-            while (i < stop && blk.size() + 5 <= block_max) {
+            while (i < stop && blk.size() + 5 <= block_max && i - block_from < span_max) {
                 const uint8_t c = src[i];
                 size_t run = 1;
                 const size_t lim = upto - i < 255 ? upto - i : 255;
@@ -727,6 +735,7 @@ public:
                     size_t more = z / 255;
                     if (i < stop) more = std::min(more, (stop - i + 254) / 255); else more = 0;
                     more = std::min(more, (block_max - blk.size()) / 5);
+                    if (i - block_from < span_max) more = std::min(more, (span_max - (i - block_from) + 254) / 255); else more = 0;
                     if (more > 0) {
                         const size_t at = blk.size();
                         blk.resize(at + 5 * more);
@@ -739,7 +748,7 @@ public:
             pos = i;
             crc = crc_update_mt(crc, src + crc_done, pos - crc_done);    // of the block's input bytes (4 threads from 2 MiB a call)
             crc_done = pos;
-            if (blk.size() + 5 > block_max) close_block(/*more_to_come=*/true);
+            if (blk.size() + 5 > block_max || pos - block_from >= span_max) close_block(/*more_to_come=*/true);
         }
         if (last && open) close_block(false);
     }
@@ -862,16 +871,18 @@ private:
     size_t block_max;
     std::deque<Block> blocks;            // (a deque: blocks stay where they are while their encoders run)
     std::deque<Helper> helpers;
-    size_t pos = 0, crc_done = 0;
+    size_t span_max;
+    size_t pos = 0, crc_done = 0, block_from = 0;
     uint32_t crc = 0;
     bool open = false;
     bool hold = false;
 };
 
 // level 1..9: blocks of level * 100000 - 19 run-length coded bytes (libbz2's limit).
-inline int bz2_compress(const uint8_t *src, size_t n, std::vector<uint8_t> &out, const DoubledSorter &sorter, int level = 9)
+inline int bz2_compress(const uint8_t *src, size_t n, std::vector<uint8_t> &out, const DoubledSorter &sorter, int level = 9,
+                        size_t span_max = kBlockSpan)
 {
-    StreamEncoder enc(sorter, level);
+    StreamEncoder enc(sorter, level, span_max);
     enc.feed(src, n, true);
     return enc.finish(out);
 }

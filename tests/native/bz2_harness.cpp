@@ -22,6 +22,9 @@ static int naive_sorter(const uint8_t *t, int64_t n, int32_t *sa)
 
 extern "C" {
 
+int64_t t_bz2_prepass_span(const uint8_t *src, int64_t n, int32_t level, int64_t max_step, uint32_t seed, uint8_t *rle, int64_t cap,
+                           uint32_t *lens, uint32_t *crcs, int64_t max_blocks, int64_t span);
+
 // returns the compressed length, or a negative code; cap = capacity of out
 int64_t t_bz2_compress(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap, int32_t level)
 {
@@ -59,7 +62,16 @@ int64_t t_bz2_compress_fed(const uint8_t *src, int64_t n, uint8_t *out, int64_t 
 int64_t t_bz2_prepass(const uint8_t *src, int64_t n, int32_t level, int64_t max_step, uint32_t seed, uint8_t *rle, int64_t cap,
                       uint32_t *lens, uint32_t *crcs, int64_t max_blocks)
 {
-    dq::bz2::StreamEncoder enc(naive_sorter, level);
+    return t_bz2_prepass_span(src, n, level, max_step, seed, rle, cap, lens, crcs, max_blocks, 0);
+}
+
+// ... with a bound on the bytes of the stream one block covers (0: none, the plain definition; the product's default is
+// dq::bz2::kBlockSpan)
+int64_t t_bz2_block_span(void) { return (int64_t)dq::bz2::kBlockSpan; }
+int64_t t_bz2_prepass_span(const uint8_t *src, int64_t n, int32_t level, int64_t max_step, uint32_t seed, uint8_t *rle, int64_t cap,
+                           uint32_t *lens, uint32_t *crcs, int64_t max_blocks, int64_t span)
+{
+    dq::bz2::StreamEncoder enc(naive_sorter, level, span > 0 ? (size_t)span : 0);
     enc.hold_blocks();
     uint64_t x = seed * 0x9e3779b97f4a7c15ull + 1;
     int64_t upto = 0;

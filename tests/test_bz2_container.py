@@ -90,9 +90,10 @@ def crc32_bzip2(data):
     return int(f"{zlib.crc32(bytes(data).translate(_REV8)) & 0xffffffff:032b}"[::-1], 2)
 
 
-def rle1_blocks(data, level):
+def rle1_blocks(data, level, span=0):
     """bzip2's first run-length pass and its block cut, written out plainly: runs of 4..255 equal bytes become four bytes
-    and a count; a block closes when fewer than 5 bytes of room are left in its level * 100000 - 19."""
+    and a count; a block closes when fewer than 5 bytes of room are left in its level * 100000 - 19 -- or, with span > 0
+    (the product: dq::bz2::kBlockSpan), once it covers span bytes of the stream."""
     a = np.frombuffer(data, np.uint8)
     block_max = level * 100000 - 19
     starts = np.flatnonzero(np.concatenate([[True], a[1:] != a[:-1]])) if a.size else np.zeros(0, np.int64)
@@ -101,7 +102,7 @@ def rle1_blocks(data, level):
     for s0, e0 in zip(starts.tolist(), ends.tolist()):
         c, left = int(a[s0]), e0 - s0
         while left > 0:
-            if len(cur) + 5 > block_max:
+            if len(cur) + 5 > block_max or (span and pos - cur_start >= span):
                 blocks.append(bytes(cur)); spans.append((cur_start, pos)); cur, cur_start = bytearray(), pos
             run = min(left, 255)
             cur += bytes([c]) * 4 + bytes([run - 4]) if run >= 4 else bytes([c]) * run
@@ -132,18 +133,27 @@ def test_prepass_cuts_the_blocks_of_the_definition(harness, oracle_mod):
     for _ in range(300):                                    # stretches of every length between noise
         mixed += bytes([int(rng.integers(0, 3))]) * int(rng.integers(1, 3000)) + rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8).tobytes()
     cases.append(bytes(mixed))
+    L.t_bz2_prepass_span.restype = ctypes.c_int64
+    L.t_bz2_prepass_span.argtypes = L.t_bz2_prepass.argtypes + [ctypes.c_int64]
+    L.t_bz2_block_span.restype = ctypes.c_int64
+    assert L.t_bz2_block_span() == 4 << 20
+    # (the plain definition; then blocks that also end once they cover `span` bytes of the stream -- the product's 4 MiB,
+    # and spans that fall inside runs, on multiples of 255 and between the pieces fed)
     for k, c in enumerate(cases):
-        want, spans = rle1_blocks(c, 1)
-        for step, seed in ((10_000_000, 1), (1000, 2), (257, 3), (70_000, 4)):
-            rle = np.empty(len(c) + 64, np.uint8); lens = np.zeros(4096, np.uint32); crcs = np.zeros(4096, np.uint32)
-            nb = L.t_bz2_prepass(c, len(c), 1, step, seed, rle.ctypes.data, rle.size, lens.ctypes.data, crcs.ctypes.data, 4096)
-            assert nb == len(want), (k, step, nb, len(want))
-            off = 0
-            for b in range(nb):
-                assert rle[off:off + lens[b]].tobytes() == want[b], (k, step, b)
-                off += int(lens[b])
-                piece = c[spans[b][0]:spans[b][1]]
-                assert int(crcs[b]) == crc32_bzip2(piece), (k, step, b)
+        for span in (0, 4 << 20, 255 * 1000, 100_003, 1 << 20):
+            if span not in (0, 4 << 20) and len(c) < 100_000:
+                continue
+            want, spans = rle1_blocks(c, 1, span)
+            for step, seed in ((10_000_000, 1), (1000, 2), (257, 3), (70_000, 4)):
+                rle = np.empty(len(c) + 64, np.uint8); lens = np.zeros(4096, np.uint32); crcs = np.zeros(4096, np.uint32)
+                nb = L.t_bz2_prepass_span(c, len(c), 1, step, seed, rle.ctypes.data, rle.size, lens.ctypes.data, crcs.ctypes.data, 4096, span)
+                assert nb == len(want), (k, span, step, nb, len(want))
+                off = 0
+                for b in range(nb):
+                    assert rle[off:off + lens[b]].tobytes() == want[b], (k, span, step, b)
+                    off += int(lens[b])
+                    piece = c[spans[b][0]:spans[b][1]]
+                    assert int(crcs[b]) == crc32_bzip2(piece), (k, span, step, b)
     assert crc32_bzip2(b"123456789") == 0xfc891918 == L.t_crc_bitwise(b"123456789", 9)      # (the catalogue's check value)
     # the stepped-over zero bytes against the bit-by-bit definition
     for n in (63, 64, 65, 71, 72, 1000, 4096 + 3, 100_000):
