@@ -186,9 +186,10 @@ def category_of(kernel_name: str) -> int:
 def last_diff_info() -> dict:
     """Shape of the last Diff.Create / index diff on this thread (dq_last_diff_info)."""
     L = load()
-    v = (ctypes.c_int64 * 5)()
-    L.dq_last_diff_info(v, 5)
-    return {"searches": v[0], "windows": v[1], "exact": v[2], "host_loop_fallbacks": v[3], "scan_groups": v[4]}
+    v = (ctypes.c_int64 * 9)()
+    L.dq_last_diff_info(v, 9)
+    return {"searches": v[0], "windows": v[1], "exact": v[2], "host_loop_fallbacks": v[3], "scan_groups": v[4],
+            "chains_launched": v[5], "chains_joined": v[6], "chains_dropped": v[7], "triples_from_chain_emitters": v[8]}
 
 
 def last_batch_info() -> dict:

@@ -546,7 +546,7 @@ int32_t dq_device_numa_node(int32_t device)
 int32_t dq_last_diff_info(int64_t *info, int32_t count)
 {
     if (!info || count < 0) return fail(DQ_ERR_BAD_ARGS, "bad arguments");
-    for (int32_t k = 0; k < count; ++k) info[k] = k < 5 ? t_diff_info[k] : 0;
+    for (int32_t k = 0; k < count; ++k) info[k] = k < 9 ? t_diff_info[k] : 0;
     return DQ_OK;
 }
 

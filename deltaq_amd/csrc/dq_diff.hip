@@ -1173,6 +1173,7 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
         searches += j.from_v - j.to_v;
     }
     raw.searches += (int64_t)searches;
+    t_diff_info[5] = n_launches; t_diff_info[6] = n_joins; t_diff_info[7] = n_dropped; t_diff_info[8] = n_adopted;
     if (em.progress) framer->complete();
     if (trace)
         fprintf(stderr, "[dq] anchor scan: %lld chain launches, %lld joins, %lld chains dropped in %.3f ms; emitter (steps 2 and 3 on the host, beside the kernels): %.2f ms "

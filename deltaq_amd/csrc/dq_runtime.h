@@ -36,7 +36,7 @@ inline thread_local std::string t_err;
 inline thread_local int64_t t_info[3] = {0, 0, 0};
 // the last Diff.Create / index diff on this thread (dq_last_diff_info): Search calls of the loop, windows, positions
 // asked again exactly, launches of the device's anchor scan that were given back to the host loop, workgroups of its grid
-inline thread_local int64_t t_diff_info[5] = {0, 0, 0, 0, 0};
+inline thread_local int64_t t_diff_info[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 // the last dq_sufsort_hip_batch_i32 on this thread (dq_last_batch_info): inputs through the pipelines, microseconds the
 // copy-in / sort / copy-out stages were busy (summed over the device shares), wall microseconds of the slowest share,

@@ -198,12 +198,15 @@ int32_t dq_profile_category_count(void);   /* DQ_K_COUNT of the loaded library *
  * over all rounds. */
 int32_t dq_last_sort_info(int64_t *rounds, int64_t *initial_active, int64_t *sum_active);
 
-/* Shape of the last dq_bsdiff_create / dq_bsdiff_scan_i32 / dq_bsdiff_index_diff on this thread, `count` entries (5 are
+/* Shape of the last dq_bsdiff_create / dq_bsdiff_scan_i32 / dq_bsdiff_index_diff on this thread, `count` entries (9 are
  * defined, further ones read 0): Search calls the reference's loop makes (Diff.cs:106), windows of scan positions,
  * positions asked again exactly, files the host loop took instead of the device's anchor scan (host_loop_fallbacks: a
  * launch whose persistent grid waited in vain -- a device kept full by other work --, AND each of the 16 diffs after it
  * that skip the device scan on that device, and devices that hold fewer than 8 workgroups of the grid; the patch is
- * the same, the call slower, dq_last_error() is left untouched by it), workgroups of that grid. */
+ * the same, the call slower, dq_last_error() is left untouched by it), workgroups of that grid; [5..8] where several
+ * grids walked the new file at once: grids launched, grids the followed one was joined to (same place, same shift:
+ * their entries are the loop's from there on), grids dropped unjoined, control triples taken over from the grids' own
+ * emitter threads. */
 int32_t dq_last_diff_info(int64_t *info, int32_t count);
 
 /* Shape of the last dq_sufsort_hip_batch_i32 on this thread, `count` entries (6 are defined, further ones read 0):

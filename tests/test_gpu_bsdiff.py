@@ -83,6 +83,43 @@ def test_raw_streams_equal_the_reference_loop(backend_lib, oracle_mod, monkeypat
         assert stats["searches"] == searches
 
 
+def test_chains_are_joined_between_similar_files_and_dropped_between_unrelated_ones(backend_lib, oracle_mod, monkeypatch):
+    """Several grids on one new file (dq_diff.hip, "chains"): between similar files every speculative grid is joined --
+    same place, same shift -- and most triples come from the grids' own emitter threads; between unrelated files the
+    grids leave after their budget of lane windows and are dropped; the raw streams and the Search count are the
+    reference loop's either way.  By default the grids start at 2 MiB of new."""
+    from deltaq_amd import Diff, _abi
+    rng = np.random.default_rng(23)
+    old = oracle_mod.gen_uniform(6_000_000, 31)
+    similar = edited(rng, old, 400)
+    text = oracle_mod.gen_enwik_like(5_000_000, 9, 16384)
+    for o, x, kind in ((old, similar, "similar"), (text, edited(rng, text, 300), "similar"),
+                       (old, oracle_mod.gen_uniform(3_000_000, 32), "unrelated"), (old, old[1_000_000:5_500_000].copy(), "similar")):
+        wc, wd, we, searches = oracle_mod.bsdiff_scan(o, oracle_mod.divsufsort(o), x)
+        for env in ({}, {"DQ_SCAN_PAR_EMIT": "0"}, {"DQ_SCAN_CHAINS": "3"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ctrl, diff, extra, stats = Diff.Scan(o, x)
+            info = _abi.last_diff_info()
+            for k in env:
+                monkeypatch.delenv(k)
+            assert np.array_equal(ctrl, wc) and np.array_equal(diff, wd) and np.array_equal(extra, we) and stats["searches"] == searches, (kind, env)
+            assert info["host_loop_fallbacks"] == 0 and info["chains_launched"] >= 2, (kind, env, info)
+            if kind == "similar":
+                assert info["chains_joined"] >= 1 and info["chains_joined"] + info["chains_dropped"] <= info["chains_launched"], (env, info)
+                if "DQ_SCAN_PAR_EMIT" in env:
+                    assert info["triples_from_chain_emitters"] == 0, info
+                elif x.size > 4_000_000 and ctrl.size >= 300:
+                    assert info["triples_from_chain_emitters"] > ctrl.size // 3 // 4, (env, info, ctrl.shape)
+            else:
+                assert info["chains_joined"] == 0, (env, info)
+    # one grid alone below 2 MiB of new
+    small = edited(rng, old[:1_500_000], 50)
+    Diff.Scan(old, small)
+    info = _abi.last_diff_info()
+    assert info["chains_launched"] == 1 and info["chains_joined"] == 0 and info["scan_groups"] == 128, info
+
+
 def test_create_apply_roundtrip_and_cross_compatibility(backend_lib, oracle_mod):
     from deltaq_amd import Diff, Patch, HipSuffixSort
     for old, new in pairs(oracle_mod):

@@ -202,6 +202,27 @@ def test_starved_anchor_scan_falls_back_loudly(backend_lib, oracle_mod, monkeypa
     assert info["host_loop_fallbacks"] == 0
 
 
+def test_starved_chains_fall_back_loudly(backend_lib, oracle_mod, monkeypatch):
+    """Several grids on one file, a spin bound of 2 polls: whichever grid gives up, every launch is taken off the stream,
+    the emitter threads end, the host loop produces the oracle's streams, and the next call works."""
+    pairs = scan_pairs(oracle_mod)[:3]
+    monkeypatch.setenv("DQ_SCAN_CHAINS", "6")
+    monkeypatch.setenv("DQ_SCAN_MIN_SEG", "512")
+    monkeypatch.setenv("DQ_SCAN_GROUPS", "16")
+    monkeypatch.setenv("DQ_SCAN_SPIN_LOG2", "1")
+    fell = 0
+    for i, (old, new) in enumerate(pairs):
+        stats, info = check_pair(oracle_mod, old, new, ("chains, spin", i))
+        fell += info["host_loop_fallbacks"]
+    assert fell >= 1, "a spin bound of 2 polls never made the grids give up"
+    monkeypatch.delenv("DQ_SCAN_SPIN_LOG2")
+    for i, (old, new) in enumerate(pairs):
+        stats, info = check_pair(oracle_mod, old, new, ("chains, after", i))
+        assert info["host_loop_fallbacks"] == 0, info
+        if new.size >= 2048:
+            assert info["chains_launched"] >= 2, info
+
+
 def test_a_device_that_holds_too_few_workgroups_takes_the_host_loop(backend_lib, oracle_mod, monkeypatch):
     """Occupancy clamp (advisor, round 4): a part that holds fewer than 8 workgroups of the persistent grid never
     launches it; between 8 and 128 the grid shrinks to what is resident."""
