@@ -775,7 +775,7 @@ public:
         size_t pending = 0;
         for (Block &b : blocks) pending += b.claimed.load() == 0;
         if (pending >= 2) {
-            size_t extra = std::min<size_t>(pending, 4) - 1;
+            size_t extra = std::min<size_t>(pending, 8) - 1;
             const int granted = framing_threads_acquire((int)extra);
             std::vector<std::thread> ts;
             for (int t = 0; t < granted; ++t) {

@@ -1041,7 +1041,10 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
                             cur = best;
                             ++n_joins;
                             serial_log2 = 0;
-                            if (trace) fprintf(stderr, "[dq] anchor scan: chain %d joined at %lld, %.3f ms (emitter %.2f ms so far)\n", best, (long long)cpos, host_ms(), emit_ms);
+                            if (trace)
+                                fprintf(stderr, "[dq] anchor scan: chain %d joined at %lld (its entry %lld), %.3f ms (emitter %.2f ms so far; its own emitter: %s, %lld entries seen, %lld marks)\n",
+                                        best, (long long)cpos, (long long)x.taken - 1, host_ms(), emit_ms, !x.em ? "none" : x.em->failed.load() ? "failed" : "running",
+                                        x.em ? (long long)x.em->seen.load() : 0ll, x.em ? (long long)x.em->n_marks.load() : 0ll);
                             return 1;
                         }
                         break;                            // its next end lies behind c, or at c under another shift
@@ -1079,8 +1082,11 @@ int scan_on_device(const DiffIndex &ix, DeviceCtx &c, char *d_new, char *scratch
                 // Then what it writes from here on is what em would write.
                 if (want_adopt && !adopting && t.em) {
                     ChainEmitter &e = *t.em;
-                    if (e.failed.load(std::memory_order_acquire)) want_adopt = false;
-                    else if (e.seen.load(std::memory_order_acquire) >= t.taken) {
+                    // (an emitter that ran out of room -- its chain walked far beyond its part -- has stopped for good; what it
+                    // wrote up to there is as good as any)
+                    if (e.seen.load(std::memory_order_acquire) < t.taken) {
+                        if (e.failed.load(std::memory_order_acquire)) want_adopt = false;
+                    } else {
                         const int64_t nm = e.n_marks.load(std::memory_order_acquire);
                         while (t.mark_at < nm && e.marks[(size_t)t.mark_at].entry < t.taken) ++t.mark_at;
                         const bsdiff::TripleEmitter::Anchor theirs = t.mark_at > 0 ? e.marks[(size_t)t.mark_at - 1].prev : e.first;
