@@ -678,7 +678,7 @@ constexpr size_t kBlockSpan = (size_t)4 << 20;              // bytes of a stream
 // pre-pass and the block CRCs (which fix the block boundaries exactly as one sweep over the finished stream would: a
 // run is only taken once the 255 bytes it may cover are known); a block that fills up goes to an encoder thread of
 // its own, if the process-wide budget has one, while the pre-pass carries on; finish() encodes what is left -- on
-// up to 4 threads -- and appends the bit strings in order.  The diff stream of two similar 16 MiB files is
+// up to 8 threads -- and appends the bit strings in order.  The diff stream of two similar 16 MiB files is
 // 16 MiB of mostly zeros: its pre-pass and CRC (3 + 2..8 ms) now run beside the device's anchor search instead of
 // behind it, and the 900 KB blocks of the extra stream of unrelated files are encoded while the search goes on.
 // One thread calls feed() / finish(); the sorter must be callable from several threads at once.
@@ -771,7 +771,7 @@ public:
     int finish(std::vector<uint8_t> &out)
     {
         if (open) close_block(false);
-        // what no thread has claimed yet: the caller and up to kBlockThreads - 1 more threads take the blocks in turn
+        // what no thread has claimed yet: the caller and up to 7 more threads take the blocks in turn
         size_t pending = 0;
         for (Block &b : blocks) pending += b.claimed.load() == 0;
         if (pending >= 2) {
