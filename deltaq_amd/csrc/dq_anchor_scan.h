@@ -198,6 +198,9 @@ __global__ __launch_bounds__(kAsThreads, kMinBlocks) void anchor_scan_kernel(
     __shared__ int32_t w_brk[kAsWaves], w_stp[kAsWaves];
     __shared__ int64_t s_v[4];
     __shared__ uint32_t s_err;
+    // one-lane-per-position windows: what every workgroup says about its own 256 positions (see "2L" below)
+    __shared__ unsigned long long sm_key[kAsMaxGroups], sm_res[kAsMaxGroups][5];
+    __shared__ uint32_t sm_agree[kAsMaxGroups];
 
     const int tid = threadIdx.x;
     const int lane = lane_id();
@@ -365,6 +368,8 @@ __global__ __launch_bounds__(kAsThreads, kMinBlocks) void anchor_scan_kernel(
             ++n_win;
             const unsigned long long lag_seen = lagging_load(win_no);
             // ---- 0. the window's answers (and each match's own agree count), one position per wave or per lane ----
+            int64_t ln_p = 0, ln_l = 0, ln_cw = 0;          // (a lane window's answers stay with the lanes that searched)
+            bool ln_live = false;
             {
                 int64_t p = 0, l = 0, cw = 0, slot = -1;
                 bool cw_bound = false;
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(kAsThreads, kMinBlocks) void anchor_scan_kernel(
                                 if (p - j == shift) cw = l;
                                 else for (int64_t k = j; k < j + l; ++k) cw += agree(k) ? 1 : 0;
                             }
-                            slot = idx;
+                            ln_p = p; ln_l = l; ln_cw = cw; ln_live = true;
                         }
                     }
                 }
@@ -422,6 +427,11 @@ __global__ __launch_bounds__(kAsThreads, kMinBlocks) void anchor_scan_kernel(
                 if (slot >= 0) publish(slot, p, l, cw, cw_bound);
             }
 
+            int64_t Mrun = M, Crun = C;                    // (M, cnt(base, M)) after the positions walked over so far
+            int brk = -1, stp = -1;                        // window index of the first break / stop point
+            int64_t b_pos = 0, b_len = 0, b_carried = 0;
+            int64_t win_agree = 0, stp_agree = 0;          // cnt(i, i + c); cnt(i, stop point)
+            if (!lane_mode) {
             // ---- 1. prefix counts of agree() over the window's positions ----
             {
                 const int lc = (int)c;
@@ -449,9 +459,6 @@ __global__ __launch_bounds__(kAsThreads, kMinBlocks) void anchor_scan_kernel(
             }
 
             // ---- 2. the positions, a step at a time: prefix maximum of the match ends (with cnt(base, end)), break test ----
-            int64_t Mrun = M, Crun = C;                    // (M, cnt(base, M)) after the positions walked over so far
-            int brk = -1, stp = -1;                        // window index of the first break / stop point
-            int64_t b_pos = 0, b_len = 0, b_carried = 0;
             // (one-wave-per-position windows: the first 64 positions on their own -- a deletion or a copied stretch breaks
             // on the first few -- then 256 a step; one-lane-per-position windows: 256 positions a step, one workgroup's answers)
             for (int off = 0; off < (int)c && brk < 0 && stp < 0;) {
@@ -533,6 +540,165 @@ __global__ __launch_bounds__(kAsThreads, kMinBlocks) void anchor_scan_kernel(
                 }
                 __syncthreads();                           // (w_* and s_v are reused)
             }
+            win_agree = (int64_t)agp[c];
+            if (stp >= 0) stp_agree = (int64_t)agp[stp];
+            if (!failed && brk < 0 && stp < 0) {
+                // (the window's last position was in the last step: the word is this window's; never a stop point here)
+                const unsigned long long v = __hip_atomic_load(&ans_w[2 * (c - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last_len = (int64_t)((v >> 31) & 0x7fffffffull);
+                last_pos = (int64_t)(v & 0x7fffffffull);
+            }
+            } else {
+            // ---- 2L. one position per lane: every workgroup evaluates ITS OWN 256 positions, two small exchanges ----
+            // Walking such a window 256 answers a step, every workgroup on its own, was 128 dependent steps of uncached
+            // loads (0.16 ms a window, 128 workgroups x 512 KB of them: 4 MiB of unrelated bytes 37 ms of evaluation
+            // beside 1.6 ms of searches).  The steps only hand on (M, cnt(base, M)) and cnt(base, .) -- a running maximum
+            // and a running sum -- so every workgroup says what its own positions do to them (farthest match end with its
+            // count, number of agreeing positions), reads the others' two words, knows the state its positions start
+            // from, evaluates them exactly as a step of the loop above would, and says what it found; the first
+            // workgroup that found a break or a stop point is the window's.  Same integer decisions everywhere, as before.
+            {
+                const int G = n_groups;
+                const int64_t my0 = (int64_t)bid * kAsThreads;            // this workgroup's first position of the window
+                const bool have = ln_live;
+                bool stop = have && ln_l < 0;
+                const int64_t l = stop ? -1 : ln_l, p = ln_p;
+                const int t = (int)my0 + tid;                               // this thread's position of the window
+                const unsigned long long kTagMask = (1ull << 62) - 1;
+                auto put2 = [&](int64_t slot, unsigned long long a0, unsigned long long a1) {
+                    __hip_atomic_store(&ans_w[2 * slot], (tag_w << 62) | a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&ans_w[2 * slot + 1], (tag_w << 62) | a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                };
+                // A. agreeing positions of the chunk (prefix inside it), its farthest match end with the count up to it
+                const uint32_t a = (have && agree(i + t)) ? 1u : 0u;
+                const uint32_t incl = wave_incl_sum(a);
+                if (lane == kWave - 1) w_u32[wv] = incl;
+                __syncthreads();
+                uint32_t pl = incl - a, chunk_agree = 0;                    // cnt(chunk start, position); cnt over the chunk
+                for (int q = 0; q < kAsWaves; ++q) { if (q < wv) pl += w_u32[q]; chunk_agree += w_u32[q]; }
+                // (lane answers are capped: an end lies at most kAsCap behind its position)
+                uint64_t krel = (!have || stop) ? 0ull : ((uint64_t)(uint32_t)(t + l + 1) << 32) | (uint64_t)(0xffffffffu - (pl + (uint32_t)ln_cw));
+#pragma unroll
+                for (int o = kWave / 2; o > 0; o >>= 1) { const uint64_t tk = __shfl_xor(krel, o, kWave); krel = tk > krel ? tk : krel; }
+                if (lane == 0) w_e[wv] = (int64_t)krel;
+                __syncthreads();
+                if (tid == 0) {
+                    uint64_t ck = 0;
+                    for (int q = 0; q < kAsWaves; ++q) ck = (uint64_t)w_e[q] > ck ? (uint64_t)w_e[q] : ck;
+                    // (end + 1 in 17 bits, the count's complement in 32)
+                    put2(bid, ((ck >> 32) << 32 | (ck & 0xffffffffull)) & kTagMask, (unsigned long long)chunk_agree);
+                }
+                lap(t_eval);
+                // B. everybody's two words
+                if (tid < G) {
+                    unsigned long long v, v2;
+                    fetch(tid, &v, &v2);
+                    sm_key[tid] = v & kTagMask;
+                    sm_agree[tid] = (uint32_t)(v2 & kTagMask);
+                }
+                __syncthreads();
+                lap(t_wait);
+                if (s_err) { failed = true; }
+                int64_t Min = M, Cin = C, Mall = M, Call = C;              // state in front of this chunk / behind the window
+                uint32_t before = 0, total = 0;
+                if (!failed) {
+                    for (int v = 0; v < G; ++v) {
+                        if (v == bid) { Min = Mall; Cin = Call; before = total; }
+                        const unsigned long long k = sm_key[v];
+                        if (k) {
+                            const int64_t e = i + (int64_t)(k >> 32) - 1;
+                            if (e > Mall) { Mall = e; Call = S + (int64_t)total + (int64_t)(0xffffffffu - (uint32_t)k); }
+                        }
+                        total += sm_agree[v];
+                    }
+                }
+                // this chunk, exactly as a step of the loop over a wave window evaluates 256 positions
+                const int64_t Sj = S + (int64_t)before + (int64_t)pl;
+                const int64_t e = (have && !stop) ? i + t + l : -1, ce = Sj + ln_cw;
+                const uint64_t key = e < 0 ? 0ull : (((uint64_t)(uint32_t)(e - i + 1)) << 32) | (uint64_t)(0xffffffffu - (uint32_t)ce);
+                uint64_t pk = key;
+#pragma unroll
+                for (int o = 1; o < kWave; o <<= 1) {
+                    const uint64_t tk = __shfl_up(pk, o, kWave);
+                    if (lane >= o && tk > pk) pk = tk;
+                }
+                auto end_of = [&](uint64_t k) -> int64_t { return k ? (int64_t)(k >> 32) - 1 + i : (int64_t)-1; };
+                auto cnt_of = [&](uint64_t k) -> int64_t { return k ? (int64_t)(0xffffffffu - (uint32_t)k) : (int64_t)0; };
+                const int64_t pe = end_of(pk), pc = cnt_of(pk);
+                __syncthreads();                           // (w_e was the chunk maximum's)
+                if (lane == kWave - 1) { w_e[wv] = pe; w_c[wv] = pc; }
+                __syncthreads();
+                int64_t ce_in = Min, cc_in = Cin;          // what comes in from the left of this wave
+                for (int q = 0; q < wv; ++q) if (w_e[q] > ce_in) { ce_in = w_e[q]; cc_in = w_c[q]; }
+                const uint64_t xk = __shfl_up(pk, 1, kWave);
+                int64_t xe = end_of(xk), xc = cnt_of(xk);
+                if (lane == 0 || xe <= ce_in) { xe = ce_in; xc = cc_in; }
+                int64_t Mj = xe, Cj = xc;
+                if (e > Mj) { Mj = e; Cj = ce; }
+                bool brk_here = false;
+                int64_t carried = 0;
+                if (have && !stop) {
+                    carried = Cj - Sj;
+                    brk_here = (l == carried && l != 0) || l > carried + 8;
+                }
+                const uint64_t mb = __ballot(brk_here), ms = __ballot(have && stop);
+                const int32_t t0w = (int32_t)my0 + (wv << 6);
+                const int32_t fb = mb ? t0w + __builtin_ctzll(mb) : 0x7fffffff, fs = ms ? t0w + __builtin_ctzll(ms) : 0x7fffffff;
+                if (lane == 0) { w_brk[wv] = fb; w_stp[wv] = fs; }
+                __syncthreads();
+                int32_t b = 0x7fffffff, s2 = 0x7fffffff;
+                for (int q = 0; q < kAsWaves; ++q) { b = w_brk[q] < b ? w_brk[q] : b; s2 = w_stp[q] < s2 ? w_stp[q] : s2; }
+                const int my_brk = b < s2 ? b : -1, my_stp = (b >= s2 && s2 != 0x7fffffff) ? s2 : -1;
+                const int at = my_brk >= 0 ? my_brk : my_stp;
+                // the thread at the break / stop point -- or, if the chunk has none, at its last position -- says it
+                const int last_t = (int)(c - 1 < my0 + kAsThreads - 1 ? c - 1 : my0 + kAsThreads - 1);
+                if (!failed && (at >= 0 ? t == at : (t == last_t || (last_t < (int)my0 && tid == 0)))) {
+                    const unsigned long long lf = l < 0 ? kAsStopLen : (unsigned long long)l, pf = l < 0 ? 0ull : (unsigned long long)p;
+                    const unsigned long long type = my_brk >= 0 ? 1ull : my_stp >= 0 ? 2ull : 0ull;
+                    put2(G + 3 * (int64_t)bid, have ? (lf << 31) | pf : 0ull,
+                         (type << 56) | ((unsigned long long)(at >= 0 ? at - (int)my0 : 0) << 40) | (unsigned long long)(at >= 0 ? carried : 0));
+                    put2(G + 3 * (int64_t)bid + 1, (unsigned long long)(xe - i + 1), (unsigned long long)xc);
+                    put2(G + 3 * (int64_t)bid + 2, (unsigned long long)before + pl, 0ull);
+                }
+                lap(t_eval);
+                // C. everybody's findings: the first workgroup with a break or a stop point has the window's
+                if (tid < G && !failed) {
+                    unsigned long long v, v2;
+                    fetch(G + 3 * (int64_t)tid, &v, &v2);
+                    sm_res[tid][0] = v & kTagMask; sm_res[tid][1] = v2 & kTagMask;
+                    fetch(G + 3 * (int64_t)tid + 1, &v, &v2);
+                    sm_res[tid][2] = v & kTagMask; sm_res[tid][3] = v2 & kTagMask;
+                    fetch(G + 3 * (int64_t)tid + 2, &v, &v2);
+                    sm_res[tid][4] = v & kTagMask;
+                }
+                __syncthreads();
+                lap(t_wait);
+                if (s_err) failed = true;
+                if (!failed) {
+                    int first = -1;
+                    for (int v = 0; v < G; ++v) if ((sm_res[v][1] >> 56) != 0) { first = v; break; }
+                    if (first >= 0) {
+                        const unsigned long long r1 = sm_res[first][1];
+                        const int where = first * kAsThreads + (int)((r1 >> 40) & 0xffffull);
+                        if ((r1 >> 56) == 1ull) brk = where; else stp = where;
+                        b_carried = (int64_t)(r1 & ((1ull << 40) - 1));
+                        const unsigned long long r0 = sm_res[first][0];
+                        b_len = (int64_t)((r0 >> 31) & 0x7fffffffull);
+                        b_pos = (int64_t)(r0 & 0x7fffffffull);
+                        Mrun = (int64_t)sm_res[first][2] - 1 + i;
+                        Crun = (int64_t)sm_res[first][3];
+                        stp_agree = (int64_t)sm_res[first][4];
+                    } else {
+                        Mrun = Mall; Crun = Call;
+                        win_agree = (int64_t)total;
+                        const unsigned long long r0 = sm_res[(c - 1) / kAsThreads][0];
+                        last_len = (int64_t)((r0 >> 31) & 0x7fffffffull);
+                        last_pos = (int64_t)(r0 & 0x7fffffffull);
+                    }
+                }
+                __syncthreads();                           // (sm_*, w_* are reused)
+            }
+            }
 
             lap(t_eval);
             if (failed) break;
@@ -544,15 +710,11 @@ __global__ __launch_bounds__(kAsThreads, kMinBlocks) void anchor_scan_kernel(
                 window_done();
                 break;
             }
-            if (stp < 0) {                                 // the whole window went by
-                // (its last position was in the last step: the word is this window's; never a stop point here)
-                const unsigned long long v = __hip_atomic_load(&ans_w[2 * (c - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last_len = (int64_t)((v >> 31) & 0x7fffffffull);
-                last_pos = (int64_t)(v & 0x7fffffffull);
+            if (stp < 0) {                                 // the whole window went by (last_pos / last_len: its last answer)
                 any_search = true;
                 window_done();
                 M = Mrun; C = Crun;
-                S += (int64_t)agp[c];
+                S += win_agree;
                 i += c;
                 // a long differing stretch: after kAsWaveWins windows of one position per wave, one per lane (an edit of a
                 // few hundred bytes is walked over by the cheaper wave windows; unrelated data by 8192 positions a step)
@@ -572,7 +734,7 @@ __global__ __launch_bounds__(kAsThreads, kMinBlocks) void anchor_scan_kernel(
                 const int64_t p = s_v[0], l = s_v[1], cw = s_v[2];
                 __syncthreads();
                 lap(t_stop);
-                const int64_t Sj = S + (int64_t)agp[stp];
+                const int64_t Sj = S + stp_agree;
                 M = Mrun; C = Crun;
                 if (j + l > M) { M = j + l; C = Sj + cw; }
                 const int64_t carried = C - Sj;

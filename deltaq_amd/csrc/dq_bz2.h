@@ -383,6 +383,42 @@ struct BitWriter {
         while (have >= 8) { out.push_back((uint8_t)(buf >> (have - 8))); have -= 8; }
     }
     void flush() { if (have > 0) { out.push_back((uint8_t)(buf << (8 - have))); have = 0; } }
+    // nbits bits of src (the most significant bit of src[0] first) behind what has been written: whole bytes 8 at a time
+    // behind the pending bits (the blocks of a stream are coded on their own and strung together here -- a byte a call,
+    // 4 MB of them took 6 ms)
+    void append(const uint8_t *src, uint64_t nbits)
+    {
+        const uint64_t whole = nbits / 8;
+        if (whole) {
+            const size_t at = out.size();
+            out.resize(at + whole);
+            uint8_t *o = out.data() + at;
+            if (have == 0) {
+                memcpy(o, src, whole);
+            } else {
+                const int k = have;                       // 1 .. 7 pending bits in front of every byte
+                uint64_t carry = buf & ((1ull << k) - 1);
+                uint64_t q = 0;
+                for (; q + 8 <= whole; q += 8) {
+                    uint64_t v;
+                    memcpy(&v, src + q, 8);
+                    v = __builtin_bswap64(v);
+                    const uint64_t w = __builtin_bswap64((carry << (64 - k)) | (v >> k));
+                    memcpy(o + q, &w, 8);
+                    carry = v & ((1ull << k) - 1);
+                }
+                for (; q < whole; ++q) {
+                    const uint64_t v = (carry << 8) | src[q];
+                    o[q] = (uint8_t)(v >> k);
+                    carry = v & ((1ull << k) - 1);
+                }
+                buf = carry;
+            }
+            total += whole * 8;
+        }
+        const int rest = (int)(nbits - whole * 8);
+        if (rest > 0) bits(rest, (uint32_t)src[whole] >> (8 - rest));
+    }
 };
 
 // Code lengths (<= max_len) of a Huffman code for freq[0..alpha): package of the classic libbz2 approach --
@@ -643,8 +679,9 @@ inline int compress_block(BitWriter &bw, const std::vector<uint8_t> &blk, uint32
     }
     lap(4);
     if (trace)
-        fprintf(stderr, "[dq] bzip2 block of %d bytes (%d symbols): transform %.2f ms, last column %.2f, move to front %.2f, tables %.2f, bits %.2f\n",
-                nblock, n_mtf, t_ph[0], t_ph[1], t_ph[2], t_ph[3], t_ph[4]);
+        fprintf(stderr, "[dq] bzip2 block of %d bytes (%d symbols): transform %.2f ms, last column %.2f, move to front %.2f, tables %.2f, bits %.2f; "
+                "done at %.3f ms of the clock\n", nblock, n_mtf, t_ph[0], t_ph[1], t_ph[2], t_ph[3], t_ph[4],
+                std::chrono::duration<double, std::milli>(now().time_since_epoch()).count() - 1e3 * (double)(long long)(std::chrono::duration<double>(now().time_since_epoch()).count() / 100.0) * 100.0);
     return 0;
 }
 
@@ -714,6 +751,19 @@ public:
             size_t i = pos;
             // run-length pre-pass: a run of 4..255 equal bytes becomes 4 bytes + (length - 4)
             while (i < stop && blk.size() + 5 <= block_max && i - block_from < span_max) {
+                // 16 bytes none of which equals its neighbour (15 of 16 such stretches of random or compressed data) are
+                // 16 runs of one: copied as they are, while each of them would have passed the tests above on its own
+                // and the byte behind them is known (4 MiB of random bytes: 18 ms of pre-pass a byte at a time)
+                while (i + 17 <= upto && i + 16 <= stop && blk.size() + 16 + 5 <= block_max && i + 15 - block_from < span_max) {
+                    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i));
+                    const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 1));
+                    if (_mm_movemask_epi8(_mm_cmpeq_epi8(a, b))) break;
+                    const size_t at = blk.size();
+                    blk.resize(at + 16);
+                    _mm_storeu_si128(reinterpret_cast<__m128i *>(blk.data() + at), a);
+                    i += 16;
+                }
+                if (!(i < stop && blk.size() + 5 <= block_max && i - block_from < span_max)) break;
                 const uint8_t c = src[i];
                 size_t run = 1;
                 const size_t lim = upto - i < 255 ? upto - i : 255;
@@ -793,10 +843,7 @@ public:
         uint32_t combined = 0;
         for (Block &b : blocks) {
             if (b.rc != 0) return b.rc;
-            size_t k = 0;
-            for (; (k + 1) * 8 <= b.nbits; ++k) bw.bits(8, b.bytes[k]);
-            const int rest = (int)(b.nbits - k * 8);
-            if (rest > 0) bw.bits(rest, (uint32_t)b.bytes[k] >> (8 - rest));
+            bw.append(b.bytes.data(), b.nbits);
             combined = ((combined << 1) | (combined >> 31)) ^ b.crc;
         }
         bw.bits(24, (uint32_t)(kEndMagic >> 24));

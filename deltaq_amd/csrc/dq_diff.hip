@@ -1202,8 +1202,10 @@ int diff_index_scan(const DiffIndex &ix, const uint8_t *nw, int64_t m, bsdiff::R
     const bool trace = env("DQ_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto stamp = [&](const char *what) {
-        if (trace) fprintf(stderr, "[dq] bsdiff %-14s at %8.3f ms\n", what,
-                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+        if (trace) fprintf(stderr, "[dq] bsdiff %-14s at %8.3f ms (%.3f ms of the clock)\n", what,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(),
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() -
+                               1e3 * (double)(long long)(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() / 100.0) * 100.0);
     };
     const size_t b_new = align_up((size_t)m + 16);
     // (+ the mailbox of the window kernel; + control block, answers and anchor list of the device's scan)
