@@ -614,7 +614,9 @@ constexpr int kScanChainGroups = 32;                      // several (DQ_SCAN_GR
                                                           // unrelated bytes: one grid of 128 workgroups 38.8 / 67.1 / 261.5 / 83.2,
                                                           // 4 x 64: 19.8 / 29.9 / 76.7 / 87.1, 6 x 40: 17.9 / 25.6 / 55.2 / 82.9,
                                                           // 8 x 32: 17.1 / 23.1 / 46.1 / 85.7 (profiles/r06/r06s_chains_variants.log)
-constexpr int64_t kScanMinSegment = 1ll << 20;            // bytes of new per grid below which no further one is started (DQ_SCAN_MIN_SEG)
+constexpr int64_t kScanMinSegment = 128ll << 10;          // bytes of new per grid below which no further one is started (DQ_SCAN_MIN_SEG):
+                                                          // 1 MiB / 128 KiB -- 1 MiB pair with 128 edits 4.2 / 2.9 ms (text 6.4 / 4.0),
+                                                          // 2 MiB 5.0 / 2.8 (text 11.2 / 4.7), 4 MiB 5.8 / 4.6 (text 9.3 / 6.6)
 constexpr int64_t kScanExtra = 8;                         // iteration ends a grid walks on into the next one's part
 constexpr int64_t kScanLaneBudget = 2;                    // one-lane-per-position windows after which a grid that is not alone leaves
 static_assert(kDiffPinnedBytes >= kDiffWindowBytes + kAnchorPinned, "pinned area of the chains");

@@ -51,7 +51,7 @@ while time.time() < t_end:
             f.write(repr(dict(count=count, n=n, m=int(new.size), t=round(time.time() - (t_end - budget), 1))) + "\n")
         np.save(os.environ["STRESS_LOG"] + ".old.npy", old); np.save(os.environ["STRESS_LOG"] + ".new.npy", new)
     # (the device's anchor search with grids of several sizes, and the host loop over windows it falls back to)
-    # (several grids on one file -- "chains", dq_diff.hip -- start at 2 MiB of new by default: forced onto these short
+    # (several grids on one file -- "chains", dq_diff.hip -- start at 256 KiB of new by default: forced onto these short
     # files with segments from 64 bytes on, 2 .. 8 grids, 1 .. 8 iteration ends walked into the next grid's part)
     for k in ("DQ_SCAN_DEVICE", "DQ_SCAN_GROUPS", "DQ_SCAN_CHAINS", "DQ_SCAN_MIN_SEG", "DQ_SCAN_EXTRA", "DQ_SCAN_LANE_BUDGET", "DQ_SCAN_PAR_EMIT"): os.environ.pop(k, None)
     mode = int(rng.integers(0, 10))

@@ -61,7 +61,7 @@ def pairs(oracle_mod):
 
 # the anchor search of the scan loop runs on the device by default (dq_anchor_scan.h: one persistent launch per new
 # file); the host loop over windows of device answers stays as the path a starved launch falls back to
-# (several grids on one new file -- "chains", dq_diff.hip -- start from 2 MiB of new by default: forced onto the small
+# (several grids on one new file -- "chains", dq_diff.hip -- start from 256 KiB of new by default: forced onto the small
 # pairs here, 4 grids of 64 workgroups from 4 KiB on, and 8 grids of 16 that leave after one iteration end behind the next
 # grid's start and after one window of one position per lane)
 SCAN_PATHS = [{}, {"DQ_SCAN_DEVICE": "0"}, {"DQ_SCAN_GROUPS": "8"}, {"DQ_SCAN_GROUPS": "48"},
@@ -87,7 +87,7 @@ def test_chains_are_joined_between_similar_files_and_dropped_between_unrelated_o
     """Several grids on one new file (dq_diff.hip, "chains"): between similar files every speculative grid is joined --
     same place, same shift -- and most triples come from the grids' own emitter threads; between unrelated files the
     grids leave after their budget of lane windows and are dropped; the raw streams and the Search count are the
-    reference loop's either way.  By default the grids start at 2 MiB of new."""
+    reference loop's either way.  By default the grids start at 256 KiB of new (128 KiB each)."""
     from deltaq_amd import Diff, _abi
     rng = np.random.default_rng(23)
     old = oracle_mod.gen_uniform(6_000_000, 31)
@@ -113,8 +113,8 @@ def test_chains_are_joined_between_similar_files_and_dropped_between_unrelated_o
                     assert info["triples_from_chain_emitters"] > ctrl.size // 3 // 4, (env, info, ctrl.shape)
             else:
                 assert info["chains_joined"] == 0, (env, info)
-    # one grid alone below 2 MiB of new
-    small = edited(rng, old[:1_500_000], 50)
+    # one grid alone below 256 KiB of new
+    small = edited(rng, old[:200_000], 20)
     Diff.Scan(old, small)
     info = _abi.last_diff_info()
     assert info["chains_launched"] == 1 and info["chains_joined"] == 0 and info["scan_groups"] == 128, info
