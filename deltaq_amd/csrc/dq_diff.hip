@@ -48,7 +48,7 @@ int match_search_dev(const void *d_old, int64_t n, const void *d_sa, const void 
         const int64_t total = (1ll << (8 * pk)) + 1;
         HIP_TRY(dq_malloc(&tmp_tab.p, (size_t)total * sizeof(IdxT)));
         hipLaunchKernelGGL(prefix_bounds_kernel<IdxT>, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           (const uint8_t *)d_old, n, (const IdxT *)d_sa, pk, (IdxT *)tmp_tab.p);
+                           (const uint8_t *)d_old, n, (const IdxT *)d_sa, pk, (IdxT *)tmp_tab.p, (const IdxT *)nullptr);
         HIP_TRY(hipGetLastError());
         d_ptab = tmp_tab.p;
     }
@@ -331,7 +331,8 @@ size_t diff_tab_bytes(int64_t n, int *pk_out)
     // prefix table of the match search: 3 bytes (64 MiB of entries) for old files from 4 MiB, 2 bytes from 64 KiB
     const int pk = n >= (4 << 20) ? 3 : n >= (1 << 16) ? 2 : 0;
     *pk_out = pk;
-    return pk ? align_up(((size_t)1 << (8 * pk)) * 4 + 16) : 0;
+    // (+ the 2-byte table the 3-byte one is built from, behind it)
+    return pk ? align_up(((size_t)1 << (8 * pk)) * 4 + 16) + (pk == 3 ? align_up(((size_t)1 << 16) * 4 + 16) : 0) : 0;
 }
 
 int grow_cached(char **buf, size_t *have, size_t want, const char *what)
@@ -387,8 +388,16 @@ int diff_index_build(const uint8_t *old, int64_t n, int32_t device, const void *
     if (pk) {
         char *tab = ix->own + b_old + b_sa;
         const int64_t total_e = (1ll << (8 * pk)) + 1;
+        const int32_t *coarse = nullptr;
+        if (pk == 3) {                                       // the 2-byte table first: it bounds every search of the 3-byte one
+            int32_t *two = reinterpret_cast<int32_t *>(tab + align_up(((size_t)1 << 24) * 4 + 16));
+            hipLaunchKernelGGL(prefix_bounds_kernel<int32_t>, dim3((unsigned)(((1 << 16) + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                               nullptr, (const uint8_t *)ix->d_old, n, (const int32_t *)ix->d_sa, 2, two, (const int32_t *)nullptr);
+            HIP_TRY(hipGetLastError());
+            coarse = two;
+        }
         hipLaunchKernelGGL(prefix_bounds_kernel<int32_t>, dim3((unsigned)((total_e + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                           nullptr, (const uint8_t *)ix->d_old, n, (const int32_t *)ix->d_sa, pk, (int32_t *)tab);
+                           nullptr, (const uint8_t *)ix->d_old, n, (const int32_t *)ix->d_sa, pk, (int32_t *)tab, coarse);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
         ix->d_tab = tab;

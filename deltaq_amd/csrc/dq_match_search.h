@@ -136,15 +136,20 @@ __device__ __forceinline__ void ms_trim_short_suffixes(const IdxT *__restrict__ 
 // it: the search starts ~8 * pk probes further down.
 // Built once per old file by the scan-loop driver (dq_diff.hip::SearchWindows), where a Search is one
 // dependent round trip to the device and its ~log2(n) probes of ~1 us each are what the round trip costs.
+// coarse: the table of pk - 1 bytes, if it has been built: the bound of v lies inside [coarse[v >> 8], coarse[(v >> 8) + 1]]
+// (the suffixes below the shorter pattern are below every pattern it begins, those below v are below the next shorter
+// pattern) -- 8 probes instead of log2(n): the 3-byte table of a 16 MiB file 0.84 -> 0.3 ms, a twelfth of a Diff.Create.
 template <typename IdxT>
 __global__ __launch_bounds__(kBlock) void prefix_bounds_kernel(const uint8_t *__restrict__ old, int64_t n,
-                                                               const IdxT *__restrict__ sa, int pk, IdxT *__restrict__ ptab)
+                                                               const IdxT *__restrict__ sa, int pk, IdxT *__restrict__ ptab,
+                                                               const IdxT *__restrict__ coarse = nullptr)
 {
     const int64_t total = 1ll << (8 * pk);
     const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (v > total) return;
     if (v == total) { ptab[v] = (IdxT)n; return; }
     int64_t L = 0, R = n;
+    if (coarse) { L = (int64_t)coarse[v >> 8]; R = (int64_t)coarse[(v >> 8) + 1]; }
     while (L < R) {
         const int64_t mid = L + ((R - L) >> 1);
         const int64_t p = (int64_t)sa[mid], la = n - p;
