@@ -120,6 +120,32 @@ def test_chains_are_joined_between_similar_files_and_dropped_between_unrelated_o
     assert info["chains_launched"] == 1 and info["chains_joined"] == 0 and info["scan_groups"] == 128, info
 
 
+def test_silent_iteration_ends_and_a_full_list(backend_lib, oracle_mod, monkeypatch):
+    """One byte changed every 60 bytes of a 4 MiB file: the loop ends ~70 000 iterations without a triple (the old
+    alignment explains every match) -- grids are joined at such ends by place AND shift -- and one grid alone writes more
+    entries than its list holds per launch (32 768): it leaves, is read to the end and launched again from where it stood."""
+    from deltaq_amd import Diff, _abi
+    old = oracle_mod.gen_uniform(4 << 20, 91)
+    new = old.copy()
+    new[100::60] ^= 0x5a
+    wc, wd, we, searches = oracle_mod.bsdiff_scan(old, oracle_mod.divsufsort(old), new)
+    for env in ({"DQ_SCAN_CHAINS": "1"}, {"DQ_SCAN_CHAINS": "2"}, {}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctrl, diff, extra, stats = Diff.Scan(old, new)
+        info = _abi.last_diff_info()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(ctrl, wc) and np.array_equal(diff, wd) and np.array_equal(extra, we) and stats["searches"] == searches, env
+        assert info["host_loop_fallbacks"] == 0, info
+        if env.get("DQ_SCAN_CHAINS") == "1":
+            assert info["chains_launched"] >= 3 and info["chains_joined"] == 0, info          # (its list was full twice)
+        elif env:
+            assert info["chains_joined"] >= 1 and info["chains_launched"] >= 3, info
+        else:
+            assert info["chains_joined"] >= 8, info
+
+
 def test_create_apply_roundtrip_and_cross_compatibility(backend_lib, oracle_mod):
     from deltaq_amd import Diff, Patch, HipSuffixSort
     for old, new in pairs(oracle_mod):
