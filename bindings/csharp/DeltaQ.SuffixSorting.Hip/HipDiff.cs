@@ -95,10 +95,12 @@ public static class HipDiff
     /// Shape of the last Create / HipDiffIndex.Create on this thread (dq_last_diff_info): Search calls of the loop
     /// (Diff.cs:106), windows, positions asked again exactly, device scans given back to the host loop, workgroups.
     /// A non-zero fourth entry means the call was correct but slow: the device was kept full by other work.
+    /// Entries 5..8 (several grids on one new file): grids launched, grids the followed one was joined to, grids dropped
+    /// unjoined, control triples taken over from the grids' own emitter threads.
     /// </summary>
     public static unsafe long[] LastDiffInfo()
     {
-        var info = new long[5];
+        var info = new long[9];
         fixed (long* p = info)
         {
             Native.Check(Native.dq_last_diff_info(p, info.Length), nameof(Native.dq_last_diff_info));
