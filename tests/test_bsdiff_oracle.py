@@ -161,6 +161,34 @@ def test_product_scan_loop_makes_the_references_decisions(oracle_mod, scan_harne
         assert got[3] == want[3], trial
 
 
+def test_product_scan_loop_on_stretches_the_files_do_not_share(oracle_mod, scan_harness):
+    """The extensions step over eight positions at once where none of them can be a new best (dq_bsdiff.h): unrelated
+    files and long inserted stretches, over alphabets of 2, 4 and 256 symbols -- with few symbols every second or fourth
+    byte agrees by chance, so the bound the step rests on is met from both sides."""
+    rng = np.random.default_rng(11)
+    for trial in range(36):
+        n = int(rng.integers(200, 20000))
+        mask = (1, 3, 255)[trial % 3]
+        old = oracle_mod.gen_uniform(n, 700 + trial) & mask
+        kind = trial % 4
+        if kind == 0:
+            new = oracle_mod.gen_uniform(int(rng.integers(100, 20000)), 900 + trial) & mask          # nothing in common
+        else:
+            x = bytearray(old.tobytes())
+            for _ in range(kind):                                                                     # long foreign stretches
+                a = int(rng.integers(0, len(x)))
+                x[a:a] = (oracle_mod.gen_uniform(int(rng.integers(500, 6000)), 1100 + trial) & mask).tobytes()
+            new = np.frombuffer(bytes(x), dtype=np.uint8)
+        new = np.ascontiguousarray(new, np.uint8)
+        sa = oracle_mod.divsufsort(old)
+        pos, ln = oracle_mod.bsdiff_search(old, sa, new)
+        want = oracle_mod.bsdiff_scan(old, sa, new)
+        got = scan_harness(old, new, pos, ln)
+        assert np.array_equal(got[0], want[0]), (trial, n, new.size)
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), trial
+        assert got[3] == want[3], trial
+
+
 def test_product_packed_longs(scan_harness):
     for v in (0, 1, -1, 127, 128, -128, 255, 256, 2**31 - 1, -2**31, 2**62, -(2**62), 2**63 - 1, -(2**63 - 1)):
         assert scan_harness.lib.t_packed_roundtrip(v) == v
